@@ -1,0 +1,225 @@
+// oracle/grto_capi.cpp -- TEST INFRASTRUCTURE ONLY (CPU restatement; never shipped).
+//
+// Per-pixel driver (grtrans_driver.f90:57-466, extra=0) and pixel loop (pgrtrans.f90:196-212)
+// on top of the restated stages, exported with a flat C API for tests/ (ctypes) and for
+// bench.py's cpu_baseline leg.  Built by oracle/Makefile into oracle/_build/libgrt_oracle.so.
+#include "grto_physics.hpp"
+#include <omp.h>
+#include <string>
+
+using namespace grto;
+
+namespace {
+
+struct Setup {
+  Camera cam;
+  double phi0 = 0, spin = 0;
+  int fluid = 0;        // 13 FFJET (fluid.f90:41)
+  int emis = 0;         // 4 POLSYNCHPL, 2 POLSYNCHTH (emis.f90:11-18)
+  int iflag = 2;        // rad_trans.f90:29-37: 1 delo, 2 formal
+  int nvals = 4;
+  double mbh = 0, nfac = 0, bfac = 0, gmin = 0, gmax = 0, p1 = 0;
+  int coefindx[7] = {1, 1, 1, 1, 1, 1, 1};
+  FFJetTable ffjet;
+  PLTables pl;
+  bool ok = false;
+};
+Setup S;
+
+struct RayWork {
+  Geodesic g;
+  std::vector<FluidPoint> f;
+  std::vector<double> s2xi, c2xi, ang, rshift, cosne, ncgsnth, bcgs, jraw, Kraw, j, K, tau, I;
+};
+
+// One pixel / one frequency, stages kept for dumping.  Returns pixel Stokes (double, before
+// the fp32 cast), fac and npts.
+void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
+  Pixel px = camera_pixel(S.cam, ii);
+  make_geodesic(S.cam, px, S.phi0, 0.0, w.g);
+  const int n = w.g.npts;
+  for (int c = 0; c < 4; ++c) pix[c] = 0.0;
+  fac = 0.0;
+  if (!(w.g.status == 1 && n > 0)) return;
+  w.f.resize(n);
+  auto rs = [&](std::vector<double> &v, int m) { v.assign((size_t)n * m, 0.0); };
+  rs(w.s2xi, 1); rs(w.c2xi, 1); rs(w.ang, 1); rs(w.rshift, 1); rs(w.cosne, 1); rs(w.ncgsnth, 1); rs(w.bcgs, 1);
+  rs(w.jraw, 4); rs(w.Kraw, 7); rs(w.j, 4); rs(w.K, 7); rs(w.tau, 1); rs(w.I, 4);
+  const double LBH = PH_G * S.mbh * PH_msun / PH_c2;
+  // emis_params are REAL(4): gmin, gmax, p1 reach polsynchpl through single precision (emis.f90:32-39)
+  const double gmin = (double)(float)S.gmin, gmax = (double)(float)S.gmax, p = (double)(float)S.p1;
+  for (int i = 0; i < n; ++i) {
+    const double *x = &w.g.x[4 * i], *k = &w.g.k[4 * i];
+    ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
+    comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
+                   w.ang[i], w.rshift[i], w.cosne[i]);
+    w.ncgsnth[i] = w.f[i].rho * S.nfac;   // fluid.f90:1171
+    w.bcgs[i] = w.f[i].bmag * S.bfac;
+    double nu = freq / w.rshift[i];
+    double e[11];
+    polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    for (int c = 0; c < 4; ++c) w.jraw[4 * i + c] = e[c];
+    for (int c = 0; c < 7; ++c) w.Kraw[7 * i + c] = S.coefindx[c] ? e[4 + c] : 0.0;
+  }
+  if (n > 1) {
+    for (int i = 0; i < n; ++i) fac += w.jraw[4 * i] * (w.g.lam[0] - w.g.lam[i]);
+  } else {
+    fac = w.jraw[0] / n;
+  }
+  if (!(fac / 1e16 > 0.0)) return;
+  for (int i = 0; i < n; ++i) {
+    double s2 = w.s2xi[i], c2 = w.c2xi[i], g = w.rshift[i];
+    double jq = w.jraw[4 * i + 1], ju = w.jraw[4 * i + 2], aq = w.Kraw[7 * i + 1], au = w.Kraw[7 * i + 2];
+    double rq = w.Kraw[7 * i + 4], ru = w.Kraw[7 * i + 5];
+    double jj[4] = {w.jraw[4 * i], c2 * jq - s2 * ju, s2 * jq + c2 * ju, w.jraw[4 * i + 3]};
+    double KK[7] = {w.Kraw[7 * i], c2 * aq - s2 * au, s2 * aq + c2 * au, w.Kraw[7 * i + 3],
+                    c2 * rq - s2 * ru, s2 * rq + c2 * ru, w.Kraw[7 * i + 6]};
+    if (n != 1) {
+      for (int c = 0; c < 4; ++c) w.j[4 * i + c] = jj[c] * g * g / fac;
+      for (int c = 0; c < 7; ++c) w.K[7 * i + c] = KK[c] / g * LBH;
+    } else {
+      for (int c = 0; c < 4; ++c) w.j[4 * i + c] = jj[c] * g * g * g;   // invariant_intensity npow=3
+    }
+  }
+  if (n != 1) {
+    std::vector<double> absa(n);
+    for (int i = 0; i < n; ++i) absa[i] = std::fabs(w.K[7 * i]);
+    tsum(n, w.g.lam.data(), absa.data(), w.tau.data());
+    for (int i = 0; i < n; ++i) w.tau[i] = -w.tau[i];
+    if (S.iflag == 1) integrate_delo(n, w.g.lam.data(), w.tau.data(), w.j.data(), w.K.data(), w.I.data());
+    else integrate_formal(n, w.g.lam.data(), w.j.data(), w.K.data(), w.I.data());
+    for (size_t q = 0; q < w.I.size(); ++q) w.I[q] = w.I[q] * fac * LBH;
+    for (int c = 0; c < 4; ++c) pix[c] = w.I[4 * (n - 1) + c];
+  } else {
+    for (int c = 0; c < 4; ++c) pix[c] = w.j[c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// leaf probes
+double grto_rf(double x, double y, double z) { return rf(x, y, z); }
+double grto_rc(double x, double y) { return rc(x, y); }
+double grto_rd(double x, double y, double z) { return rd(x, y, z); }
+double grto_rj(double x, double y, double z, double p) { return rj(x, y, z, p); }
+void grto_sncndn(double u, double emmc, double *sn, double *cn, double *dn) { sncndn(u, emmc, *sn, *cn, *dn); }
+
+int grto_setup(int standard, double mu0, double phi0, double spin, double uout, const double *gridvals,
+               const int *nn, const char *fname, const char *ename, const char *iname, const char *dfile,
+               const char *pltab, double mbh, double gmin, double gmax, double p1, double ftscl, double frscl,
+               const int *coefindx, int nvals) {
+  S = Setup();
+  camera_init(S.cam, standard, gridvals[0], gridvals[1], gridvals[2], gridvals[3], nn[0], nn[1], nn[2], spin, mu0, uout);
+  S.phi0 = phi0; S.spin = spin; S.nvals = nvals;
+  std::string fn(fname), en(ename), in(iname);
+  if (fn == "FFJET") S.fluid = 13; else return -1;
+  if (en == "POLSYNCHPL") S.emis = 4; else return -2;
+  if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2; else return -3;
+  S.mbh = mbh; S.nfac = ftscl; S.bfac = frscl; S.gmin = gmin; S.gmax = gmax; S.p1 = p1;
+  for (int i = 0; i < 7; ++i) S.coefindx[i] = coefindx[i];
+  if (!ffjet_load(dfile, S.ffjet)) return -4;
+  if (!pltables_load(pltab, S.pl)) return -5;
+  S.ok = true;
+  return 0;
+}
+
+void grto_camera(int npix, double *alpha, double *beta, double *q2, double *l, double *su, double *sm, double *uf,
+                 int *tpr, double *scal) {
+  for (int i = 0; i < npix; ++i) {
+    Pixel p = camera_pixel(S.cam, i + 1);
+    alpha[i] = p.alpha; beta[i] = p.beta; q2[i] = p.q2; l[i] = p.l; su[i] = p.su; sm[i] = p.sm; uf[i] = p.uf;
+    tpr[i] = p.tpr;
+  }
+  scal[0] = S.cam.u0; scal[1] = S.cam.uout; scal[2] = S.cam.offset; scal[3] = S.cam.mu0; scal[4] = S.cam.a;
+  scal[5] = S.cam.kext; scal[6] = S.cam.next; scal[7] = S.cam.nup;
+}
+
+void grto_geokerr_ray(int ii, int maxn, int *nout, int *ncase, double *ufi, double *mufi, double *dti, double *dphi,
+                      double *lambdai, int *tpmi, int *tpri) {
+  Pixel px = camera_pixel(S.cam, ii);
+  GeoRaw raw;
+  geokerr(S.cam, px, raw);
+  *nout = raw.n; *ncase = raw.ncase;
+  int m = std::min((int)raw.u.size(), maxn);
+  for (int i = 0; i < m; ++i) {
+    ufi[i] = raw.u[i]; mufi[i] = raw.mu[i]; dti[i] = raw.dt[i]; dphi[i] = raw.dphi[i]; lambdai[i] = raw.lam[i];
+    tpmi[i] = raw.tpm[i]; tpri[i] = raw.tpr[i];
+  }
+}
+
+// dump: row-major [64][maxn], same column map as ref_ray_dump (oracle/refbind.py COLS)
+void grto_ray_dump(int ii, double freq, int maxn, int *npts, int *status, double *fac, double *pix, double *dump) {
+  RayWork w;
+  double f;
+  ray_stages(ii, freq, w, pix, f);
+  for (int c = 0; c < 4; ++c) pix[c] = (double)(float)pix[c];
+  *fac = f; *npts = w.g.npts; *status = w.g.status;
+  int n = std::min(w.g.npts, maxn);
+  auto put = [&](int col, int i, double v) { dump[(size_t)col * maxn + i] = v; };
+  if (!(w.g.status == 1 && n > 0)) return;
+  for (int i = 0; i < n; ++i) {
+    put(0, i, w.g.lam[i]);
+    for (int c = 0; c < 4; ++c) { put(1 + c, i, w.g.x[4 * i + c]); put(5 + c, i, w.g.k[4 * i + c]); }
+    put(9, i, w.g.tpm[i]); put(10, i, w.g.tpr[i]);
+    put(11, i, w.f[i].rho); put(12, i, w.f[i].p); put(13, i, w.f[i].bmag);
+    for (int c = 0; c < 4; ++c) { put(14 + c, i, w.f[i].u[c]); put(18 + c, i, w.f[i].b[c]); }
+    put(22, i, w.s2xi[i]); put(23, i, w.c2xi[i]); put(24, i, w.ang[i]); put(25, i, w.rshift[i]); put(26, i, w.cosne[i]);
+    put(28, i, w.ncgsnth[i]); put(29, i, w.bcgs[i]);
+    for (int c = 0; c < 4; ++c) put(31 + c, i, w.jraw[4 * i + c]);
+    for (int c = 0; c < 7; ++c) put(35 + c, i, w.Kraw[7 * i + c]);
+    for (int c = 0; c < 4; ++c) put(42 + c, i, w.j[4 * i + c]);
+    for (int c = 0; c < 7; ++c) put(46 + c, i, w.K[7 * i + c]);
+    put(53, i, w.tau[i]);
+    for (int c = 0; c < 4; ++c) put(54 + c, i, w.I[4 * i + c]);
+  }
+}
+
+// pixvals: [nfreq][npix_range][nvals] fp32; raynpts as ref_trace
+void grto_trace(int i1, int i2, int nfreq, const double *freqs, int nthreads, float *pixvals, int *raynpts,
+                double *seconds) {
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  double t0 = omp_get_wtime();
+  const int n = i2 - i1 + 1;
+#pragma omp parallel
+  {
+    RayWork w;
+#pragma omp for schedule(static, 1)
+    for (int i = i1; i <= i2; ++i) {
+      for (int k = 0; k < nfreq; ++k) {
+        double pix[4], fac;
+        ray_stages(i, freqs[k], w, pix, fac);   // (geodesic recomputed per frequency: oracle favours clarity)
+        for (int c = 0; c < S.nvals; ++c) pixvals[((size_t)k * n + (i - i1)) * S.nvals + c] = (float)pix[c];
+      }
+      raynpts[i - i1] = (w.g.status == 1) ? w.g.npts : -w.g.npts;
+    }
+  }
+  *seconds = omp_get_wtime() - t0;
+}
+
+void grto_polsynchpl(int n, const double *nu, const double *nnth, const double *b, const double *th, const double *p,
+                     const double *gmin, double gmax, double *eout /* [n][11] */) {
+  for (int i = 0; i < n; ++i) polsynchpl(S.pl, nu[i], nnth[i], b[i], th[i], p[i], gmin[i], gmax, &eout[11 * i]);
+}
+int grto_load_pltables(const char *path) { return pltables_load(path, S.pl) ? 0 : -1; }
+
+void grto_polsynchth(int n, const double *nu, const double *dens, const double *b, const double *t, const double *th,
+                     double *eout) {
+  for (int i = 0; i < n; ++i) polsynchth(nu[i], dens[i], b[i], t[i], th[i], &eout[11 * i]);
+}
+
+void grto_integrate(int iflag, int n, const double *x, const double *j /*[n][4]*/, const double *K /*[n][7]*/,
+                    const double *tau, double *out /*[n][4]*/) {
+  if (iflag == 1) integrate_delo(n, x, tau, j, K, out);
+  else integrate_formal(n, x, j, K, out);
+}
+
+void grto_comoving_ortho(int n, const double *r, const double *th, double a, double alpha, double beta, double mus,
+                         const double *u, const double *b, const double *k, double *out /*[n][5]*/) {
+  for (int i = 0; i < n; ++i)
+    comoving_ortho(r[i], th[i], a, alpha, beta, mus, &u[4 * i], &b[4 * i], &k[4 * i], out[5 * i], out[5 * i + 1],
+                   out[5 * i + 2], out[5 * i + 3], out[5 * i + 4]);
+}
+
+}  // extern "C"

@@ -29,7 +29,8 @@ module grt_ref_driver
   use kerr, only: comoving_ortho, kerr_metric
   use radtrans_integrate, only: integrate, del_radtrans_integrate_data, &
        init_radtrans_integrate_data, intensity
-  use polsynchemis, only: polsynchpl, polsynchth, initialize_polsynchpl
+  use polsynchemis, only: polsynchpl, polsynchth, initialize_polsynchpl, gxvals, gyvals, xvals, &
+       yavals, ypvals, yvvals, yapvals, yavvals
   use phys_constants, only: GC => G, C2, MSUN
   implicit none
 
@@ -422,5 +423,16 @@ contains
     call comoving_ortho(rr, th, a, alpha, beta, mus, uu, bb, kk, s2xi, c2xi, ang, gg, cosne)
     out(:,1) = s2xi; out(:,2) = c2xi; out(:,3) = ang; out(:,4) = gg; out(:,5) = cosne
   end subroutine ref_comoving_ortho
+
+  ! The tabulated log G(x) integrals of polsynchpl as the compiled reference holds them
+  ! (polsynchemis.f90:107-525): out = gxvals(181) gyvals(543) xvals(81) yavals(243)
+  ! ypvals(243) yvvals(243) yapvals(243) yavvals(243) = 2020 doubles.
+  subroutine ref_polsynchpl_tables(out) bind(C, name='ref_polsynchpl_tables')
+    real(c_double), intent(out) :: out(2020)
+    call initialize_polsynchpl(4)
+    out(1:181) = gxvals; out(182:724) = gyvals; out(725:805) = xvals; out(806:1048) = yavals
+    out(1049:1291) = ypvals; out(1292:1534) = yvvals; out(1535:1777) = yapvals
+    out(1778:2020) = yavvals
+  end subroutine ref_polsynchpl_tables
 
 end module grt_ref_driver

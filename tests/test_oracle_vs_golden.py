@@ -1,0 +1,116 @@
+"""CPU tests: the C++ oracle (oracle/grto_*.hpp) against golden vectors that were produced by
+the compiled, unmodified reference (tools/make_golden.py).  Tolerances are stated per test."""
+import os
+import numpy as np
+import pytest
+
+from oracle import orabind as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def relerr(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    s = np.max(np.abs(b))
+    return np.max(np.abs(a - b)) / (s if s > 0 else 1.0)
+
+
+def test_carlson_and_jacobi_bit_exact():
+    # Same operation order as geokerr_wrapper.f:3277-3762 -> bit-identical on x86-64
+    g = load("leaf_special.npz")
+    v = g["xyzp"]
+    assert np.array_equal(np.array([O.rf(*x[:3]) for x in v]), g["rf"])
+    assert np.array_equal(np.array([O.rd(*x[:3]) for x in v]), g["rd"])
+    assert np.array_equal(np.array([O.rc(x[1], x[2]) for x in v]), g["rc"])
+    assert np.array_equal(np.array([O.rc(x[1] + x[2], -x[2]) for x in v]), g["rcn"])
+    assert np.array_equal(np.array([O.rj(*x) for x in v]), g["rj"])
+    assert np.array_equal(np.array([O.rj(x[0], x[1], x[2], -x[3]) for x in v]), g["rjn"])
+    sn = np.array([O.sncndn(u, m) for u, m in g["um"]])
+    assert np.max(np.abs(sn - g["sncndn"])) <= 4e-16
+
+
+def test_emission_coefficients():
+    g = load("coeffs.npz")
+    epl = O.polsynchpl(g["nu"], g["nnth"], g["b"], g["th"], g["p"], g["gmin"], float(g["gmax"]))
+    ref = g["polsynchpl"]
+    for c in range(11):
+        assert relerr(epl[:, c] / (np.abs(ref[:, 0]) + 1e-300), ref[:, c] / (np.abs(ref[:, 0]) + 1e-300)) < 1e-12 or \
+            np.allclose(epl[:, c], ref[:, c], rtol=1e-11, atol=0)
+    eth = O.polsynchth(g["nu"], g["dens"], g["b"], g["t"], g["th"])
+    assert np.allclose(eth, g["polsynchth"], rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize("case", ["faraday_rot", "rot_conv", "full_rho", "abs_IQ", "varying", "thin"])
+def test_integrators(case):
+    # radtrans_integrate_formal / _delo on the closed-form coefficient sets of
+    # unit_tests_integration.py:39-150 (+ two varying-coefficient rays); reference = Fortran integrate()
+    g = load("integrators.npz")
+    x, j, K, tau = g["x"], g[case + "_j"], g[case + "_K"], g[case + "_tau"]
+    for iflag, name in ((1, "delo"), (2, "formal")):
+        out = O.integrate(iflag, x, j, K, tau)
+        assert relerr(out, g[case + "_" + name]) < 1e-12, (case, name)
+
+
+@pytest.mark.parametrize("fx", ["ffjet_rays_32x32x100.npz", "ffjet_rays_100x100x400.npz"])
+def test_per_stage_ray_dumps(fx):
+    g = load(fx)
+    nx, nup = (32, 100) if "32x32" in fx else (100, 400)
+    o = O.Oracle(nn=(nx, nx, nup), iname="formal")
+    for i in g["rays"]:
+        d = o.ray_dump(int(i), float(g["freq"]))
+        raw = o.geokerr_ray(int(i))
+        assert d["npts"] == int(g["ray%d_npts" % i]) and d["status"] == int(g["ray%d_status" % i])
+        assert raw["ncase"] == int(g["ray%d_ncase" % i])
+        # integers: exact
+        assert np.array_equal(d["tpm"], g["ray%d_tpm" % i]) and np.array_equal(d["tpr"], g["ray%d_tpr" % i])
+        # raw geokerr outputs: 1e-13 relative to the array's scale (dt, lam are O(1/u0) ~ 5e8);
+        # dphi is a difference of O(1e2) elliptic terms -> 1e-10
+        for k, tol in (("u", 1e-13), ("mu", 1e-12), ("dt", 1e-13), ("dphi", 1e-10), ("lam", 1e-13)):
+            assert relerr(raw[k], g["ray%d_raw_%s" % (i, k)]) < tol, (i, k)
+        # lambda/x after the differences lose ~9 digits to cancellation -> 1e-8
+        for k, tol in (("lam", 1e-8), ("x", 1e-8), ("k", 1e-8), ("rho", 1e-6), ("bmag", 1e-6), ("u", 1e-6), ("b", 1e-6),
+                       ("s2xi", 1e-6), ("c2xi", 1e-6), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6),
+                       ("I", 1e-6)):
+            assert relerr(d[k], g["ray%d_%s" % (i, k)]) < tol, (i, k)
+        assert np.allclose(d["pix"], g["ray%d_pix" % i], rtol=2e-6, atol=1e-7 * np.abs(g["ray%d_pix" % i]).max())
+
+
+@pytest.mark.parametrize("nx,nup", [(32, 100), (100, 400)])
+def test_image_and_integer_parity(nx, nup):
+    g = load("ffjet_%dx%dx%d.npz" % (nx, nx, nup))
+    for iname in ("formal", "delo"):
+        o = O.Oracle(nn=(nx, nx, nup), iname=iname)
+        pix, npts, _ = o.trace(1, nx * nx, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g["npts"])                       # bit-exact point counts
+        ref = g["ivals_" + iname].astype(float)
+        peak = np.abs(ref).max(axis=0)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / peak
+        assert err.max() < 1e-6, (iname, err)                        # fp32 image, 1e-6 of the Stokes peak
+    cam = o.camera()
+    for k in ("alpha", "beta", "q2", "l", "su", "sm", "uf", "tpr"):
+        assert np.array_equal(np.asarray(cam[k], float), g["cam_" + k].astype(float)), k
+    # tpm/tpr/ncase of every ray, bit-exact
+    for i in range(1, nx * nx + 1, 7):
+        raw = o.geokerr_ray(i)
+        n = raw["n"]
+        assert raw["ncase"] == g["ncase"][i - 1]
+        assert np.array_equal(raw["tpm"], g["tpmi"][i - 1, :n]) and np.array_equal(raw["tpr"], g["tpri"][i - 1, :n])
+
+
+def test_reference_own_regression_golden():
+    # The reference's own FFJET regression (run_grtrans_test_problems_public.py:60-75): LSODA image
+    # test_grtrans_ffjet.p, criterion sum|x-g|/sum|g|.  formal/delo at nup=400 land at ~2% of the
+    # LSODA golden (the reference's own formal/delo do too: 0.0212); its pass mark for those two
+    # integrators is 5% on the spectrum (:88-90,103-105).
+    g = load("test_grtrans_ffjet_lsoda.npz")["ivals"].astype(float)
+    for iname in ("formal", "delo"):
+        o = O.Oracle(nn=(100, 100, 400), iname=iname)
+        pix, _, _ = o.trace(1, 10000, [3.45e11], nthreads=8)
+        terr = np.abs(pix[0] - g).sum() / np.abs(g).sum()
+        assert terr < 0.05, terr
+        spec = pix[0].sum(axis=0); gs = g.sum(axis=0)
+        assert np.max(np.abs(spec[:2] - gs[:2]) / np.abs(gs[:2])) < 0.05

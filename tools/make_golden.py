@@ -1,0 +1,120 @@
+"""Generate tests/golden/*.npz from the COMPILED, UNMODIFIED reference (oracle/_ref).
+
+Run in the build container only (needs /root/reference built by oracle/build_ref.sh); the
+fixtures it writes are data (inputs + expected outputs) and are committed.  The GPU box only
+ever reads the .npz files.
+"""
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import refbind as R
+
+G = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+os.makedirs(G, exist_ok=True)
+FREQ = 3.45e11
+FFJET = dict(fname="FFJET", ename="POLSYNCHPL", spin=0.998, standard=1, uout=0.01, mbh=3.4e9, mu0=0.906,
+             gridvals=(-40., 20., -20., 40.), ftscl=2.0, frscl=70.0, gmin=100., gmax=1e5, p1=3.5, p2=3.5)
+
+
+def leafs():
+    rng = np.random.default_rng(20261002)
+    xyzp = rng.uniform(1e-3, 8.0, size=(200, 4))
+    xyzp[:20, 0] = 0.0                      # complete integrals rf(0,m,1) etc.
+    out = dict(xyzp=xyzp,
+               rf=np.array([R.rf(*v[:3]) for v in xyzp]), rd=np.array([R.rd(*v[:3]) for v in xyzp]),
+               rc=np.array([R.rc(v[1], v[2]) for v in xyzp]), rcn=np.array([R.rc(v[1] + v[2], -v[2]) for v in xyzp]),
+               rj=np.array([R.rj(*v) for v in xyzp]), rjn=np.array([R.rj(v[0], v[1], v[2], -v[3]) for v in xyzp]))
+    um = np.stack([rng.uniform(-6, 6, 100), rng.uniform(-0.9, 0.999, 100)], 1)
+    um[:5, 1] = 0.0
+    out["um"] = um
+    out["sncndn"] = np.array([R.sncndn(u, m) for u, m in um])
+    np.savez_compressed(os.path.join(G, "leaf_special.npz"), **out)
+
+
+def coeffs():
+    rng = np.random.default_rng(7)
+    n = 300
+    nu = 10 ** rng.uniform(9, 15, n); nnth = 10 ** rng.uniform(-2, 6, n); b = 10 ** rng.uniform(-3, 3, n)
+    th = rng.uniform(0.05, np.pi - 0.05, n); p = rng.choice([2.5, 3.5, 5.5], n)
+    gmin = rng.choice([1.0, 10.0, 100.0], n).astype(float); gmin[gmin == 1.0] = 1.5
+    epl = R.polsynchpl(nu, nnth, b, th, p, gmin, 1e5)
+    dens = 10 ** rng.uniform(2, 8, n); t = 10 ** rng.uniform(8.5, 12, n)
+    eth = R.polsynchth(nu, dens, b, t, th)
+    np.savez_compressed(os.path.join(G, "coeffs.npz"), nu=nu, nnth=nnth, b=b, th=th, p=p, gmin=gmin, gmax=1e5,
+                        polsynchpl=epl, dens=dens, t=t, polsynchth=eth)
+
+
+def integrators():
+    # the closed-form cases of unit_tests_integration.py:39-150 evaluated by the Fortran integrate()
+    n = 600
+    x = np.linspace(3.0, 0.0, n)           # decreasing like g%lambda
+    cases = {}
+    def run(name, j, K):
+        tau = np.zeros(n)
+        tau[1:] = np.cumsum((x[1:] - x[:-1]) * 0.5 * (np.abs(K[1:, 0]) + np.abs(K[:-1, 0])))
+        tau = -tau
+        cases[name + "_j"] = j; cases[name + "_K"] = K; cases[name + "_tau"] = tau
+        cases[name + "_delo"] = R.integrate(1, x, j, K, tau)
+        cases[name + "_formal"] = R.integrate(2, x, j, K, tau)
+    one = np.ones(n)
+    z = np.zeros(n)
+    run("faraday_rot", np.stack([one, 0.7 * one, z, z], 1), np.stack([z + 1e-30, z, z, z, z, z, 10.0 * one], 1))
+    run("rot_conv", np.stack([one, 0.7 * one, z, z], 1), np.stack([z + 1e-30, z, z, z, 4.0 * one, z, 10.0 * one], 1))
+    run("full_rho", np.stack([one, 0.3 * one, 0.2 * one, 0.1 * one], 1),
+        np.stack([z + 1e-30, z, z, z, 4.0 * one, 2.0 * one, 10.0 * one], 1))
+    run("abs_IQ", np.stack([one, 0.7 * one, z, z], 1), np.stack([2.0 * one, 0.8 * one, z, z, z, z, z], 1))
+    s = np.sin(3 * x) ** 2
+    run("varying", np.stack([1 + s, 0.5 * s, 0.2 * one, -0.1 * s], 1),
+        np.stack([1.5 + s, 0.4 * s, 0.1 * one, 0.05 * one, 3.0 * s, one, 6.0 * one], 1))
+    run("thin", 1e-3 * np.stack([1 + s, 0.5 * s, 0.2 * one, -0.1 * s], 1),
+        1e-3 * np.stack([1.5 + s, 0.4 * s, 0.1 * one, 0.05 * one, 3.0 * s, one, 6.0 * one], 1))
+    np.savez_compressed(os.path.join(G, "integrators.npz"), x=x, **cases)
+
+
+def ffjet(nx, nup):
+    out = {}
+    for iname in ("formal", "delo"):
+        r = R.Ref(nn=(nx, nx, nup), iname=iname, **FFJET)
+        pix, npts, _ = r.trace(1, nx * nx, [FREQ], nthreads=8)
+        out["ivals_" + iname] = pix[0]
+        out["npts"] = npts
+    cam = r.camera()
+    for k in ("alpha", "beta", "q2", "l", "su", "sm", "uf", "tpr"):
+        out["cam_" + k] = cam[k]
+    out["cam_scal"] = np.array([cam[k] for k in ("u0", "uout", "offset", "mu0", "a", "kext", "next", "nup")], dtype=float)
+    # geodesic integers for every ray + full per-stage dumps for a few
+    tpm = np.zeros((nx * nx, nup + 64), dtype=np.int8); tpr = np.zeros_like(tpm); ncase = np.zeros(nx * nx, dtype=np.int8)
+    for i in range(1, nx * nx + 1):
+        g = r.geokerr_ray(i)
+        ncase[i - 1] = g["ncase"]
+        tpm[i - 1, :g["n"]] = g["tpm"]; tpr[i - 1, :g["n"]] = g["tpr"]
+    out["tpmi"] = tpm; out["tpri"] = tpr; out["ncase"] = ncase
+    np.savez_compressed(os.path.join(G, "ffjet_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ, **out)
+    rays = {}
+    pick = [1, nx // 2 * nx + nx // 2, nx // 2 * nx + nx // 2 + 1, nx * nx, nx * (nx // 3) + 2 * nx // 3, 7, nx * nx // 2 - 3]
+    cap = np.where(out["npts"] == nup)[0]
+    if len(cap):
+        pick += [int(cap[0]) + 1, int(cap[len(cap) // 2]) + 1]
+    r = R.Ref(nn=(nx, nx, nup), iname="formal", **FFJET)
+    for i in sorted(set(pick)):
+        d = r.ray_dump(i, FREQ)
+        g = r.geokerr_ray(i)
+        for k, v in d.items():
+            rays["ray%d_%s" % (i, k)] = np.asarray(v)
+        for k in ("u", "mu", "dt", "dphi", "lam"):
+            rays["ray%d_raw_%s" % (i, k)] = g[k]
+        rays["ray%d_ncase" % i] = np.array(g["ncase"])
+    rays["rays"] = np.array(sorted(set(pick)))
+    np.savez_compressed(os.path.join(G, "ffjet_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ, **rays)
+
+
+def reference_pickle():
+    g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
+    np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
+
+
+if __name__ == "__main__":
+    leafs(); coeffs(); integrators(); reference_pickle()
+    ffjet(100, 400)
+    ffjet(32, 100)
+    print("golden fixtures written to", os.path.abspath(G))
