@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the per-pixel path (BASELINE.json metric).
+
+A "step" = one pass of the hot path (set-up kernel + trace kernel) over one camera tile of
+synthetic-free, fully deterministic input: FFJET (BL09 M87 jet table shipped in grtrans_amd/data)
+POLSYNCHPL nvals=4 spin=0.998 nn=[1024,1024,400] nfreq=1, formal integrator -- the configuration
+the metric "ray-steps/sec + HBM GB/s" is quoted on.  Inputs (fluid table, coefficient tables) are
+resident in HBM before the timed region; outputs stay in HBM (16 B/ray D2H is outside).
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  Weak scaling: the camera is
+nn=[1024*N,1024,400] over the same field of view and rank r traces the contiguous pixel strip
+i1..i2 of 1024*1024 rays (the reference's own i1,i2 partition key); the only exchange is one
+gather of the fp32 tiles to rank 0 over xGMI after the timed kernels of each step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FREQ = 3.45e11
+BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lambda,I,Q,U,V) per ray-step
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(nx, ny, nup, budget_s=15.0):
+    """Reference Fortran (oracle/_ref) -- or the C++ port if that library is absent -- on a bounded
+    contiguous pixel sample around the image centre of the SAME camera, all host cores."""
+    cores = os.cpu_count() or 1
+    kw = dict(nn=(nx, ny, nup), iname="formal")
+    try:
+        from oracle import refbind
+        if not refbind.available():
+            raise RuntimeError("no _ref")
+        eng, kind = refbind.Ref(**kw), "reference"
+    except Exception:
+        from oracle import orabind
+        eng, kind = orabind.Oracle(**kw), "port"
+    centre = (nx // 2) * ny + 1
+    probe = max(cores * 8, 64)
+    _, npts, sec = eng.trace(centre, centre + probe - 1, [FREQ], nthreads=cores)
+    rate = max(float(np.abs(npts).sum()) / max(sec, 1e-6), 1.0)
+    nrays = int(min(max(budget_s * rate / (nup * 1.1), probe), 200000, nx * ny - centre))
+    _, npts, sec = eng.trace(centre, centre + nrays - 1, [FREQ], nthreads=cores)
+    steps = int(np.abs(npts).sum())
+    return {"value": steps / sec, "unit": "ray-steps/s", "cores": cores, "kind": kind,
+            "sample": "%d contiguous pixels from the image centre of the same %dx%dx%d FFJET camera, "
+                      "%d ray-steps in %.1f s, OpenMP schedule(static,1)" % (nrays, nx, ny, nup, steps, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nn", type=int, nargs=3, default=[1024, 1024, 400])
+    ap.add_argument("--iname", default="formal")
+    ap.add_argument("--no-steps-record", action="store_true", help="do not write the per-step SoA record")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from grtrans_amd import capi
+
+    nx, ny, nup = args.nn
+    nx_total = nx * world                      # weak scaling: camera widens with the rank count
+    dev = capi.Device(local_rank)
+    dev.load_ffjet()
+    dev.load_tables()
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (nx_total, ny, nup), 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    i1 = rank * nx * ny + 1
+    i2 = (rank + 1) * nx * ny
+    capi.record_steps(not args.no_steps_record)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        _, _, _, st = capi.trace_tile(cam, i1, i2, "FFJET", em, [FREQ], args.iname, resident=True)
+        return st
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    ray_steps = 0
+    ms_trace = 0.0
+    ms_setup = 0.0
+    for _ in range(args.steps):
+        st = one_step()
+        ray_steps += st.ray_steps
+        ms_trace += st.ms_trace
+        ms_setup += st.ms_setup
+    barrier()
+    dt = time.perf_counter() - t0
+    gather_ms = None
+    if dist is not None:
+        # assemble ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the fp32 tiles
+        import ctypes as C
+        p = C.c_void_p()
+        capi.check(capi.lib().grt_resident_pointers(C.byref(p), None), "grt_resident_pointers")
+        n = nx * ny * 4
+        buf = (C.c_float * n).from_address(p.value) if False else None  # device memory: wrap through torch below
+        tile = torch.empty(n, dtype=torch.float32, device="cuda")
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(tile.data_ptr()), p, C.c_size_t(n * 4), C.c_int(3))
+        outs = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        dist.gather(tile, outs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        tmax = torch.tensor([dt, float(ray_steps), ms_trace], dtype=torch.float64, device="cuda")
+        tsum = tmax.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        ray_steps_all = int(tsum[1].item())
+        ms_trace = float(tmax[2])
+    else:
+        ray_steps_all = ray_steps
+
+    if rank == 0:
+        value = ray_steps_all / dt
+        t_kernel = ms_trace / args.steps / 1e3                       # average launch duration, HIP events
+        achieved = BYTES_PER_STEP * (ray_steps / args.steps) / t_kernel / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ray-steps/sec", "value": value, "unit": "ray-steps/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "deterministic: BL09 FFJET table shipped with the reference (no RNG in the path)",
+            "config": {"workload": "FFJET POLSYNCHPL nvals=4 spin=0.998 mu0=0.906 nn=[%d,%d,%d] per GPU, nfreq=1 "
+                                   "(3.45e11 Hz), iname=%s, gridvals=[-40,20,-20,40], uout=0.01" % (nx, ny, nup, args.iname),
+                       "pixels_per_gpu": nx * ny, "ray_steps_per_step_per_gpu": ray_steps // args.steps,
+                       "parallelism": "pixel strips i1..i2 per GPU, 1 process/GPU, RCCL gather of fp32 tiles",
+                       "per_step_record_written": not args.no_steps_record,
+                       "gather_ms": gather_ms, "setup_kernel_ms": ms_setup / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "grt_trace_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "algorithmic 64 B per ray-step (SURVEY 8d) over the trace kernel's HIP-event time; "
+                                 "the kernel is fp64-VALU bound (~1e4 flop-equivalents per step), see DESIGN.md"},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, nup)
+        print(json.dumps(out))
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

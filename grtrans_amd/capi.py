@@ -1,0 +1,131 @@
+"""ctypes binding of the C ABI (include/grtrans_amd.h) in libgrtrans_amd.so.
+
+This is plumbing only: every number is produced by the gfx950 kernels behind the ABI.  Importing
+never falls back to a CPU implementation; a missing library or device raises."""
+import ctypes as C
+import os
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(PKG, "libgrtrans_amd.so")
+DATA = os.path.join(PKG, "data")
+
+FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13}       # fluid.f90:40-43
+EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8}    # emis.f90:11-18
+INTEG = {"lsoda": 0, "delo": 1, "formal": 2, "lsodasph": 3}          # rad_trans.f90:29-37
+
+
+class GrtCam(C.Structure):
+    _fields_ = [("a1", C.c_double), ("a2", C.c_double), ("b1", C.c_double), ("b2", C.c_double),
+                ("a", C.c_double), ("mu0", C.c_double), ("uout", C.c_double), ("u0", C.c_double),
+                ("offset", C.c_double), ("phi0", C.c_double),
+                ("standard", C.c_int32), ("nro", C.c_int32), ("nphi", C.c_int32), ("nup", C.c_int32),
+                ("usegeor", C.c_int32), ("phit", C.c_int32), ("mufill", C.c_int32), ("kext", C.c_int32),
+                ("next", C.c_int32), ("pad0", C.c_int32)]
+
+
+class GrtEmis(C.Structure):
+    _fields_ = [("mbh", C.c_double), ("nfac", C.c_double), ("bfac", C.c_double),
+                ("gmin", C.c_double), ("gmax", C.c_double), ("p1", C.c_double), ("muval", C.c_double),
+                ("type", C.c_int32), ("coefindx", C.c_int32 * 7)]
+
+
+class GrtStats(C.Structure):
+    _fields_ = [("ray_steps", C.c_int64), ("rays_live", C.c_int64), ("rays_dead", C.c_int64),
+                ("ms_setup", C.c_double), ("ms_trace", C.c_double), ("ms_total", C.c_double)]
+
+
+class GrtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise GrtError("libgrtrans_amd.so not built (run __graft_entry__.build()); there is no CPU fallback")
+        _lib = C.CDLL(LIB)
+        _lib.grt_version.restype = C.c_char_p
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GrtError("%s failed with code %d" % (what, rc))
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+class Device:
+    """One GPU: owns the fluid table + coefficient tables in HBM (grt_init .. grt_free)."""
+
+    def __init__(self, device=0):
+        check(lib().grt_init(C.c_int(device)), "grt_init")
+        self.device = device
+
+    def load_ffjet(self, path=None):
+        path = path or os.path.join(DATA, "m87bl09rfp10xi5a998fluidvars.bin")
+        check(lib().grt_load_ffjet_file(path.encode()), "grt_load_ffjet_file")
+
+    def load_tables(self, path=None):
+        path = path or os.path.join(DATA, "polsynchpl_tables.bin")
+        check(lib().grt_load_polsynchpl_tables_file(path.encode()), "grt_load_polsynchpl_tables_file")
+
+    def close(self):
+        lib().grt_free()
+
+
+def make_camera(standard, gridvals, nn, spin, mu0, uout, phi0=-0.5):
+    cam = GrtCam()
+    gv = (C.c_double * 4)(*[float(v) for v in gridvals])
+    n3 = (C.c_int * 3)(*[int(v) for v in nn])
+    check(lib().grt_make_camera(C.byref(cam), C.c_int(standard), gv, n3, C.c_double(spin), C.c_double(mu0),
+                                C.c_double(uout), C.c_double(phi0)), "grt_make_camera")
+    return cam
+
+
+def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7):
+    em = GrtEmis()
+    em.mbh, em.nfac, em.bfac = mbh, nfac, bfac
+    em.gmin, em.gmax, em.p1 = _f32(gmin), _f32(gmax), _f32(p1)   # REAL(4) in emis_params (emis.f90:32-39)
+    em.muval = muval
+    em.type = EMIS[ename]
+    for i in range(7):
+        em.coefindx[i] = int(coefindx[i])
+    return em
+
+
+def trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=4, nextra=0, resident=False, want_status=True):
+    freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+    nf, n = len(freqs), i2 - i1 + 1
+    st = GrtStats()
+    fp = freqs.ctypes.data_as(C.POINTER(C.c_double))
+    if resident:
+        check(lib().grt_trace_tile_resident(C.byref(cam), C.c_int64(i1), C.c_int64(i2), C.c_int(FLUID[fname]),
+                                            C.byref(em), C.c_int(nf), fp, C.c_int(INTEG[iname]), C.c_int(nvals),
+                                            C.c_int(nextra), C.byref(st)), "grt_trace_tile_resident")
+        return None, None, None, st
+    pix = np.zeros((nf, n, nvals + nextra), dtype=np.float32)
+    loc = np.zeros((n, 2), dtype=np.float32)
+    status = np.zeros(n, dtype=np.int32)
+    check(lib().grt_trace_tile(C.byref(cam), C.c_int64(i1), C.c_int64(i2), C.c_int(FLUID[fname]), C.byref(em),
+                               C.c_int(nf), fp, C.c_int(INTEG[iname]), C.c_int(nvals), C.c_int(nextra),
+                               pix.ctypes.data_as(C.POINTER(C.c_float)), loc.ctypes.data_as(C.POINTER(C.c_float)),
+                               status.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st)), "grt_trace_tile")
+    return pix, loc, status, st
+
+
+def record_steps(enable):
+    check(lib().grt_set_record_steps(C.c_int(1 if enable else 0)), "grt_set_record_steps")
+
+
+def download_steps(ray0, nrays, maxpts):
+    out = np.zeros((8, nrays, maxpts))
+    check(lib().grt_download_steps(C.c_int64(ray0), C.c_int64(nrays), C.c_int(maxpts),
+                                   out.ctypes.data_as(C.POINTER(C.c_double))), "grt_download_steps")
+    return out

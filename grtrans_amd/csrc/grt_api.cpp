@@ -1,0 +1,325 @@
+// grtrans_amd/csrc/grt_api.cpp -- host side of the C ABI declared in include/grtrans_amd.h.
+// Owns the device buffers (fluid table, coefficient tables, per-ray records, outputs), the HIP
+// stream and the events that time the two kernels.  No CPU compute path exists here: if the HIP
+// device or the code object is missing every entry point returns an error.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "grt_types.h"
+
+extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
+                                       int *ray_npts, int *live, int *counters);
+extern "C" hipError_t grt_launch_trace(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays, const int *live,
+                                       int nlive, const GrtFFJet *fj, const GrtTables *tb, const GrtEmis *em, int nfreq,
+                                       const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status,
+                                       long long i1, double *steps, long long steps_ray_stride,
+                                       long long steps_field_stride, unsigned long long *step_counter);
+
+namespace {
+
+struct Ctx {
+  bool init = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  // fluid + tables
+  float *d_cells = nullptr, *d_uniq = nullptr;
+  GrtFFJet ffjet{};
+  bool have_ffjet = false;
+  double *d_tables = nullptr;
+  GrtTables tables{};
+  bool have_tables = false;
+  // work buffers (grown on demand)
+  size_t cap_rays = 0, cap_npts = 0, cap_live = 0, cap_pix = 0, cap_freq = 0, cap_steps = 0;
+  GrtRay *d_rays = nullptr;
+  int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
+  float *d_pixvals = nullptr;
+  double *d_freqs = nullptr, *d_steps = nullptr;
+  unsigned long long *d_stepcount = nullptr;
+  int record_steps = 0;
+  long long steps_rays = 0, steps_maxpts = 0;
+};
+Ctx C;
+
+#define HIPCHK(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      fprintf(stderr, "grtrans_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                        \
+      return (int)e_;                                                                     \
+    }                                                                                     \
+  } while (0)
+
+template <class T>
+int grow(T *&p, size_t &cap, size_t need) {
+  if (need <= cap && p) return 0;
+  if (p) HIPCHK(hipFree(p));
+  p = nullptr;
+  HIPCHK(hipMalloc((void **)&p, need * sizeof(T)));
+  cap = need;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *grt_version(void) { return "grtrans_amd 0.1 (gfx950)"; }
+
+int grt_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GRT_E_NODEVICE;
+  if (device < 0 || device >= n) return GRT_E_BADARG;
+  HIPCHK(hipSetDevice(device));
+  if (C.init) return 0;
+  C.device = device;
+  HIPCHK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+  for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
+  HIPCHK(hipMalloc((void **)&C.d_counters, 4 * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&C.d_stepcount, sizeof(unsigned long long)));
+  C.init = true;
+  return 0;
+}
+
+int grt_free(void) {
+  if (!C.init) return 0;
+  hipStreamSynchronize(C.stream);
+  void *ptrs[] = {C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
+                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  for (int i = 0; i < 3; ++i)
+    if (C.ev[i]) hipEventDestroy(C.ev[i]);
+  if (C.stream) hipStreamDestroy(C.stream);
+  C = Ctx();
+  return 0;
+}
+
+int grt_upload_ffjet(int nx, const float *rc, const float *thc, const float *rho, const float *p, const float *b0,
+                     const float *br, const float *bth, const float *bph, const float *u0, const float *vr,
+                     const float *vth, const float *vph) {
+  if (!C.init) return GRT_E_NOTINIT;
+  int nx1 = (int)std::sqrt((float)nx);   // fluid_model_ffjet.f90:61
+  if (nx1 * nx1 != nx || nx1 < 2) return GRT_E_BADARG;
+  std::vector<float> cells((size_t)nx * 12, 0.f), uniq((size_t)3 * nx1);
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vr, vth, vph};
+  for (int i = 0; i < nx; ++i)
+    for (int k = 0; k < 10; ++k) cells[(size_t)i * 12 + k] = src[k] ? src[k][i] : 0.f;
+  for (int i = 0; i < nx1; ++i) {
+    uniq[i] = rc[i];                               // uniqr  (fluid_model_ffjet.f90:66)
+    uniq[nx1 + i] = thc[(size_t)i * nx1];          // uniqth (:68)
+    uniq[2 * nx1 + i] = std::log(rc[i]);           // uniqx1 (:71), REAL(4) log
+  }
+  if (C.d_cells) { hipFree(C.d_cells); C.d_cells = nullptr; }
+  if (C.d_uniq) { hipFree(C.d_uniq); C.d_uniq = nullptr; }
+  HIPCHK(hipMalloc((void **)&C.d_cells, cells.size() * sizeof(float)));
+  HIPCHK(hipMalloc((void **)&C.d_uniq, uniq.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(C.d_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(C.d_uniq, uniq.data(), uniq.size() * sizeof(float), hipMemcpyHostToDevice));
+  C.ffjet.cells = C.d_cells;
+  C.ffjet.uniqr = C.d_uniq;
+  C.ffjet.uniqth = C.d_uniq + nx1;
+  C.ffjet.uniqx1 = C.d_uniq + 2 * nx1;
+  C.ffjet.nx1 = nx1;
+  C.have_ffjet = true;
+  return 0;
+}
+
+int grt_load_ffjet_file(const char *path) {
+  if (!C.init) return GRT_E_NOTINIT;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return GRT_E_IO;
+  auto rec = [&](std::vector<char> &buf) -> bool {   // Fortran sequential record: len, payload, len
+    int32_t n1 = 0, n2 = 0;
+    if (std::fread(&n1, 4, 1, f) != 1 || n1 < 0) return false;
+    buf.resize((size_t)n1);
+    if (n1 && std::fread(buf.data(), 1, (size_t)n1, f) != (size_t)n1) return false;
+    return std::fread(&n2, 4, 1, f) == 1 && n1 == n2;
+  };
+  std::vector<char> h, r1, r2, r3;
+  bool ok = rec(h) && h.size() >= 8 && rec(r1) && rec(r2) && rec(r3);
+  std::fclose(f);
+  if (!ok) return GRT_E_IO;
+  int32_t nx;
+  std::memcpy(&nx, h.data() + 4, 4);
+  if (nx <= 0 || r1.size() < (size_t)3 * nx * 4 || r2.size() < (size_t)5 * nx * 4 || r3.size() < (size_t)4 * nx * 4)
+    return GRT_E_IO;
+  auto arr = [&](std::vector<char> &b, int k) { return reinterpret_cast<const float *>(b.data()) + (size_t)k * nx; };
+  // record 2: rc, thc, rho; record 3: b(dummy), b0, br, bth, bph; record 4: u0, vr, vth, vph.
+  // p_arr is never read by the reference (fluid_model_ffjet.f90:203-206): zeros here.
+  return grt_upload_ffjet(nx, arr(r1, 0), arr(r1, 1), arr(r1, 2), nullptr, arr(r2, 1), arr(r2, 2), arr(r2, 3),
+                          arr(r2, 4), arr(r3, 0), arr(r3, 1), arr(r3, 2), arr(r3, 3));
+}
+
+int grt_upload_polsynchpl_tables(const double *t) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!C.d_tables) HIPCHK(hipMalloc((void **)&C.d_tables, 2020 * sizeof(double)));
+  HIPCHK(hipMemcpy(C.d_tables, t, 2020 * sizeof(double), hipMemcpyHostToDevice));
+  double *d = C.d_tables;
+  C.tables.gx = d; C.tables.gy = d + 181; C.tables.xv = d + 724; C.tables.ya = d + 805;
+  C.tables.yp = d + 1048; C.tables.yv = d + 1291; C.tables.yap = d + 1534; C.tables.yav = d + 1777;
+  C.have_tables = true;
+  return 0;
+}
+
+int grt_load_polsynchpl_tables_file(const char *path) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return GRT_E_IO;
+  std::vector<double> t(2020);
+  size_t n = std::fread(t.data(), 8, 2020, f);
+  std::fclose(f);
+  if (n != 2020) return GRT_E_IO;
+  return grt_upload_polsynchpl_tables(t.data());
+}
+
+int grt_make_camera(grt_camera *cam, int standard, const double gridvals[4], const int nn[3], double spin,
+                    double mu0, double uout, double phi0) {
+  if (!cam) return GRT_E_BADARG;
+  std::memset(cam, 0, sizeof(*cam));
+  cam->a1 = gridvals[0]; cam->a2 = gridvals[1]; cam->b1 = gridvals[2]; cam->b2 = gridvals[3];
+  cam->standard = standard; cam->nro = nn[0]; cam->nphi = nn[1]; cam->nup = nn[2];
+  cam->mu0 = mu0; cam->uout = uout;
+  cam->offset = 0.5;                                                       // geokerr_wrapper.f:45
+  double ma = std::fmax(cam->a1 * cam->a1, cam->a2 * cam->a2), mb = std::fmax(cam->b1 * cam->b1, cam->b2 * cam->b2);
+  double abmax = ma * ma + mb * mb;                                        // :155
+  cam->u0 = std::fmin(1.e-4, 1.0 / (100.0 * abmax));                       // :163
+  if (cam->nup == 1) cam->offset = 1.e-8;                                  // :167
+  if (std::fabs(spin) < 1.e-5) spin = 0.0;                                 // :319
+  cam->a = spin;
+  cam->phi0 = (double)std::acos(-1.f) * phi0;                              // geodesics.f90:218
+  cam->phit = 1;
+  if (standard == 1) {                                                     // geodesics.f90:77-92
+    cam->usegeor = 0;
+    if (cam->nup > 1) {
+      cam->mufill = 1;
+      cam->kext = (int)std::ceil(3.0 * cam->nup / 400.0);
+      cam->next = (int)std::ceil(60.0 * cam->nup / 400.0);
+    }
+  } else {
+    cam->usegeor = 1;                                                      // :93-99
+    if (cam->nup == 1) cam->offset = 0.0;                                  // geokerr_wrapper.f:225
+  }
+  return 0;
+}
+
+int grt_set_record_steps(int enable) {
+  C.record_steps = enable ? 1 : 0;
+  return 0;
+}
+
+static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
+                        const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!cam || !em || !freqs || nfreq < 1 || nfreq > 32 || i2 < i1 || i1 < 1) return GRT_E_BADARG;
+  if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
+  if (fluid_model != GRT_FLUID_FFJET) return GRT_E_UNSUPPORTED;
+  if (em->type != GRT_EMIS_POLSYNCHPL) return GRT_E_UNSUPPORTED;
+  if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
+  if (cam->standard != 1 || cam->nup < 2 || nvals != 4 || nextra != 0) return GRT_E_UNSUPPORTED;
+  if (!C.have_ffjet) return GRT_E_NOFLUID;
+  if (!C.have_tables) return GRT_E_NOTABLES;
+  HIPCHK(hipSetDevice(C.device));
+  const int nrays = (int)(i2 - i1 + 1);
+  int rc;
+  if ((rc = grow(C.d_rays, C.cap_rays, (size_t)nrays))) return rc;
+  if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
+  if ((rc = grow(C.d_live, C.cap_live, (size_t)nrays))) return rc;
+  if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
+  if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)nfreq))) return rc;
+  const long long maxpts = cam->nup + cam->next;
+  double *steps = nullptr;
+  if (C.record_steps) {
+    if ((rc = grow(C.d_steps, C.cap_steps, (size_t)8 * nrays * maxpts))) return rc;
+    steps = C.d_steps;
+    C.steps_rays = nrays; C.steps_maxpts = maxpts;
+  }
+  HIPCHK(hipMemcpyAsync(C.d_freqs, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
+  HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
+  HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
+  HIPCHK(hipMemsetAsync(C.d_pixvals, 0, (size_t)nrays * nfreq * (nvals + nextra) * sizeof(float), C.stream));
+  HIPCHK(hipEventRecord(C.ev[0], C.stream));
+  HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1, nrays, C.d_rays, C.d_npts, C.d_live, C.d_counters));
+  HIPCHK(hipEventRecord(C.ev[1], C.stream));
+  int nlive = 0;
+  HIPCHK(hipMemcpyAsync(&nlive, C.d_counters, sizeof(int), hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  HIPCHK(hipEventRecord(C.ev[1], C.stream));
+  HIPCHK(grt_launch_trace(C.stream, iflag, cam, C.d_rays, C.d_live, nlive, &C.ffjet, &C.tables, em, nfreq, C.d_freqs,
+                          C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, steps, maxpts,
+                          (long long)nrays * maxpts, C.d_stepcount));
+  HIPCHK(hipEventRecord(C.ev[2], C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  if (st) {
+    unsigned long long steps_done = 0;
+    HIPCHK(hipMemcpy(&steps_done, C.d_stepcount, sizeof(steps_done), hipMemcpyDeviceToHost));
+    float ms_trace = 0;
+    HIPCHK(hipEventElapsedTime(&ms_trace, C.ev[1], C.ev[2]));
+    st->ray_steps = (int64_t)steps_done;
+    st->rays_live = nlive;
+    st->rays_dead = nrays - nlive;
+    st->ms_trace = ms_trace;
+  }
+  return 0;
+}
+
+int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
+                            int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
+  hipEvent_t t0, t1;
+  if (!C.init) return GRT_E_NOTINIT;
+  HIPCHK(hipEventCreate(&t0));
+  HIPCHK(hipEventCreate(&t1));
+  HIPCHK(hipEventRecord(t0, C.stream));
+  int rc = trace_common(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
+  if (rc == 0) {
+    HIPCHK(hipEventRecord(t1, C.stream));
+    HIPCHK(hipEventSynchronize(t1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, t0, t1));
+    if (st) { st->ms_total = ms; st->ms_setup = ms - st->ms_trace; }
+  }
+  hipEventDestroy(t0);
+  hipEventDestroy(t1);
+  return rc;
+}
+
+int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (d_pixvals) *d_pixvals = C.d_pixvals;
+  if (d_ray_status) *d_ray_status = C.d_npts;
+  return 0;
+}
+
+int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
+                   const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
+                   int32_t *ray_status, grt_stats *st) {
+  int rc = grt_trace_tile_resident(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
+  if (rc) return rc;
+  const size_t nrays = (size_t)(i2 - i1 + 1);
+  if (pixvals) HIPCHK(hipMemcpy(pixvals, C.d_pixvals, nrays * nfreq * (nvals + nextra) * sizeof(float), hipMemcpyDeviceToHost));
+  if (ray_status) HIPCHK(hipMemcpy(ray_status, C.d_npts, nrays * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (pixloc) {   // camera.f90:36: pixloc(:,i) = real(alpha), real(beta); pure host arithmetic (geokerr_wrapper.f:258-262)
+    for (size_t t = 0; t < nrays; ++t) {
+      long long ii = (long long)i1 + (long long)t;
+      int i = (int)((double)(ii - 1) / (double)cam->nphi) + 1;
+      int j = (int)((ii - 1) % cam->nphi) + 1;
+      pixloc[2 * t] = (float)(cam->a1 + (cam->a2 - cam->a1) * ((double)(i - 1) + 0.5) / (double)cam->nro);
+      pixloc[2 * t + 1] = (float)(cam->b1 + (cam->b2 - cam->b1) * ((double)(j - 1) + 0.5) / (double)cam->nphi);
+    }
+  }
+  return 0;
+}
+
+int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
+  if (!C.init || !C.d_steps) return GRT_E_NOTINIT;
+  if (ray0 < 0 || ray0 + nrays > C.steps_rays || maxpts != C.steps_maxpts) return GRT_E_BADARG;
+  for (int f = 0; f < 8; ++f)
+    HIPCHK(hipMemcpy(out + (size_t)f * nrays * maxpts, C.d_steps + ((size_t)f * C.steps_rays + ray0) * maxpts,
+                     (size_t)nrays * maxpts * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,573 @@
+// grtrans_amd/csrc/grt_dev_phys.hpp
+// gfx950 device layer for everything between a geodesic point and its transfer coefficients:
+//   BL metric / photon momentum / comoving tetrad + parallel-transported polarisation basis
+//       (kerr.f90:255-290, 360-400, 476-548, 586-730; class_four_vector.f90:115-135)
+//   FFJET sampler on a cell-interleaved copy of the BL09 table (fluid_model_ffjet.f90:42-171)
+//   power-law and thermal polarised synchrotron coefficients (polsynchemis.f90:62-92, 527-863,
+//       1014-1032; bessel.f90)
+//   per-step transfer operators: Landi Degl'Innocenti matricant (radtrans_integrate.f90:615-683)
+//       and the DELO step (:685-842), both returned as affine maps I -> A I + b so that the
+//       64 lanes of a wave can compose them with a prefix scan.
+#pragma once
+#include "grt_dev_geo.hpp"
+
+namespace grtd {
+
+struct Metric { double g[10]; };   // slots 1,4,5,8,10 (0-based 0,3,4,7,9) non-zero
+
+GRT_HD Metric blmetric_cov(double r, double th, double a) {
+  Metric m;
+  for (int i = 0; i < 10; ++i) m.g[i] = 0.0;
+  double cth = cos(th), sth = sin(th);
+  double delta = r * r - 2.0 * r + a * a;
+  double rho2 = r * r + a * a * cth * cth;
+  double sigma = sq(r * r + a * a) - a * a * delta * sth * sth;
+  m.g[0] = -(delta - a * a * sth * sth) / rho2;
+  m.g[3] = -2.0 * a * r * sth * sth / rho2;
+  m.g[4] = rho2 / delta;
+  m.g[7] = rho2;
+  m.g[9] = sigma / rho2 * sth * sth;
+  return m;
+}
+
+// single-precision metric, promoted to double slots (blmetric_cov_real + assign_metric_real)
+GRT_HD Metric blmetric_cov_real(float r, float th, float a) {
+  Metric m;
+  for (int i = 0; i < 10; ++i) m.g[i] = 0.0;
+  float cth = cos(th), sth = sin(th);
+  float delta = r * r - 2.f * r + a * a;
+  float rho2 = r * r + a * a * cth * cth;
+  float t = r * r + a * a;
+  float sigma = t * t - a * a * delta * sth * sth;
+  m.g[0] = (double)(-(delta - a * a * sth * sth) / rho2);
+  m.g[3] = (double)(-2.f * a * r * sth * sth / rho2);
+  m.g[4] = (double)(rho2 / delta);
+  m.g[7] = (double)rho2;
+  m.g[9] = (double)(sigma / rho2 * sth * sth);
+  return m;
+}
+
+// a*b with a's metric: lower(a) . b   (class_four_vector.f90:115-135)
+GRT_HD double dot4(const double *a, const Metric &m, const double *b) {
+  const double *g = m.g;
+  double d0 = g[0] * a[0] + g[1] * a[1] + g[2] * a[2] + g[3] * a[3];
+  double d1 = g[1] * a[0] + g[4] * a[1] + g[5] * a[2] + g[6] * a[3];
+  double d2 = g[2] * a[0] + g[5] * a[1] + g[7] * a[2] + g[8] * a[3];
+  double d3 = g[3] * a[0] + g[6] * a[1] + g[8] * a[2] + g[9] * a[3];
+  return d0 * b[0] + d1 * b[1] + d2 * b[2] + d3 * b[3];   // dot_product: sequential sum
+}
+
+// kerr.f90:255 with rcomp and thcomp present
+GRT_HD void calc_nullp(double q2, double l, double a, double r, double mu, double su, double smu, double *k) {
+  double u = 1.0 / r;
+  double rho2 = r * r + a * a * mu * mu;
+  double delta = r * r - 2.0 * r + a * a;
+  double Mfunc = q2 + (a * a - q2 - l * l) * mu * mu - a * a * mu * mu * mu * mu;
+  if (!(Mfunc > 0.0)) Mfunc = 0.0;
+  double pmu = 1.0 / rho2 * smu * sqrt(Mfunc / (1.0 - mu * mu));
+  double Ufunc = 1.0 + (a * a - q2 - l * l) * u * u + 2.0 * (sq(a - l) + q2) * u * u * u - a * a * q2 * u * u * u * u;
+  if (!(Ufunc > 0.0)) Ufunc = 0.0;
+  double Rfunc = r * r * sqrt(Ufunc);
+  double pu = su * Rfunc / rho2;
+  double pt = (-a * (a * (1.0 - mu * mu) - l) + (r * r + a * a) / delta * (r * r + a * a - a * l)) / rho2;
+  double pphi = (-a + l / (1.0 - mu * mu) + a / delta * (r * r + a * a - a * l)) / rho2;
+  k[0] = pt; k[1] = pu; k[2] = pmu; k[3] = pphi;
+}
+
+// kerr.f90:476  lnrf_frame_inv_real (single precision)
+GRT_HD void lnrf_frame_inv_real(float vr, float vt, float omega, float r, float a, float th, float &vrl,
+                                float &vtl, float &vpl) {
+  float mu = cos(th);
+  float D = r * r - 2.f * r + a * a;
+  float t = r * r + a * a;
+  float AR = t * t - a * a * D * (1.f - mu * mu);
+  float RHO = r * r + a * a * mu * mu;
+  float ENU = sqrt(D * RHO / AR);
+  float EMU1 = sqrt(RHO / D);
+  float EMU2 = sqrt(RHO);
+  float EPSI = sqrt(1.f - mu * mu) * sqrt(AR / RHO);
+  float OM = 2.f * a * r / AR;
+  vrl = ENU / EMU1 * vr;
+  vtl = ENU / EMU2 * vt;
+  vpl = ENU / EPSI * omega + OM;
+  if (!(D > 0.f)) { vrl = 0.f; vtl = 0.f; vpl = 0.f; }
+}
+
+// kerr.f90:502
+GRT_HD void transport_perpk(const double *k, double r, double th, double a, const Metric &m, double Kap1,
+                            double Kap2, double &f1, double &f2, double &f3) {
+  double g03 = m.g[3], g11 = m.g[4], g22 = m.g[7], g33 = m.g[9];
+  double cth = cos(th), sth = sin(th);
+  double k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+  double gam1 = a * cth * k0 - a * a * cth * sth * sth * k3;
+  double gam2 = r * (r * r + a * a) * sth * k3 - a * r * sth * k0;
+  double gam3 = a * a * cth * sth * sth * k1 - r * (r * r + a * a) * sth * k2;
+  double del1 = r * k0 - r * a * sth * sth * k3;
+  double del2 = -a * cth * sth * (r * r + a * a) * k3 + a * a * sth * cth * k0;
+  double del3 = r * a * sth * sth * k1 + a * cth * sth * (r * r + a * a) * k2;
+  double denom = (gam2 * del1 - gam1 * del2) * (g33 * k3 + g03 * k0) + (gam3 * del2 - gam2 * del3) * g11 * k1 -
+                 (gam3 * del1 - gam1 * del3) * g22 * k2;
+  f1 = (gam2 * Kap1 - del2 * Kap2) * (g33 * k3 + g03 * k0) - g22 * k2 * (gam3 * Kap1 - del3 * Kap2);
+  f2 = (del1 * Kap2 - gam1 * Kap1) * (g33 * k3 + g03 * k0) + g11 * k1 * (gam3 * Kap1 - del3 * Kap2);
+  f3 = g22 * k2 * (gam1 * Kap1 - del1 * Kap2) - g11 * k1 * (gam2 * Kap1 - del2 * Kap2);
+  if (fabs(denom) > 0.0) { f1 /= denom; f2 /= denom; f3 /= denom; }
+}
+
+// kerr.f90:586.  u,b,k: contravariant BL components (t,r,th,phi).
+GRT_HD void comoving_ortho(double r, double th, double a, double alpha, double beta, double mus, const double *u,
+                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang,
+                           double &g, double &cosne) {
+  Metric m = blmetric_cov(r, th, a);
+  double gtt = m.g[0], gtp = m.g[3], grr = m.g[4], gmm = m.g[7], gpp = m.g[9];
+  double ut = u[0], ur = u[1], um = u[2], up = u[3];
+  double utc = gtt * ut + gtp * up, upc = gpp * up + gtp * ut, urc = grr * ur, umc = um * gmm;
+  double Kap1 = alpha + a * sqrt(1.0 - mus * mus);
+  double Kap2 = -beta;
+  double al1, al2, al3;
+  if (Kap1 != 0.0 || Kap2 != 0.0) {
+    transport_perpk(k, r, th, a, m, Kap1, Kap2, al1, al2, al3);
+  } else {
+    al1 = 0.0; al2 = 0.0; al3 = 1.0 / sqrt(m.g[9]);
+  }
+  double aa[4] = {0.0, al1, al2, al3};
+  double delta = r * r + a * a - 2.0 * r;
+  double nr2 = -grr * (utc * ut + upc * up) * (1.0 + umc * um);
+  double nm2 = gmm * (1.0 + umc * um);
+  double np2 = -(utc * ut + upc * up) * delta * sin(th) * sin(th);
+  double ekt[4] = {-1.0 * u[0], -1.0 * u[1], -1.0 * u[2], -1.0 * u[3]};
+  double ekr[4] = {(urc * ut) / sqrt(nr2), -(utc * ut + upc * up) / sqrt(nr2), 0.0, (urc * up) / sqrt(nr2)};
+  double ekm[4] = {(umc * ut) / sqrt(nm2), (umc * ur) / sqrt(nm2), (1 + umc * um) / sqrt(nm2),
+                   (umc * up) / sqrt(nm2)};
+  double ekp[4] = {upc / sqrt(np2), 0.0, 0.0, -utc / sqrt(np2)};
+  double bhatr = dot4(ekr, m, b), bhatm = dot4(ekm, m, b), bhatp = dot4(ekp, m, b);
+  double khatt = dot4(ekt, m, k), khatr = dot4(ekr, m, k), khatm = dot4(ekm, m, k), khatp = dot4(ekp, m, k);
+  double ahatt = dot4(ekt, m, aa), ahatr = dot4(ekr, m, aa), ahatm = dot4(ekm, m, aa), ahatp = dot4(ekp, m, aa);
+  double bdotb = dot4(b, m, b);
+  double aahat1 = ahatr - khatr * ahatt / khatt;
+  double aahat2 = ahatm - khatm * ahatt / khatt;
+  double aahat3 = ahatp - khatp * ahatt / khatt;
+  double knorm = khatr * khatr + khatm * khatm + khatp * khatp;
+  double bb1 = -(aahat2 * khatp - aahat3 * khatm) / sqrt(knorm);
+  double bb2 = -(aahat3 * khatr - aahat1 * khatp) / sqrt(knorm);
+  double bb3 = -(aahat1 * khatm - aahat2 * khatr) / sqrt(knorm);
+  double bdotk = bhatr * khatr + bhatm * khatm + bhatp * khatp;
+  double angnorm;
+  if (bdotb > 0.0) {
+    double aadotbp = bhatr * aahat1 + bhatm * aahat2 + bhatp * aahat3;
+    double bpdotbb = bhatr * bb1 + bhatm * bb2 + bhatp * bb3;
+    s2xi = -2.0 * aadotbp * bpdotbb / (aadotbp * aadotbp + bpdotbb * bpdotbb);
+    c2xi = (bpdotbb * bpdotbb - aadotbp * aadotbp) / (aadotbp * aadotbp + bpdotbb * bpdotbb);
+    angnorm = bdotk / sqrt(knorm) / sqrt(bdotb);
+  } else {
+    s2xi = 0.0; c2xi = 1.0; angnorm = 0.5;
+  }
+  const double angmin = -0.99, angmax = 0.99;
+  double t = (angnorm <= angmax) ? angnorm : angmax;
+  t = (angnorm >= angmin) ? t : angmin;
+  ang = acos(t);
+  g = 1.0 / khatt;
+  cosne = g * sqrt(beta * beta + mus * mus * (alpha * alpha - a * a)) / r;
+}
+
+// phys_constants.f90
+#define PH_h 6.626e-27
+#define PH_k 1.38e-16
+#define PH_c 2.99792458e10
+#define PH_e 4.8032e-10
+#define PH_G 6.67e-8
+#define PH_m 9.10938188e-28
+#define PH_msun 1.998e33
+#define PH_pi 3.141592653589793
+#define PH_c2 (PH_c * PH_c)
+
+struct FluidPoint {
+  float rho = 0, p = 0, bmag = 0;
+  double u[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+};
+
+GRT_HD float bilin(const float *v, float xd, float yd) {   // interpolate.f90:171
+  float w1 = v[0] * (1.f - yd) + v[1] * yd;
+  float w2 = v[2] * (1.f - yd) + v[3] * yd;
+  return w1 * (1.f - xd) + w2 * xd;
+}
+
+GRT_HD void find_inds_gxp(double xx, double p, const double *xv, int nx, int &ix, int &iy) {
+  ix = (int)((xx - xv[0]) / (xv[nx - 1] - xv[0]) * (nx));
+  ix = (ix < nx - 1) ? ((ix > 1) ? ix : 1) : (nx - 1);
+  iy = (p < 5.0) ? ((p > 3.2) ? 1 : 0) : 2;
+}
+
+GRT_HD double interp_gxp(double xx, int ix, int iy, const double *xv, int nx, const double *yv) {
+  int indx = iy * nx + ix;            // 1-based into yv
+  double yix = yv[indx - 1], yix1 = yv[indx], xix1 = xv[ix], xix = xv[ix - 1];
+  double slope = (yix1 - yix) / (xix1 - xix);
+  return exp(yix + slope * (xx - xix));
+}
+
+// polsynchemis.f90:527  -> e[11] = jI,jQ,jU,jV, aI,aQ,aU,aV, rhoQ,rhoU,rhoV
+GRT_HD void polsynchpl(const GrtTables &T, double nu, double nnth, double B, double th, double p, double gmin,
+                       double gmax, double *e) {
+  const double nufloor = 1e-10, thsafe = 1e-10;
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
+  double tanth = tan(th) + fsign(1.0, cos(th)) * thsafe;
+  double sinth = sin(th) + thsafe;
+  double nubperp = ec * B / m / c / 2.0 / pi * sinth + nufloor;
+  double nucmin = 3.0 / 2.0 * nubperp * (gmin * gmin), nucmax = 3.0 / 2.0 * nubperp * (gmax * gmax);
+  double omega0 = nubperp * 2.0 * pi, omega = nu * 2.0 * pi;
+  double xmin = nu / nucmin, xmax = nu / nucmax;
+  double A = (p - 1.0) * nnth / (pow(gmin, 1.0 - p) - pow(gmax, 1.0 - p));
+  // six G-integrals, each a difference of two log-log table lookups (the logs are shared)
+  const double lxmax = log(xmax), lxmin = log(xmin);
+  int ix1, ix2, iy1, iy2;
+  find_inds_gxp(lxmax, p, T.gx, 181, ix2, iy2);
+  find_inds_gxp(lxmin, p, T.gx, 181, ix1, iy1);
+  double gxfac = interp_gxp(lxmax, ix2, iy2, T.gx, 181, T.gy) - interp_gxp(lxmin, ix1, iy1, T.gx, 181, T.gy);
+  find_inds_gxp(lxmax, p, T.xv, 81, ix2, iy2);
+  find_inds_gxp(lxmin, p, T.xv, 81, ix1, iy1);
+  double gafac = interp_gxp(lxmax, ix2, iy2, T.xv, 81, T.ya) - interp_gxp(lxmin, ix1, iy1, T.xv, 81, T.ya);
+  double gpfac = interp_gxp(lxmax, ix2, iy2, T.xv, 81, T.yp) - interp_gxp(lxmin, ix1, iy1, T.xv, 81, T.yp);
+  double gapfac = interp_gxp(lxmax, ix2, iy2, T.xv, 81, T.yap) - interp_gxp(lxmin, ix1, iy1, T.xv, 81, T.yap);
+  double gvfac = interp_gxp(lxmax, ix2, iy2, T.xv, 81, T.yv) - interp_gxp(lxmin, ix1, iy1, T.xv, 81, T.yv);
+  double gavfac = interp_gxp(lxmax, ix2, iy2, T.xv, 81, T.yav) - interp_gxp(lxmin, ix1, iy1, T.xv, 81, T.yav);
+  double jfac = A * ec * ec / c * sqrt(3.0) / 4.0 * pow(3.0 * nubperp / 2.0 / nu, (p - 1.0) / 2.0) * nubperp;
+  double ji = jfac * gxfac;
+  double jq = jfac * gpfac;
+  double jv = jfac * 4.0 / 3.0 / tanth * sqrt(3.0 * nubperp / 2.0 / nu) * gvfac;
+  double alpha = (p - 1) / 2.0;
+  double kperp = A * ec * ec / m / c / nubperp;
+  double nui = gmin * gmin * nubperp;
+  double kstaralphaq = 1.0;
+  double kstaralphav = 2.0 * (alpha + 3.0 / 2.0) / (alpha + 1);
+  double kstarq = kstaralphaq * kperp * pow(nubperp / nu, 3.0) * pow(gmin, -2.0 * alpha + 1.0) *
+                  (1.0 - pow(nui / nu, alpha - 1.0 / 2.0)) * pow(alpha - 1.0 / 2.0, -1.0);
+  double kstarv = kstaralphav * kperp * pow(nubperp / nu, 2.0) * log(gmin) *
+                  pow(gmin, -2 * (alpha + 1)) / tanth;
+  double afac = pow(2.0 * pi, 3) * A * ec * ec * sqrt(3.0) * omega0 * (p + 2.0) / 32.0 / (pi * pi) / m / c /
+                (omega * omega) * pow(2.0 * omega / 3.0 / omega0, -p / 2.0);
+  double ai = afac * gafac;
+  double aq = afac * gapfac;
+  double av = afac * 4.0 / 3.0 / tanth * gavfac * pow(2.0 * omega / 3.0 / omega0, -1.0 / 2.0);
+  e[0] = ji; e[1] = jq; e[2] = 0.0; e[3] = jv;
+  e[4] = ai; e[5] = aq; e[6] = 0.0; e[7] = av;
+  e[8] = kstarq; e[9] = 0.0; e[10] = kstarv;
+}
+
+// bessel.f90
+GRT_HD double poly(double x, const double *c, int m) {
+  double r = c[m - 1];
+  for (int i = m - 2; i >= 0; --i) r = x * r + c[i];
+  return r;
+}
+GRT_HD double besseli0(double x) {
+  const double p[7] = {1.00, 3.51562290, 3.08994240, 1.20674920, 0.26597320, 0.360768e-10, 0.45813e-20};
+  const double q[9] = {0.398942280, 0.1328592e-10, 0.225319e-20, -0.157565e-20, 0.916281e-20,
+                              -0.2057706e-10, 0.2635537e-10, -0.1647633e-10, 0.392377e-20};
+  double ax = fabs(x);
+  if (ax < 3.75) return poly(sq(x / 3.750), p, 7);
+  double y = 3.750 / ax;
+  return (exp(ax) / sqrt(ax)) * poly(y, q, 9);
+}
+GRT_HD double besseli1(double x) {
+  const double p[7] = {0.50, 0.878905940, 0.514988690, 0.150849340, 0.2658733e-10, 0.301532e-20, 0.32411e-30};
+  const double q[9] = {0.398942280, -0.3988024e-10, -0.362018e-20, 0.163801e-20, -0.1031555e-10,
+                              0.2282967e-10, -0.2895312e-10, 0.1787654e-10, -0.420059e-20};
+  double ax = fabs(x), r;
+  if (ax < 3.75) r = ax * poly(sq(x / 3.750), p, 7);
+  else { double y = 3.750 / ax; r = (exp(ax) / sqrt(ax)) * poly(y, q, 9); }
+  if (x < 0.0) r = -r;
+  return r;
+}
+GRT_HD double besselk0(double x) {
+  const double p[7] = {-0.57721566, 0.42278420, 0.23069756, 0.3488590e-1, 0.262698e-2, 0.10750e-3, 0.74e-5};
+  const double q[7] = {1.25331414, -0.7832358e-1, 0.2189568e-1, -0.1062446e-1, 0.587872e-2, -0.251540e-2, 0.53208e-3};
+  if (x <= 2.0) { double y = x * x / 4.0; return (-log(x / 2.0) * besseli0(x)) + poly(y, p, 7); }
+  double y = 2.0 / x;
+  return (exp(-x) / sqrt(x)) * poly(y, q, 7);
+}
+GRT_HD double besselk1(double x) {
+  const double p[7] = {1.0, 0.15443144, -0.67278579, -0.18156897, -0.1919402e-1, -0.110404e-2, -0.4686e-4};
+  const double q[7] = {1.25331414, 0.23498619, -0.3655620e-1, 0.1504268e-1, -0.780353e-2, 0.325614e-2, -0.68245e-3};
+  if (x <= 2.0) { double y = x * x / 4.0; return (log(x / 2.0) * besseli1(x)) + (1.0 / x) * poly(y, p, 7); }
+  double y = 2.0 / x;
+  return (exp(-x) / sqrt(x)) * poly(y, q, 7);
+}
+GRT_HD double besselk(int n, double x) {
+  double tox = 2.0 / x, bkm = besselk0(x), bk = besselk1(x);
+  for (int j = 1; j <= n - 1; ++j) { double bkp = bkm + j * tox * bk; bkm = bk; bk = bkp; }
+  return bk;
+}
+
+GRT_HD double bnu(double T, double nu) {   // polsynchemis.f90:1014
+  double b;
+  if (PH_h * nu / PH_k / T < 1e-6) b = 2.0 * nu * nu * PH_k * T / PH_c2;
+  else b = 2.0 * PH_h * nu / PH_c2 * nu * nu / (exp(PH_h * nu / PH_k / T) - 1.0);
+  if (b == 0) b = 2.220446049250313e-16;   // epsilon(T)
+  return b;
+}
+
+// polsynchemis.f90:700
+GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, double *e) {
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
+  const double nucminval = 1.0, thetaemin = 1e-10;
+  double thetae = k * T / m / c / c + thetaemin;
+  double nuc = 3.0 * ec * B * sin(theta) / 4.0 / pi / m / c * (thetae * thetae) + nucminval;
+  double xm = nu / nuc;
+  double x13 = pow(xm, 1.0 / 3.0), x23 = pow(xm, 2.0 / 3.0);
+  double ex = exp(-1.8899 * x13);
+  double iix = 2.5651 * (1.0 + 1.92 / x13 + .9977 / x23) * ex;
+  double iqx = 2.5651 * (1.0 + .93193 / x13 + .499873 / x23) * ex;
+  double ivx = (1.81384 / xm + 3.42319 / x23 + 0.0292545 / sqrt(xm) + 2.03773 / x13) * ex;
+  double ji = ec * ec / c / sqrt(3.0) / 2.0 * n / (thetae * thetae) * nu * iix;
+  double jq = ec * ec / c / sqrt(3.0) / 2.0 * n / (thetae * thetae) * nu * iqx;
+  double jv = 4.0 * (ec * ec) / c / 3.0 / sqrt(3.0) / tan(theta) * n / 2.0 / pow(thetae, 3.0) * nu * ivx;
+  double ju = 0.0;
+  double bnutnu = bnu(T, nu);
+  double ai = ji / bnutnu, aq = jq / bnutnu, av = jv / bnutnu, au = ju / bnutnu;
+  double rhou = au;
+  double wp2 = 4.0 * pi * n * (ec * ec) / m;
+  double omega0 = ec * B / m / c;
+  double xarg = thetae * sqrt(sqrt(2.0) * sin(theta) * (1e3 * omega0 / 2.0 / pi / nu));
+  auto jffunc = [&](double x) {
+    double extraterm = (.011 * exp(-x / 47.2) - pow(2.0, -1.0 / 3.0) / pow(3.0, 23.0 / 6.0) * pi * 1e4 *
+                                                           pow(x + 1e-16, -8.0 / 3.0)) *
+                       (0.5 + 0.5 * tanh((log(x) - log(120.0)) / 0.1));
+    return 2.011 * exp(-pow(x, 1.035) / 4.7) - cos(x / 2.0) * exp(-pow(x, 1.2) / 2.73) -
+           .011 * exp(-x / 47.2) + extraterm;
+  };
+  auto shgmfunc = [&](double x) {
+    // single-precision literals in the reference (polsynchemis.f90:820)
+    return (double)0.43793091f * log(1.0 + (double)0.00185777f * pow(x, (double)1.50316886f));
+  };
+  double eps11m22, eps12;
+  double w4 = pow(2.0 * pi * nu, 4), w3 = pow(2.0 * pi * nu, 3);
+  if (thetae > 1e-2) {
+    eps11m22 = jffunc(xarg) * wp2 * (omega0 * omega0) / w4 *
+               (besselk1(1.0 / thetae) / besselk(2, 1.0 / thetae) + 6.0 * thetae) * sq(sin(theta));
+    double step = 0.5 + 0.5 * tanh((thetae - 1.0) / 0.05);
+    eps12 = wp2 * omega0 / w3 * (besselk0(1.0 / thetae) - step * shgmfunc(xarg)) / besselk(2, 1.0 / thetae) *
+            cos(theta);
+  } else {
+    eps11m22 = jffunc(xarg) * wp2 * (omega0 * omega0) / w4 * (1.0 + 6.0 * thetae) * sq(sin(theta));
+    eps12 = wp2 * omega0 / w3 * cos(theta);
+  }
+  double rhov = 2.0 * pi * nu / c * eps12;
+  double rhoq = 2.0 * pi * nu / 2.0 / c * eps11m22;
+  e[0] = ji; e[1] = jq; e[2] = ju; e[3] = jv; e[4] = ai; e[5] = aq; e[6] = au; e[7] = av;
+  e[8] = rhoq; e[9] = rhou; e[10] = rhov;
+}
+
+// ------------------------------------------------------------------ integrators
+// calc_O  radtrans_integrate.f90:615   O[i][j] row i col j
+GRT_HD void calc_O(const double *a, const double *rho, double dx, double O[4][4]) {
+  double onopol = exp(-a[0] * dx);
+  double aq = a[1], au = a[2], av = a[3], rhoq = rho[0], rhou = rho[1], rhov = rho[2];
+  double a2 = aq * aq + au * au + av * av;
+  double p2 = rhoq * rhoq + rhou * rhou + rhov * rhov;
+  if (a2 == 0.0 && p2 == 0.0) {
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) O[i][j] = (i == j ? 1.0 : 0.0) * onopol;
+    return;
+  }
+  double ap = aq * rhoq + au * rhou + av * rhov;
+  double lam1 = sqrt(sqrt(sq(a2 - p2) / 4.0 + ap * ap) + (a2 - p2) / 2.0);
+  double lam2 = sqrt(sqrt(sq(a2 - p2) / 4.0 + ap * ap) - (a2 - p2) / 2.0);
+  double theta = lam1 * lam1 + lam2 * lam2;
+  double sig = fsign(1.0, ap);
+  double M2[4][4], M3[4][4], M4[4][4];
+  M2[0][0] = 0; M2[1][0] = lam2 * aq - sig * lam1 * rhoq; M2[2][0] = lam2 * au - sig * lam1 * rhou; M2[3][0] = lam2 * av - sig * lam1 * rhov;
+  M2[0][1] = lam2 * aq - sig * lam1 * rhoq; M2[1][1] = 0; M2[2][1] = -sig * lam1 * av - lam2 * rhov; M2[3][1] = sig * lam1 * au + lam2 * rhou;
+  M2[0][2] = lam2 * au - sig * lam1 * rhou; M2[1][2] = sig * lam1 * av + lam2 * rhov; M2[2][2] = 0; M2[3][2] = -sig * lam1 * aq - lam2 * rhoq;
+  M2[0][3] = lam2 * av - sig * lam1 * rhov; M2[1][3] = -sig * lam1 * au - lam2 * rhou; M2[2][3] = sig * lam1 * aq + lam2 * rhoq; M2[3][3] = 0;
+  M3[0][0] = 0; M3[1][0] = lam1 * aq + sig * lam2 * rhoq; M3[2][0] = lam1 * au + sig * lam2 * rhou; M3[3][0] = lam1 * av + sig * lam2 * rhov;
+  M3[0][1] = lam1 * aq + sig * lam2 * rhoq; M3[1][1] = 0; M3[2][1] = sig * lam2 * av - lam1 * rhov; M3[3][1] = -sig * lam2 * au + lam1 * rhou;
+  M3[0][2] = lam1 * au + sig * lam2 * rhou; M3[1][2] = -sig * lam2 * av + lam1 * rhov; M3[2][2] = 0; M3[3][2] = sig * lam2 * aq - lam1 * rhoq;
+  M3[0][3] = lam1 * av + sig * lam2 * rhov; M3[1][3] = sig * lam2 * au - lam1 * rhou; M3[2][3] = -sig * lam2 * aq + lam1 * rhoq; M3[3][3] = 0;
+  M4[0][0] = (a2 + p2) / 2.0; M4[1][0] = au * rhov - av * rhou; M4[2][0] = av * rhoq - aq * rhov; M4[3][0] = aq * rhou - au * rhoq;
+  M4[0][1] = av * rhou - au * rhov; M4[1][1] = aq * aq + rhoq * rhoq - (a2 + p2) / 2.0; M4[2][1] = aq * au + rhoq * rhou; M4[3][1] = av * aq + rhov * rhoq;
+  M4[0][2] = aq * rhov - av * rhoq; M4[1][2] = aq * au + rhoq * rhou; M4[2][2] = au * au + rhou * rhou - (a2 + p2) / 2.0; M4[3][2] = au * av + rhou * rhov;
+  M4[0][3] = au * rhoq - aq * rhou; M4[1][3] = av * aq + rhov * rhoq; M4[2][3] = au * av + rhou * rhov; M4[3][3] = av * av + rhov * rhov - (a2 + p2) / 2.0;
+  double c1 = 1.0 / 2.0 * (cosh(lam1 * dx) + cos(lam2 * dx));
+  double c2 = sin(lam2 * dx), c3 = sinh(lam1 * dx);
+  double c4 = 1.0 / 2.0 * (cosh(lam1 * dx) - cos(lam2 * dx));
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double m1 = (i == j) ? 1.0 : 0.0;
+      double m2 = 1.0 / theta * M2[i][j], m3 = 1.0 / theta * M3[i][j], m4 = 2.0 / theta * M4[i][j];
+      O[i][j] = onopol * (c1 * m1 - c2 * m2 - c3 * m3 + c4 * m4);
+    }
+}
+
+GRT_HD void imatrix_4(const double a[4][4], double b[4][4]) {   // :685
+  double a11 = a[0][0], a12 = a[0][1], a13 = a[0][2], a14 = a[0][3];
+  double a21 = a[1][0], a22 = a[1][1], a23 = a[1][2], a24 = a[1][3];
+  double a31 = a[2][0], a32 = a[2][1], a33 = a[2][2], a34 = a[2][3];
+  double a41 = a[3][0], a42 = a[3][1], a43 = a[3][2], a44 = a[3][3];
+  b[0][0] = a22 * a33 * a44 + a23 * a34 * a42 + a24 * a32 * a43 - a22 * a34 * a43 - a23 * a32 * a44 - a24 * a33 * a42;
+  b[0][1] = a12 * a34 * a43 + a13 * a32 * a44 + a14 * a33 * a42 - a12 * a33 * a44 - a13 * a34 * a42 - a14 * a32 * a43;
+  b[0][2] = a12 * a23 * a44 + a13 * a24 * a42 + a14 * a22 * a43 - a12 * a24 * a43 - a13 * a22 * a44 - a14 * a23 * a42;
+  b[0][3] = a12 * a24 * a33 + a13 * a22 * a34 + a14 * a23 * a32 - a12 * a23 * a34 - a13 * a24 * a32 - a14 * a22 * a33;
+  b[1][0] = a21 * a34 * a43 + a23 * a31 * a44 + a24 * a33 * a41 - a21 * a33 * a44 - a23 * a34 * a41 - a24 * a31 * a43;
+  b[1][1] = a11 * a33 * a44 + a13 * a34 * a41 + a14 * a31 * a43 - a11 * a34 * a43 - a13 * a31 * a44 - a14 * a33 * a41;
+  b[1][2] = a11 * a24 * a43 + a13 * a21 * a44 + a14 * a23 * a41 - a11 * a23 * a44 - a13 * a24 * a41 - a14 * a21 * a43;
+  b[1][3] = a11 * a23 * a34 + a13 * a24 * a31 + a14 * a21 * a33 - a11 * a24 * a33 - a13 * a21 * a34 - a14 * a23 * a31;
+  b[2][0] = a21 * a32 * a44 + a22 * a34 * a41 + a24 * a31 * a42 - a21 * a34 * a42 - a22 * a31 * a44 - a24 * a32 * a41;
+  b[2][1] = a11 * a34 * a42 + a12 * a31 * a44 + a14 * a32 * a41 - a11 * a32 * a44 - a12 * a34 * a41 - a14 * a31 * a42;
+  b[2][2] = a11 * a22 * a44 + a12 * a24 * a41 + a14 * a21 * a42 - a11 * a24 * a42 - a12 * a21 * a44 - a14 * a22 * a41;
+  b[2][3] = a11 * a24 * a32 + a12 * a21 * a34 + a14 * a22 * a31 - a11 * a22 * a34 - a12 * a24 * a31 - a14 * a21 * a32;
+  b[3][0] = a21 * a33 * a42 + a22 * a31 * a43 + a23 * a32 * a41 - a21 * a32 * a43 - a22 * a33 * a41 - a23 * a31 * a42;
+  b[3][1] = a11 * a32 * a43 + a12 * a33 * a41 + a13 * a31 * a42 - a11 * a33 * a42 - a12 * a31 * a43 - a13 * a32 * a41;
+  b[3][2] = a11 * a23 * a42 + a12 * a21 * a43 + a13 * a22 * a41 - a11 * a22 * a43 - a12 * a23 * a41 - a13 * a21 * a42;
+  b[3][3] = a11 * a22 * a33 + a12 * a23 * a31 + a13 * a21 * a32 - a11 * a23 * a32 - a12 * a21 * a33 - a13 * a22 * a31;
+  double detA = a[0][0] * b[0][0] + a[1][0] * b[0][1] + a[2][0] * b[0][2] + a[3][0] * b[0][3];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) b[i][j] = b[i][j] / detA;
+}
+
+GRT_HD void opacity_matrix(const double *K7, double M[4][4]) {   // :735 ; K7 = aI,aQ,aU,aV,rQ,rU,rV
+  const double *a = K7, *p = K7 + 4;
+  M[0][0] = a[0]; M[1][1] = a[0]; M[2][2] = a[0]; M[3][3] = a[0];
+  M[1][0] = a[1]; M[2][0] = a[2]; M[3][0] = a[3];
+  M[0][1] = a[1]; M[0][2] = a[2]; M[0][3] = a[3];
+  M[2][1] = -p[2]; M[3][1] = p[1]; M[1][2] = p[2]; M[1][3] = -p[1];
+  M[3][2] = -p[0]; M[2][3] = p[0];
+}
+
+
+
+// ------------------------------------------------------------------ FFJET sampler
+// The reference gathers 4 corners x 10 fields from ten separate 128x128 arrays (40 scattered
+// 4-byte reads).  Here the table is re-laid out once on upload as [cell][12 floats]
+// (rho,p,b0,br,bth,bph,u0,vr,vth,vph,0,0): the two r-neighbours of a sample are 96 contiguous
+// bytes, so one sample is two 96-byte segments served from L2 (the 16384-cell table is 768 KB,
+// larger than the 160 KB LDS, smaller than one XCD's 4 MB L2).
+GRT_HD void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, FluidPoint &f) {
+  const int nx1 = t.nx1, nx2 = t.nx1;
+  float theta = (float)th_d;
+  float zm = cosf(theta);
+  float x2 = acosf(fabsf(zm));
+  theta = x2;
+  float zr = (float)r;
+  float x1 = logf(zr);
+  const float x1lo = t.uniqx1[0], x1hi = t.uniqx1[nx1 - 1], thlo = t.uniqth[0], thhi = t.uniqth[nx2 - 1];
+  int lx1 = (int)((x1 - x1lo) / (x1hi - x1lo) * (nx1 - 1)) + 1;
+  int lx2 = (int)((x2 - thlo) / (thhi - thlo) * (nx2 - 1)) + 1;
+  lx2 = (lx2 <= nx2 - 1) ? ((lx2 >= 1) ? lx2 : 1) : (nx2 - 1);
+  int ux2 = lx2 + 1;
+  int lx1c = lx1 < 1 ? 1 : (lx1 > nx1 - 1 ? nx1 - 1 : lx1);   // address clamp only (see oracle note)
+  int ux1c = lx1c + 1;
+  bool inside = x1 > x1lo;
+  float td = (theta - t.uniqth[lx2 - 1]) / (t.uniqth[ux2 - 1] - t.uniqth[lx2 - 1]);
+  float rd = (zr - t.uniqr[lx1c - 1]) / (t.uniqr[ux1c - 1] - t.uniqr[lx1c - 1]);
+  const float *c00 = t.cells + (size_t)((lx1c - 1) + (lx2 - 1) * nx1) * 12;   // (x1l, x2l); +12 -> x1u
+  const float *c01 = t.cells + (size_t)((lx1c - 1) + (ux2 - 1) * nx1) * 12;   // (x1l, x2u)
+  float q[10];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 10; ++k) {
+    float v[4] = {c00[k], c01[k], c00[12 + k], c01[12 + k]};   // order of fluid_model_ffjet.f90:98
+    q[k] = bilin(v, rd, td);
+  }
+  f.rho = inside ? q[0] : 0.f;
+  f.p = inside ? q[1] : 1.f;
+  f.b[0] = (double)(inside ? q[2] : 1.f);
+  f.b[1] = (double)(inside ? q[3] : 1.f);
+  f.b[2] = (double)(inside ? q[4] : 1.f);
+  f.b[3] = (double)(inside ? q[5] : 1.f);
+  f.u[0] = inside ? (double)q[6] : 1.0;
+  float vrl0 = inside ? q[7] : 0.f;
+  float vtl0 = inside ? q[8] : 1.f;
+  float vpl0 = inside ? q[9] : 0.f;
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  float bm = (float)dot4(f.b, ms, f.b);
+  bm = (bm >= 0.f) ? bm : 0.f;
+  f.bmag = sqrtf(bm);
+  float vr0, vth0, vph0;
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  f.u[1] = f.u[0] * (double)vr0;
+  f.u[2] = f.u[0] * (double)vth0;
+  f.u[3] = f.u[0] * (double)vph0;
+}
+
+// ------------------------------------------------------------------ transfer steps as affine maps
+struct Affine {   // I -> A I + b
+  double A[4][4], b[4];
+};
+
+GRT_HD void affine_identity(Affine &m) {
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) m.A[i][j] = (i == j) ? 1.0 : 0.0;
+    m.b[i] = 0.0;
+  }
+}
+
+// later o earlier: (L.A, L.b) o (E.A, E.b) = (L.A E.A, L.A E.b + L.b)
+GRT_HD void affine_compose(const Affine &L, const Affine &E, Affine &out) {
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j)
+      out.A[i][j] = L.A[i][0] * E.A[0][j] + L.A[i][1] * E.A[1][j] + L.A[i][2] * E.A[2][j] + L.A[i][3] * E.A[3][j];
+    out.b[i] = L.A[i][0] * E.b[0] + L.A[i][1] * E.b[1] + L.A[i][2] * E.b[2] + L.A[i][3] * E.b[3] + L.b[i];
+  }
+}
+
+// formal step at point k: I <- O_k (j_k dx_k + I)   (radtrans_integrate.f90:863-871)
+GRT_HD void formal_map(const double *j, const double *K, double dx, Affine &m) {
+  calc_O(K, K + 4, dx, m.A);
+  for (int i = 0; i < 4; ++i)
+    m.b[i] = m.A[i][0] * (j[0] * dx) + m.A[i][1] * (j[1] * dx) + m.A[i][2] * (j[2] * dx) + m.A[i][3] * (j[3] * dx);
+}
+
+// DELO step between point k (j0,K0) and k+1 (j1,K1): I <- P + Q I   (radtrans_integrate.f90:811-837)
+GRT_HD void delo_map(const double *j0, const double *K0p, const double *j1, const double *K1p, double dx, double delta,
+                     Affine &m) {
+  const double thin = 1e-2;
+  double K0[4][4], K1[4][4], mat[4][4], im[4][4];
+  opacity_matrix(K0p, K0);
+  opacity_matrix(K1p, K1);
+  double ki = K0p[0], ki1 = K1p[0];
+  if (delta > thin) {
+    double E = exp(-delta), F = 1.0 - E, G = (1.0 - (1.0 + delta) * E) / delta;
+    double Sp[4], Sp1[4], Kp1[4][4];
+    for (int c = 0; c < 4; ++c) { Sp[c] = j0[c] / ki; Sp1[c] = j1[c] / ki1; }
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double id = (r == c) ? 1.0 : 0.0;
+        double Kp = K0[r][c] / ki - id;
+        Kp1[r][c] = K1[r][c] / ki1 - id;
+        mat[r][c] = id + (F - G) * Kp;
+      }
+    imatrix_4(mat, im);
+    for (int r = 0; r < 4; ++r) {
+      double acc = 0.0;
+      for (int c = 0; c < 4; ++c) acc += im[r][c] * ((F - G) * Sp[c] + G * Sp1[c]);
+      m.b[r] = acc;
+      for (int c = 0; c < 4; ++c) {
+        double q = 0.0;
+        for (int s = 0; s < 4; ++s) q += im[r][s] * (((s == c) ? 1.0 : 0.0) * E - G * Kp1[s][c]);
+        m.A[r][c] = q;
+      }
+    }
+  } else {
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double id = (r == c) ? 1.0 : 0.0;
+        mat[r][c] = (1.0 - delta / 2.0 + delta * delta / 6.0) * id + (0.5 * dx - 1.0 / 6.0 * dx * dx * ki) * K0[r][c];
+      }
+    imatrix_4(mat, im);
+    for (int r = 0; r < 4; ++r) {
+      double acc = 0.0;
+      for (int c = 0; c < 4; ++c)
+        acc += im[r][c] * ((0.5 * dx * j0[c] - 1.0 / 6.0 * dx * dx * ki * j0[c]) + (0.5 * j1[c] * dx - 1.0 / 3.0 * dx * dx * ki * j1[c]));
+      m.b[r] = acc;
+      for (int c = 0; c < 4; ++c) {
+        double q = 0.0;
+        for (int s = 0; s < 4; ++s)
+          q += im[r][s] * (((s == c) ? 1.0 : 0.0) * (1.0 - 0.5 * dx * ki + 1.0 / 6.0 * dx * dx * ki * ki) -
+                           (0.5 * dx - 1.0 / 3.0 * dx * dx) * K1[s][c]);
+        m.A[r][c] = q;
+      }
+    }
+  }
+}
+
+}  // namespace grtd

@@ -1,0 +1,166 @@
+// grtrans_amd/csrc/grt_dev_ray.hpp
+// Per-ray set-up and per-point evaluation, written so that the 64 lanes of a wave can each take
+// one stored point of the SAME geodesic:
+//   setup_ray   : everything GEOKERR does once per geodesic (geokerr_wrapper.f:463-516, 538-551):
+//                 pixel constants, roots + case, turning-point bookkeeping, loop schedule, the
+//                 cached end-point integrals, the mu-fill segment constants and the TPR state the
+//                 outbound leg inherits.  One lane per ray (set-up kernel).
+//   ray_point   : stored point `idx` (1-based, final array order of geokerr_wrapper.f:508-590)
+//                 -> (u, mu, dt, dphi, Lambda, tpm, tpr), reading only the GrtRay record.
+#pragma once
+#include "grt_dev_phys.hpp"
+
+namespace grtd {
+
+GRT_HD void cache_from_ray(const GrtRay &R, GKCache &c) {
+  c.ncase = R.ncase; c.h1 = R.h1; c.u1 = R.u1; c.u2 = R.u2; c.u3 = R.u3; c.u4 = R.u4;
+  c.rffu0 = R.rffu0; c.rffu1 = 0.0; c.rffmu1 = R.rffmu1; c.rffmu2 = 0.0; c.rffmu3 = R.rffmu3;
+  c.iu0 = R.iu0; c.i1mu = R.i1mu; c.i3mu = R.i3mu; c.rdc = R.rdc; c.rjc = R.rjc;
+  c.tu01 = R.tu01; c.tu02 = R.tu02; c.tu03 = R.tu03; c.tu04 = R.tu04;
+  c.tmu1 = R.tmu1; c.tmu3 = R.tmu3; c.phimu1 = R.phimu1; c.phimu3 = R.phimu3;
+}
+
+GRT_HD void cache_to_ray(const GKCache &c, GrtRay &R) {
+  R.ncase = c.ncase; R.h1 = c.h1; R.u1 = c.u1; R.u2 = c.u2; R.u3 = c.u3; R.u4 = c.u4;
+  R.rffu0 = c.rffu0; R.rffmu1 = c.rffmu1; R.rffmu3 = c.rffmu3;
+  R.iu0 = c.iu0; R.i1mu = c.i1mu; R.i3mu = c.i3mu; R.rdc = c.rdc; R.rjc = c.rjc;
+  R.tu01 = c.tu01; R.tu02 = c.tu02; R.tu03 = c.tu03; R.tu04 = c.tu04;
+  R.tmu1 = c.tmu1; R.tmu3 = c.tmu3; R.phimu1 = c.phimu1; R.phimu3 = c.phimu3;
+}
+
+// Pixel ii (1-based) of the rectangular camera, standard=1 (geokerr_wrapper.f:249-334)
+GRT_HD void camera_pixel(const GrtCam &cam, int ii, GrtRay &R) {
+  const double INPUT_LIMIT = 1.e-5;
+  int i = (int)((double)(ii - 1) / (double)cam.nphi) + 1;
+  int j = (ii - 1) % cam.nphi + 1;
+  double alpha = cam.a1 + (cam.a2 - cam.a1) * ((double)(i - 1) + 0.5) / (double)cam.nro;
+  double beta = cam.b1 + (cam.b2 - cam.b1) * ((double)(j - 1) + 0.5) / (double)cam.nphi;
+  double mu0 = cam.mu0, a = cam.a;
+  double l = -alpha * sqrt(1.0 - mu0 * mu0);
+  double q2 = beta * beta - (a * a - alpha * alpha) * mu0 * mu0;
+  if (fabs(q2) < INPUT_LIMIT * INPUT_LIMIT) q2 = 0.0;
+  if (fabs(l) < INPUT_LIMIT) l = 0.0;
+  R.alpha = alpha; R.beta = beta; R.l = l; R.q2 = q2; R.su = 1.0;
+  R.sm = (mu0 < 1.0 && beta >= 0.0) ? 1.0 : -1.0;
+  R.pix = ii;
+}
+
+GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
+  const double one = 1.0, two = 2.0;
+  camera_pixel(cam, ii, R);
+  const double a = cam.a, mu0 = cam.mu0, uout = cam.uout, offset = cam.offset, l = R.l, q2 = R.q2, su = R.su, sm = R.sm;
+  const int nup = cam.nup, kext = cam.kext, next = cam.next;
+  const double uplus = one / (one + sqrt(one - a * a));
+  GKCache c;
+  double u0 = cam.u0, uf = uplus, muf = 0.0, l2 = l * l, iu = 0.0, mun = 0.0;
+  int tpm = 0, tpr = 1;
+  R.npts = 0; R.kmax = 0; R.tpr = 0; R.tpr_out = 0; R.fill_tpm0 = 0; R.fill_tpm1 = 0;
+  R.fill_muminus = R.fill_muplus = R.fill_mu0 = R.fill_muf = 0.0; R.dt1 = 0.0; R.lam1 = 0.0;
+  geomu(u0, uf, mu0, muf, a, l, l2, q2, iu, tpm, tpr, su, sm, c, true, true);
+  const int ncase = c.ncase;
+  if ((ncase > 2 && ncase < 7) || (ncase == 1 && su < 0.0) || (ncase == 7 && su < 0.0) || (ncase == 2 && su > 0.0) ||
+      (ncase == 8 && su > 0.0))
+    tpr = 0;
+  double ub;
+  if (ncase > 2 && ncase < 7) {
+    ub = (su > 0.0) ? uplus : 0.0;
+  } else if (ncase == 1 || ncase == 7) {
+    ub = c.u2;
+    if (tpr == 1 && uf == ub) uf = uout;
+  } else {
+    ub = c.u3;
+    if (tpr == 1 && uf == ub) uf = uout;
+  }
+  double du = fsign(one, ub - uout) * su * ((ub - uout) + (two * tpr - one) * (ub - uf));
+  du = du / (double)nup;
+  int kmax = fint((ub - uout) / du + offset);
+  if (kmax > nup) kmax = nup;
+  if (du == 0.0) kmax = 0;
+  R.ub = ub; R.du = du; R.uf = uf; R.tpr = tpr; R.kmax = kmax;
+  cache_to_ray(c, R);
+  bool enters = (fsign(1.0, uout - ub) != fsign(1.0, uout - u0)) || (uout == u0);
+  if (!enters || kmax < 1 || ncase == 0) {   // NUP=0 in the reference (geokerr_wrapper.f:597): zero pixel
+    R.npts = 0;
+    return;
+  }
+  // first stored point: fills the GEOPHITIME caches (geokerr_wrapper.f:496-516)
+  double phimu, tmu, phiu, tu, lambda;
+  int tpr1 = 0;
+  double un = uout + (1 - offset) * du;
+  geomu(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tpr1, su, sm, c, true, false);
+  geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tpr1, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, true);
+  R.dt1 = tmu + tu;
+  R.lam1 = lambda;
+  cache_to_ray(c, R);
+  int npts = nup;
+  if (tpr == 1 && cam.mufill && nup > 1) {
+    int kk = kmax - kext;
+    if (kk < 1) { R.npts = 0; return; }
+    int tpm_s = 0, tpm1 = 0, tprs = tpr, tpmk = 0;
+    un = uout + (kk - offset) * du;
+    double u0l = u0;
+    geomu(u0l, un, mu0, mun, a, l, l2, q2, iu, tpm_s, tpr1, su, sm, c, true, false);
+    R.fill_mu0 = mun; R.fill_tpm0 = tpm_s;
+    int k = kmax + kext + 1;
+    un = two * ub - (uout + (k - offset) * du);
+    double ufl = uf;
+    geomu(ufl, un, mu0, mun, a, l, l2, q2, iu, tpm1, tprs, su, sm, c, true, false);
+    R.fill_muf = mun; R.fill_tpm1 = tpm1;
+    findmroots(q2, l, a, mu0, R.fill_muminus, R.fill_muplus);
+    // TPR as the last mu-fill GEOR call leaves it (inherited by the outbound leg, :575-582)
+    indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, sm, next, next, offset, mun, tpmk);
+    double imu = 0.0;
+    u0l = u0;
+    geor(u0l, un, mu0, mun, a, l, l2, q2, imu, tpmk, tprs, su, sm, c, true, false);
+    R.tpr_out = tprs;
+    npts = nup + next - 2 * kext;
+  } else {
+    R.tpr_out = tpr;
+  }
+  R.npts = npts;
+}
+
+struct GeoPoint {
+  double u, mu, dt, dphi, lam;
+  int tpm, tpr;
+};
+
+// Stored point idx (1..npts) of ray R.
+GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P) {
+  const double two = 2.0;
+  const double a = cam.a, mu0 = cam.mu0, uout = cam.uout, offset = cam.offset, l = R.l, q2 = R.q2, su = R.su, sm = R.sm;
+  const int kext = cam.kext, next = cam.next, kmax = R.kmax;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  GKCache c;
+  cache_from_ray(R, c);
+  double l2 = l * l, iu = 0.0, mun = 0.0, un, phimu, tmu, phiu, tu, lambda;
+  int tpm = 0, tprp;
+  const int lo = fill ? (kmax - kext) : kmax;          // last pure inbound index
+  if (idx <= lo || R.tpr == 0) {
+    int tpr1 = 0;
+    double u0 = cam.u0;
+    un = uout + (idx - offset) * R.du;
+    geomu(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tpr1, su, sm, c, true, false);
+    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tpr1, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false);
+    tprp = 0;
+  } else if (fill && idx <= lo + next) {
+    int k = idx - lo, tprs = R.tpr;
+    double u0 = cam.u0;
+    indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, sm, k, next, offset, mun, tpm);
+    un = 0.0;
+    geor(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tprs, su, sm, c, true, false);
+    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tprs, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false);
+    tprp = tprs;
+  } else {
+    int K = fill ? (idx - (next - 2 * kext)) : idx;
+    int tprs = R.tpr_out;
+    double u0 = R.uf;
+    un = two * R.ub - (uout + (K - offset) * R.du);
+    geomu(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tprs, su, sm, c, true, false);
+    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tprs, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false);
+    tprp = 1;
+  }
+  P.u = un; P.mu = mun; P.dt = tmu + tu; P.dphi = phimu + phiu; P.lam = lambda; P.tpm = tpm; P.tpr = tprp;
+}
+
+}  // namespace grtd

@@ -1,0 +1,306 @@
+// grtrans_amd/csrc/grt_dev_special.hpp
+// gfx950 device layer: Carlson symmetric integrals, Jacobi sn/cn/dn and the Laguerre root
+// finder that geokerr is built on (reference: geokerr_wrapper.f:3277-3762).
+//
+// Written for one-lane-per-evaluation use inside a 64-wide wave: the duplication loops run
+// until the slowest lane of the wave converges, so they are kept free of side exits and use
+// reciprocal-free updates where the reference does.  Arithmetic order follows the reference
+// (results agree with it to the last few ulp; integer decisions built on them are verified
+// in tests/).
+#pragma once
+#include "grt_types.h"
+#include <math.h>
+
+namespace grtd {
+
+GRT_HD double sq(double x) { return x * x; }
+GRT_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
+GRT_HD double powm1(int n) { return (n & 1) ? -1.0 : 1.0; }
+GRT_HD int fint(double x) { return (int)x; }
+GRT_HD double dmax(double a, double b) { return a > b ? a : b; }
+GRT_HD double dmin(double a, double b) { return a < b ? a : b; }
+
+// R_F  (geokerr_wrapper.f:3444)
+GRT_HD double rf(double x, double y, double z) {
+  const double ERRTOL = 0.0025, THIRD = 1.0 / 3.0, c1 = 1.0 / 24.0, C2 = 0.1, C3 = 3.0 / 44.0, C4 = 1.0 / 14.0;
+  double xt = x, yt = y, zt = z, ave, delx, dely, delz;
+  do {
+    double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+    double alamb = sx * (sy + sz) + sy * sz;
+    xt = 0.25 * (xt + alamb);
+    yt = 0.25 * (yt + alamb);
+    zt = 0.25 * (zt + alamb);
+    ave = THIRD * (xt + yt + zt);
+    if (ave == 0.0) {
+      delx = dely = delz = 0.0;
+    } else {
+      delx = (ave - xt) / ave;
+      dely = (ave - yt) / ave;
+      delz = (ave - zt) / ave;
+    }
+  } while (dmax(dmax(fabs(delx), fabs(dely)), fabs(delz)) > ERRTOL);
+  double e2 = delx * dely - delz * delz, e3 = delx * dely * delz;
+  return (1.0 + (c1 * e2 - C2 - C3 * e3) * e2 + C4 * e3) / sqrt(ave);
+}
+
+// R_C  (geokerr_wrapper.f:3608)
+GRT_HD double rc(double x, double y) {
+  const double ERRTOL = 0.0012, THIRD = 1.0 / 3.0, c1 = .3, C2 = 1.0 / 7.0, C3 = .375, C4 = 9.0 / 22.0;
+  double xt, yt, w, ave, s;
+  if (y > 0.0) {
+    xt = x; yt = y; w = 1.0;
+  } else {
+    xt = x - y; yt = -y; w = sqrt(x) / sqrt(xt);
+  }
+  do {
+    double alamb = 2.0 * sqrt(xt) * sqrt(yt) + yt;
+    xt = .25 * (xt + alamb);
+    yt = .25 * (yt + alamb);
+    ave = THIRD * (xt + yt + yt);
+    s = (yt - ave) / ave;
+  } while (fabs(s) > ERRTOL);
+  return w * (1.0 + s * s * (c1 + s * (C2 + s * (C3 + s * C4)))) / sqrt(ave);
+}
+
+// R_D  (geokerr_wrapper.f:3648)
+GRT_HD double rd(double x, double y, double z) {
+  const double ERRTOL = 0.0015, c1 = 3.0 / 14.0, C2 = 1.0 / 6.0, C3 = 9.0 / 22.0, C4 = 3.0 / 26.0, C5 = 0.25 * C3,
+               C6 = 1.5 * C4;
+  double xt = x, yt = y, zt = z, sum = 0.0, fac = 1.0, ave, delx, dely, delz;
+  do {
+    double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+    double alamb = sx * (sy + sz) + sy * sz;
+    sum = sum + fac / (sz * (zt + alamb));
+    fac = 0.25 * fac;
+    xt = .25 * (xt + alamb);
+    yt = .25 * (yt + alamb);
+    zt = .25 * (zt + alamb);
+    ave = .2 * (xt + yt + 3.0 * zt);
+    delx = (ave - xt) / ave;
+    dely = (ave - yt) / ave;
+    delz = (ave - zt) / ave;
+  } while (dmax(dmax(fabs(delx), fabs(dely)), fabs(delz)) > ERRTOL);
+  double ea = delx * dely, eb = delz * delz, ec = ea - eb, ed = ea - 6.0 * eb, ee = ed + ec + ec;
+  return 3.0 * sum + fac * (1.0 + ed * (-c1 + C5 * ed - C6 * delz * ee) + delz * (C2 * ee + delz * (-C3 * ec + delz * C4 * ea))) /
+                         (ave * sqrt(ave));
+}
+
+// R_J  (geokerr_wrapper.f:3697)
+GRT_HD double rj(double x, double y, double z, double p) {
+  const double ERRTOL = 0.0015, c1 = 3.0 / 14.0, C2 = 1.0 / 3.0, C3 = 3.0 / 22.0, C4 = 3.0 / 26.0, C5 = .75 * C3,
+               C6 = 1.5 * C4, C7 = .5 * C2, C8 = C3 + C3;
+  double sum = 0.0, fac = 1.0, xt, yt, zt, pt, a = 0.0, b = 0.0, rcx = 0.0;
+  if (p > 0.0) {
+    xt = x; yt = y; zt = z; pt = p;
+  } else {
+    xt = dmin(x, dmin(y, z));
+    zt = dmax(x, dmax(y, z));
+    yt = x + y + z - xt - zt;
+    a = 1.0 / (yt - p);
+    b = a * (zt - yt) * (yt - xt);
+    pt = yt + b;
+    double rho = xt * zt / yt, tau = p * pt / yt;
+    rcx = rc(rho, tau);
+  }
+  double ave, delx, dely, delz, delp;
+  do {
+    double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+    double alamb = sx * (sy + sz) + sy * sz;
+    double t = pt * (sx + sy + sz) + sx * sy * sz;
+    double alpha = t * t;
+    double t2 = pt + alamb;
+    double beta = pt * (t2 * t2);
+    sum = sum + fac * rc(alpha, beta);
+    fac = .25 * fac;
+    xt = .25 * (xt + alamb);
+    yt = .25 * (yt + alamb);
+    zt = .25 * (zt + alamb);
+    pt = .25 * (pt + alamb);
+    ave = .2 * (xt + yt + zt + pt + pt);
+    delx = (ave - xt) / ave;
+    dely = (ave - yt) / ave;
+    delz = (ave - zt) / ave;
+    delp = (ave - pt) / ave;
+  } while (dmax(dmax(fabs(delx), fabs(dely)), dmax(fabs(delz), fabs(delp))) > ERRTOL);
+  double ea = delx * (dely + delz) + dely * delz;
+  double eb = delx * dely * delz;
+  double ec = delp * delp;
+  double ed = ea - 3.0 * ec;
+  double ee = eb + 2.0 * delp * (ea - ec);
+  double r = 3.0 * sum + fac * (1.0 + ed * (-c1 + C5 * ed - C6 * ee) + eb * (C7 + delp * (-C8 + delp * C4)) +
+                                delp * ea * (C2 - delp * C3) - C2 * delp * ec) /
+                             (ave * sqrt(ave));
+  if (p <= 0.0) r = a * (b * r + 3.0 * (rcx - rf(xt, yt, zt)));
+  return r;
+}
+
+// Jacobi sn, cn, dn by descending Landen/AGM (geokerr_wrapper.f:3277)
+GRT_HD void sncndn(double uu, double emmc, double &sn, double &cn, double &dn) {
+  const double CA = 3.e-8;
+  double emc = emmc, u = uu, a, b, c = 0.0, d = 0.0;
+  double em[14], en[14];
+  bool bo = false;
+  if (emc != 0.0) {
+    bo = (emc < 0.0);
+    if (bo) {
+      d = 1.0 - emc;
+      emc = -emc / d;
+      d = sqrt(d);
+      u = d * u;
+    }
+    a = 1.0;
+    dn = 1.0;
+    int l = 13;
+    for (int i = 1; i <= 13; ++i) {
+      l = i;
+      em[i] = a;
+      emc = sqrt(emc);
+      en[i] = emc;
+      c = 0.5 * (a + emc);
+      if (fabs(a - emc) <= CA * a) break;
+      emc = a * emc;
+      a = c;
+    }
+    u = c * u;
+    sn = sin(u);
+    cn = cos(u);
+    if (sn != 0.0) {
+      a = cn / sn;
+      c = a * c;
+      for (int ii = l; ii >= 1; --ii) {
+        b = em[ii];
+        a = c * a;
+        c = dn * c;
+        dn = (en[ii] + a) / (b + a);
+        a = c / b;
+      }
+      a = 1.0 / sqrt(c * c + 1.0);
+      sn = (sn < 0.0) ? -a : a;
+      cn = c * sn;
+    }
+    if (bo) {
+      a = dn;
+      dn = cn;
+      cn = a;
+      sn = sn / d;
+    }
+  } else {
+    cn = 1.0 / cosh(u);
+    dn = cn;
+    sn = tanh(u);
+  }
+}
+
+GRT_HD double asech(double x) { return (x > 0.0) ? log((1.0 + sqrt(1.0 - x * x)) / x) : 0.0; }
+
+// ---- complex double, only used by the once-per-ray root finder ----
+struct cd {
+  double re, im;
+};
+GRT_HD cd cmk(double r, double i) { cd z; z.re = r; z.im = i; return z; }
+GRT_HD cd cadd(cd a, cd b) { return cmk(a.re + b.re, a.im + b.im); }
+GRT_HD cd csub(cd a, cd b) { return cmk(a.re - b.re, a.im - b.im); }
+GRT_HD cd cmul(cd a, cd b) { return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+GRT_HD cd cscale(double s, cd a) { return cmk(s * a.re, s * a.im); }
+GRT_HD double cabs_(cd a) { return hypot(a.re, a.im); }
+GRT_HD cd cdiv(cd a, cd b) {   // Smith's algorithm
+  if (fabs(b.re) >= fabs(b.im)) {
+    double r = b.im / b.re, den = b.re + b.im * r;
+    return cmk((a.re + a.im * r) / den, (a.im - a.re * r) / den);
+  } else {
+    double r = b.re / b.im, den = b.re * r + b.im;
+    return cmk((a.re * r + a.im) / den, (a.im * r - a.re) / den);
+  }
+}
+GRT_HD cd csqrt_(cd z) {
+  if (z.re == 0.0 && z.im == 0.0) return cmk(0.0, z.im);
+  double m = cabs_(z);
+  double t = sqrt(0.5 * (m + fabs(z.re)));
+  if (z.re >= 0.0) return cmk(t, z.im / (2.0 * t));
+  return cmk(fabs(z.im) / (2.0 * t), copysign(t, z.im));
+}
+
+// LAGUER (geokerr_wrapper.f:3533); a[0..m], a[0] constant term
+GRT_HD void laguer(const cd *a, int m, cd &x) {
+  const int MT = 10, MAXIT = 80;
+  const double EPSS = 1.e-15;
+  const double frac[9] = {0.0, 0.5, 0.25, 0.75, 0.13, 0.38, 0.62, 0.88, 1.0};
+  for (int iter = 1; iter <= MAXIT; ++iter) {
+    cd b = a[m];
+    double err = cabs_(b);
+    cd d = cmk(0, 0), f = cmk(0, 0);
+    double abx = cabs_(x);
+    for (int j = m - 1; j >= 0; --j) {
+      f = cadd(cmul(x, f), d);
+      d = cadd(cmul(x, d), b);
+      b = cadd(cmul(x, b), a[j]);
+      err = cabs_(b) + abx * err;
+    }
+    err = EPSS * err;
+    if (cabs_(b) <= err) return;
+    cd g = cdiv(d, b);
+    cd g2 = cmul(g, g);
+    cd h = csub(g2, cscale(2.0, cdiv(f, b)));
+    cd sqv = csqrt_(cscale((double)(m - 1), csub(cscale((double)m, h), g2)));
+    cd gp = cadd(g, sqv), gm = csub(g, sqv);
+    double abp = cabs_(gp), abm = cabs_(gm);
+    if (abp < abm) gp = gm;
+    cd dx;
+    if (dmax(abp, abm) > 0.0) {
+      dx = cdiv(cmk((double)m, 0.0), gp);
+    } else {
+      float re = (float)log(1.0 + abx), im = (float)iter;   // CEXP(CMPLX(.)) is single precision there
+      float ex = expf(re);
+      dx = cmk((double)(ex * cosf(im)), (double)(ex * sinf(im)));
+    }
+    cd x1 = csub(x, dx);
+    if (x.re == x1.re && x.im == x1.im) return;
+    if (iter % MT != 0) x = x1;
+    else x = csub(x, cscale(frac[iter / MT], dx));
+  }
+}
+
+// ZROOTS (geokerr_wrapper.f:3348): all m roots, polished, sorted by real part
+GRT_HD void zroots(const cd *a, int m, cd *roots) {
+  const double EPS = 1e-6;
+  cd ad[8];
+  for (int j = 0; j <= m; ++j) ad[j] = a[j];
+  cd xstart = cmk(0, 0);
+  int ncc = 0;
+  for (int j = m; j >= 1; --j) {
+    cd x = xstart;
+    if (j < m) {
+      if (roots[j].im != 0.0 && ncc == 0) {
+        xstart = cmk(roots[j].re, -roots[j].re);
+        ncc = 1;
+      } else {
+        xstart = cmk(0, 0);
+        ncc = 0;
+      }
+    } else {
+      xstart = cmk(0, 0);
+      ncc = 0;
+    }
+    laguer(ad, j, x);
+    if (fabs(x.im) <= 2.0 * EPS * EPS * fabs(x.re)) x = cmk(x.re, 0.0);
+    roots[j - 1] = x;
+    cd b = ad[j];
+    for (int jj = j - 1; jj >= 0; --jj) {
+      cd c = ad[jj];
+      ad[jj] = b;
+      b = cadd(cmul(x, b), c);
+    }
+  }
+  for (int j = 0; j < m; ++j) laguer(a, m, roots[j]);
+  for (int j = 1; j < m; ++j) {
+    cd x = roots[j];
+    int i;
+    for (i = j - 1; i >= 0; --i) {
+      if (roots[i].re <= x.re) break;
+      roots[i + 1] = roots[i];
+    }
+    roots[i + 1] = x;
+  }
+}
+
+}  // namespace grtd

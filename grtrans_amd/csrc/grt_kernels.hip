@@ -1,0 +1,251 @@
+// grtrans_amd/csrc/grt_kernels.hip -- gfx950 kernels of the per-pixel path.
+//
+// Replaces the OpenMP pixel loop of the reference (pgrtrans.f90:196-212 -> grtrans_driver.f90:57-466):
+//
+//   grt_setup_kernel : one LANE per camera pixel.  Everything geokerr does once per geodesic
+//                      (roots, case, cached end-point integrals, loop schedule) -> one GrtRay
+//                      record per ray + its stored-point count.  Rays that never enter r<1/uout
+//                      or fail are dropped from the work list with a wave ballot / prefix-sum
+//                      compaction (they keep their zero pixel).
+//   grt_trace_kernel : one WAVE per live ray, one stored POINT per lane.  The GrtRay record is
+//                      wave-uniform (scalar loads, SGPRs), so the root-case and segment branches
+//                      of geokerr are wave-uniform instead of divergent.  Each lane computes its
+//                      point of the geodesic, samples the fluid, builds the comoving tetrad and the
+//                      synchrotron coefficients and turns its transfer step into an affine map
+//                      I -> A I + b; the 64 maps of a chunk are composed with a Kogge-Stone scan of
+//                      wave shuffles (no LDS, no HBM intermediates) and applied to the intensity
+//                      carried from the previous (farther) chunk.  HBM traffic is the optional
+//                      per-step SoA record plus 16 B per ray per camera.
+#include <hip/hip_runtime.h>
+#include "grt_dev_ray.hpp"
+
+using namespace grtd;
+
+#define GRT_WAVES_PER_BLOCK 4
+#define GRT_MAXF 32
+
+__global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
+                                                         int *__restrict__ ray_npts, int *__restrict__ live,
+                                                         int *__restrict__ counters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  bool inr = tid < nrays;
+  GrtRay R;
+  R.npts = 0;
+  if (inr) {
+    setup_ray(cam, (int)(i1 + tid), R);
+    rays[tid] = R;
+    ray_npts[tid] = R.npts;
+  }
+  // wave-level compaction of live rays (ballot + prefix popcount + one atomic per wave)
+  bool alive = inr && R.npts > 0;
+  unsigned long long mask = __ballot(alive);
+  int lane = threadIdx.x & 63;
+  int before = __popcll(mask & ((1ull << lane) - 1ull));
+  int total = __popcll(mask);
+  int base = 0;
+  if (lane == 0 && total > 0) base = atomicAdd(&counters[0], total);
+  base = __shfl(base, 0);
+  if (alive) live[base + before] = tid;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__device__ __forceinline__ void affine_shfl_up(const Affine &m, int d, Affine &e) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e.A[i][j] = __shfl_up(m.A[i][j], d);
+    e.b[i] = __shfl_up(m.b[i], d);
+  }
+}
+
+__device__ __forceinline__ void affine_bcast(const Affine &m, int src, Affine &e) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e.A[i][j] = __shfl(m.A[i][j], src);
+    e.b[i] = __shfl(m.b[i], src);
+  }
+}
+
+template <int IFLAG>
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK) void grt_trace_kernel(
+    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFFJet fj, GrtTables tb,
+    GrtEmis em, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile, int nvals,
+    int *__restrict__ ray_status, long long i1, double *__restrict__ steps, long long steps_ray_stride, long long steps_field_stride,
+    unsigned long long *__restrict__ step_counter) {
+  __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
+  __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
+  __shared__ double s_nb[IFLAG == GRT_INT_DELO ? GRT_WAVES_PER_BLOCK : 1][IFLAG == GRT_INT_DELO ? GRT_MAXF : 1][11];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
+  if (slot >= nlive) return;   // whole wave leaves together
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  const int rayidx = live[slot];
+  const GrtRay &R = rays[rayidx];
+  const int n = R.npts;
+  const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
+  const double alpha = R.alpha, beta = R.beta;
+
+  for (int f = lane; f < nfreq; f += 64) {
+    s_carry[wave][f][0] = 0.0; s_carry[wave][f][1] = 0.0; s_carry[wave][f][2] = 0.0; s_carry[wave][f][3] = 0.0;
+    s_fac[wave][f] = 0.0;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  double LamN = 0.0, sumr = 0.0;
+  double nb_lam = 0.0;            // lambda of the point stored just after this chunk's first one (carry)
+  for (int base = n; base >= 1; base -= 64) {
+    const int idx = base - lane;
+    const bool valid = idx >= 1;
+    GeoPoint P;
+    P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
+    if (valid) ray_point(cam, R, idx, P);
+    if (base == n) LamN = __shfl(P.lam, 0);
+    // geodesics.f90:333-364
+    const double r = 1.0 / P.u;
+    const double th = acos(P.mu);
+    const double lam_i = LamN - P.lam;
+    const double lam_1 = LamN - R.lam1;
+    double kv[4];
+    calc_nullp(R.q2, R.l, cam.a, r, cos(th), R.su * powm1(P.tpr), R.sm * powm1(P.tpm), kv);
+    sumr += valid ? r : 0.0;
+    // fluid + frame (grtrans_driver.f90:126-130)
+    FluidPoint fl;
+    ffjet_sample(fj, r, th, (float)cam.a, fl);
+    double s2xi, c2xi, ang, g, cosne;
+    comoving_ortho(r, th, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g, cosne);
+    const double ncgsnth = (double)fl.rho * em.nfac, bcgs = (double)fl.bmag * em.bfac;
+    // neighbour along the integration direction = stored point idx+1 = lane-1 (or previous chunk)
+    double lam_nb = __shfl_up(lam_i, 1);
+    if (lane == 0) lam_nb = nb_lam;
+    const double dx = lam_i - lam_nb;
+    const bool step = valid && (idx < n);
+
+    for (int f = 0; f < nfreq; ++f) {
+      const double nu = freqs[f] / g;
+      double e[11];
+      polsynchpl(tb, nu, ncgsnth, bcgs, ang, em.p1, em.gmin, em.gmax, e);
+#pragma unroll
+      for (int c = 0; c < 7; ++c)
+        if (!em.coefindx[c]) e[4 + c] = 0.0;
+      double facp = valid ? e[0] * (lam_1 - lam_i) : 0.0;
+      // rotate_emis + invariant_emis + cgs scaling (emis.f90:797-838, grtrans_driver.f90:201-217)
+      double jj[4] = {e[0], c2xi * e[1] - s2xi * e[2], s2xi * e[1] + c2xi * e[2], e[3]};
+      double KK[7] = {e[4], c2xi * e[5] - s2xi * e[6], s2xi * e[5] + c2xi * e[6], e[7],
+                      c2xi * e[8] - s2xi * e[9], s2xi * e[8] + c2xi * e[9], e[10]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) jj[c] = jj[c] * g * g;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) KK[c] = KK[c] / g * LBH;
+      Affine M;
+      if (IFLAG == GRT_INT_FORMAL) {
+        if (step) formal_map(jj, KK, dx, M);
+        else affine_identity(M);
+      } else {
+        // DELO couples point idx with idx+1: fetch the neighbour's coefficients (lane-1, or the
+        // previous chunk's last lane, parked in LDS)
+        double jn[4], Kn[7];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) jn[c] = __shfl_up(jj[c], 1);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) Kn[c] = __shfl_up(KK[c], 1);
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) jn[c] = s_nb[wave][f][c];
+#pragma unroll
+          for (int c = 0; c < 7; ++c) Kn[c] = s_nb[wave][f][4 + c];
+        }
+        // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 / math.f90:30-44 is local: dx * mean |alpha_I|
+        double delta = dx * ((fabs(KK[0]) + fabs(Kn[0])) / 2.0);
+        if (step) delo_map(jj, KK, jn, Kn, dx, delta, M);
+        else affine_identity(M);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 63) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s_nb[wave][f][c] = jj[c];
+#pragma unroll
+          for (int c = 0; c < 7; ++c) s_nb[wave][f][4 + c] = KK[c];
+        }
+      }
+      // inclusive Kogge-Stone scan: M_l <- M_l o M_{l-1} o ... o M_0
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        Affine E, N;
+        affine_shfl_up(M, d, E);
+        if (lane >= d) {
+          affine_compose(M, E, N);
+          M = N;
+        }
+      }
+      double ci[4] = {s_carry[wave][f][0], s_carry[wave][f][1], s_carry[wave][f][2], s_carry[wave][f][3]};
+      double io[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) io[i] = M.A[i][0] * ci[0] + M.A[i][1] * ci[1] + M.A[i][2] * ci[2] + M.A[i][3] * ci[3] + M.b[i];
+      double facs = wave_sum(facp);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_carry[wave][f][i] = io[i];
+      }
+      if (lane == 0) s_fac[wave][f] += facs;
+      __builtin_amdgcn_wave_barrier();
+      if (steps != nullptr && f == 0 && valid) {
+        double *sp = steps + (long long)rayidx * steps_ray_stride + (idx - 1);
+        sp[0 * steps_field_stride] = r;
+        sp[1 * steps_field_stride] = th;
+        sp[2 * steps_field_stride] = cam.phi0 - P.dphi;
+        sp[3 * steps_field_stride] = lam_i;
+        sp[4 * steps_field_stride] = io[0] * LBH;
+        sp[5 * steps_field_stride] = io[1] * LBH;
+        sp[6 * steps_field_stride] = io[2] * LBH;
+        sp[7 * steps_field_stride] = io[3] * LBH;
+      }
+    }
+    nb_lam = __shfl(lam_i, 63);
+  }
+  sumr = wave_sum(sumr);
+  __builtin_amdgcn_wave_barrier();
+  const int pixslot = R.pix - (int)i1;
+  for (int f = lane; f < nfreq; f += 64) {
+    double fac = s_fac[wave][f];
+    bool ok = (fac / 1e16 > 0.0) && !(sumr < 0.0);
+    for (int c = 0; c < nvals && c < 4; ++c) {
+      double v = ok ? s_carry[wave][f][c] * LBH : 0.0;
+      pixvals[((long long)f * npix_tile + pixslot) * nvals + c] = (float)v;
+    }
+  }
+  if (lane == 0) {
+    if (sumr < 0.0) ray_status[rayidx] = -n;
+    atomicAdd(step_counter, (unsigned long long)n);
+  }
+}
+
+// ---- host-side launch helpers (called from grt_api.cpp) ----
+extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
+                                       int *ray_npts, int *live, int *counters) {
+  int blocks = (nrays + 255) / 256;
+  hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t grt_launch_trace(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays, const int *live,
+                                       int nlive, const GrtFFJet *fj, const GrtTables *tb, const GrtEmis *em, int nfreq,
+                                       const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status,
+                                       long long i1, double *steps, long long steps_ray_stride, long long steps_field_stride,
+                                       unsigned long long *step_counter) {
+  if (nlive <= 0) return hipSuccess;
+  int blocks = (nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK;
+  dim3 g(blocks), b(64 * GRT_WAVES_PER_BLOCK);
+  if (iflag == GRT_INT_DELO)
+    hipLaunchKernelGGL(grt_trace_kernel<GRT_INT_DELO>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq, freqs,
+                       pixvals, npix_tile, nvals, ray_status, i1, steps, steps_ray_stride, steps_field_stride, step_counter);
+  else
+    hipLaunchKernelGGL(grt_trace_kernel<GRT_INT_FORMAL>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq,
+                       freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, steps_ray_stride, steps_field_stride,
+                       step_counter);
+  return hipGetLastError();
+}

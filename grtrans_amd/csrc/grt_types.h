@@ -1,0 +1,43 @@
+// grtrans_amd/csrc/grt_types.h
+// Plain-old-data shared between the host side of the C-ABI (grt_api.hip) and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GRT_HD __host__ __device__ inline
+#else
+#define GRT_HD inline
+#endif
+
+#include "../../include/grtrans_amd.h"
+
+// Everything GEOKERR computes once per geodesic ("firstpt" caches, geokerr_wrapper.f:789-809,
+// 1676-1692) plus the loop schedule (:468-491) and the mu-fill segment constants (:538-551).
+// AoS on purpose: the trace kernel reads one record per WAVE through scalar loads.
+struct GrtRay {
+  // pixel (geokerr_wrapper.f:258-285)
+  double alpha, beta, l, q2, su, sm;
+  // roots / case (GEOMU firstpt)
+  double u1, u2, u3, u4, h1;
+  double iu0, i1mu, i3mu, rffu0, rffmu1, rffmu3;
+  // GEOPHITIME firstpt caches
+  double tu01, tu02, tu03, tu04, rdc, rjc, tmu1, tmu3, phimu1, phimu3;
+  // loop schedule
+  double ub, du, uf;        // uf: GEOKERR's UF after its modifications (u0 argument of the outbound leg)
+  // reference values of the first point (index 1): dt(1) and Lambda(1)
+  double dt1, lam1;
+  // mu-fill segment
+  double fill_muminus, fill_muplus, fill_mu0, fill_muf;
+  int32_t ncase, tpr, kmax, npts;          // npts: stored points (0 = ray never enters uout)
+  int32_t fill_tpm0, fill_tpm1, tpr_out, pix;   // tpr_out: TPR seen by the outbound leg; pix: 1-based pixel
+};
+
+struct GrtFFJet {               // device pointers; cell-interleaved copy of the BL09 table
+  const float *cells;           // [nx1*nx1][12]: rho,p,b0,br,bth,bph,u0,vr,vth,vph,pad,pad
+  const float *uniqr, *uniqth, *uniqx1;
+  int32_t nx1, pad;
+};
+
+struct GrtTables {              // polsynchpl log-G tables (polsynchemis.f90:107-525), device pointers
+  const double *gx, *gy, *xv, *ya, *yp, *yv, *yap, *yav;
+};

@@ -1,0 +1,114 @@
+/* include/grtrans_amd.h -- C ABI of the MI355X per-pixel ray-tracing path of grtrans.
+ *
+ * What this library replaces in the reference (jadexter/grtrans):
+ *   the OpenMP pixel loop   do i=i1,i2: call grtrans_driver(gargs,gunit,c,i,l,iname,ename,fname,
+ *                           sparams,eparams,nfreq,nparams,freqs,nup,extra,debug)
+ *   pgrtrans.f90:196-212 -> grtrans_driver.f90:57-466, i.e. per pixel:
+ *   geokerr geodesic (geodesics.f90:206-377, geokerr_wrapper.f) -> fluid sample (fluid.f90:473) ->
+ *   comoving frame (kerr.f90:550-730) -> emissivity (emis.f90:461) -> transfer integration
+ *   (radtrans_integrate.f90:139-198) -> save_raytrace_camera_pixel (camera.f90:28-39).
+ *
+ * Calling convention: plain C, pointers + sizes, no ownership transfer.  Host buffers are owned by
+ * the caller; device buffers are owned by the library between grt_init and grt_free.  One host
+ * thread per process may call in (the reference is single-threaded outside its OpenMP loop).
+ * Every function returns 0 on success or a negative GRT_E* / positive hipError_t code; numeric
+ * failures of individual rays are NOT errors: such rays produce zero pixels and a status word, as
+ * grtrans_driver.f90:452-462 does.  There is no CPU fallback: without a HIP device grt_init fails.
+ */
+#ifndef GRTRANS_AMD_H
+#define GRTRANS_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRT_E_NODEVICE (-1)
+#define GRT_E_NOTINIT (-2)
+#define GRT_E_BADARG (-3)
+#define GRT_E_NOFLUID (-4)
+#define GRT_E_NOTABLES (-5)
+#define GRT_E_IO (-6)
+#define GRT_E_UNSUPPORTED (-7)
+
+/* ids follow the reference so host Fortran can pass its own constants through:
+ * fluid.f90:40-43, emis.f90:11-18, rad_trans.f90:29-37 */
+enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13 };
+enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8 };
+enum { GRT_INT_LSODA = 0, GRT_INT_DELO = 1, GRT_INT_FORMAL = 2 };
+
+/* Camera scalars: what initialize_pixels / INITIALIZE_CAMERA_GEOKERR derive once per camera
+ * (geodesics.f90:64-111, geokerr_wrapper.f:1-354).  Fill with grt_make_camera. */
+typedef struct GrtCam {
+  double a1, a2, b1, b2;                  /* gridvals: alpha min/max, beta min/max */
+  double a, mu0, uout, u0, offset, phi0;  /* phi0 = acos(-1.)*phi0 (single-precision pi), geodesics.f90:218 */
+  int32_t standard, nro, nphi, nup;
+  int32_t usegeor, phit, mufill, kext, next, pad0;
+} grt_camera;
+
+/* source_params + emis_params for one mdot (pgrtrans.f90:117-136, emis.f90:32-39) */
+typedef struct GrtEmis {
+  double mbh, nfac, bfac;     /* nfac = ftscl, bfac = frscl for FFJET (pgrtrans.f90:128, fluid.f90:1171) */
+  double gmin, gmax, p1;      /* rounded through REAL(4) exactly as emis_params stores them */
+  double muval;
+  int32_t type, coefindx[7];
+} grt_emis;
+
+typedef struct GrtStats {
+  int64_t ray_steps;          /* sum of stored points over traced rays (the metric's numerator) */
+  int64_t rays_live, rays_dead;
+  double ms_setup, ms_trace, ms_total;   /* HIP-event times on the library stream */
+} grt_stats;
+
+/* replaces: nothing in the reference (device bring-up).  device = HIP ordinal. */
+int grt_init(int device);
+int grt_free(void);
+
+/* replaces load_fluid_model / initialize_ffjet_model (fluid.f90:163-243, fluid_model_ffjet.f90:181-210):
+ * the twelve nx-long REAL(4) arrays of the BL09 table, r fastest. */
+int grt_upload_ffjet(int nx, const float *rc, const float *thc, const float *rho, const float *p, const float *b0,
+                     const float *br, const float *bth, const float *bph, const float *u0, const float *vr,
+                     const float *vth, const float *vph);
+/* convenience: read the Fortran sequential file itself (same records as fluid_model_ffjet.f90:200-207) */
+int grt_load_ffjet_file(const char *path);
+
+/* replaces initialize_polsynchpl (polsynchemis.f90:107-525): 2020 doubles,
+ * gxvals[181] gyvals[543] xvals[81] yavals[243] ypvals[243] yvvals[243] yapvals[243] yavvals[243] */
+int grt_upload_polsynchpl_tables(const double *tables2020);
+int grt_load_polsynchpl_tables_file(const char *path);
+
+/* replaces initialize_pixels (geodesics.f90:64-111) + the scalar part of INITIALIZE_CAMERA_GEOKERR */
+int grt_make_camera(grt_camera *cam, int standard, const double gridvals[4], const int nn[3], double spin,
+                    double mu0, double uout, double phi0);
+
+/* replaces the i=i1..i2 loop over grtrans_driver (pgrtrans.f90:200-207).
+ *   i1,i2     1-based inclusive pixel range, reference semantics (read_inputs.f90:8-9)
+ *   pixvals   HOST out, [nfreq][i2-i1+1][nvals+nextra] REAL(4): c(cam)%pixvals(:,i) (camera.f90:35)
+ *   pixloc    HOST out or NULL, [i2-i1+1][2] REAL(4): alpha,beta (camera.f90:36)
+ *   ray_status HOST out or NULL, [i2-i1+1]: stored points of the ray; 0 = never enters uout,
+ *             negative = geodesic rejected (status=-1, geodesics.f90:255) */
+int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
+                   const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
+                   int32_t *ray_status, grt_stats *st);
+
+/* Same work, results left in HBM (bench / multi-GPU gather): device pointers valid until the next call. */
+int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
+                            int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st);
+int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status);
+
+/* Optional per-step SoA record (r,theta,phi,lambda,I,Q,U,V) fp64, [8][nrays][maxpts] in HBM, of the
+ * first frequency: what geodebug.out holds per ray (grtrans_driver.f90:94-110,370-373).  0 disables. */
+int grt_set_record_steps(int enable);
+int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out);
+
+/* Multi-GPU assembly of ivals (pgrtrans.f90:221-242): every rank passes its tile (device resident);
+ * comm is an ncclComm_t owned by the caller (RCCL), root receives [sum counts] floats. */
+int grt_gather(const float *d_tile, int64_t count, float *d_full, const int64_t *counts, int nranks, int rank,
+               int root, void *comm, void *stream);
+
+const char *grt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+// tests/hostsim/hostsim.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the product's per-lane device functions (grtrans_amd/csrc/grt_dev_*.hpp) for the HOST
+// with g++ so that the per-ray set-up and per-point evaluation can be compared with the oracle on
+// a machine without a GPU.  Not part of the product: libgrtrans_amd.so has no CPU path.
+#include "grt_dev_ray.hpp"
+#include <cstring>
+using namespace grtd;
+
+extern "C" {
+
+void hs_make_cam(GrtCam *cam, int standard, const double *gridvals, const int *nn, double a, double mu0, double uout,
+                 double phi0) {
+  std::memset(cam, 0, sizeof(*cam));
+  cam->a1 = gridvals[0]; cam->a2 = gridvals[1]; cam->b1 = gridvals[2]; cam->b2 = gridvals[3];
+  cam->standard = standard; cam->nro = nn[0]; cam->nphi = nn[1]; cam->nup = nn[2];
+  cam->mu0 = mu0; cam->uout = uout; cam->offset = 0.5;
+  double abmax = sq(dmax(cam->a1 * cam->a1, cam->a2 * cam->a2)) + sq(dmax(cam->b1 * cam->b1, cam->b2 * cam->b2));
+  cam->u0 = dmin(1.e-4, 1.0 / (100.0 * abmax));
+  if (cam->nup == 1) cam->offset = 1.e-8;
+  if (fabs(a) < 1.e-5) a = 0.0;
+  cam->a = a;
+  cam->phi0 = (double)(acosf(-1.f)) * phi0;
+  cam->usegeor = 0; cam->phit = 1;
+  if (cam->nup > 1) { cam->mufill = 1; cam->kext = (int)ceil(3.0 * cam->nup / 400.0); cam->next = (int)ceil(60.0 * cam->nup / 400.0); }
+}
+
+int hs_sizeof_ray() { return (int)sizeof(GrtRay); }
+int hs_sizeof_cam() { return (int)sizeof(GrtCam); }
+
+void hs_setup_ray(const GrtCam *cam, int ii, GrtRay *R) { setup_ray(*cam, ii, *R); }
+
+int hs_ray_points(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *dt, double *dphi, double *lam,
+                  int *tpm, int *tpr, int *ncase) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  *ncase = R.ncase;
+  for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
+    GeoPoint P;
+    ray_point(*cam, R, idx, P);
+    u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
+    tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
+  }
+  return R.npts;
+}
+}
