@@ -28,9 +28,29 @@ BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lam
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+class _quiet_stdout:
+    """The reference Fortran writes banners to unit 6; keep fd 1 clean for the single JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 1)
+        os.close(self.null)
+        os.close(self.saved)
+
+
 def cpu_baseline(nx, ny, nup, budget_s=15.0):
     """Reference Fortran (oracle/_ref) -- or the C++ port if that library is absent -- on a bounded
     contiguous pixel sample around the image centre of the SAME camera, all host cores."""
+    with _quiet_stdout():
+        return _cpu_baseline(nx, ny, nup, budget_s)
+
+
+def _cpu_baseline(nx, ny, nup, budget_s):
     cores = os.cpu_count() or 1
     kw = dict(nn=(nx, ny, nup), iname="formal")
     try:

@@ -87,14 +87,14 @@ int grt_init(int device) {
 
 int grt_free(void) {
   if (!C.init) return 0;
-  hipStreamSynchronize(C.stream);
+  (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount};
   for (void *p : ptrs)
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
-    if (C.ev[i]) hipEventDestroy(C.ev[i]);
-  if (C.stream) hipStreamDestroy(C.stream);
+    if (C.ev[i]) (void)hipEventDestroy(C.ev[i]);
+  if (C.stream) (void)hipStreamDestroy(C.stream);
   C = Ctx();
   return 0;
 }
@@ -114,8 +114,8 @@ int grt_upload_ffjet(int nx, const float *rc, const float *thc, const float *rho
     uniq[nx1 + i] = thc[(size_t)i * nx1];          // uniqth (:68)
     uniq[2 * nx1 + i] = std::log(rc[i]);           // uniqx1 (:71), REAL(4) log
   }
-  if (C.d_cells) { hipFree(C.d_cells); C.d_cells = nullptr; }
-  if (C.d_uniq) { hipFree(C.d_uniq); C.d_uniq = nullptr; }
+  if (C.d_cells) { (void)hipFree(C.d_cells); C.d_cells = nullptr; }
+  if (C.d_uniq) { (void)hipFree(C.d_uniq); C.d_uniq = nullptr; }
   HIPCHK(hipMalloc((void **)&C.d_cells, cells.size() * sizeof(float)));
   HIPCHK(hipMalloc((void **)&C.d_uniq, uniq.size() * sizeof(float)));
   HIPCHK(hipMemcpy(C.d_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -281,8 +281,8 @@ int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int f
     HIPCHK(hipEventElapsedTime(&ms, t0, t1));
     if (st) { st->ms_total = ms; st->ms_setup = ms - st->ms_trace; }
   }
-  hipEventDestroy(t0);
-  hipEventDestroy(t1);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
   return rc;
 }
 

@@ -13,6 +13,23 @@
 
 namespace grtd {
 
+// REAL(4) islands must round every product and sum separately, as the reference's compiler does
+// (no FMA contraction), or the fluid variables stop being bit-identical.
+#if defined(__clang__)
+#define GRT_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define GRT_NO_CONTRACT
+#endif
+
+
+// The reference evaluates these in REAL(4) with glibc (cosf, sinf, acosf, logf are correctly rounded
+// there for all practical inputs).  Device ocml f32 versions are ~1-2 ulp; evaluating in fp64 and
+// rounding once reproduces the reference's fp32 values, which keeps the fluid variables bit-identical.
+GRT_HD float cosf_cr(float x) { return (float)cos((double)x); }
+GRT_HD float sinf_cr(float x) { return (float)sin((double)x); }
+GRT_HD float acosf_cr(float x) { return (float)acos((double)x); }
+GRT_HD float logf_cr(float x) { return (float)log((double)x); }
+
 struct Metric { double g[10]; };   // slots 1,4,5,8,10 (0-based 0,3,4,7,9) non-zero
 
 GRT_HD Metric blmetric_cov(double r, double th, double a) {
@@ -32,9 +49,10 @@ GRT_HD Metric blmetric_cov(double r, double th, double a) {
 
 // single-precision metric, promoted to double slots (blmetric_cov_real + assign_metric_real)
 GRT_HD Metric blmetric_cov_real(float r, float th, float a) {
+  GRT_NO_CONTRACT
   Metric m;
   for (int i = 0; i < 10; ++i) m.g[i] = 0.0;
-  float cth = cos(th), sth = sin(th);
+  float cth = cosf_cr(th), sth = sinf_cr(th);
   float delta = r * r - 2.f * r + a * a;
   float rho2 = r * r + a * a * cth * cth;
   float t = r * r + a * a;
@@ -77,7 +95,8 @@ GRT_HD void calc_nullp(double q2, double l, double a, double r, double mu, doubl
 // kerr.f90:476  lnrf_frame_inv_real (single precision)
 GRT_HD void lnrf_frame_inv_real(float vr, float vt, float omega, float r, float a, float th, float &vrl,
                                 float &vtl, float &vpl) {
-  float mu = cos(th);
+  GRT_NO_CONTRACT
+  float mu = cosf_cr(th);
   float D = r * r - 2.f * r + a * a;
   float t = r * r + a * a;
   float AR = t * t - a * a * D * (1.f - mu * mu);
@@ -186,6 +205,7 @@ struct FluidPoint {
 };
 
 GRT_HD float bilin(const float *v, float xd, float yd) {   // interpolate.f90:171
+  GRT_NO_CONTRACT
   float w1 = v[0] * (1.f - yd) + v[1] * yd;
   float w2 = v[2] * (1.f - yd) + v[3] * yd;
   return w1 * (1.f - xd) + w2 * xd;
@@ -441,13 +461,14 @@ GRT_HD void opacity_matrix(const double *K7, double M[4][4]) {   // :735 ; K7 = 
 // bytes, so one sample is two 96-byte segments served from L2 (the 16384-cell table is 768 KB,
 // larger than the 160 KB LDS, smaller than one XCD's 4 MB L2).
 GRT_HD void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, FluidPoint &f) {
+  GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx1;
   float theta = (float)th_d;
-  float zm = cosf(theta);
-  float x2 = acosf(fabsf(zm));
+  float zm = cosf_cr(theta);
+  float x2 = acosf_cr(fabsf(zm));
   theta = x2;
   float zr = (float)r;
-  float x1 = logf(zr);
+  float x1 = logf_cr(zr);
   const float x1lo = t.uniqx1[0], x1hi = t.uniqx1[nx1 - 1], thlo = t.uniqth[0], thhi = t.uniqth[nx2 - 1];
   int lx1 = (int)((x1 - x1lo) / (x1hi - x1lo) * (nx1 - 1)) + 1;
   int lx2 = (int)((x2 - thlo) / (thhi - thlo) * (nx2 - 1)) + 1;
