@@ -132,20 +132,19 @@ def main():
     dt = time.perf_counter() - t0
     gather_ms = None
     if dist is not None:
-        # assemble ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the fp32 tiles
+        # assemble ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the fp32 tiles over xGMI
         import ctypes as C
-        p = C.c_void_p()
-        capi.check(capi.lib().grt_resident_pointers(C.byref(p), None), "grt_resident_pointers")
-        n = nx * ny * 4
-        buf = (C.c_float * n).from_address(p.value) if False else None  # device memory: wrap through torch below
-        tile = torch.empty(n, dtype=torch.float32, device="cuda")
-        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(tile.data_ptr()), p, C.c_size_t(n * 4), C.c_int(3))
-        outs = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
+        from grtrans_amd.tiling import gather_tiles
+        tile = torch.empty((1, nx * ny, 4), dtype=torch.float32, device="cuda")
+        capi.check(capi.lib().grt_copy_resident_pixvals(C.c_void_p(tile.data_ptr()), C.c_int64(tile.numel())),
+                   "grt_copy_resident_pixvals")
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        dist.gather(tile, outs, dst=0)
+        full = gather_tiles(tile, dist, 0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert full.shape[1] == nx * ny * world
         tmax = torch.tensor([dt, float(ray_steps), ms_trace], dtype=torch.float64, device="cuda")
         tsum = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

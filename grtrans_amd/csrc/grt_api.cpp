@@ -293,6 +293,13 @@ int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status) {
   return 0;
 }
 
+int grt_copy_resident_pixvals(void *d_dst, int64_t count) {
+  if (!C.init || !C.d_pixvals) return GRT_E_NOTINIT;
+  if (!d_dst || count < 0 || (size_t)count > C.cap_pix) return GRT_E_BADARG;
+  HIPCHK(hipMemcpy(d_dst, C.d_pixvals, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice));
+  return 0;
+}
+
 int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
                    const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
                    int32_t *ray_status, grt_stats *st) {

@@ -1,0 +1,207 @@
+"""Python harness with the calling convention of grtrans' grtrans_batch.py, on top of the MI355X path.
+
+Mirrors (reference grtrans_batch.py): the defaults table and kwargs (:23-170), i1/i2 clamping
+(:155-164), nweights/delta (:165-170), the inputs.in / files.in writer (:172-330, :378-388),
+run_grtrans (:334-357, executes ./grtrans = grtrans_amd/host/grtrans), run_pgrtrans (:397-414,
+same kwargs -> ivals(nvals, npix, ncams), ab(2, npix), nu), the binary reader (:450-477, cflag=0)
+and calc_spec / calc_spec_pgrtrans (:499-542).  The f2py module `pgrtrans` of the reference is
+replaced by calls into the C ABI; there is no CPU path behind it.
+"""
+import os
+import subprocess
+import numpy as np
+
+from . import namelist as nm
+from . import capi
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+HOST_EXE = os.path.join(PKG, "host", "grtrans")
+
+
+class grtrans_inputs:
+    def init(self):
+        d = dict(cflag=1, standard=2, mumin=.1, mumax=1., phi0=-0.5, nmu=10, spin=0.998, uout=0.04, uin=1.,
+                 rcut=1., nrotype=2, gridvals=[-25., 25., -25., 25.], nn=[100, 100, 1], i1=-1, i2=-1,
+                 fname='THINDISK', dt=5., nt=1, nload=1, ename='BB', mbh=10., nmdot=1, mdotmin=1.5e15,
+                 mdotmax=1.5e15, nfreq=1, fmin=1.e17, fmax=3.e19, muval=1. / 4., sigcut=1.e10, gmin=100,
+                 gmax=1e5, p1=3.5, p2=3.5, epotherargs=[1., 1.], epcoefindx=[1, 1, 1, 1, 1, 1, 1],
+                 jetalpha=0.02, stype='const', use_geokerr='T', nvals=1, iname='lsoda', tmdot=0.1, pnw=500,
+                 pwmin=1.e-4, pwmax=1.e4, pnfreq_tab=100, prmax=1.e4, pnr=500, psigt=0.4, pfcol=1.7,
+                 jdfile='m87bl09rfp10xi5a998fluidvars.bin', ndfile='phatdiskm8st25.bin', ntscl=1., nrscl=6.,
+                 snscl=3e7, snnthscl=8e4, snnthp=2.9, sbeta=10., snp=0., snt=0., sbl06=0, srin=-1.,
+                 srout=1e8, sthin=-10., sthout=10., sphiin=0., sphiout=1e4, hrspot=1.5, hr0spot=6.0,
+                 hn0spot=1e4, ofile='grtrans.out', outfile='', ifile='inputs.in', hhfile='dump040',
+                 hdfile='dump', hnt=1, hindf=40, tdfile='fieldline', tgfile='dump0000rr2.bin', tnt=1,
+                 tnfiles=1, tindf=5206, tjonfix=1, toff=0, tsim='thickdiskrr2', tdindf=1, tmagcrit=0,
+                 extra=0, debug=0, fdfile='fieldline', fgfile='dump0000rr2.bin', fhfile='dump040', fnt=1,
+                 fnfiles=1, findf=5206, fjonfix=1, foffset=0, fsim='thickdiskrr2', fdindf=1, fmagcrit=0,
+                 fscalefac=1.)
+        self.__dict__.update(d)
+        self.pfmin = self.fmin / 3.
+        self.pfmax = self.fmax * 3.
+
+    def __init__(self, **kwargs):
+        self.init()
+        self.__dict__.update(kwargs)
+        npix = self.nn[0] * self.nn[1]
+        if self.i1 < 0:
+            self.i1 = 1
+        if self.i2 < 0:
+            self.i2 = npix
+        if self.i1 > npix - 1:
+            self.i1 = npix - 1
+        if self.i2 > npix:
+            self.i2 = npix
+        self.nweights = len(self.epotherargs) - (2 if self.ename == 'MAXCOMP' else 1)
+        self.nep = len(self.epotherargs)
+        self.delta = self.epotherargs[0]
+        # per-model overrides of the generic fluid arguments (grtrans_batch.py:219-322)
+        if self.fname == 'FFJET':
+            self.fdfile = self.jdfile
+        elif self.fname in ('HARM', 'HARM3D', 'KORAL', 'KORALNTH'):
+            self.fdfile, self.fhfile, self.fnt, self.findf = self.hdfile, self.hhfile, self.hnt, self.hindf
+        else:
+            self.fdfile, self.fgfile, self.fhfile = self.tdfile, self.tgfile, self.hhfile
+            self.fnt, self.fnfiles, self.findf = self.tnt, self.tnfiles, self.tindf
+
+    def write(self, fname):
+        q = lambda s: "'" + s + "'"  # noqa: E731
+        csv = lambda v: ",".join(str(x) for x in v)  # noqa: E731
+        names = ['geodata', 'fluiddata', 'emisdata', 'general', 'harm', 'analytic']
+        blocks = [
+            (['standard', 'mumin', 'mumax', 'nmu', 'phi0', 'spin', 'uout', 'uin', 'rcut', 'nrotype', 'gridvals', 'nn',
+              'i1', 'i2', 'extra', 'debug'],
+             [self.standard, self.mumin, self.mumax, self.nmu, self.phi0, self.spin, self.uout, self.uin, self.rcut,
+              self.nrotype, csv(self.gridvals), csv(self.nn), self.i1, self.i2, self.extra, self.debug]),
+            (['fname', 'dt', 'nt', 'nload', 'nmdot', 'mdotmin', 'mdotmax', 'sigcut'],
+             [q(self.fname), self.dt, self.nt, self.nload, self.nmdot, self.mdotmin, self.mdotmax, self.sigcut]),
+            (['ename', 'mbh', 'nfreq', 'fmin', 'fmax', 'muval', 'gmin', 'gmax', 'p1', 'p2', 'jetalpha', 'stype', 'delta',
+              'nweights', 'coefindx'],
+             [q(self.ename), self.mbh, self.nfreq, self.fmin, self.fmax, self.muval, self.gmin, self.gmax, self.p1,
+              self.p2, self.jetalpha, q(self.stype), self.delta, self.nweights, csv(self.epcoefindx)]),
+            (['use_geokerr', 'nvals', 'iname', 'cflag'], [self.use_geokerr, self.nvals, q(self.iname), self.cflag]),
+            (['fdfile', 'fgfile', 'fhfile', 'fnt', 'fnfiles', 'findf', 'fjonfix', 'foffset', 'fsim', 'fdindf', 'fmagcrit',
+              'fscalefac'],
+             [q(self.fdfile), q(self.fgfile), q(self.fhfile), self.fnt, self.fnfiles, self.findf, self.fjonfix,
+              self.foffset, q(self.fsim), self.fdindf, self.fmagcrit, self.fscalefac]),
+            (['fnw', 'fwmin', 'fwmax', 'fnfreq_tab', 'ffmin', 'ffmax', 'frmax', 'fnr', 'fsigt', 'ffcol', 'frspot', 'fr0spot',
+              'fn0spot', 'ftscl', 'frscl', 'fmdot', 'fnscl', 'fnnthscl', 'fnnthp', 'fbeta', 'fbl06', 'fnp', 'ftp', 'frin',
+              'frout', 'fthin', 'fthout', 'fphiin', 'fphiout'],
+             [self.pnw, self.pwmin, self.pwmax, self.pnfreq_tab, self.pfmin, self.pfmax, self.prmax, self.pnr, self.psigt,
+              self.pfcol, self.hrspot, self.hr0spot, self.hn0spot, self.ntscl, self.nrscl, self.tmdot, self.snscl,
+              self.snnthscl, self.snnthp, self.sbeta, self.sbl06, self.snp, self.snt, self.srin, self.srout, self.sthin,
+              self.sthout, self.sphiin, self.sphiout])]
+        args, vals, nargs = [], [], []
+        for a, v in blocks:
+            args += a
+            vals += v
+            nargs.append(len(a))
+        nm.write_namelist(fname, names, args, vals, nargs)
+
+
+class grtrans:
+    """run & analyze grtrans on the MI355X path (same methods as the reference's class grtrans)"""
+
+    def write_grtrans_inputs(self, ifile, oname='grtrans.out', **kwargs):
+        self.inputs = grtrans_inputs(**kwargs)
+        self.inputs.write(ifile)
+        self.set_grtrans_input_file(ifile, oname)
+
+    def set_grtrans_input_file(self, fname, oname):
+        nm.write_namelist('files.in', ['files'], ['ifile', 'ofile'], ['"' + fname + '"', '"' + oname + '"'], [2])
+        self.ifile = fname
+        self.ofile = oname
+
+    def run_grtrans(self, exe=None, **kwargs):
+        if os.path.exists(self.ofile):
+            os.remove(self.ofile)
+        env = dict(os.environ)
+        env.setdefault("GRTRANS_AMD_DATA", capi.DATA)
+        subprocess.check_call([exe or HOST_EXE], env=env)
+
+    def run_pgrtrans(self, device=0, **kwargs):
+        """Same kwargs as write_grtrans_inputs; fills ivals(nvals,npix,ncams), ab(2,npix), nu."""
+        inp = self.inputs = grtrans_inputs(**kwargs)
+        if inp.nt != 1 or inp.nload != 1 or inp.extra != 0:
+            raise capi.GrtError("nt/nload > 1 and extra=1 are not on the device yet")
+        nfreq, nmu, nmdot = int(inp.nfreq), int(inp.nmu), int(inp.nmdot)
+        freqs = np.array([inp.fmin]) if nfreq == 1 else inp.fmin * np.exp(np.arange(nfreq) * np.log(inp.fmax / inp.fmin) / (nfreq - 1))
+        mu0 = np.array([inp.mumin]) if nmu == 1 else inp.mumin + (inp.mumax - inp.mumin) / (nmu - 1) * np.arange(nmu)
+        npix = inp.nn[0] * inp.nn[1]
+        ncams = nmdot * nfreq * nmu
+        dev = capi.Device(device)
+        try:
+            dev.load_tables()
+            if inp.fname == 'FFJET':
+                path = inp.fdfile if os.path.exists(inp.fdfile) else os.path.join(capi.DATA, inp.fdfile)
+                dev.load_ffjet(path)
+            ivals = np.zeros((inp.nvals, npix, ncams))
+            ab = np.zeros((2, npix))
+            for j in range(nmu):
+                cam = capi.make_camera(inp.standard, inp.gridvals, inp.nn, inp.spin, float(mu0[j]), inp.uout, inp.phi0)
+                for m in range(nmdot):
+                    em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
+                                        inp.muval, inp.epcoefindx)
+                    pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
+                                                           nvals=inp.nvals)
+                    for k in range(nfreq):
+                        c = (j * nfreq * nmdot) + m * nfreq + k          # grtrans_driver.f90:324
+                        ivals[:, inp.i1 - 1:inp.i2, c] = pix[k].T
+                    ab[:, inp.i1 - 1:inp.i2] = loc.T
+        finally:
+            dev.close()
+        self.ivals, self.ab, self.nu = ivals, ab, freqs
+        self.nx, self.ny, self.nvals = int(inp.nn[0]), int(inp.nn[1]), int(inp.nvals)
+
+    def read_grtrans_output(self, bin=1):
+        """cflag=0 binary file (camera.f90:321-340): Fortran sequential records per camera."""
+        if bin == 0:
+            raise capi.GrtError("FITS output (cflag=1) needs cfitsio; write cflag=0 and read with bin=1")
+        ivals, nus = [], []
+        with open(self.ofile, 'rb') as f:
+            def rec(dtype):
+                n = np.fromfile(f, dtype='i4', count=1)
+                if n.size == 0:
+                    return None
+                a = np.fromfile(f, dtype=dtype, count=int(n[0]) // np.dtype(dtype).itemsize)
+                np.fromfile(f, dtype='i4', count=1)
+                return a
+            while True:
+                h = rec('i4')
+                if h is None:
+                    break
+                nx, ny, nvals = [int(x) for x in h]
+                nkey = int(rec('i4')[0])
+                keys = [float(rec('f4')[0]) for _ in range(nkey)]
+                ab = rec('f4').reshape(nx * ny, 2)
+                ivals.append(rec('f4').reshape(nx * ny, nvals))
+                nus.append(keys[2] if nkey >= 3 else 0.0)
+        self.ab = ab
+        self.ivals = np.stack(ivals, axis=2)
+        self.nu = np.array(nus)
+        self.nx, self.ny, self.nvals = nx, ny, nvals
+        self.calc_spec(len(nus))
+
+    def calc_spec(self, n):
+        if self.ny != 1:
+            da = self.ab[self.ny, 0] - self.ab[0, 0]
+            db = self.ab[1, 1] - self.ab[0, 1]
+            spec = np.sum(self.ivals, 0) * da * db
+        else:
+            da = self.ab[1, 0] - self.ab[0, 0]
+            db = 0.
+            spec = np.array([[np.sum(self.ivals[:, j, i] * self.ab[:, 0], 0) * da * 2. * 3.14
+                              for j in range(self.nvals)] for i in range(n)])
+        self.spec, self.da, self.db = spec, da, db
+
+    def calc_spec_pgrtrans(self, n):
+        if self.ny != 1:
+            da = self.ab[0, self.ny] - self.ab[0, 0]
+            db = self.ab[1, 1] - self.ab[1, 0]
+            spec = np.sum(self.ivals, 1) * da * db
+        else:
+            da = self.ab[0, 1] - self.ab[0, 0]
+            db = 0.
+            spec = np.array([[np.sum(self.ivals[j, :, i] * self.ab[0, :], 0) * da * 2. * np.arccos(-1.)
+                              for j in range(self.nvals)] for i in range(n)])
+        self.spec, self.da, self.db = spec, da, db

@@ -1,0 +1,90 @@
+! grtrans_amd/host/grt_cabi.f90
+! ISO_C_BINDING view of include/grtrans_amd.h: the only door between the Fortran 90 host
+! (namelists, parameter grids, result arrays, output files) and the gfx950 kernels.
+module grt_cabi
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: GRT_FLUID_FFJET = 13, GRT_FLUID_HARM = 12, GRT_FLUID_SPHACC = 1, &
+       GRT_FLUID_THINDISK = 2
+  integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
+       GRT_EMIS_BB = 8
+
+  type, bind(C) :: grt_camera          ! GrtCam
+     real(c_double) :: a1, a2, b1, b2
+     real(c_double) :: a, mu0, uout, u0, offset, phi0
+     integer(c_int32_t) :: standard, nro, nphi, nup
+     integer(c_int32_t) :: usegeor, phit, mufill, kext, next, pad0
+  end type grt_camera
+
+  type, bind(C) :: grt_emis            ! GrtEmis
+     real(c_double) :: mbh, nfac, bfac
+     real(c_double) :: gmin, gmax, p1
+     real(c_double) :: muval
+     integer(c_int32_t) :: etype
+     integer(c_int32_t) :: coefindx(7)
+  end type grt_emis
+
+  type, bind(C) :: grt_stats           ! GrtStats
+     integer(c_int64_t) :: ray_steps, rays_live, rays_dead
+     real(c_double) :: ms_setup, ms_trace, ms_total
+  end type grt_stats
+
+  interface
+     function grt_init(device) bind(C, name='grt_init') result(rc)
+       import :: c_int
+       integer(c_int), value :: device
+       integer(c_int) :: rc
+     end function grt_init
+     function grt_free() bind(C, name='grt_free') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function grt_free
+     function grt_load_ffjet_file(path) bind(C, name='grt_load_ffjet_file') result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), dimension(*), intent(in) :: path
+       integer(c_int) :: rc
+     end function grt_load_ffjet_file
+     function grt_load_polsynchpl_tables_file(path) bind(C, name='grt_load_polsynchpl_tables_file') result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), dimension(*), intent(in) :: path
+       integer(c_int) :: rc
+     end function grt_load_polsynchpl_tables_file
+     function grt_make_camera(cam, standard, gridvals, nn, spin, mu0, uout, phi0) &
+          bind(C, name='grt_make_camera') result(rc)
+       import :: c_int, c_double, grt_camera
+       type(grt_camera), intent(out) :: cam
+       integer(c_int), value :: standard
+       real(c_double), intent(in) :: gridvals(4)
+       integer(c_int), intent(in) :: nn(3)
+       real(c_double), value :: spin, mu0, uout, phi0
+       integer(c_int) :: rc
+     end function grt_make_camera
+     function grt_trace_tile(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, pixvals, pixloc, &
+          ray_status, st) bind(C, name='grt_trace_tile') result(rc)
+       import :: c_int, c_int64_t, c_double, c_float, c_int32_t, grt_camera, grt_emis, grt_stats
+       type(grt_camera), intent(in) :: cam
+       integer(c_int64_t), value :: i1, i2
+       integer(c_int), value :: fluid_model, nfreq, iflag, nvals, nextra
+       type(grt_emis), intent(in) :: em
+       real(c_double), intent(in) :: freqs(*)
+       real(c_float), intent(out) :: pixvals(*), pixloc(*)
+       integer(c_int32_t), intent(out) :: ray_status(*)
+       type(grt_stats), intent(out) :: st
+       integer(c_int) :: rc
+     end function grt_trace_tile
+  end interface
+
+contains
+
+  function cstr(s) result(c)
+    character(len=*), intent(in) :: s
+    character(kind=c_char), dimension(len_trim(s)+1) :: c
+    integer :: i
+    do i = 1, len_trim(s)
+       c(i) = s(i:i)
+    end do
+    c(len_trim(s)+1) = c_null_char
+  end function cstr
+
+end module grt_cabi

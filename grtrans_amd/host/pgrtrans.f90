@@ -1,0 +1,206 @@
+! grtrans_amd/host/pgrtrans.f90
+! Drop-in for the reference's module pgrtrans (pgrtrans.f90:1-260): same module name, same
+! grtrans_main argument list (85 positional arguments, types as pgrtrans.f90:35-58), same module
+! results ivals(nvals+nextra, nx*ny, ncams), ab(2, nx*ny), freqs(nfreq), same del_pgrtrans_data.
+! What changes is what happens inside the i=i1..i2 loop: instead of one grtrans_driver call per
+! pixel on the host (pgrtrans.f90:196-212) the whole pixel range goes to the MI355X through the
+! C ABI (grt_trace_tile), once per (mu0, mdot) pair.
+module pgrtrans
+  use iso_c_binding
+  implicit none
+
+  real(8), allocatable, dimension(:,:,:) :: ivals
+  real(8), allocatable, dimension(:,:) :: ab
+  real(8), allocatable, dimension(:) :: freqs
+  real(8) :: last_ray_steps = 0d0, last_kernel_ms = 0d0    ! extra: what the tracer reported
+
+contains
+
+  subroutine grtrans_main(standard,mumin,mumax,nmu,phi0,spin,&
+       uout,uin, rcut, nrotype, gridvals, nn,i1,i2,fname, dt, nt, nload, &
+       nmdot, mdotmin, mdotmax,ename, mbh, nfreq, fmin, fmax, muval,&
+       gmin, gmax,p1, p2, jetalpha, stype,use_geokerr, nvals, iname,&
+       cflag, extra, debug,outfile, fdfile,fhfile,fgfile,fsim,fnt,findf,fnfiles,fjonfix, &
+       fnw,fnfreq_tab,fnr,foffset,fdindf,fmagcrit,frspot,fr0spot,fn0spot,ftscl,frscl, &
+       fwmin,fwmax,ffmin,ffmax,frmax,fsigt,ffcol,fmdot,fnscl,fnnthscl,fnnthp,fbeta, &
+       fbl06,fnp,ftp,frin,frout,fthin,fthout,fphiin,fphiout,fscalefac,sigcut,epcoefindx,epotherargs,nepotherargs)
+    use grt_cabi
+    use omp_lib
+    integer, intent(in) :: standard,nrotype,nvals,nfreq,nmu,cflag,nt,nmdot,nload,extra,i1,i2,nepotherargs,debug
+    logical, intent(in) :: use_geokerr
+    real(kind=8), intent(in) :: mumax,mumin,rcut,mbh,uout,uin,fmin,fmax,dt,mdotmin,mdotmax,phi0,muval,gmin,gmax,&
+         p1,p2,jetalpha
+    character(len=*), intent(in) :: ename,fname,iname,stype
+    character(len=*), intent(in) :: outfile
+    real(kind=8), dimension(4), intent(in) :: gridvals
+    real(kind=8) :: spin
+    integer, dimension(3), intent(in) :: nn
+    character(len=*), intent(in) :: fdfile,fhfile,fgfile,fsim
+    integer, intent(in) :: fnt,findf,fnfiles,fjonfix,fnw,fnfreq_tab,fnr,foffset,fdindf,fmagcrit,fbl06
+    real(8), intent(in) :: frspot,fr0spot,fn0spot,ftscl,frscl,fwmin,fwmax,ffmin,ffmax,frmax,fsigt,ffcol,fmdot,&
+         fnnthp,fnnthscl,fnscl,fbeta,ftp,fnp,frin,frout,fthin,fthout,fphiin,fphiout,fscalefac,sigcut
+    real(8), dimension(nepotherargs), intent(in) :: epotherargs
+    integer, dimension(7), intent(in) :: epcoefindx
+
+    integer :: nro, nphi, nup, ncams, nextra, j, l, m, k, cam_index, rc, fluid_id, emis_id, iflag, npix, ntile, dev
+    real(8), allocatable :: mdots(:), mu0(:)
+    real(c_float), allocatable :: pixvals(:), pixloc(:)
+    integer(c_int32_t), allocatable :: status(:)
+    type(grt_camera) :: cam
+    type(grt_emis) :: em
+    type(grt_stats) :: st
+    real(8) :: wtime
+    character(len=512) :: datadir, path
+    integer :: tempi
+
+    nro = nn(1); nphi = nn(2); nup = nn(3); npix = nro*nphi
+    allocate(freqs(nfreq), mu0(nmu), mdots(nmdot))
+    ncams = nmdot*nfreq*nmu*nt
+    ! log-spaced frequencies / mdots, linear mu0 (pgrtrans.f90:87-104)
+    if (nfreq == 1) then
+       freqs = (/fmin/)
+    else
+       freqs = fmin*exp((/(tempi-1,tempi=1,nfreq)/)*log(fmax/fmin)/(nfreq-1))
+    end if
+    if (nmdot == 1) then
+       mdots = (/mdotmin/)
+    else
+       mdots = mdotmin*exp((/(tempi-1,tempi=1,nmdot)/)*log(mdotmax/mdotmin)/(nmdot-1))
+    end if
+    if (nmu == 1) then
+       mu0 = (/mumin/)
+    else
+       mu0 = mumin+(mumax-mumin)/(nmu-1)*(/(tempi-1,tempi=1,nmu)/)
+    end if
+    nextra = 0
+    if (extra == 1) then
+       if (nup > 1) then
+          nextra = 19
+       else
+          nextra = 7
+       end if
+    end if
+
+    ! ---- what this build can put on the device; everything else stops loudly (no CPU path) ----
+    if (.not. use_geokerr) call die('use_geokerr=F is not supported')
+    if (nt /= 1 .or. nload /= 1) call die('time-dependent runs (nt,nload > 1) are not supported yet')
+    if (extra /= 0 .or. debug /= 0) call die('extra=1 / debug=1 are not supported yet')
+    select case (trim(fname))
+    case ('FFJET'); fluid_id = GRT_FLUID_FFJET
+    case default; call die('fluid model '//trim(fname)//' is not on the device yet')
+    end select
+    select case (trim(ename))
+    case ('POLSYNCHPL'); emis_id = GRT_EMIS_POLSYNCHPL
+    case default; call die('emissivity '//trim(ename)//' is not on the device yet')
+    end select
+    select case (trim(iname))          ! rad_trans.f90:29-37
+    case ('delo'); iflag = 1
+    case ('formal'); iflag = 2
+    case ('lsoda', 'lsodasph')
+       call die('iname='//trim(iname)//': LSODA has no device implementation, use formal or delo')
+    case default; call die('unknown iname '//trim(iname))
+    end select
+
+    call get_environment_variable('GRT_DEVICE', path)
+    dev = 0
+    if (len_trim(path) > 0) read(path, *) dev
+    rc = grt_init(int(dev, c_int)); if (rc /= 0) call die_rc('grt_init', rc)
+    call get_environment_variable('GRTRANS_AMD_DATA', datadir)
+    if (len_trim(datadir) == 0) datadir = '.'
+    path = trim(datadir)//'/polsynchpl_tables.bin'
+    rc = grt_load_polsynchpl_tables_file(cstr(path)); if (rc /= 0) call die_rc('grt_load_polsynchpl_tables_file '//trim(path), rc)
+    if (fluid_id == GRT_FLUID_FFJET) then
+       path = trim(fdfile)              ! as load_fluid_model does (fluid.f90:226-228)
+       rc = grt_load_ffjet_file(cstr(path))
+       if (rc /= 0) then
+          path = trim(datadir)//'/'//trim(fdfile)
+          rc = grt_load_ffjet_file(cstr(path))
+       end if
+       if (rc /= 0) call die_rc('grt_load_ffjet_file '//trim(fdfile), rc)
+    end if
+
+    write(6,*) 'welcome to grtrans! (MI355X per-pixel path)'
+    allocate(ivals(nvals+nextra, npix, ncams)); ivals = 0d0
+    allocate(ab(2, npix)); ab = 0d0
+    ntile = i2 - i1 + 1
+    allocate(pixvals(int(nvals+nextra,8)*ntile*nfreq), pixloc(2*ntile), status(ntile))
+    last_ray_steps = 0d0; last_kernel_ms = 0d0
+    do j = 1, nmu
+       rc = grt_make_camera(cam, int(standard, c_int), gridvals, int(nn, c_int), spin, mu0(j), uout, phi0)
+       if (rc /= 0) call die_rc('grt_make_camera', rc)
+       wtime = omp_get_wtime()
+       do l = 1, nt
+          do m = 1, nmdot
+             em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
+             em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
+             em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
+             rc = grt_trace_tile(cam, int(i1, c_int64_t), int(i2, c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &
+                  int(iflag, c_int), int(nvals, c_int), int(nextra, c_int), pixvals, pixloc, status, st)
+             if (rc /= 0) call die_rc('grt_trace_tile', rc)
+             last_ray_steps = last_ray_steps + dble(st%ray_steps); last_kernel_ms = last_kernel_ms + st%ms_total
+             do k = 1, nfreq
+                ! camera index (l-1)*nfreq*nparams+(m-1)*nfreq+k with l -> (j-1)*nt+l (grtrans_driver.f90:324)
+                cam_index = ((j-1)*nt + l - 1)*nfreq*nmdot + (m-1)*nfreq + k
+                ivals(:, i1:i2, cam_index) = reshape(dble(pixvals((k-1)*int(nvals+nextra,8)*ntile+1 : &
+                     k*int(nvals+nextra,8)*ntile)), (/nvals+nextra, ntile/))
+             end do
+          end do
+       end do
+       write(6,*) 'grtrans wall time elapsed: ', omp_get_wtime() - wtime
+       write(6,*) 'ray-steps: ', last_ray_steps, ' device ms: ', last_kernel_ms
+    end do
+    ab(:, i1:i2) = reshape(dble(pixloc), (/2, ntile/))      ! c(1)%pixloc (pgrtrans.f90:227)
+    if (len_trim(outfile) > 0) then
+       do m = 1, ncams
+          call write_camera(trim(outfile), m, nro, nphi, nvals+nextra, freqs(1+mod(m-1,nfreq)), ab, ivals(:,:,m), cflag)
+       end do
+    end if
+    deallocate(pixvals, pixloc, status, mu0, mdots)
+    rc = grt_free()
+  end subroutine grtrans_main
+
+  ! Binary camera file, one block per camera: the record structure of camera.f90:321-340
+  ! (nx,ny,nvals / nkey / nkey x real(4) records / pixloc / pixvals), Fortran sequential unformatted.
+  subroutine write_camera(outfile, cnum, nx, ny, nv, freq, abv, iv, cflag)
+    character(len=*), intent(in) :: outfile
+    integer, intent(in) :: cnum, nx, ny, nv, cflag
+    real(8), intent(in) :: freq, abv(:,:), iv(:,:)
+    integer :: k
+    real(4) :: kvals(3)
+    if (cflag == 1) call die('cflag=1 (FITS) needs cfitsio, which this build does not link; use cflag=0')
+    if (cnum == 1) then
+       open(unit=12, file=outfile, form='unformatted', status='replace')
+    else
+       open(unit=12, file=outfile, form='unformatted', position='append', status='old')
+    end if
+    kvals = (/real(nx), real(ny), real(freq)/)
+    write(12) nx, ny, nv
+    write(12) 3
+    do k = 1, 3
+       write(12) kvals(k)
+    end do
+    write(12) real(abv)
+    write(12) real(iv)
+    close(12)
+  end subroutine write_camera
+
+  subroutine del_pgrtrans_data()
+    if (allocated(ivals)) deallocate(ivals)
+    if (allocated(ab)) deallocate(ab)
+    if (allocated(freqs)) deallocate(freqs)
+  end subroutine del_pgrtrans_data
+
+  subroutine die(msg)
+    character(len=*), intent(in) :: msg
+    write(0,*) 'grtrans_amd: ', trim(msg)
+    error stop 2
+  end subroutine die
+
+  subroutine die_rc(what, rc)
+    character(len=*), intent(in) :: what
+    integer, intent(in) :: rc
+    write(0,*) 'grtrans_amd: ', trim(what), ' failed, code ', rc
+    error stop 3
+  end subroutine die_rc
+
+end module pgrtrans

@@ -95,6 +95,9 @@ int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_mode
 int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
                             int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st);
 int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status);
+/* device-to-device copy of the resident pixvals into a caller-owned device buffer (e.g. a torch tensor
+ * that RCCL then gathers); count = number of floats */
+int grt_copy_resident_pixvals(void *d_dst, int64_t count);
 
 /* Optional per-step SoA record (r,theta,phi,lambda,I,Q,U,V) fp64, [8][nrays][maxpts] in HBM, of the
  * first frequency: what geodebug.out holds per ray (grtrans_driver.f90:94-110,370-373).  0 disables. */

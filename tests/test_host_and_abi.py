@@ -1,0 +1,131 @@
+"""CPU tests: host-side logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+CONFIGS = {
+    'ffjet': dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=1, nmu=1, fmin=3.45e11, fmax=3.45e11,
+                  ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1, nn=[100, 100, 400], uout=0.01, mbh=3.4e9,
+                  mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], ntscl=2., nrscl=70.),
+    'ffjet_formal25': dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=25, nmu=1, fmin=2.41e10,
+                           fmax=6.31e14, ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1, nn=[1024, 1024, 400],
+                           uout=0.01, mbh=3.4e9, mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], ntscl=2.,
+                           nrscl=70., iname='formal', cflag=0),
+    'sphacc': dict(fname='SPHACC', nfreq=1, nmu=1, fmin=2.41e11, fmax=2.41e11, ename='POLSYNCHTH', nvals=4, spin=0.,
+                   mbh=10., standard=1, uout=.04, nn=[256, 256, 200], mumin=0.5, mumax=0.5, iname='formal'),
+    'thindisk': dict(),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_inputs_in_text_identical_to_reference_writer(name, tmp_path, monkeypatch):
+    # golden text = what the reference's grtrans_batch.py wrote for the same kwargs (tools/make_golden_inputs.py)
+    from grtrans_amd import grtrans_batch as gb
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', **CONFIGS[name])
+    assert open('inputs.in').read() == open(os.path.join(G, 'inputs_%s.in' % name)).read()
+    assert open('files.in').read() == open(os.path.join(G, 'files_%s.in' % name)).read()
+
+
+def test_input_defaults_and_clamping():
+    from grtrans_amd.grtrans_batch import grtrans_inputs
+    i = grtrans_inputs(nn=[10, 10, 50], i1=500, i2=5000)
+    assert (i.i1, i.i2) == (99, 100)                     # grtrans_batch.py:159-164
+    i = grtrans_inputs(ename='MAXCOMP', epotherargs=[1., 2., 3., 4.])
+    assert i.nweights == 2 and i.delta == 1. and i.nep == 4
+    i = grtrans_inputs(fname='FFJET', jdfile='x.bin')
+    assert i.fdfile == 'x.bin'
+
+
+def declared_symbols():
+    h = open(os.path.join(ROOT, "include", "grtrans_amd.h")).read()
+    h = re.sub(r'/\*.*?\*/', '', h, flags=re.S)
+    return sorted(set(re.findall(r'\b(grt_[a-z_0-9]+)\s*\(', h)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from grtrans_amd import capi
+    lib = capi.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), "libgrtrans_amd.so does not export %s" % s
+
+
+def test_abi_struct_layouts_match_header():
+    from grtrans_amd import capi
+    assert C.sizeof(capi.GrtCam) == 10 * 8 + 10 * 4
+    assert C.sizeof(capi.GrtEmis) == 7 * 8 + 8 * 4
+    assert C.sizeof(capi.GrtStats) == 3 * 8 + 3 * 8
+
+
+def test_no_cpu_fallback_without_device():
+    # Without a HIP device the product must fail loudly, never compute on the host.
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from grtrans_amd import capi
+    with pytest.raises(capi.GrtError):
+        capi.Device(0)
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (8, 8, 50), 0.998, 0.906, 0.01)   # pure host arithmetic
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    with pytest.raises(capi.GrtError):
+        capi.trace_tile(cam, 1, 64, "FFJET", em, [3.45e11], "formal")
+
+
+def test_make_camera_matches_reference_camera_scalars():
+    from grtrans_amd import capi
+    g = np.load(os.path.join(G, "ffjet_100x100x400.npz"))
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (100, 100, 400), 0.998, 0.906, 0.01)
+    u0, uout, offset, mu0, a, kext, nxt, nup = g["cam_scal"]
+    assert (cam.u0, cam.uout, cam.offset, cam.mu0, cam.a) == (u0, uout, offset, mu0, a)
+    assert (cam.kext, cam.next, cam.nup) == (int(kext), int(nxt), int(nup))
+
+
+def test_strips_tile_the_image():
+    from grtrans_amd.tiling import strip
+    for npix in (1024, 1000, 7):
+        for world in (1, 2, 3, 8):
+            if world > npix:
+                continue
+            edges = [strip(r, world, npix) for r in range(world)]
+            assert edges[0][0] == 1 and edges[-1][1] == npix
+            assert all(edges[r][1] + 1 == edges[r + 1][0] for r in range(world - 1))
+
+
+def test_two_rank_gloo_gather_equals_single_image(tmp_path):
+    # N>1 path on CPU: two processes (gloo), each traces its strip with the CPU oracle standing in for
+    # the device, tiles gathered with the same helper bench.py uses; must equal the one-process image exactly.
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from grtrans_amd.tiling import strip, gather_tiles
+from oracle import orabind
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+nn = (12, 11, 60)
+o = orabind.Oracle(nn=nn, iname="formal")
+i1, i2 = strip(rank, world, nn[0] * nn[1])
+pix, npts, _ = o.trace(i1, i2, [3.45e11], nthreads=1)
+full = gather_tiles(torch.from_numpy(pix), dist, 0)
+if rank == 0:
+    ref, _, _ = o.trace(1, nn[0] * nn[1], [3.45e11], nthreads=1)
+    assert np.array_equal(full.numpy(), ref), "gathered image differs"
+    open(%r, "w").write("ok")
+dist.destroy_process_group()
+''' % (ROOT, str(tmp_path / "ok")))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)], env=env,
+                          timeout=600)
+    assert (tmp_path / "ok").read_text() == "ok"
