@@ -110,3 +110,32 @@ def test_library_refuses_unsupported(dev):
     em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
     with pytest.raises(capi.GrtError):
         capi.trace_tile(cam, 1, 64, "FFJET", em, [FREQ], "lsoda")   # LSODA stays CPU-only
+
+
+def test_fortran_host_exe_and_harness_end_to_end(tmp_path, monkeypatch):
+    # files.in -> ./grtrans (Fortran 90 host, ISO_C_BINDING -> C ABI -> kernels) -> binary output file
+    # -> reader; and the same problem through run_pgrtrans.  Both against the reference golden image.
+    import subprocess
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "ffjet_32x32x100.npz"))
+    kw = dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=1, nmu=1, fmin=FREQ, fmax=FREQ,
+              ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1, nn=[32, 32, 100], uout=0.01, mbh=3.4e9,
+              mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], ntscl=2., nrscl=70., iname='formal', cflag=0)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (1024, 4, 1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal"]) < STOKES_TOL
+    assert np.array_equal(x.ab[:, 0], g["cam_alpha"].astype(np.float32))
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert y.ivals.shape == (4, 1024, 1) and y.ab.shape == (2, 1024)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
+    y.calc_spec_pgrtrans(1)
+    x.calc_spec(1)
+    assert np.allclose(y.spec[:, 0], x.spec[:, 0], rtol=1e-6)
