@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(PKG, "libgrtrans_amd.so")
+LIB = os.environ.get("GRTRANS_AMD_LIB", os.path.join(PKG, "libgrtrans_amd.so"))
 DATA = os.path.join(PKG, "data")
 
 FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13}       # fluid.f90:40-43
@@ -32,7 +32,8 @@ class GrtEmis(C.Structure):
 
 class GrtStats(C.Structure):
     _fields_ = [("ray_steps", C.c_int64), ("rays_live", C.c_int64), ("rays_dead", C.c_int64),
-                ("ms_setup", C.c_double), ("ms_trace", C.c_double), ("ms_total", C.c_double)]
+                ("ms_setup", C.c_double), ("ms_trace", C.c_double), ("ms_total", C.c_double),
+                ("ms_geo", C.c_double), ("ms_transfer", C.c_double)]
 
 
 class GrtError(RuntimeError):

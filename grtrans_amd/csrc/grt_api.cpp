@@ -11,12 +11,17 @@
 #include "grt_types.h"
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters);
-extern "C" hipError_t grt_launch_trace(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays, const int *live,
-                                       int nlive, const GrtFFJet *fj, const GrtTables *tb, const GrtEmis *em, int nfreq,
-                                       const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status,
-                                       long long i1, double *steps, long long steps_ray_stride,
-                                       long long steps_field_stride, unsigned long long *step_counter);
+                                       int *ray_npts, int *live, int *counters, void *rrays);
+extern "C" size_t grt_sizeof_realray(void);
+extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
+                                     const int *live, int nlive, double *steps, unsigned char *flags,
+                                     long long ray_stride, long long field_stride, int nfields);
+extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays,
+                                          const int *live, int nlive, const GrtFFJet *fj, const GrtTables *tb,
+                                          const GrtEmis *em, int nfreq, const double *freqs, float *pixvals,
+                                          int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
+                                          const unsigned char *flags, long long ray_stride, long long field_stride,
+                                          int nfields, unsigned long long *step_counter);
 
 namespace {
 
@@ -35,9 +40,15 @@ struct Ctx {
   // work buffers (grown on demand)
   size_t cap_rays = 0, cap_npts = 0, cap_live = 0, cap_pix = 0, cap_freq = 0, cap_steps = 0;
   GrtRay *d_rays = nullptr;
+  char *d_rrays = nullptr;
+  size_t cap_rrays = 0;
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
+  unsigned char *d_flags = nullptr;
+  size_t cap_flags = 0;
+  int steps_fields = 0;
+  hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long *d_stepcount = nullptr;
   int record_steps = 0;
   long long steps_rays = 0, steps_maxpts = 0;
@@ -79,6 +90,7 @@ int grt_init(int device) {
   C.device = device;
   HIPCHK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
+  for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&C.evk[i]));
   HIPCHK(hipMalloc((void **)&C.d_counters, 4 * sizeof(int)));
   HIPCHK(hipMalloc((void **)&C.d_stepcount, sizeof(unsigned long long)));
   C.init = true;
@@ -88,12 +100,14 @@ int grt_init(int device) {
 int grt_free(void) {
   if (!C.init) return 0;
   (void)hipStreamSynchronize(C.stream);
-  void *ptrs[] = {C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
-                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount};
+  void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
+                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
     if (C.ev[i]) (void)hipEventDestroy(C.ev[i]);
+  for (int i = 0; i < 4; ++i)
+    if (C.evk[i]) (void)hipEventDestroy(C.evk[i]);
   if (C.stream) (void)hipStreamDestroy(C.stream);
   C = Ctx();
   return 0;
@@ -226,31 +240,41 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
   if ((rc = grow(C.d_rays, C.cap_rays, (size_t)nrays))) return rc;
+  if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)nrays * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)nfreq))) return rc;
+  // per-step record in HBM: [field][ray][maxpts] fp64, fields r,theta,lambda always (they carry the
+  // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
   const long long maxpts = cam->nup + cam->next;
-  double *steps = nullptr;
-  if (C.record_steps) {
-    if ((rc = grow(C.d_steps, C.cap_steps, (size_t)8 * nrays * maxpts))) return rc;
-    steps = C.d_steps;
-    C.steps_rays = nrays; C.steps_maxpts = maxpts;
-  }
+  const int nfields = C.record_steps ? 8 : 3;
+  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nfields * nrays * maxpts))) return rc;
+  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * maxpts))) return rc;
+  C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields;
+  const long long fstride = (long long)nrays * maxpts;
   HIPCHK(hipMemcpyAsync(C.d_freqs, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
   HIPCHK(hipMemsetAsync(C.d_pixvals, 0, (size_t)nrays * nfreq * (nvals + nextra) * sizeof(float), C.stream));
   HIPCHK(hipEventRecord(C.ev[0], C.stream));
-  HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1, nrays, C.d_rays, C.d_npts, C.d_live, C.d_counters));
-  HIPCHK(hipEventRecord(C.ev[1], C.stream));
-  int nlive = 0;
-  HIPCHK(hipMemcpyAsync(&nlive, C.d_counters, sizeof(int), hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1, nrays, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays));
+  int ncls[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
+  const int nlive = ncls[0] + ncls[1];
   HIPCHK(hipEventRecord(C.ev[1], C.stream));
-  HIPCHK(grt_launch_trace(C.stream, iflag, cam, C.d_rays, C.d_live, nlive, &C.ffjet, &C.tables, em, nfreq, C.d_freqs,
-                          C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, steps, maxpts,
-                          (long long)nrays * maxpts, C.d_stepcount));
+  // class 0 (four real roots, fast path) sits at the front of live[], class 1 (generic) at the back
+  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, maxpts, fstride, nfields));
+  HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
+                        maxpts, fstride, nfields));
+  HIPCHK(hipEventRecord(C.evk[0], C.stream));
+  HIPCHK(grt_launch_transfer(C.stream, iflag, cam, C.d_rays, C.d_live, ncls[0], &C.ffjet, &C.tables, em, nfreq, C.d_freqs,
+                             C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, maxpts,
+                             fstride, nfields, C.d_stepcount));
+  HIPCHK(grt_launch_transfer(C.stream, iflag, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &C.ffjet, &C.tables, em,
+                             nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
+                             C.d_flags, maxpts, fstride, nfields, C.d_stepcount));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
   if (st) {
@@ -262,6 +286,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
     st->rays_live = nlive;
     st->rays_dead = nrays - nlive;
     st->ms_trace = ms_trace;
+    float ms_geo = 0;
+    HIPCHK(hipEventElapsedTime(&ms_geo, C.ev[1], C.evk[0]));
+    st->ms_geo = ms_geo;
+    st->ms_transfer = ms_trace - ms_geo;
   }
   return 0;
 }
@@ -321,10 +349,11 @@ int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_mode
 }
 
 int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
-  if (!C.init || !C.d_steps) return GRT_E_NOTINIT;
+  if (!C.init || !C.d_steps || C.steps_fields < 8) return GRT_E_NOTINIT;
   if (ray0 < 0 || ray0 + nrays > C.steps_rays || maxpts != C.steps_maxpts) return GRT_E_BADARG;
+  static const int src[8] = {0, 1, 3, 2, 4, 5, 6, 7};   // public r,theta,phi,lambda,I,Q,U,V <- internal order
   for (int f = 0; f < 8; ++f)
-    HIPCHK(hipMemcpy(out + (size_t)f * nrays * maxpts, C.d_steps + ((size_t)f * C.steps_rays + ray0) * maxpts,
+    HIPCHK(hipMemcpy(out + (size_t)f * nrays * maxpts, C.d_steps + ((size_t)src[f] * C.steps_rays + ray0) * maxpts,
                      (size_t)nrays * maxpts * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }

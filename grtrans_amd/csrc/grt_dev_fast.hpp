@@ -1,0 +1,369 @@
+// grtrans_amd/csrc/grt_dev_fast.hpp
+// Fast per-point evaluation for rays whose U(u) has four real roots (Table 1 rows 7/8 of Dexter &
+// Agol 2009; >95 % of the rays of a=0.998 cameras, all escaping rays).  Same mathematics as
+// geomu / geor / geophitime (grt_dev_geo.hpp; reference geokerr_wrapper.f:771-1186, 1648-2357,
+// 2672-3134) but organised for the GPU:
+//
+//   * everything that depends only on the ray (roots, d_ij, M(mu) roots, Eq. 47-49 coefficient
+//     combinations, the u0-side integrals) is folded into a wave-uniform RealRay record once per wave;
+//   * the FIVE Carlson integrals that the reference evaluates with five separate duplication loops
+//     on the same triple (R_F, R_D and three R_J of (U12^2,U13^2,U14^2): geokerr_wrapper.f:1400-1436
+//     called from :1085, :2203-2210) run in ONE loop that shares the three square roots and lambda per
+//     iteration; likewise R_F, R_D, R_J of the mu end-point (:2572-2578, :3266-3270);
+//   * X_i, Y_i, U_1j^2 are computed once per point instead of once per integral.
+// The values agree with the literal evaluation to ~1e-15 relative (continuing a duplication loop past
+// its own tolerance only shrinks the series remainder); the integer outputs (tpm, tpr) are identical
+// (tests/test_hostsim_fast.py, tests/test_gpu_parity.py).
+#pragma once
+#include "grt_dev_ray.hpp"
+
+namespace grtd {
+
+// R_F, R_D(x,y,z) and NJ x R_J(x,y,z,p_k) with one shared duplication sequence.
+template <int NJ>
+GRT_NI void carlson_bundle(double x, double y, double z, const double *p, double &orf, double &ord, double *orj) {
+  const double TOLF = 0.0025, TOLD = 0.0015;
+  double xt = x, yt = y, zt = z, fac = 1.0, sumd = 0.0;
+  double pt[NJ], sumj[NJ], aa[NJ], bb[NJ], rcx[NJ];
+  bool neg[NJ];
+  // R_J with p<=0: Carlson's transformation (geokerr_wrapper.f:3723-3733); x,y,z enter symmetrically
+  double xs = dmin(x, dmin(y, z)), zs = dmax(x, dmax(y, z)), ys = x + y + z - xs - zs;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < NJ; ++k) {
+    sumj[k] = 0.0;
+    neg[k] = !(p[k] > 0.0);
+    if (neg[k]) {
+      aa[k] = 1.0 / (ys - p[k]);
+      bb[k] = aa[k] * (zs - ys) * (ys - xs);
+      pt[k] = ys + bb[k];
+      rcx[k] = rc(xs * zs / ys, p[k] * pt[k] / ys);
+    } else {
+      aa[k] = 0.0; bb[k] = 0.0; rcx[k] = 0.0;
+      pt[k] = p[k];
+    }
+  }
+  double avef, dfx, dfy, dfz, aved, ddx, ddy, ddz;
+  double avej[NJ], djx[NJ], djy[NJ], djz[NJ], djp[NJ];
+  bool more;
+  do {
+    double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+    double alamb = sx * (sy + sz) + sy * sz;
+    sumd = sumd + fac / (sz * (zt + alamb));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NJ; ++k) {
+      double t = pt[k] * (sx + sy + sz) + sx * sy * sz;
+      double t2 = pt[k] + alamb;
+      sumj[k] = sumj[k] + fac * rc(t * t, pt[k] * (t2 * t2));
+      pt[k] = .25 * (pt[k] + alamb);
+    }
+    fac = .25 * fac;
+    xt = .25 * (xt + alamb);
+    yt = .25 * (yt + alamb);
+    zt = .25 * (zt + alamb);
+    avef = (1.0 / 3.0) * (xt + yt + zt);
+    dfx = (avef - xt) / avef; dfy = (avef - yt) / avef; dfz = (avef - zt) / avef;
+    aved = .2 * (xt + yt + 3.0 * zt);
+    ddx = (aved - xt) / aved; ddy = (aved - yt) / aved; ddz = (aved - zt) / aved;
+    more = dmax(dmax(fabs(dfx), fabs(dfy)), fabs(dfz)) > TOLF || dmax(dmax(fabs(ddx), fabs(ddy)), fabs(ddz)) > TOLD;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NJ; ++k) {
+      avej[k] = .2 * (xt + yt + zt + pt[k] + pt[k]);
+      djx[k] = (avej[k] - xt) / avej[k]; djy[k] = (avej[k] - yt) / avej[k];
+      djz[k] = (avej[k] - zt) / avej[k]; djp[k] = (avej[k] - pt[k]) / avej[k];
+      more = more || dmax(dmax(fabs(djx[k]), fabs(djy[k])), dmax(fabs(djz[k]), fabs(djp[k]))) > TOLD;
+    }
+  } while (more);
+  {  // R_F series (geokerr_wrapper.f:3485-3487)
+    double e2 = dfx * dfy - dfz * dfz, e3 = dfx * dfy * dfz;
+    orf = (1.0 + ((1.0 / 24.0) * e2 - 0.1 - (3.0 / 44.0) * e3) * e2 + (1.0 / 14.0) * e3) / sqrt(avef);
+  }
+  {  // R_D series (:3686-3692)
+    const double c1 = 3.0 / 14.0, C2 = 1.0 / 6.0, C3 = 9.0 / 22.0, C4 = 3.0 / 26.0, C5 = 0.25 * C3, C6 = 1.5 * C4;
+    double ea = ddx * ddy, eb = ddz * ddz, ec = ea - eb, ed = ea - 6.0 * eb, ee = ed + ec + ec;
+    ord = 3.0 * sumd + fac * (1.0 + ed * (-c1 + C5 * ed - C6 * ddz * ee) + ddz * (C2 * ee + ddz * (-C3 * ec + ddz * C4 * ea))) /
+                           (aved * sqrt(aved));
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < NJ; ++k) {  // R_J series (:3753-3760)
+    const double c1 = 3.0 / 14.0, C2 = 1.0 / 3.0, C3 = 3.0 / 22.0, C4 = 3.0 / 26.0, C5 = .75 * C3, C6 = 1.5 * C4,
+                 C7 = .5 * C2, C8 = C3 + C3;
+    double ea = djx[k] * (djy[k] + djz[k]) + djy[k] * djz[k];
+    double eb = djx[k] * djy[k] * djz[k];
+    double ec = djp[k] * djp[k];
+    double ed = ea - 3.0 * ec;
+    double ee = eb + 2.0 * djp[k] * (ea - ec);
+    double r = 3.0 * sumj[k] + fac * (1.0 + ed * (-c1 + C5 * ed - C6 * ee) + eb * (C7 + djp[k] * (-C8 + djp[k] * C4)) +
+                                      djp[k] * ea * (C2 - djp[k] * C3) - C2 * djp[k] * ec) /
+                                   (avej[k] * sqrt(avej[k]));
+    if (neg[k]) r = aa[k] * (bb[k] * r + 3.0 * (rcx[k] - orf));
+    orj[k] = r;
+  }
+}
+
+// Wave-uniform constants of a real-quartic ray.
+struct RealRay {
+  int ncase;                       // 7 or 8
+  double a, l, q2, su, sm, mu0, u0;
+  double u1, u2, u3, u4;
+  double a1, b1, a2, b2, a3, b3, a4, b4;         // factor coefficients of Table 1 row 7 / 8
+  double d12, d13, d14, d24, d34;                // Carlson (1988) 2.1
+  double a5[3], b5[3], d15[3], d25[3], d35[3], d45[3];   // the three [-1,-1,-1,-1,-2] integrals
+  double d15t, d25t, d35t, d45t;                 // (a5,b5) = (0,1): the [-2] and [-4] integrals of Eq. 47
+  double r12, r13, r25i, r35i;
+  double sqee, ur, cA, cB, cC, cD, cP, cQ;
+  double iu0, tu0, phiu0, tu01;                  // u0-side pieces (cached by the set-up kernel)
+  double jfac, m1u, sqmee;                       // geor (Table 2 rows 7/8)
+  // M(mu)
+  int sym;
+  double mneg, mpos, muplus, muminus, mposR, muplusR;
+  double facm, facmR, m1m, akm, nn, fac2, i1mu, i3mu, rfc, rdc, rjc, tmu1, tmu3, phimu1, phimu3;
+  double sgna_pi;
+};
+
+GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
+  const double one = 1.0, two = 2.0;
+  const double a = cam.a, l = R.l, q2 = R.q2;
+  K.ncase = R.ncase; K.a = a; K.l = l; K.q2 = q2; K.su = R.su; K.sm = R.sm; K.mu0 = cam.mu0; K.u0 = cam.u0;
+  K.u1 = R.u1; K.u2 = R.u2; K.u3 = R.u3; K.u4 = R.u4;
+  const double uplus = one / (one + sqrt(one - a * a)), umi = one - sqrt(one - a * a);
+  const double ee = -a * a * q2, l2 = l * l, ql2 = q2 + l2;
+  K.sqee = sqrt(fabs(ee)); K.sqmee = sqrt(-ee);
+  K.ur = -one / (two * sqrt(one - a * a));
+  K.cA = umi - one / uplus; K.cB = umi * umi - one / (uplus * uplus);
+  K.cC = 2.0 * a * (a - l) + a * a / uplus + one / (uplus * uplus * uplus);
+  K.cD = 2.0 * a * (a - l) + a * a * umi + umi * umi * umi;
+  K.cP = l / uplus + 2.0 * (a - l); K.cQ = l * umi + 2.0 * (a - l);
+  K.a1 = -R.u1; K.b1 = one; K.a4 = R.u4; K.b4 = -one;
+  if (R.ncase == 7) { K.a2 = R.u2; K.b2 = -one; K.a3 = R.u3; K.b3 = -one; }
+  else { K.a2 = -R.u2; K.b2 = one; K.a3 = -R.u3; K.b3 = one; }
+  K.d12 = K.a1 * K.b2 - K.a2 * K.b1; K.d13 = K.a1 * K.b3 - K.a3 * K.b1; K.d14 = K.a1 * K.b4 - K.a4 * K.b1;
+  K.d24 = K.a2 * K.b4 - K.a4 * K.b2; K.d34 = K.a3 * K.b4 - K.a4 * K.b3;
+  const double A5[3] = {one, one, 0.0}, B5[3] = {-one / uplus, -umi, one};
+  for (int k = 0; k < 3; ++k) {
+    K.a5[k] = A5[k]; K.b5[k] = B5[k];
+    K.d15[k] = K.a1 * B5[k] - A5[k] * K.b1; K.d25[k] = K.a2 * B5[k] - A5[k] * K.b2;
+    K.d35[k] = K.a3 * B5[k] - A5[k] * K.b3; K.d45[k] = K.a4 * B5[k] - A5[k] * K.b4;
+  }
+  K.d15t = K.d15[2]; K.d25t = K.d25[2]; K.d35t = K.d35[2]; K.d45t = K.d45[2];
+  K.r12 = K.a1 / K.b1 - K.a2 / K.b2; K.r13 = K.a1 / K.b1 - K.a3 / K.b3;
+  K.r25i = K.b2 * one / (K.a2 * one - 0.0 * K.b2); K.r35i = K.b3 * one / (K.a3 * one - 0.0 * K.b3);
+  K.iu0 = R.iu0; K.tu01 = R.tu01;
+  K.tu0 = K.cA * R.tu01 + K.cB * R.tu02 - K.cC * R.tu03 + K.cD * R.tu04;
+  K.phiu0 = -K.cP * R.tu03 + K.cQ * R.tu04;
+  K.jfac = sqrt(fabs(ee) * (R.u3 - R.u1) * (R.u4 - R.u2)) * 0.5;
+  K.m1u = (R.u4 - R.u1) * (R.u3 - R.u2) / ((R.u4 - R.u2) * (R.u3 - R.u1));
+  // roots of M(mu) with the guards of geokerr_wrapper.f:1116-1160 / 2299-2340
+  double mneg, mpos;
+  mroots(a, q2, ql2, mneg, mpos);
+  K.mposR = mpos;                       // GEOR does not clamp (:2902-2910)
+  if (mpos > 1.0) mpos = 1.0;
+  double muplus = sqrt(mpos), muplusR = sqrt(K.mposR), muminus;
+  K.sym = (mneg < 0.0) ? 1 : 0;
+  if (K.sym) {
+    if (muplus < cam.mu0) { muplus = cam.mu0; mpos = muplus * muplus; }
+    if (cam.mu0 > muplusR) { muplusR = cam.mu0; K.mposR = muplusR * muplusR; }
+    muminus = -muplus;
+    K.facm = fabs(a) * sqrt(mpos - mneg);
+    K.facmR = fabs(a) * sqrt(K.mposR - mneg);
+    K.m1m = -mneg / (mpos - mneg);
+  } else {
+    muplus = fsign(1.0, cam.mu0) * muplus;
+    muminus = fsign(1.0, cam.mu0) * sqrt(mneg);
+    if (fabs(muminus) > fabs(cam.mu0)) { muminus = cam.mu0; mneg = muminus * muminus; }
+    if (fabs(cam.mu0) > fabs(muplus)) { muplus = cam.mu0; mpos = muplus * muplus; }
+    if (fsign(1.0, cam.mu0) == -1) muplusR = -muplusR;
+    if (fabs(muplusR) < fabs(cam.mu0)) { muplusR = cam.mu0; K.mposR = muplusR * muplusR; }
+    K.facm = fabs(a) * muplus;
+    K.facmR = fabs(a) * muplusR;
+    K.m1m = mneg / mpos;
+  }
+  K.mneg = mneg; K.mpos = mpos; K.muplus = muplus; K.muminus = muminus; K.muplusR = muplusR;
+  K.akm = sqrt(1.0 - K.m1m);
+  if (mpos != 1.0) {
+    double n = K.sym ? mpos / (1.0 - mpos) : (mpos - mneg) / (1.0 - mpos);
+    K.nn = -n; K.fac2 = 1.0 - mpos;
+  } else {
+    K.nn = 1.0; K.fac2 = 1.0;       // n=-1 passed as -n=1: phi terms switched off (:2408-2412)
+  }
+  K.i1mu = R.i1mu; K.i3mu = R.i3mu; K.rfc = R.rffmu3; K.rdc = R.rdc; K.rjc = R.rjc;
+  K.tmu1 = R.tmu1; K.tmu3 = R.tmu3; K.phimu1 = R.phimu1; K.phimu3 = R.phimu3;
+  K.sgna_pi = fsign(1.0, a) * 3.141592653589793;
+}
+
+// u end-point: I_u1 and the four uf-side integrals of Eq. 47-49 for the pair (uf, root).
+struct UPart { double iu1, tu1, phiu1, tu11; };
+
+GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
+  const double one = 1.0, two = 2.0, three = 3.0, half = 0.5;
+  const bool c7 = (K.ncase == 7);
+  const double root = c7 ? K.u2 : K.u3;
+  o.iu1 = 0.0; o.tu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0;
+  if (uf == root) return;
+  const double y = c7 ? uf : K.u3, x = c7 ? K.u2 : uf, sg = c7 ? 1.0 : -1.0;
+  double X1 = sqrt(K.a1 + K.b1 * x), X2 = sqrt(K.a2 + K.b2 * x), X3 = sqrt(K.a3 + K.b3 * x), X4 = sqrt(K.a4 + K.b4 * x);
+  double Y1 = sqrt(K.a1 + K.b1 * y), Y2 = sqrt(K.a2 + K.b2 * y), Y3 = sqrt(K.a3 + K.b3 * y), Y4 = sqrt(K.a4 + K.b4 * y);
+  double dxy = x - y;
+  double U122 = sq((X1 * X2 * Y3 * Y4 + Y1 * Y2 * X3 * X4) / dxy);
+  double U132 = sq((X1 * X3 * Y2 * Y4 + Y1 * Y3 * X2 * X4) / dxy);
+  double U142 = sq((X1 * X4 * Y2 * Y3 + Y1 * Y4 * X2 * X3) / dxy);
+  double W22[3], rj3[3], rff, rdd;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 3; ++k) W22[k] = U122 - K.d13 * K.d14 * K.d25[k] / K.d15[k];
+  carlson_bundle<3>(U122, U132, U142, W22, rff, rdd, rj3);
+  double I1 = two * rff;
+  o.iu1 = sg * I1;
+  // GEOPHITIME skips the end-point terms when uf sits on the turning point (:2200, :2258)
+  if (c7 ? !(fabs(uf - K.u2) > 1e-12) : false) return;
+  double v[3];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 3; ++k) {   // [-1,-1,-1,-1,-2], Carlson (1988) 2.35
+    double X52 = K.a5[k] + K.b5[k] * x, Y52 = K.a5[k] + K.b5[k] * y;
+    double Q22 = X52 * Y52 / sq(X1 * Y1) * W22[k];
+    double P22 = Q22 + K.d25[k] * K.d35[k] * K.d45[k] / K.d15[k];
+    double I3 = two * K.d12 * K.d13 * K.d14 / three / K.d15[k] * rj3[k] + two * rc(P22, Q22);
+    v[k] = sg * (K.b5[k] * I3 - K.b1 * I1) / K.d15[k];
+  }
+  // [-1,-1,-1,-1,-4] with (a5,b5)=(0,1), Carlson (1988) 2.48
+  double X52 = x, Y52 = y;
+  double I2 = two / three * K.d12 * K.d13 * rdd + two * X1 * Y1 / X4 / Y4 / sqrt(U142);
+  double A111m1m2 = X1 * X2 * X3 / X4 / X52 - Y1 * Y2 * Y3 / Y4 / Y52;
+  double t4 = half * K.d24 * K.d34 / K.d15t / K.d25t / K.d35t / K.d45t * I2 +
+              sq(K.b1 / K.d15t) * (one - half * K.r12 * K.r13 * K.r25i * K.r35i) * I1 - one / K.d15t / K.d25t / K.d35t * A111m1m2;
+  o.tu11 = sg * t4;
+  double tu13 = v[0], tu14 = v[1], tu12 = v[2];
+  o.tu1 = K.cA * o.tu11 + K.cB * tu12 - K.cC * tu13 + K.cD * tu14;
+  o.phiu1 = -K.cP * tu13 + K.cQ * tu14;
+}
+
+// mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)
+struct MuPart { double i2mu, tmuf, phimuf; };
+
+GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
+  const double pi = 3.141592653589793;
+  double sf, phif;
+  if (K.sym) {
+    phif = acos(muf / K.muplus);
+    sf = sin(phif);
+  } else {
+    sf = sqrt((K.mpos - muf * muf) / (K.mpos - K.mneg));
+    phif = asin(sf);
+  }
+  double qf = (1.0 - sf * K.akm) * (1.0 + sf * K.akm);
+  double pj[1] = {1.0 - K.nn * sf * sf}, rff, rdf, rjf[1];
+  carlson_bundle<1>(1.0 - sf * sf, qf, 1.0, pj, rff, rdf, rjf);
+  // I_mu piece (calcimusymf / calcimuasymf, geokerr_wrapper.f:3175-3274)
+  double imuf = sf * rff;
+  if (K.sym) {
+    double fac = forgeor ? K.facmR : K.facm;
+    double phg = forgeor ? acos(muf / K.muplusR) : phif;
+    if (forgeor) {   // GEOR's own (unclamped) muplus: re-evaluate the F piece consistently
+      double sfr = sin(phg), qfr = (1.0 - sfr * K.akm) * (1.0 + sfr * K.akm);
+      double rfr = (K.muplusR == K.muplus) ? rff : rf(1.0 - sfr * sfr, qfr, 1.0);
+      imuf = sfr * rfr;
+    }
+    if (tan(phg) < 0.0) imuf = K.i3mu * fac - imuf;
+    o.i2mu = imuf / fac;
+  } else {
+    o.i2mu = imuf / (forgeor ? K.facmR : K.facm);
+  }
+  // E and Pi pieces (ellphitmu, :2571-2588)
+  double ellef = sf * (rff - sq(sf * K.akm) * rdf / 3.0), ellpif = 0.0;
+  if (K.nn != 1.0) ellpif = sf * (rff + K.nn * sf * sf * rjf[0] / 3.0);
+  if (phif > pi / 2.0) {
+    double ellpic = 2.0 * (K.rfc + K.nn * K.rjc / 3.0);
+    double ellec = 2.0 * (K.rfc - K.akm * K.akm * K.rdc / 3.0);
+    ellpif = ellpic - ellpif;
+    ellef = ellec - ellef;
+  }
+  o.tmuf = K.facm * ellef;
+  o.phimuf = ellpif / K.fac2 / K.facm;
+}
+
+// Stored point idx of a real-quartic ray (same contract as ray_point).
+GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P) {
+  const double one = 1.0, two = 2.0;
+  const int kext = cam.kext, next = cam.next, kmax = R.kmax;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const int lo = fill ? (kmax - kext) : kmax;
+  const bool c7 = (K.ncase == 7);
+  const double root = c7 ? K.u2 : K.u3;
+  double un, mun, iu;
+  int tpm, tprs, tprp;
+  UPart U;
+  MuPart M;
+  const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
+  if (!isfill) {
+    if (idx <= lo || R.tpr == 0) {
+      un = cam.uout + (idx - cam.offset) * R.du; tprs = 0; tprp = 0;
+    } else {
+      int Kk = fill ? (idx - (next - 2 * kext)) : idx;
+      un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
+    }
+    if (c7 ? (un > root) : (un < root)) un = root;        // geokerr_wrapper.f:1079,1089
+    real_upart(K, un, U);
+    iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) / K.sqee;
+    // mu_f from I_u (Eq. 30-42)
+    double a1 = K.sm, r1 = (iu - K.i1mu) / K.i3mu;
+    if (K.sm == 1) tpm = fint(r1) + (K.sym ? fint((1 + fsign(1.0, r1)) / 2.0) : fint(fabs((1 + fsign(1.0, r1)) / 2.0)));
+    else tpm = fint((iu + K.i1mu) / K.i3mu);
+    double a2 = K.sm * powm1(tpm);
+    double a3 = two * fint((two * (double)tpm + 3.0 - K.sm) / 4.0) - one;
+    double iarg = fabs(K.a) / a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
+    double sn, cn, dn;
+    if (K.sym) {
+      sncndn(sqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn);
+      mun = K.muminus * cn;
+    } else {
+      sncndn(fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
+      mun = K.muminus / dn;
+    }
+    real_mupart(K, mun, M, false);
+  } else {
+    int k = idx - lo;
+    indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, K.sm, k, next, cam.offset, mun, tpm);
+    real_mupart(K, mun, M, true);
+    double b1 = K.sm, b2 = K.sm * powm1(tpm + 1), b3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+    double imu = b1 * K.i1mu + b2 * M.i2mu + b3 * K.i3mu;
+    double sn, cn, dn;
+    if (c7) {
+      double arg = imu - K.su * K.iu0 / K.sqmee;
+      sncndn(K.jfac * arg, K.m1u, sn, cn, dn);
+      un = ((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1)) / ((K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
+      tprs = (int)((fsign(1.0, K.su * (imu - K.su * K.iu0 / K.sqee)) + 1.0) / 2.0);
+    } else {
+      double arg = imu + K.su * K.iu0 / K.sqmee;
+      sncndn(K.jfac * arg, K.m1u, sn, cn, dn);
+      un = ((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2)) / ((K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
+      tprs = (int)((-fsign(1.0, K.su * (imu + K.su * K.iu0 / K.sqmee)) + 1.0) / 2.0);
+    }
+    real_upart(K, un, U);
+    iu = imu;
+    tprp = tprs;
+  }
+  // Eq. 47-49, 45-46 (geokerr_wrapper.f:2219-2234, 2313-2351)
+  const double s = powm1(tprs);
+  double tu = K.su * (K.tu0 - s * U.tu1) / K.sqee * K.ur;
+  double phiu = K.su * (K.phiu0 - s * U.phiu1) / K.sqee * K.ur;
+  double lambdau = K.su * (K.tu01 - s * U.tu11) / K.sqee;
+  double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+  double tmu, phimu;
+  if (K.sym) tmu = K.a * K.a * K.mneg * iu + (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
+  else tmu = (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
+  phimu = -K.l * iu + K.l * (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3);
+  if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
+  P.u = un; P.mu = mun; P.dt = tmu + tu; P.dphi = phimu + phiu; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
+}
+
+}  // namespace grtd

@@ -133,7 +133,7 @@ GRT_HD void transport_perpk(const double *k, double r, double th, double a, cons
 }
 
 // kerr.f90:586.  u,b,k: contravariant BL components (t,r,th,phi).
-GRT_HD void comoving_ortho(double r, double th, double a, double alpha, double beta, double mus, const double *u,
+GRT_NI void comoving_ortho(double r, double th, double a, double alpha, double beta, double mus, const double *u,
                            const double *b, const double *k, double &s2xi, double &c2xi, double &ang,
                            double &g, double &cosne) {
   Metric m = blmetric_cov(r, th, a);
@@ -225,7 +225,7 @@ GRT_HD double interp_gxp(double xx, int ix, int iy, const double *xv, int nx, co
 }
 
 // polsynchemis.f90:527  -> e[11] = jI,jQ,jU,jV, aI,aQ,aU,aV, rhoQ,rhoU,rhoV
-GRT_HD void polsynchpl(const GrtTables &T, double nu, double nnth, double B, double th, double p, double gmin,
+GRT_NI void polsynchpl(const GrtTables &T, double nu, double nnth, double B, double th, double p, double gmin,
                        double gmax, double *e) {
   const double nufloor = 1e-10, thsafe = 1e-10;
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
@@ -378,7 +378,7 @@ GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, do
 
 // ------------------------------------------------------------------ integrators
 // calc_O  radtrans_integrate.f90:615   O[i][j] row i col j
-GRT_HD void calc_O(const double *a, const double *rho, double dx, double O[4][4]) {
+GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]) {
   double onopol = exp(-a[0] * dx);
   double aq = a[1], au = a[2], av = a[3], rhoq = rho[0], rhou = rho[1], rhov = rho[2];
   double a2 = aq * aq + au * au + av * av;
@@ -460,7 +460,7 @@ GRT_HD void opacity_matrix(const double *K7, double M[4][4]) {   // :735 ; K7 = 
 // (rho,p,b0,br,bth,bph,u0,vr,vth,vph,0,0): the two r-neighbours of a sample are 96 contiguous
 // bytes, so one sample is two 96-byte segments served from L2 (the 16384-cell table is 768 KB,
 // larger than the 160 KB LDS, smaller than one XCD's 4 MB L2).
-GRT_HD void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, FluidPoint &f) {
+GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, FluidPoint &f) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx1;
   float theta = (float)th_d;

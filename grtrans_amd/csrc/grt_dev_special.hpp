@@ -44,7 +44,7 @@ GRT_HD double rf(double x, double y, double z) {
 }
 
 // R_C  (geokerr_wrapper.f:3608)
-GRT_HD double rc(double x, double y) {
+GRT_NI double rc(double x, double y) {
   const double ERRTOL = 0.0012, THIRD = 1.0 / 3.0, c1 = .3, C2 = 1.0 / 7.0, C3 = .375, C4 = 9.0 / 22.0;
   double xt, yt, w, ave, s;
   if (y > 0.0) {
@@ -135,7 +135,7 @@ GRT_HD double rj(double x, double y, double z, double p) {
 }
 
 // Jacobi sn, cn, dn by descending Landen/AGM (geokerr_wrapper.f:3277)
-GRT_HD void sncndn(double uu, double emmc, double &sn, double &cn, double &dn) {
+GRT_NI void sncndn(double uu, double emmc, double &sn, double &cn, double &dn) {
   const double CA = 3.e-8;
   double emc = emmc, u = uu, a, b, c = 0.0, d = 0.0;
   double em[14], en[14];

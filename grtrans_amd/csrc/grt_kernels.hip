@@ -7,26 +7,36 @@
 //                      record per ray + its stored-point count.  Rays that never enter r<1/uout
 //                      or fail are dropped from the work list with a wave ballot / prefix-sum
 //                      compaction (they keep their zero pixel).
-//   grt_trace_kernel : one WAVE per live ray, one stored POINT per lane.  The GrtRay record is
-//                      wave-uniform (scalar loads, SGPRs), so the root-case and segment branches
-//                      of geokerr are wave-uniform instead of divergent.  Each lane computes its
-//                      point of the geodesic, samples the fluid, builds the comoving tetrad and the
-//                      synchrotron coefficients and turns its transfer step into an affine map
-//                      I -> A I + b; the 64 maps of a chunk are composed with a Kogge-Stone scan of
-//                      wave shuffles (no LDS, no HBM intermediates) and applied to the intensity
-//                      carried from the previous (farther) chunk.  HBM traffic is the optional
-//                      per-step SoA record plus 16 B per ray per camera.
+//   grt_geo_kernel   : one WAVE per live ray, one stored POINT per lane.  The per-ray record is
+//                      wave-uniform (scalar loads), so the root-case and segment branches of geokerr
+//                      are wave-uniform instead of divergent.  Each lane evaluates its point of the
+//                      geodesic and writes (r, theta, phi, lambda) of the per-step SoA record, lanes =
+//                      consecutive points -> 512-byte coalesced rows, plus one byte of turning-point
+//                      parities.
+//   grt_transfer_kernel : same wave/lane mapping.  Reads (r, theta, lambda) back, samples the fluid,
+//                      builds the comoving tetrad and the synchrotron coefficients and turns the lane's
+//                      transfer step into an affine map I -> A I + b; the 64 maps of a chunk are composed
+//                      with a Kogge-Stone scan of wave shuffles and applied to the intensity carried from
+//                      the previous (farther) chunk; optionally writes (I,Q,U,V) of the record.
+// Splitting the two keeps each kernel's live state small (the fused version needed 512 registers per
+// lane plus scratch); the 24 B/step that cross HBM between them are part of the record anyway.
 #include <hip/hip_runtime.h>
-#include "grt_dev_ray.hpp"
+#include "grt_dev_fast.hpp"
 
 using namespace grtd;
 
 #define GRT_WAVES_PER_BLOCK 4
+#ifndef GRT_WPE_GEO
+#define GRT_WPE_GEO 2     // waves per SIMD the register allocator must make room for
+#endif
+#ifndef GRT_WPE_XFER
+#define GRT_WPE_XFER 2
+#endif
 #define GRT_MAXF 32
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
-                                                         int *__restrict__ counters) {
+                                                         int *__restrict__ counters, RealRay *__restrict__ rrays) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
   GrtRay R;
@@ -36,16 +46,32 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
     rays[tid] = R;
     ray_npts[tid] = R.npts;
   }
-  // wave-level compaction of live rays (ballot + prefix popcount + one atomic per wave)
-  bool alive = inr && R.npts > 0;
-  unsigned long long mask = __ballot(alive);
-  int lane = threadIdx.x & 63;
-  int before = __popcll(mask & ((1ull << lane) - 1ull));
-  int total = __popcll(mask);
-  int base = 0;
-  if (lane == 0 && total > 0) base = atomicAdd(&counters[0], total);
-  base = __shfl(base, 0);
-  if (alive) live[base + before] = tid;
+  // wave-level compaction of live rays (ballot + prefix popcount + one atomic per wave and class).
+  // Class 0: four distinct real roots (fast path), filled from the front of live[];
+  // class 1: every other root structure (generic path), filled from the back.
+  const int lane = threadIdx.x & 63;
+  const bool alive = inr && R.npts > 0;
+  const bool fastc = alive && (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool slowc = alive && !fastc;
+  if (fastc) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
+    RealRay K;
+    realray_init(cam, R, K);
+    rrays[tid] = K;
+  }
+  {
+    unsigned long long mask = __ballot(fastc);
+    int before = __popcll(mask & ((1ull << lane) - 1ull)), total = __popcll(mask), base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(&counters[0], total);
+    base = __shfl(base, 0);
+    if (fastc) live[base + before] = tid;
+  }
+  {
+    unsigned long long mask = __ballot(slowc);
+    int before = __popcll(mask & ((1ull << lane) - 1ull)), total = __popcll(mask), base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(&counters[1], total);
+    base = __shfl(base, 0);
+    if (slowc) live[nrays - 1 - (base + before)] = tid;
+  }
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -71,24 +97,73 @@ __device__ __forceinline__ void affine_bcast(const Affine &m, int src, Affine &e
   }
 }
 
-template <int IFLAG>
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK) void grt_trace_kernel(
-    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFFJet fj, GrtTables tb,
-    GrtEmis em, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile, int nvals,
-    int *__restrict__ ray_status, long long i1, double *__restrict__ steps, long long steps_ray_stride, long long steps_field_stride,
-    unsigned long long *__restrict__ step_counter) {
-  __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
-  __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
-  __shared__ double s_nb[IFLAG == GRT_INT_DELO ? GRT_WAVES_PER_BLOCK : 1][IFLAG == GRT_INT_DELO ? GRT_MAXF : 1][11];
+
+// field order of the per-step record: r, theta, lambda, phi, I, Q, U, V  (fields 0..2 always exist)
+#define GRT_F_R 0
+#define GRT_F_TH 1
+#define GRT_F_LAM 2
+#define GRT_F_PHI 3
+#define GRT_F_I 4
+
+template <bool FAST>
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
+    GrtCam cam, const GrtRay *__restrict__ rays, const RealRay *__restrict__ rrays, const int *__restrict__ live,
+    int nlive, double *__restrict__ steps, unsigned char *__restrict__ flags, long long ray_stride,
+    long long field_stride, int nfields) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
   if (slot >= nlive) return;   // whole wave leaves together
   slot = __builtin_amdgcn_readfirstlane(slot);
   const int rayidx = live[slot];
+  const GrtRay *Rp = rays + rayidx;
+  const RealRay *Kp = rrays + (FAST ? rayidx : 0);
+  const int n = Rp->npts;
+  double LamN = 0.0;
+  for (int base = n; base >= 1; base -= 64) {
+    // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
+    // re-read through the scalar cache where used instead of being hoisted and parked in registers
+    asm volatile("" : "+s"(Rp), "+s"(Kp));
+    const int idx = base - lane;
+    const bool valid = idx >= 1;
+    GeoPoint P;
+    P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
+    if (valid) {
+      if (FAST) ray_point_real(cam, *Rp, *Kp, idx, P);
+      else ray_point(cam, *Rp, idx, P);
+    }
+    if (base == n) LamN = __shfl(P.lam, 0);
+    if (valid) {   // geodesics.f90:333-347
+      double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
+      sp[GRT_F_R * field_stride] = 1.0 / P.u;
+      sp[GRT_F_TH * field_stride] = acos(P.mu);
+      sp[GRT_F_LAM * field_stride] = LamN - P.lam;
+      if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = cam.phi0 - P.dphi;
+      flags[(long long)rayidx * ray_stride + (idx - 1)] = (unsigned char)((P.tpm & 1) | ((P.tpr & 1) << 1));
+    }
+  }
+}
+
+template <int IFLAG>
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_transfer_kernel(
+    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFFJet fj, GrtTables tb,
+    GrtEmis em, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile, int nvals,
+    int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned char *__restrict__ flags,
+    long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
+  __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
+  __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
+  __shared__ double s_nb[IFLAG == GRT_INT_DELO ? GRT_WAVES_PER_BLOCK : 1][IFLAG == GRT_INT_DELO ? GRT_MAXF : 1][11];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
+  if (slot >= nlive) return;
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  const int rayidx = live[slot];
   const GrtRay &R = rays[rayidx];
   const int n = R.npts;
   const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
-  const double alpha = R.alpha, beta = R.beta;
+  const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
+  const double *sp0 = steps + (long long)rayidx * ray_stride;
+  const unsigned char *fp0 = flags + (long long)rayidx * ray_stride;
+  const double lam_1 = sp0[GRT_F_LAM * field_stride];   // g%lambda(1)
 
   for (int f = lane; f < nfreq; f += 64) {
     s_carry[wave][f][0] = 0.0; s_carry[wave][f][1] = 0.0; s_carry[wave][f][2] = 0.0; s_carry[wave][f][3] = 0.0;
@@ -96,22 +171,18 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK) void grt_trace_kernel(
   }
   __builtin_amdgcn_wave_barrier();
 
-  double LamN = 0.0, sumr = 0.0;
+  double sumr = 0.0;
   double nb_lam = 0.0;            // lambda of the point stored just after this chunk's first one (carry)
   for (int base = n; base >= 1; base -= 64) {
     const int idx = base - lane;
     const bool valid = idx >= 1;
-    GeoPoint P;
-    P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
-    if (valid) ray_point(cam, R, idx, P);
-    if (base == n) LamN = __shfl(P.lam, 0);
-    // geodesics.f90:333-364
-    const double r = 1.0 / P.u;
-    const double th = acos(P.mu);
-    const double lam_i = LamN - P.lam;
-    const double lam_1 = LamN - R.lam1;
+    const int ic = valid ? idx - 1 : 0;
+    const double r = sp0[GRT_F_R * field_stride + ic];
+    const double th = sp0[GRT_F_TH * field_stride + ic];
+    const double lam_i = sp0[GRT_F_LAM * field_stride + ic];
+    const int fl8 = fp0[ic];
     double kv[4];
-    calc_nullp(R.q2, R.l, cam.a, r, cos(th), R.su * powm1(P.tpr), R.sm * powm1(P.tpm), kv);
+    calc_nullp(q2, l, cam.a, r, cos(th), su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
     sumr += valid ? r : 0.0;
     // fluid + frame (grtrans_driver.f90:126-130)
     FluidPoint fl;
@@ -193,16 +264,10 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK) void grt_trace_kernel(
       }
       if (lane == 0) s_fac[wave][f] += facs;
       __builtin_amdgcn_wave_barrier();
-      if (steps != nullptr && f == 0 && valid) {
-        double *sp = steps + (long long)rayidx * steps_ray_stride + (idx - 1);
-        sp[0 * steps_field_stride] = r;
-        sp[1 * steps_field_stride] = th;
-        sp[2 * steps_field_stride] = cam.phi0 - P.dphi;
-        sp[3 * steps_field_stride] = lam_i;
-        sp[4 * steps_field_stride] = io[0] * LBH;
-        sp[5 * steps_field_stride] = io[1] * LBH;
-        sp[6 * steps_field_stride] = io[2] * LBH;
-        sp[7 * steps_field_stride] = io[3] * LBH;
+      if (nfields > GRT_F_I && f == 0 && valid) {
+        double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sp[(GRT_F_I + c) * field_stride] = io[c] * LBH;
       }
     }
     nb_lam = __shfl(lam_i, 63);
@@ -225,27 +290,45 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK) void grt_trace_kernel(
 }
 
 // ---- host-side launch helpers (called from grt_api.cpp) ----
+extern "C" size_t grt_sizeof_realray(void) { return sizeof(RealRay); }
+
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters) {
+                                       int *ray_npts, int *live, int *counters, void *rrays) {
   int blocks = (nrays + 255) / 256;
-  hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters);
+  hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
+                     (RealRay *)rrays);
   return hipGetLastError();
 }
 
-extern "C" hipError_t grt_launch_trace(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays, const int *live,
-                                       int nlive, const GrtFFJet *fj, const GrtTables *tb, const GrtEmis *em, int nfreq,
-                                       const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status,
-                                       long long i1, double *steps, long long steps_ray_stride, long long steps_field_stride,
-                                       unsigned long long *step_counter) {
+extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
+                                     const int *live, int nlive, double *steps, unsigned char *flags,
+                                     long long ray_stride, long long field_stride, int nfields) {
   if (nlive <= 0) return hipSuccess;
-  int blocks = (nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK;
-  dim3 g(blocks), b(64 * GRT_WAVES_PER_BLOCK);
-  if (iflag == GRT_INT_DELO)
-    hipLaunchKernelGGL(grt_trace_kernel<GRT_INT_DELO>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq, freqs,
-                       pixvals, npix_tile, nvals, ray_status, i1, steps, steps_ray_stride, steps_field_stride, step_counter);
+  dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
+  if (fast)
+    hipLaunchKernelGGL(grt_geo_kernel<true>, g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps, flags,
+                       ray_stride, field_stride, nfields);
   else
-    hipLaunchKernelGGL(grt_trace_kernel<GRT_INT_FORMAL>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq,
-                       freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, steps_ray_stride, steps_field_stride,
+    hipLaunchKernelGGL(grt_geo_kernel<false>, g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps, flags,
+                       ray_stride, field_stride, nfields);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays,
+                                          const int *live, int nlive, const GrtFFJet *fj, const GrtTables *tb,
+                                          const GrtEmis *em, int nfreq, const double *freqs, float *pixvals,
+                                          int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
+                                          const unsigned char *flags, long long ray_stride, long long field_stride,
+                                          int nfields, unsigned long long *step_counter) {
+  if (nlive <= 0) return hipSuccess;
+  dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
+  if (iflag == GRT_INT_DELO)
+    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_DELO>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq, freqs,
+                       pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields,
                        step_counter);
+  else
+    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_FORMAL>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq,
+                       freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride,
+                       nfields, step_counter);
   return hipGetLastError();
 }

@@ -5,8 +5,11 @@
 
 #if defined(__HIPCC__)
 #define GRT_HD __host__ __device__ inline
+// (real calls for the leaf routines crashed at run time with ROCm 7.2; everything is inlined)
+#define GRT_NI __host__ __device__ inline
 #else
 #define GRT_HD inline
+#define GRT_NI inline
 #endif
 
 #include "../../include/grtrans_amd.h"

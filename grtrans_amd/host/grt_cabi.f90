@@ -27,7 +27,7 @@ module grt_cabi
 
   type, bind(C) :: grt_stats           ! GrtStats
      integer(c_int64_t) :: ray_steps, rays_live, rays_dead
-     real(c_double) :: ms_setup, ms_trace, ms_total
+     real(c_double) :: ms_setup, ms_trace, ms_total, ms_geo, ms_transfer
   end type grt_stats
 
   interface

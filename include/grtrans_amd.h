@@ -57,7 +57,8 @@ typedef struct GrtEmis {
 typedef struct GrtStats {
   int64_t ray_steps;          /* sum of stored points over traced rays (the metric's numerator) */
   int64_t rays_live, rays_dead;
-  double ms_setup, ms_trace, ms_total;   /* HIP-event times on the library stream */
+  double ms_setup, ms_trace, ms_total;   /* HIP-event times on the library stream; ms_trace = geo + transfer */
+  double ms_geo, ms_transfer;            /* the two kernels of the trace phase */
 } grt_stats;
 
 /* replaces: nothing in the reference (device bring-up).  device = HIP ordinal. */

@@ -2,7 +2,7 @@
 // Compiles the product's per-lane device functions (grtrans_amd/csrc/grt_dev_*.hpp) for the HOST
 // with g++ so that the per-ray set-up and per-point evaluation can be compared with the oracle on
 // a machine without a GPU.  Not part of the product: libgrtrans_amd.so has no CPU path.
-#include "grt_dev_ray.hpp"
+#include "grt_dev_fast.hpp"
 #include <cstring>
 using namespace grtd;
 
@@ -28,6 +28,23 @@ int hs_sizeof_ray() { return (int)sizeof(GrtRay); }
 int hs_sizeof_cam() { return (int)sizeof(GrtCam); }
 
 void hs_setup_ray(const GrtCam *cam, int ii, GrtRay *R) { setup_ray(*cam, ii, *R); }
+
+int hs_ray_points_fast(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *dt, double *dphi, double *lam,
+                       int *tpm, int *tpr, int *ncase) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  *ncase = R.ncase;
+  bool fast = (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12;
+  RealRay K;
+  if (fast) realray_init(*cam, R, K);
+  for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
+    GeoPoint P;
+    if (fast) ray_point_real(*cam, R, K, idx, P); else ray_point(*cam, R, idx, P);
+    u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
+    tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
+  }
+  return fast ? R.npts : -R.npts;
+}
 
 int hs_ray_points(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *dt, double *dphi, double *lam,
                   int *tpm, int *tpr, int *ncase) {
