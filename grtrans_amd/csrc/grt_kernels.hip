@@ -105,7 +105,7 @@ __device__ __forceinline__ void affine_bcast(const Affine &m, int src, Affine &e
 #define GRT_F_PHI 3
 #define GRT_F_I 4
 
-template <bool FAST>
+template <bool FAST, bool PHI>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const RealRay *__restrict__ rrays, const int *__restrict__ live,
     int nlive, double *__restrict__ steps, unsigned char *__restrict__ flags, long long ray_stride,
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     GeoPoint P;
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
     if (valid) {
-      if (FAST) ray_point_real(cam, *Rp, *Kp, idx, P);
+      if (FAST) ray_point_real<PHI>(cam, *Rp, *Kp, idx, P);
       else ray_point(cam, *Rp, idx, P);
     }
     if (base == n) LamN = __shfl(P.lam, 0);
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 template <int IFLAG>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFFJet fj, GrtTables tb,
-    GrtEmis em, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile, int nvals,
-    int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned char *__restrict__ flags,
+    GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
+    int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned char *__restrict__ flags,
     long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
   __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
   __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
     for (int f = 0; f < nfreq; ++f) {
       const double nu = freqs[f] / g;
       double e[11];
-      polsynchpl(tb, nu, ncgsnth, bcgs, ang, em.p1, em.gmin, em.gmax, e);
+      polsynchpl_fast(tb, plc, nu, ncgsnth, bcgs, ang, e);
 #pragma unroll
       for (int c = 0; c < 7; ++c)
         if (!em.coefindx[c]) e[4 + c] = 0.0;
@@ -305,29 +305,32 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
                                      long long ray_stride, long long field_stride, int nfields) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
-  if (fast)
-    hipLaunchKernelGGL(grt_geo_kernel<true>, g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps, flags,
+  if (fast && nfields > GRT_F_PHI)
+    hipLaunchKernelGGL((grt_geo_kernel<true, true>), g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps, flags,
                        ray_stride, field_stride, nfields);
+  else if (fast)
+    hipLaunchKernelGGL((grt_geo_kernel<true, false>), g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps,
+                       flags, ray_stride, field_stride, nfields);
   else
-    hipLaunchKernelGGL(grt_geo_kernel<false>, g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps, flags,
-                       ray_stride, field_stride, nfields);
+    hipLaunchKernelGGL((grt_geo_kernel<false, true>), g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps,
+                       flags, ray_stride, field_stride, nfields);
   return hipGetLastError();
 }
 
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFFJet *fj, const GrtTables *tb,
-                                          const GrtEmis *em, int nfreq, const double *freqs, float *pixvals,
-                                          int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
+                                          const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
+                                          float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned char *flags, long long ray_stride, long long field_stride,
                                           int nfields, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
   if (iflag == GRT_INT_DELO)
-    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_DELO>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq, freqs,
+    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_DELO>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, *plc, nfreq, freqs,
                        pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields,
                        step_counter);
   else
-    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_FORMAL>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, nfreq,
+    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_FORMAL>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, *plc, nfreq,
                        freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride,
                        nfields, step_counter);
   return hipGetLastError();

@@ -43,4 +43,19 @@ struct GrtFFJet {               // device pointers; cell-interleaved copy of the
 
 struct GrtTables {              // polsynchpl log-G tables (polsynchemis.f90:107-525), device pointers
   const double *gx, *gy, *xv, *ya, *yp, *yv, *yap, *yav;
+  // log-log slopes (y[i+1]-y[i])/(x[i+1]-x[i]) of the same tables, computed once on upload
+  const double *sgy, *sya, *syp, *syv, *syap, *syav;
+};
+
+// Ray- and point-independent factors of polsynchpl (polsynchemis.f90:557-591), computed on the host
+// once per call from (p, gmin, gmax): every pow() with a constant base or exponent is folded here.
+struct GrtPLConst {
+  double p, gmin, gmax;
+  double A0;          // (p-1)/(gmin^(1-p)-gmax^(1-p))
+  double lmin, lmax;  // log(1.5 gmin^2), log(1.5 gmax^2):  log(xmin) = -log(nub/nu) - lmin
+  double alpha;       // (p-1)/2
+  double kq, kv;      // gmin^(-2a+1)/(a-1/2),  2(a+3/2)/(a+1) log(gmin) gmin^(-2(a+1))
+  double l2g;         // 2 log(gmin)
+  double gx0, gxs, xv0, xvs;   // table origins and index scales nx/(x[n-1]-x[0])
+  int32_t iy, pad;    // p bin of the tables
 };

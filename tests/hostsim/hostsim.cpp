@@ -39,11 +39,27 @@ int hs_ray_points_fast(const GrtCam *cam, int ii, int maxn, double *u, double *m
   if (fast) realray_init(*cam, R, K);
   for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
     GeoPoint P;
-    if (fast) ray_point_real(*cam, R, K, idx, P); else ray_point(*cam, R, idx, P);
+    if (fast) ray_point_real<true>(*cam, R, K, idx, P); else ray_point(*cam, R, idx, P);
     u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
     tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
   }
   return fast ? R.npts : -R.npts;
+}
+
+// PHI=false variant: only u, mu, lambda, tpm, tpr are meaningful
+int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *lam, int *tpm, int *tpr) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  bool fast = (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12;
+  if (!fast) return -R.npts;
+  RealRay K;
+  realray_init(*cam, R, K);
+  for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
+    GeoPoint P;
+    ray_point_real<false>(*cam, R, K, idx, P);
+    u[idx - 1] = P.u; mu[idx - 1] = P.mu; lam[idx - 1] = P.lam; tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
+  }
+  return R.npts;
 }
 
 int hs_ray_points(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *dt, double *dphi, double *lam,

@@ -1,0 +1,64 @@
+"""CPU test: the product's per-lane device functions compiled for the host (tests/hostsim) against the
+oracle's literal sequential GEOKERR.  Integers (npts, tpm, tpr) exact; u, mu, dt, dphi, lambda to 1e-10 of
+scale (dphi is a difference of O(100) elliptic terms).  Covers the generic per-point path, the fast
+real-quartic path with and without the azimuth integrals."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+from oracle import orabind as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HS = os.path.join(ROOT, "tests", "hostsim")
+
+
+@pytest.fixture(scope="module")
+def L():
+    so = os.path.join(HS, "libhostsim.so")
+    src = os.path.join(HS, "hostsim.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I",
+                           os.path.join(ROOT, "grtrans_amd", "csrc"), "-o", so, src])
+    return C.CDLL(so)
+
+
+CAMS = [(0.998, 0.906, (-40., 20., -20., 40.), (100, 100, 400), 0.01, 41),
+        (0.9375, 0.6428, (-13., 13., -13., 13.), (64, 64, 400), 0.04, 17),
+        (0.5, -0.3, (-20., 20., -20., 20.), (48, 48, 200), 0.02, 11),
+        (0.998, 0.1, (-25., 25., -25., 25.), (48, 48, 160), 0.04, 11)]
+
+
+@pytest.mark.parametrize("spin,mu0,gv,nn,uout,stride", CAMS)
+def test_per_point_paths_match_sequential_oracle(L, spin, mu0, gv, nn, uout, stride):
+    cam = (C.c_char * L.hs_sizeof_cam())()
+    gva = np.array(gv, dtype=float)
+    nna = np.array(nn, dtype=np.int32)
+    L.hs_make_cam(cam, 1, gva.ctypes.data_as(C.POINTER(C.c_double)), nna.ctypes.data_as(C.POINTER(C.c_int)),
+                  C.c_double(spin), C.c_double(mu0), C.c_double(uout), C.c_double(-0.5))
+    o = O.Oracle(nn=nn, spin=spin, mu0=mu0, gridvals=gv, uout=uout)
+    maxn = nn[2] * 2 + 64
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    nfast = 0
+    for i in range(1, nn[0] * nn[1] + 1, stride):
+        g = o.geokerr_ray(i)
+        for fn in (L.hs_ray_points, L.hs_ray_points_fast):
+            d = [np.zeros(maxn) for _ in range(5)]
+            tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
+            n = abs(fn(cam, i, maxn, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc)))
+            assert n == g["n"] and nc.value == g["ncase"]
+            assert np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"])
+            keys = ("u", "mu", "dt", "dphi", "lam") if fn is L.hs_ray_points else ("u", "mu", "dphi", "lam")
+            for k, key in enumerate(("u", "mu", "dt", "dphi", "lam")):
+                if key in keys and n:
+                    assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, key)
+        u = np.zeros(maxn); mu = np.zeros(maxn); lam = np.zeros(maxn)
+        tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32)
+        n = L.hs_ray_points_fast_nophi(cam, i, maxn, dp(u), dp(mu), dp(lam), ip(tpm), ip(tpr))
+        if n > 0:
+            nfast += 1
+            assert n == g["n"] and np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"])
+            for a, key in ((u, "u"), (mu, "mu"), (lam, "lam")):
+                assert np.max(np.abs(a[:n] - g[key])) <= 1e-10 * np.max(np.abs(g[key]))
+    assert nfast > 0
