@@ -28,26 +28,18 @@ BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lam
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-class _quiet_stdout:
-    """The reference Fortran writes banners to unit 6; keep fd 1 clean for the single JSON line."""
-
-    def __enter__(self):
-        sys.stdout.flush()
-        self.saved = os.dup(1)
-        self.null = os.open(os.devnull, os.O_WRONLY)
-        os.dup2(self.null, 1)
-
-    def __exit__(self, *a):
-        os.dup2(self.saved, 1)
-        os.close(self.null)
-        os.close(self.saved)
-
-
 def cpu_baseline(nx, ny, nup, budget_s=15.0):
     """Reference Fortran (oracle/_ref) -- or the C++ port if that library is absent -- on a bounded
-    contiguous pixel sample around the image centre of the SAME camera, all host cores."""
-    with _quiet_stdout():
-        return _cpu_baseline(nx, ny, nup, budget_s)
+    contiguous pixel sample around the image centre of the SAME camera, all host cores.  Runs in a child
+    process: the reference writes banners to Fortran unit 6, which must not reach this process's stdout
+    (one JSON line only)."""
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".json") as tf:
+        code = ("import sys, json; sys.path.insert(0, %r); import bench; "
+                "json.dump(bench._cpu_baseline(%d, %d, %d, %f), open(%r, 'w'))" % (ROOT, nx, ny, nup, budget_s, tf.name))
+        subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        return json.load(open(tf.name))
 
 
 def _cpu_baseline(nx, ny, nup, budget_s):
