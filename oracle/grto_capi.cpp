@@ -21,6 +21,7 @@ struct Setup {
   double mbh = 0, nfac = 0, bfac = 0, gmin = 0, gmax = 0, p1 = 0;
   int coefindx[7] = {1, 1, 1, 1, 1, 1, 1};
   FFJetTable ffjet;
+  SphaccTable sphacc;
   PLTables pl;
   bool ok = false;
 };
@@ -29,7 +30,7 @@ Setup S;
 struct RayWork {
   Geodesic g;
   std::vector<FluidPoint> f;
-  std::vector<double> s2xi, c2xi, ang, rshift, cosne, ncgsnth, bcgs, jraw, Kraw, j, K, tau, I;
+  std::vector<double> s2xi, c2xi, ang, rshift, cosne, ncgsnth, bcgs, ncgs, tcgs, jraw, Kraw, j, K, tau, I;
 };
 
 // One pixel / one frequency, stages kept for dumping.  Returns pixel Stokes (double, before
@@ -43,21 +44,27 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
   if (!(w.g.status == 1 && n > 0)) return;
   w.f.resize(n);
   auto rs = [&](std::vector<double> &v, int m) { v.assign((size_t)n * m, 0.0); };
-  rs(w.s2xi, 1); rs(w.c2xi, 1); rs(w.ang, 1); rs(w.rshift, 1); rs(w.cosne, 1); rs(w.ncgsnth, 1); rs(w.bcgs, 1);
+  rs(w.s2xi, 1); rs(w.c2xi, 1); rs(w.ang, 1); rs(w.rshift, 1); rs(w.cosne, 1); rs(w.ncgsnth, 1); rs(w.bcgs, 1); rs(w.ncgs, 1); rs(w.tcgs, 1);
   rs(w.jraw, 4); rs(w.Kraw, 7); rs(w.j, 4); rs(w.K, 7); rs(w.tau, 1); rs(w.I, 4);
   const double LBH = PH_G * S.mbh * PH_msun / PH_c2;
   // emis_params are REAL(4): gmin, gmax, p1 reach polsynchpl through single precision (emis.f90:32-39)
   const double gmin = (double)(float)S.gmin, gmax = (double)(float)S.gmax, p = (double)(float)S.p1;
   for (int i = 0; i < n; ++i) {
     const double *x = &w.g.x[4 * i], *k = &w.g.k[4 * i];
-    ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
+    if (S.fluid == 13) ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
+    else sphacc_point(S.sphacc, x[1], w.f[i]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
-    w.ncgsnth[i] = w.f[i].rho * S.nfac;   // fluid.f90:1171
-    w.bcgs[i] = w.f[i].bmag * S.bfac;
     double nu = freq / w.rshift[i];
     double e[11];
-    polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    if (S.fluid == 13) {
+      w.ncgsnth[i] = w.f[i].rho * S.nfac;   // fluid.f90:1171
+      w.bcgs[i] = w.f[i].bmag * S.bfac;
+    } else {                                // fluid.f90:1249-1259
+      w.ncgs[i] = w.f[i].rho; w.bcgs[i] = w.f[i].bmag; w.tcgs[i] = w.f[i].p;
+    }
+    if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    else polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);
     for (int c = 0; c < 4; ++c) w.jraw[4 * i + c] = e[c];
     for (int c = 0; c < 7; ++c) w.Kraw[7 * i + c] = S.coefindx[c] ? e[4 + c] : 0.0;
   }
@@ -114,12 +121,13 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   camera_init(S.cam, standard, gridvals[0], gridvals[1], gridvals[2], gridvals[3], nn[0], nn[1], nn[2], spin, mu0, uout);
   S.phi0 = phi0; S.spin = spin; S.nvals = nvals;
   std::string fn(fname), en(ename), in(iname);
-  if (fn == "FFJET") S.fluid = 13; else return -1;
-  if (en == "POLSYNCHPL") S.emis = 4; else return -2;
+  if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else return -1;
+  if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else return -2;
   if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2; else return -3;
   S.mbh = mbh; S.nfac = ftscl; S.bfac = frscl; S.gmin = gmin; S.gmax = gmax; S.p1 = p1;
   for (int i = 0; i < 7; ++i) S.coefindx[i] = coefindx[i];
-  if (!ffjet_load(dfile, S.ffjet)) return -4;
+  if (S.fluid == 13 && !ffjet_load(dfile, S.ffjet)) return -4;
+  if (S.fluid == 1 && !sphacc_load(dfile, S.sphacc)) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;
@@ -166,7 +174,7 @@ void grto_ray_dump(int ii, double freq, int maxn, int *npts, int *status, double
     put(11, i, w.f[i].rho); put(12, i, w.f[i].p); put(13, i, w.f[i].bmag);
     for (int c = 0; c < 4; ++c) { put(14 + c, i, w.f[i].u[c]); put(18 + c, i, w.f[i].b[c]); }
     put(22, i, w.s2xi[i]); put(23, i, w.c2xi[i]); put(24, i, w.ang[i]); put(25, i, w.rshift[i]); put(26, i, w.cosne[i]);
-    put(28, i, w.ncgsnth[i]); put(29, i, w.bcgs[i]);
+    put(27, i, w.ncgs[i]); put(28, i, w.ncgsnth[i]); put(29, i, w.bcgs[i]); put(30, i, w.tcgs[i]);
     for (int c = 0; c < 4; ++c) put(31 + c, i, w.jraw[4 * i + c]);
     for (int c = 0; c < 7; ++c) put(35 + c, i, w.Kraw[7 * i + c]);
     for (int c = 0; c < 4; ++c) put(42 + c, i, w.j[4 * i + c]);

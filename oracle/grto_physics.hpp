@@ -123,6 +123,62 @@ inline void ffjet_vals(const FFJetTable &t, const double *x, float a, FluidPoint
   f.u[3] = f.u[0] * (double)vph0;
 }
 
+// ------------------------------------------------------------------ SPHACC (GR Bondi flow)
+// sphacc_vals fluid_model_sphacc.f90:450-497 ; get_sphacc_fluidvars fluid.f90:1215-1247 ; hunt.f
+struct SphaccTable { std::vector<float> uvals, vvals, rvals, tvals, uv; };
+
+inline bool sphacc_load(const char *path, SphaccTable &t) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return false;
+  std::vector<float> a(1918);
+  size_t n = std::fread(a.data(), 4, 1918, f);
+  std::fclose(f);
+  if (n != 1918) return false;
+  t.uvals.assign(a.begin(), a.begin() + 498); t.vvals.assign(a.begin() + 498, a.begin() + 996);
+  t.rvals.assign(a.begin() + 996, a.begin() + 1457); t.tvals.assign(a.begin() + 1457, a.end());
+  t.uv.resize(461);
+  for (int i = 0; i < 461; ++i) t.uv[i] = (float)(1.0 / (double)t.rvals[i]);   // uv=1d0/rvals
+  return true;
+}
+
+// hunt(): the bracketing index is independent of the starting guess; 1-based jlo in [0,n]
+inline int hunt_index(const std::vector<float> &xx, float x) {
+  int n = (int)xx.size();
+  bool ascnd = xx[n - 1] >= xx[0];
+  int jlo = 0, jhi = n + 1;
+  while (jhi - jlo > 1) {
+    int jm = (jhi + jlo) / 2;
+    if ((x >= xx[jm - 1]) == ascnd) jlo = jm; else jhi = jm;
+  }
+  if (x == xx[n - 1]) jlo = n - 1;
+  if (x == xx[0]) jlo = 1;
+  return jlo;
+}
+
+inline void sphacc_point(const SphaccTable &t, double r, FluidPoint &f) {
+  const float gamma = (float)(5.0 / 3.0), alpha = (float)(1.0 / 4.0), ninf = 1.f, Tinf = (float).917e-9, us = (float).94;
+  float u = (float)(1.0 / r);
+  float n = (float)((double)(ninf * alpha / 4.f / us) * std::pow((double)(2 * gamma * Tinf), -1.5) * std::pow(2.0 * (double)u, 1.5));
+  auto lookup = [&](const std::vector<float> &xx, const std::vector<float> &yy) {
+    int j = hunt_index(xx, u);
+    j = std::min(std::max(j, 1), (int)xx.size() - 1);      // address clamp only
+    float w = (u - xx[j - 1]) / (xx[j] - xx[j - 1]);
+    return (float)((1.0 - (double)w) * (double)yy[j - 1] + (double)(w * yy[j]));
+  };
+  float T = lookup(t.uv, t.tvals);
+  float B = (float)std::sqrt(8.0 * PH_pi * (double)n * 1.67262158e-24 / 2.0 * PH_c2 * (double)u);   // 8.*pi*n*mp/2.*c2*u
+  float ur = lookup(t.uvals, t.vvals);
+  float g00 = -(1.f - 2.f * u);
+  float grr = (float)(-1.0 / (double)g00);
+  f.u[1] = -(double)ur; f.u[2] = 0.0; f.u[3] = 0.0;
+  f.u[0] = std::sqrt((-(double)grr * f.u[1] * f.u[1] - 1) / (double)g00);
+  f.b[2] = 0.0; f.b[3] = 0.0;
+  double B2 = (double)(B * B);   // B**2 in REAL(4)
+  f.b[0] = std::sqrt(f.u[1] * f.u[1] * (double)grr * B2 / (f.u[1] * f.u[1] * (double)g00 * (double)grr + f.u[0] * f.u[0] * (double)g00 * (double)g00));
+  f.b[1] = -std::sqrt(B2 / (double)grr - f.b[0] * f.b[0] * (double)g00 / (double)grr);
+  f.rho = n; f.p = T; f.bmag = B;
+}
+
 // ------------------------------------------------------------------ emissivity
 struct PLTables {   // polsynchemis.f90:107-525 (values dumped from the compiled reference)
   std::vector<double> gx, gy, xv, ya, yp, yv, yap, yav;

@@ -57,6 +57,8 @@ class Oracle:
     def __init__(self, **kw):
         p = dict(DEFAULTS)
         p.update({k: v for k, v in kw.items() if k in DEFAULTS})
+        if p["fname"] == "SPHACC" and "dfile" not in kw:
+            p["dfile"] = os.path.join(DATA, "sphacc_tables.bin")
         self.p = p
         gv = np.asarray(p["gridvals"], dtype=np.float64)
         nn = np.asarray(p["nn"], dtype=np.int32)

@@ -435,4 +435,16 @@ contains
     out(1778:2020) = yavvals
   end subroutine ref_polsynchpl_tables
 
+  ! The SPHACC 1-D tables as the compiled reference holds them (fluid_model_sphacc.f90:13-443):
+  ! out = uvals(498) vvals(498) rvals(461) tvals(461), REAL(4)
+  subroutine ref_sphacc_tables(out) bind(C, name='ref_sphacc_tables')
+    use fluid_model_sphacc, only: uvals, vvals, rvals, tvals, init_sphacc, del_sphacc
+    real(c_float), intent(out) :: out(1918)
+    logical :: mine
+    mine = .not. allocated(uvals)
+    if (mine) call init_sphacc()
+    out(1:498) = uvals; out(499:996) = vvals; out(997:1457) = rvals; out(1458:1918) = tvals
+    if (mine) call del_sphacc()
+  end subroutine ref_sphacc_tables
+
 end module grt_ref_driver

@@ -108,6 +108,36 @@ def ffjet(nx, nup):
     np.savez_compressed(os.path.join(G, "ffjet_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ, **rays)
 
 
+SPHACC = dict(fname="SPHACC", ename="POLSYNCHTH", spin=0.0, standard=1, uout=0.04, mbh=10.0, mu0=0.5,
+              gridvals=(-25., 25., -25., 25.))
+FREQ_SPHACC = 2.41e11
+
+
+def sphacc(nx, nup):
+    # BASELINE config 2 (inputs_sphacc.in) on a smaller camera.  nthreads=1 ON PURPOSE: the reference's
+    # SPHACC path is not thread-safe (module-level state in fluid_model_sphacc.f90 is not threadprivate):
+    # two 8-thread runs of the compiled reference differ from each other in ~3 % of the pixels by up to
+    # 3 % of the Stokes peak, the 1-thread run is reproducible.
+    out = {}
+    for iname in ("formal", "delo"):
+        r = R.Ref(nn=(nx, nx, nup), iname=iname, **SPHACC)
+        pix, npts, _ = r.trace(1, nx * nx, [FREQ_SPHACC], nthreads=1)
+        out["ivals_" + iname] = pix[0]
+        out["npts"] = npts
+    np.savez_compressed(os.path.join(G, "sphacc_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_SPHACC, **out)
+    rays = {}
+    pick = sorted(set([1, nx // 2 * nx + nx // 2 + 1, nx * (nx // 3) + 2 * nx // 3, nx * nx,
+                       int(np.where(out["npts"] == nup)[0][0]) + 1]))
+    r = R.Ref(nn=(nx, nx, nup), iname="formal", **SPHACC)
+    for i in pick:
+        d = r.ray_dump(i, FREQ_SPHACC)
+        for k, v in d.items():
+            rays["ray%d_%s" % (i, k)] = np.asarray(v)
+        rays["ray%d_ncase" % i] = np.array(r.geokerr_ray(i)["ncase"])
+    rays["rays"] = np.array(pick)
+    np.savez_compressed(os.path.join(G, "sphacc_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_SPHACC, **rays)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -117,4 +147,5 @@ if __name__ == "__main__":
     leafs(); coeffs(); integrators(); reference_pickle()
     ffjet(100, 400)
     ffjet(32, 100)
+    sphacc(64, 200)
     print("golden fixtures written to", os.path.abspath(G))
