@@ -24,6 +24,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 FREQ = 3.45e11
+# headline workload first; the others are BASELINE.json's smaller configs, selectable for profiling only
+WORKLOADS = {
+    "ffjet": dict(fname="FFJET", ename="POLSYNCHPL", spin=0.998, mu0=0.906, uout=0.01, gridvals=(-40., 20., -20., 40.),
+                  mbh=3.4e9, nfac=2.0, bfac=70.0, freq=3.45e11),
+    "sphacc": dict(fname="SPHACC", ename="POLSYNCHTH", spin=0.0, mu0=0.5, uout=0.04, gridvals=(-25., 25., -25., 25.),
+                   mbh=10.0, nfac=1.0, bfac=6.0, freq=2.41e11),
+}
 BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lambda,I,Q,U,V) per ray-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -72,6 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nn", type=int, nargs=3, default=[1024, 1024, 400])
     ap.add_argument("--iname", default="formal")
+    ap.add_argument("--workload", default="ffjet", choices=sorted(WORKLOADS))
     ap.add_argument("--no-steps-record", action="store_true", help="do not write the per-step SoA record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -91,10 +99,12 @@ def main():
     nx, ny, nup = args.nn
     nx_total = nx * world                      # weak scaling: camera widens with the rank count
     dev = capi.Device(local_rank)
+    W = WORKLOADS[args.workload]
     dev.load_ffjet()
+    dev.load_sphacc()
     dev.load_tables()
-    cam = capi.make_camera(1, (-40., 20., -20., 40.), (nx_total, ny, nup), 0.998, 0.906, 0.01, -0.5)
-    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    cam = capi.make_camera(1, W["gridvals"], (nx_total, ny, nup), W["spin"], W["mu0"], W["uout"], -0.5)
+    em = capi.make_emis(W["ename"], W["mbh"], W["nfac"], W["bfac"], 100., 1e5, 3.5)
     i1 = rank * nx * ny + 1
     i2 = (rank + 1) * nx * ny
     capi.record_steps(not args.no_steps_record)
@@ -105,7 +115,7 @@ def main():
         torch.cuda.synchronize()
 
     def one_step():
-        _, _, _, st = capi.trace_tile(cam, i1, i2, "FFJET", em, [FREQ], args.iname, resident=True)
+        _, _, _, st = capi.trace_tile(cam, i1, i2, W["fname"], em, [W["freq"]], args.iname, resident=True)
         return st
 
     # secondary figure: image-only mode (no per-step record, azimuth integrals skipped), untimed region
@@ -178,8 +188,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "deterministic: BL09 FFJET table shipped with the reference (no RNG in the path)",
-            "config": {"workload": "FFJET POLSYNCHPL nvals=4 spin=0.998 mu0=0.906 nn=[%d,%d,%d] per GPU, nfreq=1 "
-                                   "(3.45e11 Hz), iname=%s, gridvals=[-40,20,-20,40], uout=0.01" % (nx, ny, nup, args.iname),
+            "config": {"workload": "%s %s nvals=4 spin=%g mu0=%g nn=[%d,%d,%d] per GPU, nfreq=1 (%g Hz), iname=%s, "
+                                   "gridvals=%s, uout=%g" % (W["fname"], W["ename"], W["spin"], W["mu0"], nx, ny, nup,
+                                                             W["freq"], args.iname, list(W["gridvals"]), W["uout"]),
                        "pixels_per_gpu": nx * ny, "ray_steps_per_step_per_gpu": ray_steps // args.steps,
                        "parallelism": "pixel strips i1..i2 per GPU, 1 process/GPU, RCCL gather of fp32 tiles",
                        "per_step_record_written": not args.no_steps_record,
@@ -191,7 +202,7 @@ def main():
                          "note": "algorithmic 64 B per ray-step (SURVEY 8d) over the trace kernel's HIP-event time; "
                                  "the kernel is fp64-VALU bound (~1e4 flop-equivalents per step), see DESIGN.md"},
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "ffjet":
             out["cpu_baseline"] = cpu_baseline(nx, ny, nup)
         print(json.dumps(out))
     dev.close()

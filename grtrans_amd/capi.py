@@ -73,6 +73,10 @@ class Device:
         path = path or os.path.join(DATA, "m87bl09rfp10xi5a998fluidvars.bin")
         check(lib().grt_load_ffjet_file(path.encode()), "grt_load_ffjet_file")
 
+    def load_sphacc(self, path=None):
+        path = path or os.path.join(DATA, "sphacc_tables.bin")
+        check(lib().grt_load_sphacc_tables_file(path.encode()), "grt_load_sphacc_tables_file")
+
     def load_tables(self, path=None):
         path = path or os.path.join(DATA, "polsynchpl_tables.bin")
         check(lib().grt_load_polsynchpl_tables_file(path.encode()), "grt_load_polsynchpl_tables_file")

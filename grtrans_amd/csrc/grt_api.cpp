@@ -16,8 +16,8 @@ extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, int nlive, double *steps, unsigned char *flags,
                                      long long ray_stride, long long field_stride, int nfields);
-extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays,
-                                          const int *live, int nlive, const GrtFFJet *fj, const GrtTables *tb,
+extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, const GrtCam *cam, const GrtRay *rays,
+                                          const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned char *flags, long long ray_stride, long long field_stride,
@@ -34,6 +34,7 @@ struct Ctx {
   float *d_cells = nullptr, *d_uniq = nullptr;
   GrtFFJet ffjet{};
   bool have_ffjet = false;
+  float *d_sphacc = nullptr;
   double *d_tables = nullptr;
   GrtTables tables{};
   double h_tables[2020] = {0};
@@ -102,7 +103,7 @@ int grt_free(void) {
   if (!C.init) return 0;
   (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
-                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags};
+                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -168,6 +169,29 @@ int grt_load_ffjet_file(const char *path) {
   // p_arr is never read by the reference (fluid_model_ffjet.f90:203-206): zeros here.
   return grt_upload_ffjet(nx, arr(r1, 0), arr(r1, 1), arr(r1, 2), nullptr, arr(r2, 1), arr(r2, 2), arr(r2, 3),
                           arr(r2, 4), arr(r3, 0), arr(r3, 1), arr(r3, 2), arr(r3, 3));
+}
+
+int grt_upload_sphacc(const float *uvals, const float *vvals, const float *rvals, const float *tvals) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!uvals || !vvals || !rvals || !tvals) return GRT_E_BADARG;
+  std::vector<float> h(2 * 498 + 2 * 461);
+  std::memcpy(h.data(), uvals, 498 * sizeof(float));
+  std::memcpy(h.data() + 498, vvals, 498 * sizeof(float));
+  for (int i = 0; i < 461; ++i) h[996 + i] = (float)(1.0 / (double)rvals[i]);   // uv=1d0/rvals, fluid_model_sphacc.f90:505
+  std::memcpy(h.data() + 1457, tvals, 461 * sizeof(float));
+  if (!C.d_sphacc) HIPCHK(hipMalloc((void **)&C.d_sphacc, h.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(C.d_sphacc, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int grt_load_sphacc_tables_file(const char *path) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return GRT_E_IO;
+  std::vector<float> t(1918);
+  size_t n = std::fread(t.data(), 4, 1918, f);
+  std::fclose(f);
+  if (n != 1918) return GRT_E_IO;
+  return grt_upload_sphacc(t.data(), t.data() + 498, t.data() + 996, t.data() + 1457);
 }
 
 int grt_upload_polsynchpl_tables(const double *t) {
@@ -247,12 +271,18 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (!C.init) return GRT_E_NOTINIT;
   if (!cam || !em || !freqs || nfreq < 1 || nfreq > 32 || i2 < i1 || i1 < 1) return GRT_E_BADARG;
   if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
-  if (fluid_model != GRT_FLUID_FFJET) return GRT_E_UNSUPPORTED;
-  if (em->type != GRT_EMIS_POLSYNCHPL) return GRT_E_UNSUPPORTED;
+  // (fluid, emissivity) pairs that have a kernel; everything else is refused, never emulated
+  const bool pair_ok = (fluid_model == GRT_FLUID_FFJET && em->type == GRT_EMIS_POLSYNCHPL) ||
+                       (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH);
+  if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   if (cam->standard != 1 || cam->nup < 2 || nvals != 4 || nextra != 0) return GRT_E_UNSUPPORTED;
-  if (!C.have_ffjet) return GRT_E_NOFLUID;
-  if (!C.have_tables) return GRT_E_NOTABLES;
+  if (fluid_model == GRT_FLUID_FFJET && !C.have_ffjet) return GRT_E_NOFLUID;
+  if (fluid_model == GRT_FLUID_SPHACC && !C.d_sphacc) return GRT_E_NOFLUID;
+  if (em->type == GRT_EMIS_POLSYNCHPL && !C.have_tables) return GRT_E_NOTABLES;
+  GrtFluidDev fd{};
+  fd.fj = C.ffjet;
+  fd.sphacc = C.d_sphacc;
   HIPCHK(hipSetDevice(C.device));
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
@@ -299,10 +329,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
                         maxpts, fstride, nfields));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
-  HIPCHK(grt_launch_transfer(C.stream, iflag, cam, C.d_rays, C.d_live, ncls[0], &C.ffjet, &C.tables, em, &plc, nfreq, C.d_freqs,
+  HIPCHK(grt_launch_transfer(C.stream, iflag, fluid_model, em->type, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, maxpts,
                              fstride, nfields, C.d_stepcount));
-  HIPCHK(grt_launch_transfer(C.stream, iflag, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &C.ffjet, &C.tables, em, &plc,
+  HIPCHK(grt_launch_transfer(C.stream, iflag, fluid_model, em->type, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
                              C.d_flags, maxpts, fstride, nfields, C.d_stepcount));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));

@@ -565,6 +565,54 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
   f.u[3] = f.u[0] * (double)vph0;
 }
 
+// ------------------------------------------------------------------ SPHACC (GR Bondi flow)
+// sphacc_vals fluid_model_sphacc.f90:450-497, get_sphacc_fluidvars fluid.f90:1215-1247.  The four 1-D
+// tables (u->v: 498 points, 1/r->T: 461 points; 7.7 KB) are staged in LDS by the transfer kernel, `tab`
+// points at [uvals 498][vvals 498][uv 461][tvals 461].
+#define GRT_SPHACC_NU 498
+#define GRT_SPHACC_NT 461
+#define GRT_SPHACC_NTAB (2 * GRT_SPHACC_NU + 2 * GRT_SPHACC_NT)
+
+// hunt.f: the bracket it returns does not depend on its starting guess; 1-based jlo in [0,n]
+GRT_HD int hunt_index(const float *xx, int n, float x) {
+  const bool ascnd = xx[n - 1] >= xx[0];
+  int jlo = 0, jhi = n + 1;
+  while (jhi - jlo > 1) {
+    int jm = (jhi + jlo) >> 1;
+    if ((x >= xx[jm - 1]) == ascnd) jlo = jm; else jhi = jm;
+  }
+  if (x == xx[n - 1]) jlo = n - 1;
+  if (x == xx[0]) jlo = 1;
+  return jlo;
+}
+
+GRT_HD float sphacc_lookup(const float *xx, const float *yy, int n, float u) {
+  GRT_NO_CONTRACT
+  int j = hunt_index(xx, n, u);
+  j = j < 1 ? 1 : (j > n - 1 ? n - 1 : j);      // address clamp only
+  float w = (u - xx[j - 1]) / (xx[j] - xx[j - 1]);
+  return (float)((1.0 - (double)w) * (double)yy[j - 1] + (double)(w * yy[j]));
+}
+
+GRT_HD void sphacc_sample(const float *tab, double r, FluidPoint &f) {
+  GRT_NO_CONTRACT
+  const float gamma = (float)(5.0 / 3.0), alpha = 0.25f, ninf = 1.f, Tinf = (float).917e-9, us = (float).94;
+  const float u = (float)(1.0 / r);
+  const float n = (float)((double)(ninf * alpha / 4.f / us) * pow((double)(2 * gamma * Tinf), -1.5) * pow(2.0 * (double)u, 1.5));
+  const float T = sphacc_lookup(tab + 2 * GRT_SPHACC_NU, tab + 2 * GRT_SPHACC_NU + GRT_SPHACC_NT, GRT_SPHACC_NT, u);
+  const float B = (float)sqrt(8.0 * PH_pi * (double)n * 1.67262158e-24 / 2.0 * PH_c2 * (double)u);
+  const float ur = sphacc_lookup(tab, tab + GRT_SPHACC_NU, GRT_SPHACC_NU, u);
+  const float g00 = -(1.f - 2.f * u);
+  const float grr = (float)(-1.0 / (double)g00);
+  f.u[1] = -(double)ur; f.u[2] = 0.0; f.u[3] = 0.0;
+  f.u[0] = sqrt((-(double)grr * f.u[1] * f.u[1] - 1) / (double)g00);
+  f.b[2] = 0.0; f.b[3] = 0.0;
+  const double B2 = (double)(B * B);
+  f.b[0] = sqrt(f.u[1] * f.u[1] * (double)grr * B2 / (f.u[1] * f.u[1] * (double)g00 * (double)grr + f.u[0] * f.u[0] * (double)g00 * (double)g00));
+  f.b[1] = -sqrt(B2 / (double)grr - f.b[0] * f.b[0] * (double)g00 / (double)grr);
+  f.rho = n; f.p = T; f.bmag = B;
+}
+
 // ------------------------------------------------------------------ transfer steps as affine maps
 struct Affine {   // I -> A I + b
   double A[4][4], b[4];

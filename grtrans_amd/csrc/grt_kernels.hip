@@ -143,16 +143,21 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
 }
 
-template <int IFLAG>
+template <int IFLAG, int FLUID, int EMIS>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_transfer_kernel(
-    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFFJet fj, GrtTables tb,
+    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned char *__restrict__ flags,
     long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
   __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
   __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
   __shared__ double s_nb[IFLAG == GRT_INT_DELO ? GRT_WAVES_PER_BLOCK : 1][IFLAG == GRT_INT_DELO ? GRT_MAXF : 1][11];
+  __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches
+    for (int i = threadIdx.x; i < GRT_SPHACC_NTAB; i += blockDim.x) s_sphacc[i] = fd.sphacc[i];
+    __syncthreads();
+  }
   int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
   if (slot >= nlive) return;
   slot = __builtin_amdgcn_readfirstlane(slot);
@@ -186,10 +191,14 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
     sumr += valid ? r : 0.0;
     // fluid + frame (grtrans_driver.f90:126-130)
     FluidPoint fl;
-    ffjet_sample(fj, r, th, (float)cam.a, fl);
+    if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
+    else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
     double s2xi, c2xi, ang, g, cosne;
     comoving_ortho(r, th, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g, cosne);
-    const double ncgsnth = (double)fl.rho * em.nfac, bcgs = (double)fl.bmag * em.bfac;
+    // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC)
+    double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
+    if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }
+    else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
     // neighbour along the integration direction = stored point idx+1 = lane-1 (or previous chunk)
     double lam_nb = __shfl_up(lam_i, 1);
     if (lane == 0) lam_nb = nb_lam;
@@ -199,7 +208,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
     for (int f = 0; f < nfreq; ++f) {
       const double nu = freqs[f] / g;
       double e[11];
-      polsynchpl_fast(tb, plc, nu, ncgsnth, bcgs, ang, e);
+      if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_fast(tb, plc, nu, ncgsnth, bcgs, ang, e);
+      else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth(nu, ncgs, bcgs, tcgs, ang, e);
 #pragma unroll
       for (int c = 0; c < 7; ++c)
         if (!em.coefindx[c]) e[4 + c] = 0.0;
@@ -317,21 +327,36 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   return hipGetLastError();
 }
 
-extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, const GrtCam *cam, const GrtRay *rays,
-                                          const int *live, int nlive, const GrtFFJet *fj, const GrtTables *tb,
+template <int IFLAG, int FLUID, int EMIS>
+static void launch_transfer_t(hipStream_t s, dim3 g, dim3 b, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
+                              const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
+                              const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
+                              double *steps, const unsigned char *flags, long long ray_stride, long long field_stride,
+                              int nfields, unsigned long long *step_counter) {
+  hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS>), g, b, 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq,
+                     freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields,
+                     step_counter);
+}
+
+// returns hipErrorInvalidValue for a (fluid, emissivity, integrator) combination that has no kernel
+extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, const GrtCam *cam, const GrtRay *rays,
+                                          const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned char *flags, long long ray_stride, long long field_stride,
                                           int nfields, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
-  if (iflag == GRT_INT_DELO)
-    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_DELO>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, *plc, nfreq, freqs,
-                       pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields,
-                       step_counter);
-  else
-    hipLaunchKernelGGL(grt_transfer_kernel<GRT_INT_FORMAL>, g, b, 0, s, *cam, rays, live, nlive, *fj, *tb, *em, *plc, nfreq,
-                       freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride,
-                       nfields, step_counter);
-  return hipGetLastError();
+#define GRT_XFER_CASE(I, F, E)                                                                                          \
+  if (iflag == I && fluid == F && emis == E) {                                                                          \
+    launch_transfer_t<I, F, E>(s, g, b, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals, \
+                               ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);           \
+    return hipGetLastError();                                                                                           \
+  }
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
+#undef GRT_XFER_CASE
+  return hipErrorInvalidValue;
 }

@@ -41,6 +41,11 @@ struct GrtFFJet {               // device pointers; cell-interleaved copy of the
   int32_t nx1, pad;
 };
 
+struct GrtFluidDev {            // what the transfer kernel samples; only the selected model's part is read
+  GrtFFJet fj;
+  const float *sphacc;          // [uvals 498][vvals 498][1/rvals 461][tvals 461], fluid_model_sphacc.f90
+};
+
 struct GrtTables {              // polsynchpl log-G tables (polsynchemis.f90:107-525), device pointers
   const double *gx, *gy, *xv, *ya, *yp, *yv, *yap, *yav;
   // log-log slopes (y[i+1]-y[i])/(x[i+1]-x[i]) of the same tables, computed once on upload

@@ -135,6 +135,8 @@ class grtrans:
             if inp.fname == 'FFJET':
                 path = inp.fdfile if os.path.exists(inp.fdfile) else os.path.join(capi.DATA, inp.fdfile)
                 dev.load_ffjet(path)
+            elif inp.fname == 'SPHACC':
+                dev.load_sphacc()
             ivals = np.zeros((inp.nvals, npix, ncams))
             ab = np.zeros((2, npix))
             for j in range(nmu):

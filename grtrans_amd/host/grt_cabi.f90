@@ -45,6 +45,11 @@ module grt_cabi
        character(kind=c_char), dimension(*), intent(in) :: path
        integer(c_int) :: rc
      end function grt_load_ffjet_file
+     function grt_load_sphacc_tables_file(path) bind(C, name='grt_load_sphacc_tables_file') result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), dimension(*), intent(in) :: path
+       integer(c_int) :: rc
+     end function grt_load_sphacc_tables_file
      function grt_load_polsynchpl_tables_file(path) bind(C, name='grt_load_polsynchpl_tables_file') result(rc)
        import :: c_int, c_char
        character(kind=c_char), dimension(*), intent(in) :: path

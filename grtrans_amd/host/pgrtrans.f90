@@ -87,10 +87,12 @@ contains
     if (extra /= 0 .or. debug /= 0) call die('extra=1 / debug=1 are not supported yet')
     select case (trim(fname))
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
+    case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
     select case (trim(ename))
     case ('POLSYNCHPL'); emis_id = GRT_EMIS_POLSYNCHPL
+    case ('POLSYNCHTH'); emis_id = GRT_EMIS_POLSYNCHTH
     case default; call die('emissivity '//trim(ename)//' is not on the device yet')
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37
@@ -117,6 +119,10 @@ contains
           rc = grt_load_ffjet_file(cstr(path))
        end if
        if (rc /= 0) call die_rc('grt_load_ffjet_file '//trim(fdfile), rc)
+    else if (fluid_id == GRT_FLUID_SPHACC) then
+       ! the reference holds these tables as DATA statements (fluid_model_sphacc.f90:40-448)
+       path = trim(datadir)//'/sphacc_tables.bin'
+       rc = grt_load_sphacc_tables_file(cstr(path)); if (rc /= 0) call die_rc('grt_load_sphacc_tables_file '//trim(path), rc)
     end if
 
     write(6,*) 'welcome to grtrans! (MI355X per-pixel path)'

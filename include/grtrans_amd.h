@@ -73,6 +73,12 @@ int grt_upload_ffjet(int nx, const float *rc, const float *thc, const float *rho
 /* convenience: read the Fortran sequential file itself (same records as fluid_model_ffjet.f90:200-207) */
 int grt_load_ffjet_file(const char *path);
 
+/* replaces init_sphacc / initialize_sphacc_model (fluid_model_sphacc.f90:40-448,499-507): the module's
+ * DATA tables uvals[498], vvals[498] (radial velocity) and rvals[461], tvals[461] (temperature), REAL(4).
+ * The file form is those 1918 floats back to back. */
+int grt_upload_sphacc(const float *uvals, const float *vvals, const float *rvals, const float *tvals);
+int grt_load_sphacc_tables_file(const char *path);
+
 /* replaces initialize_polsynchpl (polsynchemis.f90:107-525): 2020 doubles,
  * gxvals[181] gyvals[543] xvals[81] yavals[243] ypvals[243] yvvals[243] yapvals[243] yavvals[243] */
 int grt_upload_polsynchpl_tables(const double *tables2020);

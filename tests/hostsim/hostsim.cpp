@@ -75,4 +75,13 @@ int hs_ray_points(const GrtCam *cam, int ii, int maxn, double *u, double *mu, do
   }
   return R.npts;
 }
+
+// fluid / emissivity device functions, for the CPU-side check against the oracle's per-stage dumps
+void hs_sphacc_point(const float *tab, double r, double *out11) {
+  FluidPoint f;
+  sphacc_sample(tab, r, f);
+  out11[0] = f.rho; out11[1] = f.p; out11[2] = f.bmag;
+  for (int i = 0; i < 4; ++i) { out11[3 + i] = f.u[i]; out11[7 + i] = f.b[i]; }
+}
+void hs_polsynchth(double nu, double n, double B, double T, double th, double *e11) { polsynchth(nu, n, B, T, th, e11); }
 }

@@ -104,12 +104,56 @@ def test_per_step_record_matches_reference_dump(dev):
         capi.record_steps(False)
 
 
+FREQ_SPHACC = 2.41e11
+
+
+def run_sphacc(nn, iname, freqs=(FREQ_SPHACC,)):
+    from grtrans_amd import capi
+    cam = capi.make_camera(1, (-25., 25., -25., 25.), nn, 0.0, 0.5, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+    return capi.trace_tile(cam, 1, nn[0] * nn[1], "SPHACC", em, list(freqs), iname)
+
+
+@pytest.mark.parametrize("iname", ["formal", "delo"])
+def test_sphacc_polsynchth_vs_reference_golden(dev, iname):
+    # BASELINE config 2 (spin 0 -> cubic root cases, thermal coefficients, 1-D Bondi tables in LDS)
+    dev.load_sphacc()
+    g = np.load(os.path.join(G, "sphacc_64x64x200.npz"))
+    pix, loc, status, st = run_sphacc((64, 64, 200), iname)
+    assert np.array_equal(status, g["npts"])
+    assert st.rays_dead == int((g["npts"] == 0).sum())       # image corners outside uout: compacted away
+    assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL
+
+
+def test_sphacc_per_step_record(dev):
+    from grtrans_amd import capi
+    dev.load_sphacc()
+    g = np.load(os.path.join(G, "sphacc_rays_64x64x200.npz"))
+    capi.record_steps(True)
+    try:
+        run_sphacc((64, 64, 200), "formal")
+        for i in g["rays"]:
+            n = int(g["ray%d_npts" % i])
+            if n == 0:
+                continue
+            rec = capi.download_steps(int(i) - 1, 1, 230)[:, 0, :n]
+            x = g["ray%d_x" % i]
+            assert np.allclose(rec[0], x[:, 1], rtol=1e-9)
+            assert np.allclose(rec[1], x[:, 2], rtol=1e-9, atol=1e-12)
+            I = g["ray%d_I" % i]
+            assert np.abs(rec[4:8, ::-1].T[:n] - I).max() / (np.abs(I).max() + 1e-300) < 1e-5
+    finally:
+        capi.record_steps(False)
+
+
 def test_library_refuses_unsupported(dev):
     from grtrans_amd import capi
     cam = capi.make_camera(1, (-40., 20., -20., 40.), (8, 8, 50), 0.998, 0.906, 0.01, -0.5)
     em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
     with pytest.raises(capi.GrtError):
         capi.trace_tile(cam, 1, 64, "FFJET", em, [FREQ], "lsoda")   # LSODA stays CPU-only
+    with pytest.raises(capi.GrtError):
+        capi.trace_tile(cam, 1, 64, "SPHACC", em, [FREQ], "formal")  # no (SPHACC, POLSYNCHPL) kernel: refused, not emulated
 
 
 def test_fortran_host_exe_and_harness_end_to_end(tmp_path, monkeypatch):
