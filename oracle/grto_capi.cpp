@@ -3,7 +3,7 @@
 // Per-pixel driver (grtrans_driver.f90:57-466, extra=0) and pixel loop (pgrtrans.f90:196-212)
 // on top of the restated stages, exported with a flat C API for tests/ (ctypes) and for
 // bench.py's cpu_baseline leg.  Built by oracle/Makefile into oracle/_build/libgrt_oracle.so.
-#include "grto_physics.hpp"
+#include "grto_harm.hpp"
 #include <omp.h>
 #include <string>
 
@@ -22,6 +22,8 @@ struct Setup {
   int coefindx[7] = {1, 1, 1, 1, 1, 1, 1};
   FFJetTable ffjet;
   SphaccTable sphacc;
+  HarmTable harm;
+  double mdot = 0, muval = 0;
   PLTables pl;
   bool ok = false;
 };
@@ -52,7 +54,8 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
   for (int i = 0; i < n; ++i) {
     const double *x = &w.g.x[4 * i], *k = &w.g.k[4 * i];
     if (S.fluid == 13) ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
-    else sphacc_point(S.sphacc, x[1], w.f[i]);
+    else if (S.fluid == 1) sphacc_point(S.sphacc, x[1], w.f[i]);
+    else harm_vals(S.harm, x, (float)S.cam.a, w.f[i]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
     double nu = freq / w.rshift[i];
@@ -60,8 +63,10 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
     if (S.fluid == 13) {
       w.ncgsnth[i] = w.f[i].rho * S.nfac;   // fluid.f90:1171
       w.bcgs[i] = w.f[i].bmag * S.bfac;
-    } else {                                // fluid.f90:1249-1259
+    } else if (S.fluid == 1) {              // fluid.f90:1249-1259
       w.ncgs[i] = w.f[i].rho; w.bcgs[i] = w.f[i].bmag; w.tcgs[i] = w.f[i].p;
+    } else {                                // fluid.f90:957-973
+      harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
     if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
     else polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);
@@ -116,18 +121,20 @@ void grto_sncndn(double u, double emmc, double *sn, double *cn, double *dn) { sn
 int grto_setup(int standard, double mu0, double phi0, double spin, double uout, const double *gridvals,
                const int *nn, const char *fname, const char *ename, const char *iname, const char *dfile,
                const char *pltab, double mbh, double gmin, double gmax, double p1, double ftscl, double frscl,
-               const int *coefindx, int nvals) {
+               const int *coefindx, int nvals, const char *hfile, int indf, double mdot, double muval) {
   S = Setup();
   camera_init(S.cam, standard, gridvals[0], gridvals[1], gridvals[2], gridvals[3], nn[0], nn[1], nn[2], spin, mu0, uout);
   S.phi0 = phi0; S.spin = spin; S.nvals = nvals;
   std::string fn(fname), en(ename), in(iname);
-  if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else return -1;
+  if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else if (fn == "HARM") S.fluid = 12; else return -1;
+  S.mdot = mdot; S.muval = muval;
   if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else return -2;
   if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2; else return -3;
   S.mbh = mbh; S.nfac = ftscl; S.bfac = frscl; S.gmin = gmin; S.gmax = gmax; S.p1 = p1;
   for (int i = 0; i < 7; ++i) S.coefindx[i] = coefindx[i];
   if (S.fluid == 13 && !ffjet_load(dfile, S.ffjet)) return -4;
   if (S.fluid == 1 && !sphacc_load(dfile, S.sphacc)) return -4;
+  if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm) != 0) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;

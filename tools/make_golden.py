@@ -138,6 +138,40 @@ def sphacc(nx, nup):
     np.savez_compressed(os.path.join(G, "sphacc_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_SPHACC, **rays)
 
 
+HARM = dict(fname="HARM", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1.57e15, mu0=0.6428,
+            gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=1., dfile="dump", hfile="dump040", findf=40, fnt=1)
+FREQ_HARM = 2.3e11
+
+
+def harm(nx, nup, nzone=64):
+    # BASELINE config 4 on the synthetic HARM-format dump of tools/make_harm_dump.py (dump040 is not shipped
+    # with the reference: parity on real GRMHD data stays unpinned)
+    import hashlib
+    import tempfile
+    import make_harm_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = make_harm_dump.write(td, n=nzone)
+        out["dump_sha256"] = np.array(hashlib.sha256(open(path, "rb").read()).hexdigest())
+        for iname in ("formal", "delo"):
+            r = R.Ref(nn=(nx, nx, nup), iname=iname, datadir=td, **HARM)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=8)
+            out["ivals_" + iname] = pix[0]
+            out["npts"] = npts
+        rays = {}
+        pick = sorted(set([3, nx // 2 * nx + nx // 2, nx * 10 + 30, nx * 30 + 12, nx * nx - 4,
+                           int(np.where(npts == nup)[0][0]) + 1]))
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **HARM)
+        for i in pick:
+            d = r.ray_dump(i, FREQ_HARM)
+            for k, v in d.items():
+                rays["ray%d_%s" % (i, k)] = np.asarray(v)
+            rays["ray%d_ncase" % i] = np.array(r.geokerr_ray(i)["ncase"])
+        rays["rays"] = np.array(pick)
+    np.savez_compressed(os.path.join(G, "harm_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, nzone=nzone, **out)
+    np.savez_compressed(os.path.join(G, "harm_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, nzone=nzone, **rays)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -148,4 +182,5 @@ if __name__ == "__main__":
     ffjet(100, 400)
     ffjet(32, 100)
     sphacc(64, 200)
+    harm(48, 200)
     print("golden fixtures written to", os.path.abspath(G))
