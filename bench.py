@@ -30,6 +30,9 @@ WORKLOADS = {
                   mbh=3.4e9, nfac=2.0, bfac=70.0, freq=3.45e11),
     "sphacc": dict(fname="SPHACC", ename="POLSYNCHTH", spin=0.0, mu0=0.5, uout=0.04, gridvals=(-25., 25., -25., 25.),
                    mbh=10.0, nfac=1.0, bfac=6.0, freq=2.41e11),
+    # synthetic 256x256-zone HARM-format dump written by tools/make_harm_dump.py (seed 20261002) at start-up
+    "harm": dict(fname="HARM", ename="POLSYNCHTH", spin=0.9375, mu0=0.6428, uout=0.04, gridvals=(-13., 13., -13., 13.),
+                 mbh=4e6, nfac=1.0, bfac=6.0, freq=2.3e11, gmin=1.0, mdot=1.57e15),
 }
 BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lambda,I,Q,U,V) per ray-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -103,8 +106,15 @@ def main():
     dev.load_ffjet()
     dev.load_sphacc()
     dev.load_tables()
+    if args.workload == "harm":
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_harm_dump
+        hd = tempfile.mkdtemp(prefix="grt_harm_")
+        make_harm_dump.write(hd, n=256)
+        dev.load_harm(os.path.join(hd, "dump"), os.path.join(hd, "dump040"), 40, W["spin"])
     cam = capi.make_camera(1, W["gridvals"], (nx_total, ny, nup), W["spin"], W["mu0"], W["uout"], -0.5)
-    em = capi.make_emis(W["ename"], W["mbh"], W["nfac"], W["bfac"], 100., 1e5, 3.5)
+    em = capi.make_emis(W["ename"], W["mbh"], W["nfac"], W["bfac"], W.get("gmin", 100.), 1e5, 3.5, mdot=W.get("mdot", 0.0))
     i1 = rank * nx * ny + 1
     i2 = (rank + 1) * nx * ny
     capi.record_steps(not args.no_steps_record)

@@ -27,6 +27,7 @@ class GrtCam(C.Structure):
 class GrtEmis(C.Structure):
     _fields_ = [("mbh", C.c_double), ("nfac", C.c_double), ("bfac", C.c_double),
                 ("gmin", C.c_double), ("gmax", C.c_double), ("p1", C.c_double), ("muval", C.c_double),
+                ("mdot", C.c_double), ("gminval", C.c_double),
                 ("type", C.c_int32), ("coefindx", C.c_int32 * 7)]
 
 
@@ -77,6 +78,10 @@ class Device:
         path = path or os.path.join(DATA, "sphacc_tables.bin")
         check(lib().grt_load_sphacc_tables_file(path.encode()), "grt_load_sphacc_tables_file")
 
+    def load_harm(self, dfile, hfile, indf, spin):
+        check(lib().grt_load_harm_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin)),
+              "grt_load_harm_files")
+
     def load_tables(self, path=None):
         path = path or os.path.join(DATA, "polsynchpl_tables.bin")
         check(lib().grt_load_polsynchpl_tables_file(path.encode()), "grt_load_polsynchpl_tables_file")
@@ -94,11 +99,12 @@ def make_camera(standard, gridvals, nn, spin, mu0, uout, phi0=-0.5):
     return cam
 
 
-def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7):
+def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7, mdot=0.0):
     em = GrtEmis()
     em.mbh, em.nfac, em.bfac = mbh, nfac, bfac
     em.gmin, em.gmax, em.p1 = _f32(gmin), _f32(gmax), _f32(p1)   # REAL(4) in emis_params (emis.f90:32-39)
     em.muval = muval
+    em.mdot, em.gminval = mdot, gmin                             # REAL(8) in source_params (fluid.f90:67-74)
     em.type = EMIS[ename]
     for i in range(7):
         em.coefindx[i] = int(coefindx[i])

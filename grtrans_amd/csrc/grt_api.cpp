@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 #include "grt_types.h"
+#include "grt_harm_pack.hpp"
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
                                        int *ray_npts, int *live, int *counters, void *rrays);
@@ -35,6 +36,9 @@ struct Ctx {
   GrtFFJet ffjet{};
   bool have_ffjet = false;
   float *d_sphacc = nullptr;
+  float *d_harm_cells = nullptr, *d_harm_coords = nullptr;
+  GrtHarm harm{};
+  bool have_harm = false;
   double *d_tables = nullptr;
   GrtTables tables{};
   double h_tables[2020] = {0};
@@ -103,7 +107,8 @@ int grt_free(void) {
   if (!C.init) return 0;
   (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
-                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc};
+                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
+                  C.d_harm_cells, C.d_harm_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -194,6 +199,29 @@ int grt_load_sphacc_tables_file(const char *path) {
   return grt_upload_sphacc(t.data(), t.data() + 498, t.data() + 996, t.data() + 1457);
 }
 
+int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
+                    const float *p, const float *b0, const float *br, const float *bth, const float *bph,
+                    const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (nx1 < 2 || nx2 < 2 || nx1 + nx2 > GRT_HARM_MAXCOORD || !x1_arr || !x2_arr) return GRT_E_BADARG;
+  const size_t n = (size_t)nx1 * nx2;
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  for (const float *q : src)
+    if (!q) return GRT_E_BADARG;
+  std::vector<float> cells, crd;
+  grt_harm_pack(nx1, nx2, h, x1_arr, x2_arr, src, cells, crd);
+  if (C.d_harm_cells) { (void)hipFree(C.d_harm_cells); C.d_harm_cells = nullptr; }
+  if (C.d_harm_coords) { (void)hipFree(C.d_harm_coords); C.d_harm_coords = nullptr; }
+  HIPCHK(hipMalloc((void **)&C.d_harm_cells, cells.size() * sizeof(float)));
+  HIPCHK(hipMalloc((void **)&C.d_harm_coords, crd.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(C.d_harm_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(C.d_harm_coords, crd.data(), crd.size() * sizeof(float), hipMemcpyHostToDevice));
+  C.harm.cells = C.d_harm_cells; C.harm.coords = C.d_harm_coords;
+  C.harm.nx1 = nx1; C.harm.nx2 = nx2; C.harm.h = h;
+  C.have_harm = true;
+  return 0;
+}
+
 int grt_upload_polsynchpl_tables(const double *t) {
   if (!C.init) return GRT_E_NOTINIT;
   // 2020 table values + 6 slope tables (543 + 5*243) computed here once
@@ -273,16 +301,19 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
   // (fluid, emissivity) pairs that have a kernel; everything else is refused, never emulated
   const bool pair_ok = (fluid_model == GRT_FLUID_FFJET && em->type == GRT_EMIS_POLSYNCHPL) ||
-                       (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH);
+                       (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH) ||
+                       (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH);
   if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   if (cam->standard != 1 || cam->nup < 2 || nvals != 4 || nextra != 0) return GRT_E_UNSUPPORTED;
   if (fluid_model == GRT_FLUID_FFJET && !C.have_ffjet) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_SPHACC && !C.d_sphacc) return GRT_E_NOFLUID;
+  if (fluid_model == GRT_FLUID_HARM && !C.have_harm) return GRT_E_NOFLUID;
   if (em->type == GRT_EMIS_POLSYNCHPL && !C.have_tables) return GRT_E_NOTABLES;
   GrtFluidDev fd{};
   fd.fj = C.ffjet;
   fd.sphacc = C.d_sphacc;
+  fd.hm = C.harm;
   HIPCHK(hipSetDevice(C.device));
   const int nrays = (int)(i2 - i1 + 1);
   int rc;

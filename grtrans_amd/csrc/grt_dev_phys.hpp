@@ -613,6 +613,125 @@ GRT_HD void sphacc_sample(const float *tab, double r, FluidPoint &f) {
   f.rho = n; f.p = T; f.bmag = B;
 }
 
+// ------------------------------------------------------------------ HARM (2-D GRMHD slice, nt=1)
+// harm_vals fluid_model_harm.f90:100-265.  theta -> x2 needs the reference's own Brent iteration
+// (math.f90:56-135, tol 1e-6): its stopping point, not the exact root, decides the interpolation weights.
+struct HarmX2 {
+  double th, h;
+  GRT_HD double operator()(double x) const { return th - PH_pi * x - .5 * (1 - h) * sin(2. * PH_pi * x); }   // :50-56
+};
+
+GRT_HD double zbrent_x2(const HarmX2 &func, double x1, double x2, double tol) {
+  GRT_NO_CONTRACT
+  const double eps = 2.220446049250313e-16;
+  double a = x1, b = x2, c, d = 0, e = 0, fa = func(a), fb = func(b), fc, p, q, r, s, tol1, xm;
+  if ((fa > 0.0 && fb > 0.0) || (fa < 0.0 && fb < 0.0)) return b - b / 0.0 * 0.0;   // NaN: the reference STOPs here
+  c = b; fc = fb;
+  for (int iter = 1; iter <= 100; ++iter) {
+    if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) { c = a; fc = fa; d = b - a; e = d; }
+    if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+    tol1 = 2.0 * eps * fabs(b) + 0.5 * tol;
+    xm = 0.5 * (c - b);
+    if (fabs(xm) <= tol1 || fb == 0.0) return b;
+    if (fabs(e) >= tol1 && fabs(fa) > fabs(fb)) {
+      s = fb / fa;
+      if (a == c) { p = 2.0 * xm * s; q = 1.0 - s; }
+      else {
+        q = fa / fc; r = fb / fc;
+        p = s * (2.0 * xm * q * (q - r) - (b - a) * (r - 1.0));
+        q = (q - 1.0) * (r - 1.0) * (s - 1.0);
+      }
+      if (p > 0.0) q = -q;
+      p = fabs(p);
+      double m1 = 3.0 * xm * q - fabs(tol1 * q), m2 = fabs(e * q);
+      if (2.0 * p < (m1 < m2 ? m1 : m2)) { e = d; d = p / q; }
+      else { d = xm; e = d; }
+    } else { d = xm; e = d; }
+    a = b; fa = fb;
+    b = b + ((fabs(d) > tol1) ? d : (xm >= 0.0 ? fabs(tol1) : -fabs(tol1)));
+    fb = func(b);
+  }
+  return b;
+}
+
+// crd = [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2] (LDS in the kernel)
+GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_d, float a, FluidPoint &f) {
+  GRT_NO_CONTRACT
+  const int nx1 = t.nx1, nx2 = t.nx2;
+  const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2;
+  const float theta = (float)th_d, zr = (float)r;
+  const float x1 = logf_cr(zr);
+  HarmX2 fn{(double)theta, (double)t.h};
+  const float x2 = (float)zbrent_x2(fn, 0.0, 1.0, 1e-6);
+  int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
+  int lx2 = (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
+  int ux2 = lx2 + 1;
+  lx2 = (lx2 >= 1) ? lx2 : 1;
+  ux2 = (ux2 <= nx2) ? ux2 : nx2;
+  // lx1 is not clamped by the reference (out-of-table reads are masked by its merges); only addresses are clamped here
+  const int lx1c = lx1 < 1 ? 1 : (lx1 > nx1 - 1 ? nx1 - 1 : lx1), ux1c = lx1c + 1;
+  const int lx2c = lx2 < nx2 ? lx2 : nx2;
+  const float dth = (ux2 != lx2c) ? (uniqth[ux2 - 1] - uniqth[lx2c - 1]) : uniqth[0];     // poles, :156-160
+  const float td = fabsf(theta - uniqth[lx2c - 1]) / dth;
+  float rd = (zr - uniqr[lx1c - 1]) / (uniqr[ux1c - 1] - uniqr[lx1c - 1]);
+  const float rh = 1.f + sqrtf(1.f - a * a);
+  if (uniqr[lx1c - 1] <= rh) rd = 1.f;                                                     // :165-167
+  const float *c00 = t.cells + (size_t)((lx1c - 1) * nx2 + (lx2c - 1)) * 12;   // (x1l, x2l)
+  const float *c01 = t.cells + (size_t)((lx1c - 1) * nx2 + (ux2 - 1)) * 12;    // (x1l, x2u)
+  const float *c10 = c00 + (size_t)nx2 * 12, *c11 = c01 + (size_t)nx2 * 12;    // x1u
+  float q[10];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 10; ++k) {
+    // trilininterp with a zero time weight and both slices equal (interpolate.f90:185-203)
+    float i1 = c00[k] * (1.f - td) + c01[k] * td;
+    float i2 = c10[k] * (1.f - td) + c11[k] * td;
+    float w1 = i1 * (1.f - rd) + i2 * rd;
+    q[k] = w1 * (1.f - 0.f) + w1 * 0.f;
+  }
+  const bool inside = x1 > uniqx1[0];
+  f.rho = inside ? q[0] : 0.f;
+  f.p = inside ? q[1] : 1.f;
+  f.b[0] = (double)(inside ? q[2] : 1.f);
+  f.b[1] = (double)(inside ? q[3] : 1.f);
+  f.b[2] = (double)(inside ? q[4] : 1.f);
+  f.b[3] = (double)(inside ? q[5] : 1.f);
+  f.u[0] = inside ? (double)q[6] : 1.0;
+  const float vrl0 = inside ? q[7] : 0.f;
+  const float vtl0 = inside ? q[8] : 1.f;
+  const float vpl0 = inside ? q[9] : 0.f;
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  float bm = (float)dot4(f.b, ms, f.b);
+  bm = (bm >= 0.f) ? bm : 0.f;
+  f.bmag = sqrtf(bm);
+  float vr0, vth0, vph0;
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  f.u[1] = f.u[0] * (double)vr0;
+  f.u[2] = f.u[0] * (double)vth0;
+  f.u[3] = f.u[0] * (double)vph0;
+}
+
+// convert_fluidvars_harm fluid.f90:957-973 (scale_sim_units :765-790, monika_e :870-892)
+GRT_HD void harm_convert(const FluidPoint &f, double mbh, double mdotcgs, double muval, double gminval, double &ncgs,
+                         double &bcgs, double &tcgs) {
+  GRT_NO_CONTRACT
+  const double mdot = (double).003f, mp = 1.67262158e-24;     // REAL(4) literal held in a REAL(8)
+  const double lcgs = PH_G * mbh * PH_msun / (PH_c * PH_c), tc = lcgs / PH_c;
+  const double rho = (double)f.rho, p = (double)f.p, bmag = (double)f.bmag;
+  const double rhocgs = mdotcgs / mdot / (lcgs * lcgs * lcgs) * tc * rho;
+  ncgs = rhocgs / mp;
+  const double pcgs = p * rhocgs / rho * (PH_c * PH_c);
+  tcgs = pcgs / ncgs / PH_k;
+  bcgs = bmag * sqrt(rhocgs / rho) * PH_c;
+  bcgs = bcgs * sqrt(4.0 * PH_pi);
+  const double rlow = muval, rhigh = muval / gminval;
+  const double beta = (double)(f.p / (f.bmag * f.bmag)) / 0.5;
+  const double b2 = beta * beta;
+  const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
+  tcgs = tcgs * trat;
+}
+
 // ------------------------------------------------------------------ transfer steps as affine maps
 struct Affine {   // I -> A I + b
   double A[4][4], b[4];

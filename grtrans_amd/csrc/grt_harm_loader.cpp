@@ -1,0 +1,114 @@
+// grtrans_amd/csrc/grt_harm_loader.cpp -- host-side reader of 2-D HARM text dumps.
+//
+// Replaces initialize_harm_model / read_harm_data_header / read_harm_data_file / load_harm_data
+// (fluid_model_harm.f90:275-509) for one time slice (nt = 1): parses the header (26 numbers) and the
+// 34-column zone table, turns the modified-Kerr-Schild four-vectors into Boyer-Lindquist ones
+// (umksh2uks :72-98, uks2ubl kerr.f90:131-144), the velocity into LNRF three-velocities in REAL(4)
+// (lnrf_frame_real kerr.f90:427-449) and hands the module arrays to grt_upload_harm.  Pure data
+// preparation; nothing here traces rays.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "../../include/grtrans_amd.h"
+
+namespace {
+
+const double kPi = 3.141592653589793;
+
+// whole file -> doubles (list-directed Fortran input accepts any blank/newline layout; so does this)
+bool slurp_numbers(const std::string &path, size_t want_at_least, std::vector<double> &out) {
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::fseek(f, 0, SEEK_END);
+  long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  if (sz <= 0) { std::fclose(f); return false; }
+  std::string buf((size_t)sz, '\0');
+  size_t got = std::fread(&buf[0], 1, (size_t)sz, f);
+  std::fclose(f);
+  if (got != (size_t)sz) return false;
+  out.clear();
+  out.reserve(want_at_least ? want_at_least : 64);
+  const char *p = buf.c_str(), *end = p + buf.size();
+  while (p < end) {
+    char *q = nullptr;
+    double v = std::strtod(p, &q);
+    if (q == p) {            // not a number here: skip one separator character
+      ++p;
+      continue;
+    }
+    out.push_back(v);
+    p = q;
+    if (want_at_least && out.size() >= want_at_least) break;
+  }
+  return out.size() >= (want_at_least ? want_at_least : 1);
+}
+
+struct Zone4 { double t, r, th, ph; };
+
+// MKS -> KS -> BL for one contravariant vector at (r, x2)
+Zone4 mks_to_bl(const double *w, float r_f, float x2_f, float h, float asim) {
+  // d(theta)/d(x2) is held in REAL(4) by the reference
+  const float dthdx2 = (float)(kPi * (1.0 + (double)(1.f - h) * std::cos(2.0 * kPi * (double)x2_f)));
+  const double r = (double)r_f, a = (double)asim;
+  const double wr = r * w[1], wth = w[2] * (double)dthdx2;
+  const double delta = r * r - 2.0 * r + a * a;
+  Zone4 o;
+  o.t = w[0] - 2.0 * r / delta * wr;
+  o.r = wr;
+  o.th = wth;
+  o.ph = w[3] - a / delta * wr;
+  return o;
+}
+
+void lnrf_real(float vr, float vt, float omega, float r, float a, float th, float &vrl, float &vtl, float &vpl) {
+  const float mu = std::cos(th);
+  const float D = r * r - 2.f * r + a * a;
+  const float s = r * r + a * a;
+  const float AR = s * s - a * a * D * (1.f - mu * mu);
+  const float RHO = r * r + a * a * mu * mu;
+  const float ENU = std::sqrt(D * RHO / AR), EMU1 = std::sqrt(RHO / D), EMU2 = std::sqrt(RHO);
+  const float EPSI = std::sqrt(1.f - mu * mu) * std::sqrt(AR / RHO);
+  const float OM = 2.f * a * r / AR;
+  const bool ok = D > 0.f;
+  vrl = ok ? EMU1 / ENU * vr : 0.f;
+  vtl = ok ? EMU2 / ENU * vt : 0.f;
+  vpl = ok ? EPSI / ENU * (omega - OM) : 0.f;
+}
+
+}  // namespace
+
+extern "C" int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin) {
+  if (!dfile || !hfile) return GRT_E_BADARG;
+  const size_t nhead = 26, dlen = 34;
+  std::vector<double> head;
+  if (!slurp_numbers(hfile, nhead, head)) return GRT_E_IO;
+  const int nx1 = (int)head[1], nx2 = (int)head[2];
+  const float asim = (float)head[9], gam = (float)head[10], h = (float)head[nhead - 2];
+  if (nx1 < 2 || nx2 < 2) return GRT_E_IO;
+  if (std::fabs((double)asim - spin) > 1e-4) {     // fluid_model_harm.f90:435-438
+    std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
+    return GRT_E_BADARG;
+  }
+  char suffix[16];
+  std::snprintf(suffix, sizeof suffix, "%03d", indf);      // write(append, fmt='(I3.3)') indf  (:463)
+  const size_t n = (size_t)nx1 * nx2;
+  std::vector<double> all;
+  if (!slurp_numbers(std::string(dfile) + suffix, nhead + n * dlen, all)) return GRT_E_IO;
+  const double *z = all.data() + nhead;
+  std::vector<float> x1(n), x2(n), rho(n), p(n), u0(n), vrl(n), vtl(n), vpl(n), b0(n), br(n), bth(n), bph(n);
+  for (size_t i = 0; i < n; ++i, z += dlen) {
+    x1[i] = (float)z[0]; x2[i] = (float)z[1];
+    const float r = (float)z[2], th = (float)z[3];
+    const Zone4 u = mks_to_bl(z + 13, r, x2[i], h, asim), b = mks_to_bl(z + 21, r, x2[i], h, asim);
+    lnrf_real((float)(u.r / u.t), (float)(u.th / u.t), (float)(u.ph / u.t), r, asim, th, vrl[i], vtl[i], vpl[i]);
+    rho[i] = (float)z[4];
+    p[i] = (float)(z[5] * (double)(gam - 1.f));            // internal energy -> pressure (:477)
+    u0[i] = (float)u.t;
+    b0[i] = (float)b.t; br[i] = (float)b.r; bth[i] = (float)b.th; bph[i] = (float)b.ph;
+  }
+  return grt_upload_harm(nx1, nx2, h, x1.data(), x2.data(), rho.data(), p.data(), b0.data(), br.data(), bth.data(),
+                         bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data());
+}

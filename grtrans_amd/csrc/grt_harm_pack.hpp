@@ -1,0 +1,27 @@
+// grtrans_amd/csrc/grt_harm_pack.hpp -- host-side packing of the HARM module arrays into the device layout.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <vector>
+
+// cells: [nx1*nx2][12] zone-interleaved (x2 fastest) so the four corners of a sample are two pairs of
+// adjacent 48-byte records; crd: [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2], the per-call vectors of
+// harm_vals (fluid_model_harm.f90:126-129) built once.
+inline void grt_harm_pack(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *const src[10],
+                          std::vector<float> &cells, std::vector<float> &crd) {
+  const size_t n = (size_t)nx1 * nx2;
+  cells.assign(n * 12, 0.f);
+  crd.assign((size_t)2 * (nx1 + nx2), 0.f);
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 10; ++k) cells[i * 12 + k] = src[k][i];
+  const double pi = std::acos(-1.0);
+  for (int i = 0; i < nx1; ++i) {
+    crd[i] = x1_arr[(size_t)i * nx2];             // uniqx1 = x1_arr(1:(nx2-1)*nx1+1:nx2)
+    crd[nx1 + i] = std::exp(crd[i]);              // uniqr = exp(uniqx1), REAL(4)
+  }
+  for (int j = 0; j < nx2; ++j) {
+    const float x2 = x2_arr[j];                   // uniqx2 = x2_arr(1:nx2)
+    crd[2 * nx1 + j] = x2;
+    crd[2 * nx1 + nx2 + j] = (float)(pi * (double)x2 + (double)((1.f - h) / 2.f) * std::sin(2.0 * pi * (double)x2));   // uniqth
+  }
+}

@@ -154,6 +154,12 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
   __shared__ double s_nb[IFLAG == GRT_INT_DELO ? GRT_WAVES_PER_BLOCK : 1][IFLAG == GRT_INT_DELO ? GRT_MAXF : 1][11];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ float s_harm[FLUID == GRT_FLUID_HARM ? 2 * GRT_HARM_MAXCOORD : 1];
+  if (FLUID == GRT_FLUID_HARM) {     // coordinate vectors (x1, r, x2, theta of the zone centres) in LDS
+    const int nc = 2 * (fd.hm.nx1 + fd.hm.nx2);
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.hm.coords[i];
+    __syncthreads();
+  }
   if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches
     for (int i = threadIdx.x; i < GRT_SPHACC_NTAB; i += blockDim.x) s_sphacc[i] = fd.sphacc[i];
     __syncthreads();
@@ -193,12 +199,14 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
     FluidPoint fl;
     if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
     else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
+    else if (FLUID == GRT_FLUID_HARM) harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl);
     double s2xi, c2xi, ang, g, cosne;
     comoving_ortho(r, th, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g, cosne);
     // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC)
     double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
     if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }
     else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
+    else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, em.mbh, em.mdot, em.muval, em.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
     // neighbour along the integration direction = stored point idx+1 = lane-1 (or previous chunk)
     double lam_nb = __shfl_up(lam_i, 1);
     if (lane == 0) lam_nb = nb_lam;
@@ -293,6 +301,16 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
       pixvals[((long long)f * npix_tile + pixslot) * nvals + c] = (float)v;
     }
   }
+  if (nfields > GRT_F_I) {
+    // a ray the reference skips (fac <= 0 or NaN, grtrans_driver.f90:183,314-317) keeps rt%I = 0 in its dump
+    const double fac0 = s_fac[wave][0];
+    if (!((fac0 / 1e16 > 0.0) && !(sumr < 0.0))) {
+      double *spz = steps + (long long)rayidx * ray_stride;
+      for (int i = lane; i < n; i += 64)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) spz[(GRT_F_I + c) * field_stride + i] = 0.0;
+    }
+  }
   if (lane == 0) {
     if (sumr < 0.0) ray_status[rayidx] = -n;
     atomicAdd(step_counter, (unsigned long long)n);
@@ -357,6 +375,8 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
 #undef GRT_XFER_CASE
   return hipErrorInvalidValue;
 }

@@ -41,9 +41,18 @@ struct GrtFFJet {               // device pointers; cell-interleaved copy of the
   int32_t nx1, pad;
 };
 
+struct GrtHarm {                // device pointers; one 2-D HARM slice (nt=1), fluid_model_harm.f90:15-21
+  const float *cells;           // [nx1*nx2][12], x2 fastest: rho,p,b0,br,bth,bph,u0,vrl,vtl,vpl,pad,pad
+  const float *coords;          // [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2] (staged in LDS by the kernel)
+  int32_t nx1, nx2;
+  float h, pad;
+};
+#define GRT_HARM_MAXCOORD 2048  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats)
+
 struct GrtFluidDev {            // what the transfer kernel samples; only the selected model's part is read
   GrtFFJet fj;
   const float *sphacc;          // [uvals 498][vvals 498][1/rvals 461][tvals 461], fluid_model_sphacc.f90
+  GrtHarm hm;
 };
 
 struct GrtTables {              // polsynchpl log-G tables (polsynchemis.f90:107-525), device pointers

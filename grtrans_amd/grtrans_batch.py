@@ -137,13 +137,18 @@ class grtrans:
                 dev.load_ffjet(path)
             elif inp.fname == 'SPHACC':
                 dev.load_sphacc()
+            elif inp.fname == 'HARM':
+                if int(inp.fnt) != 1:
+                    raise capi.GrtError("HARM with hnt > 1 (time-dependent) is not on the device yet")
+                dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
             ivals = np.zeros((inp.nvals, npix, ncams))
             ab = np.zeros((2, npix))
             for j in range(nmu):
                 cam = capi.make_camera(inp.standard, inp.gridvals, inp.nn, inp.spin, float(mu0[j]), inp.uout, inp.phi0)
                 for m in range(nmdot):
+                    mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
                     em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
-                                        inp.muval, inp.epcoefindx)
+                                        inp.muval, inp.epcoefindx, mdot=float(mdot))
                     pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
                                                            nvals=inp.nvals)
                     for k in range(nfreq):

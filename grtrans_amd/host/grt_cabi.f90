@@ -21,6 +21,7 @@ module grt_cabi
      real(c_double) :: mbh, nfac, bfac
      real(c_double) :: gmin, gmax, p1
      real(c_double) :: muval
+     real(c_double) :: mdot, gminval
      integer(c_int32_t) :: etype
      integer(c_int32_t) :: coefindx(7)
   end type grt_emis
@@ -45,6 +46,13 @@ module grt_cabi
        character(kind=c_char), dimension(*), intent(in) :: path
        integer(c_int) :: rc
      end function grt_load_ffjet_file
+     function grt_load_harm_files(dfile, hfile, indf, spin) bind(C, name='grt_load_harm_files') result(rc)
+       import :: c_int, c_char, c_double
+       character(kind=c_char), dimension(*), intent(in) :: dfile, hfile
+       integer(c_int), value :: indf
+       real(c_double), value :: spin
+       integer(c_int) :: rc
+     end function grt_load_harm_files
      function grt_load_sphacc_tables_file(path) bind(C, name='grt_load_sphacc_tables_file') result(rc)
        import :: c_int, c_char
        character(kind=c_char), dimension(*), intent(in) :: path

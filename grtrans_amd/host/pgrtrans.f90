@@ -88,6 +88,7 @@ contains
     select case (trim(fname))
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
     case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC
+    case ('HARM'); fluid_id = GRT_FLUID_HARM
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
     select case (trim(ename))
@@ -119,6 +120,11 @@ contains
           rc = grt_load_ffjet_file(cstr(path))
        end if
        if (rc /= 0) call die_rc('grt_load_ffjet_file '//trim(fdfile), rc)
+    else if (fluid_id == GRT_FLUID_HARM) then
+       ! initialize_harm_model(a,ifile,fdfile,fhfile,fnt,findf), fluid.f90:193-194
+       if (fnt /= 1) call die('HARM with fnt > 1 (time-dependent) is not supported yet')
+       rc = grt_load_harm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
+       if (rc /= 0) call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc)
     else if (fluid_id == GRT_FLUID_SPHACC) then
        ! the reference holds these tables as DATA statements (fluid_model_sphacc.f90:40-448)
        path = trim(datadir)//'/sphacc_tables.bin'
@@ -140,6 +146,7 @@ contains
              em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
              em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
              em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
+             em%mdot = mdots(m); em%gminval = gmin                   ! sparams%mdot, %gminval (pgrtrans.f90:127-131)
              rc = grt_trace_tile(cam, int(i1, c_int64_t), int(i2, c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &
                   int(iflag, c_int), int(nvals, c_int), int(nextra, c_int), pixvals, pixloc, status, st)
              if (rc /= 0) call die_rc('grt_trace_tile', rc)

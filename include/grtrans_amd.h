@@ -51,6 +51,8 @@ typedef struct GrtEmis {
   double mbh, nfac, bfac;     /* nfac = ftscl, bfac = frscl for FFJET (pgrtrans.f90:128, fluid.f90:1171) */
   double gmin, gmax, p1;      /* rounded through REAL(4) exactly as emis_params stores them */
   double muval;
+  double mdot, gminval;       /* sparams%mdot (cgs accretion rate) and the unrounded REAL(8) gmin: HARM unit
+                                 conversion and electron-temperature model (fluid.f90:957-973) */
   int32_t type, coefindx[7];
 } grt_emis;
 
@@ -78,6 +80,16 @@ int grt_load_ffjet_file(const char *path);
  * The file form is those 1918 floats back to back. */
 int grt_upload_sphacc(const float *uvals, const float *vvals, const float *rvals, const float *tvals);
 int grt_load_sphacc_tables_file(const char *path);
+
+/* replaces init_harm_data + load_harm_data for one time slice (fluid_model_harm.f90:429-509): the module
+ * arrays after loading, n = nx1*nx2 zones with x2 (theta) fastest, REAL(4): grid x1_arr, x2_arr and
+ * rho_arr, p_arr, b0_arr, br_arr, bth_arr, bph_arr, u0_arr, vrl_arr, vtl_arr, vpl_arr; h = hslope. */
+int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
+                    const float *p, const float *b0, const float *br, const float *bth, const float *bph,
+                    const float *u0, const float *vrl, const float *vtl, const float *vpl);
+/* replaces initialize_harm_model (fluid_model_harm.f90:275-427): header file + text dump `dfile`//I3.3(indf);
+ * refuses a spin that differs from the dump's by more than 1e-4 as the reference does (:435-438). */
+int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin);
 
 /* replaces initialize_polsynchpl (polsynchemis.f90:107-525): 2020 doubles,
  * gxvals[181] gyvals[543] xvals[81] yavals[243] ypvals[243] yvvals[243] yapvals[243] yavvals[243] */

@@ -3,6 +3,8 @@
 // with g++ so that the per-ray set-up and per-point evaluation can be compared with the oracle on
 // a machine without a GPU.  Not part of the product: libgrtrans_amd.so has no CPU path.
 #include "grt_dev_fast.hpp"
+#include "grt_harm_pack.hpp"
+#include <vector>
 #include <cstring>
 using namespace grtd;
 
@@ -84,4 +86,24 @@ void hs_sphacc_point(const float *tab, double r, double *out11) {
   for (int i = 0; i < 4; ++i) { out11[3 + i] = f.u[i]; out11[7 + i] = f.b[i]; }
 }
 void hs_polsynchth(double nu, double n, double B, double T, double th, double *e11) { polsynchth(nu, n, B, T, th, e11); }
+
+// HARM: the product's text-dump loader (grt_harm_loader.cpp, compiled into this test library) hands its arrays
+// to grt_upload_harm; here that entry point is a capture stub that packs them exactly as grt_api.cpp does.
+static GrtHarm g_harm;
+static std::vector<float> g_cells, g_crd;
+int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
+                    const float *p, const float *b0, const float *br, const float *bth, const float *bph,
+                    const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  grt_harm_pack(nx1, nx2, h, x1_arr, x2_arr, src, g_cells, g_crd);
+  g_harm.cells = g_cells.data(); g_harm.coords = g_crd.data(); g_harm.nx1 = nx1; g_harm.nx2 = nx2; g_harm.h = h;
+  return 0;
+}
+void hs_harm_point(double r, double th, double a, double mbh, double mdot, double muval, double gminval, double *out14) {
+  FluidPoint f;
+  harm_sample(g_harm, g_crd.data(), r, th, (float)a, f);
+  out14[0] = f.rho; out14[1] = f.p; out14[2] = f.bmag;
+  for (int i = 0; i < 4; ++i) { out14[3 + i] = f.u[i]; out14[7 + i] = f.b[i]; }
+  harm_convert(f, mbh, mdot, muval, gminval, out14[11], out14[12], out14[13]);
+}
 }

@@ -146,6 +146,64 @@ def test_sphacc_per_step_record(dev):
         capi.record_steps(False)
 
 
+FREQ_HARM = 2.3e11
+
+
+@pytest.fixture(scope="module")
+def harm_dir(tmp_path_factory):
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_harm_dump
+    g = np.load(os.path.join(G, "harm_48x48x200.npz"))
+    d = tmp_path_factory.mktemp("harm")
+    path = make_harm_dump.write(str(d), n=int(g["nzone"]))
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(g["dump_sha256"])
+    return str(d)
+
+
+def run_harm(dev, harm_dir, nn, iname):
+    from grtrans_amd import capi
+    dev.load_harm(os.path.join(harm_dir, "dump"), os.path.join(harm_dir, "dump040"), 40, 0.9375)
+    cam = capi.make_camera(1, (-13., 13., -13., 13.), nn, 0.9375, 0.6428, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5, muval=0.25, mdot=1.57e15)
+    return capi.trace_tile(cam, 1, nn[0] * nn[1], "HARM", em, [FREQ_HARM], iname)
+
+
+@pytest.mark.parametrize("iname", ["formal", "delo"])
+def test_harm_polsynchth_vs_reference_golden(dev, harm_dir, iname):
+    # BASELINE config 4: 2-D GRMHD slice (synthetic HARM-format dump read by the product's own loader),
+    # Brent theta->x2 inversion per point, thermal coefficients, Moscibrodzka electron temperatures
+    g = np.load(os.path.join(G, "harm_48x48x200.npz"))
+    pix, loc, status, st = run_harm(dev, harm_dir, (48, 48, 200), iname)
+    assert np.array_equal(status, g["npts"])
+    assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL
+
+
+def test_harm_per_step_record(dev, harm_dir):
+    from grtrans_amd import capi
+    g = np.load(os.path.join(G, "harm_rays_48x48x200.npz"))
+    capi.record_steps(True)
+    try:
+        run_harm(dev, harm_dir, (48, 48, 200), "formal")
+        for i in g["rays"]:
+            n = int(g["ray%d_npts" % i])
+            rec = capi.download_steps(int(i) - 1, 1, 230)[:, 0, :n]
+            x = g["ray%d_x" % i]
+            assert np.allclose(rec[0], x[:, 1], rtol=1e-9)
+            assert np.allclose(rec[1], x[:, 2], rtol=1e-9, atol=1e-12)
+            I = np.nan_to_num(g["ray%d_I" % i])
+            assert np.abs(np.nan_to_num(rec[4:8, ::-1].T[:n]) - I).max() / (np.abs(I).max() + 1e-300) < 1e-5
+    finally:
+        capi.record_steps(False)
+
+
+def test_harm_loader_refuses_wrong_spin(dev, harm_dir):
+    from grtrans_amd import capi
+    with pytest.raises(capi.GrtError):
+        dev.load_harm(os.path.join(harm_dir, "dump"), os.path.join(harm_dir, "dump040"), 40, 0.5)
+
+
 def test_library_refuses_unsupported(dev):
     from grtrans_amd import capi
     cam = capi.make_camera(1, (-40., 20., -20., 40.), (8, 8, 50), 0.998, 0.906, 0.01, -0.5)

@@ -19,7 +19,8 @@ def L():
     so = os.path.join(HS, "libhostsim.so")
     src = os.path.join(HS, "hostsim.cpp")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I",
-                           os.path.join(ROOT, "grtrans_amd", "csrc"), "-o", so, src])
+                           os.path.join(ROOT, "grtrans_amd", "csrc"), "-o", so, src,
+                           os.path.join(ROOT, "grtrans_amd", "csrc", "grt_harm_loader.cpp")])
     return C.CDLL(so)
 
 
@@ -87,3 +88,33 @@ def test_sphacc_sampler_and_thermal_coefficients_match_oracle(L):
             e = np.zeros(11)
             L.hs_polsynchth(freq / d["rshift"][k], d["ncgs"][k], d["bcgs"][k], d["tcgs"][k], d["ang"][k], e.ctypes.data)
             assert np.allclose(e[:4], d["jraw"][k], rtol=1e-12, atol=0) and np.allclose(e[4:], d["Kraw"][k], rtol=1e-12, atol=0)
+
+
+def test_harm_loader_sampler_and_units_match_oracle(L, tmp_path):
+    # product loader (text dump -> BL/LNRF arrays) + device harm_sample/harm_convert, compiled for the host,
+    # against the oracle's per-stage dump on the synthetic HARM-format dump
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_harm_dump
+    make_harm_dump.write(str(tmp_path), n=64)
+    kw = dict(fname="HARM", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1.57e15, mu0=0.6428,
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=1., dfile="dump", hfile="dump040", findf=40, nn=(48, 48, 200))
+    o = O.Oracle(iname="formal", datadir=str(tmp_path), **kw)
+    L.grt_load_harm_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+    assert L.grt_load_harm_files(str(tmp_path / "dump").encode(), str(tmp_path / "dump040").encode(), 40, 0.9375) == 0
+    assert L.grt_load_harm_files(str(tmp_path / "dump").encode(), str(tmp_path / "dump040").encode(), 40, 0.5) != 0   # spin check
+    assert L.grt_load_harm_files(str(tmp_path / "nope").encode(), str(tmp_path / "dump040").encode(), 40, 0.9375) != 0
+    L.hs_harm_point.argtypes = [C.c_double] * 7 + [C.c_void_p]
+    for i in (1176, 510, 1452, 5, 2300):
+        d = o.ray_dump(i, 2.3e11)
+        for k in range(0, d["npts"], 5):
+            out = np.zeros(14)
+            L.hs_harm_point(float(d["x"][k, 1]), float(d["x"][k, 2]), 0.9375, 4e6, 1.57e15, 0.25, 1.0, out.ctypes.data)
+            want = np.concatenate([[d["rho"][k], d["p"][k], d["bmag"][k]], d["u"][k], d["b"][k],
+                                   [d["ncgs"][k], d["bcgs"][k], d["tcgs"][k]]])
+            # bmag (and B in gauss) go through the REAL(4) metric, whose cosf/sinf are correctly rounded in the
+            # product and glibc's in the oracle: one fp32 ulp; everything else is identical
+            tol = np.full(14, 1e-12); tol[2:7] = 3e-7; tol[12] = 3e-7      # bmag, u^mu (REAL(4) LNRF transform), B
+            with np.errstate(all="ignore"):
+                err = np.abs(out - want) / np.abs(want)
+            assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
