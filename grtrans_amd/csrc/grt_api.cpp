@@ -305,7 +305,9 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH);
   if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
-  if (cam->standard != 1 || cam->nup < 2 || nvals != 4 || nextra != 0) return GRT_E_UNSUPPORTED;
+  if (cam->standard != 1 || cam->nup < 2 || (nvals != 4 && nvals != 1) || nextra != 0) return GRT_E_UNSUPPORTED;
+  // nvals=1: both iname=delo and iname=formal fall through to the quadrature (radtrans_integrate.f90:176-189)
+  const int kflag = (nvals == 1) ? 4 /* GRT_INT_QUAD */ : iflag;
   if (fluid_model == GRT_FLUID_FFJET && !C.have_ffjet) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_SPHACC && !C.d_sphacc) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM && !C.have_harm) return GRT_E_NOFLUID;
@@ -360,10 +362,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
                         maxpts, fstride, nfields));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
-  HIPCHK(grt_launch_transfer(C.stream, iflag, fluid_model, em->type, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
+  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, maxpts,
                              fstride, nfields, C.d_stepcount));
-  HIPCHK(grt_launch_transfer(C.stream, iflag, fluid_model, em->type, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
+  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
                              C.d_flags, maxpts, fstride, nfields, C.d_stepcount));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));

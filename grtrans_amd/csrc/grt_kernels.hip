@@ -33,6 +33,7 @@ using namespace grtd;
 #define GRT_WPE_XFER 2
 #endif
 #define GRT_MAXF 32
+#define GRT_INT_QUAD 4    // internal: nvals=1 quadrature (radtrans_integrate.f90:878-882), chosen for either iname
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
     long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
   __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
   __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
-  __shared__ double s_nb[IFLAG == GRT_INT_DELO ? GRT_WAVES_PER_BLOCK : 1][IFLAG == GRT_INT_DELO ? GRT_MAXF : 1][11];
+  constexpr bool NEEDS_NB = (IFLAG == GRT_INT_DELO || IFLAG == GRT_INT_QUAD);   // step couples points idx and idx+1
+  __shared__ double s_nb[NEEDS_NB ? GRT_WAVES_PER_BLOCK : 1][NEEDS_NB ? GRT_MAXF : 1][11];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ float s_harm[FLUID == GRT_FLUID_HARM ? 2 * GRT_HARM_MAXCOORD : 1];
@@ -218,62 +220,87 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
       double e[11];
       if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_fast(tb, plc, nu, ncgsnth, bcgs, ang, e);
       else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth(nu, ncgs, bcgs, tcgs, ang, e);
-#pragma unroll
-      for (int c = 0; c < 7; ++c)
-        if (!em.coefindx[c]) e[4 + c] = 0.0;
       double facp = valid ? e[0] * (lam_1 - lam_i) : 0.0;
-      // rotate_emis + invariant_emis + cgs scaling (emis.f90:797-838, grtrans_driver.f90:201-217)
-      double jj[4] = {e[0], c2xi * e[1] - s2xi * e[2], s2xi * e[1] + c2xi * e[2], e[3]};
-      double KK[7] = {e[4], c2xi * e[5] - s2xi * e[6], s2xi * e[5] + c2xi * e[6], e[7],
-                      c2xi * e[8] - s2xi * e[9], s2xi * e[8] + c2xi * e[9], e[10]};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) jj[c] = jj[c] * g * g;
-#pragma unroll
-      for (int c = 0; c < 7; ++c) KK[c] = KK[c] / g * LBH;
-      Affine M;
-      if (IFLAG == GRT_INT_FORMAL) {
-        if (step) formal_map(jj, KK, dx, M);
-        else affine_identity(M);
-      } else {
-        // DELO couples point idx with idx+1: fetch the neighbour's coefficients (lane-1, or the
-        // previous chunk's last lane, parked in LDS)
-        double jn[4], Kn[7];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) jn[c] = __shfl_up(jj[c], 1);
-#pragma unroll
-        for (int c = 0; c < 7; ++c) Kn[c] = __shfl_up(KK[c], 1);
-        if (lane == 0) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) jn[c] = s_nb[wave][f][c];
-#pragma unroll
-          for (int c = 0; c < 7; ++c) Kn[c] = s_nb[wave][f][4 + c];
-        }
-        // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 / math.f90:30-44 is local: dx * mean |alpha_I|
-        double delta = dx * ((fabs(KK[0]) + fabs(Kn[0])) / 2.0);
-        if (step) delo_map(jj, KK, jn, Kn, dx, delta, M);
-        else affine_identity(M);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 63) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) s_nb[wave][f][c] = jj[c];
-#pragma unroll
-          for (int c = 0; c < 7; ++c) s_nb[wave][f][4 + c] = KK[c];
-        }
-      }
-      // inclusive Kogge-Stone scan: M_l <- M_l o M_{l-1} o ... o M_0
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        Affine E, N;
-        affine_shfl_up(M, d, E);
-        if (lane >= d) {
-          affine_compose(M, E, N);
-          M = N;
-        }
-      }
-      double ci[4] = {s_carry[wave][f][0], s_carry[wave][f][1], s_carry[wave][f][2], s_carry[wave][f][3]};
       double io[4];
+      if constexpr (IFLAG == GRT_INT_QUAD) {
+        // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
+        // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end is the scalar affine recurrence
+        // I <- e^{-dtau} I + dx/2 (j_k + j_k+1 e^{-dtau}) over the same neighbour pairs as DELO.
+        const double j0 = e[0] * g * g, K0 = e[4] / g * LBH;
+        double jn = __shfl_up(j0, 1), Kn = __shfl_up(K0, 1);
+        if (lane == 0) { jn = s_nb[wave][f][0]; Kn = s_nb[wave][f][4]; }
+        const double delta = dx * ((fabs(K0) + fabs(Kn)) / 2.0);
+        double a = 1.0, b = 0.0;
+        if (step) {
+          const double E = exp(-delta);
+          a = E;
+          b = 0.5 * dx * (j0 + jn * E);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 63) { s_nb[wave][f][0] = j0; s_nb[wave][f][4] = K0; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) io[i] = M.A[i][0] * ci[0] + M.A[i][1] * ci[1] + M.A[i][2] * ci[2] + M.A[i][3] * ci[3] + M.b[i];
+        for (int d = 1; d < 64; d <<= 1) {
+          const double ea = __shfl_up(a, d), eb = __shfl_up(b, d);
+          if (lane >= d) { b = a * eb + b; a = a * ea; }
+        }
+        io[0] = a * s_carry[wave][f][0] + b;
+        io[1] = 0.0; io[2] = 0.0; io[3] = 0.0;
+      } else {
+  #pragma unroll
+        for (int c = 0; c < 7; ++c)
+          if (!em.coefindx[c]) e[4 + c] = 0.0;
+        // rotate_emis + invariant_emis + cgs scaling (emis.f90:797-838, grtrans_driver.f90:201-217)
+        double jj[4] = {e[0], c2xi * e[1] - s2xi * e[2], s2xi * e[1] + c2xi * e[2], e[3]};
+        double KK[7] = {e[4], c2xi * e[5] - s2xi * e[6], s2xi * e[5] + c2xi * e[6], e[7],
+                        c2xi * e[8] - s2xi * e[9], s2xi * e[8] + c2xi * e[9], e[10]};
+  #pragma unroll
+        for (int c = 0; c < 4; ++c) jj[c] = jj[c] * g * g;
+  #pragma unroll
+        for (int c = 0; c < 7; ++c) KK[c] = KK[c] / g * LBH;
+        Affine M;
+        if (IFLAG == GRT_INT_FORMAL) {
+          if (step) formal_map(jj, KK, dx, M);
+          else affine_identity(M);
+        } else {
+          // DELO couples point idx with idx+1: fetch the neighbour's coefficients (lane-1, or the
+          // previous chunk's last lane, parked in LDS)
+          double jn[4], Kn[7];
+  #pragma unroll
+          for (int c = 0; c < 4; ++c) jn[c] = __shfl_up(jj[c], 1);
+  #pragma unroll
+          for (int c = 0; c < 7; ++c) Kn[c] = __shfl_up(KK[c], 1);
+          if (lane == 0) {
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) jn[c] = s_nb[wave][f][c];
+  #pragma unroll
+            for (int c = 0; c < 7; ++c) Kn[c] = s_nb[wave][f][4 + c];
+          }
+          // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 / math.f90:30-44 is local: dx * mean |alpha_I|
+          double delta = dx * ((fabs(KK[0]) + fabs(Kn[0])) / 2.0);
+          if (step) delo_map(jj, KK, jn, Kn, dx, delta, M);
+          else affine_identity(M);
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 63) {
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) s_nb[wave][f][c] = jj[c];
+  #pragma unroll
+            for (int c = 0; c < 7; ++c) s_nb[wave][f][4 + c] = KK[c];
+          }
+        }
+        // inclusive Kogge-Stone scan: M_l <- M_l o M_{l-1} o ... o M_0
+  #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          Affine E, N;
+          affine_shfl_up(M, d, E);
+          if (lane >= d) {
+            affine_compose(M, E, N);
+            M = N;
+          }
+        }
+        double ci[4] = {s_carry[wave][f][0], s_carry[wave][f][1], s_carry[wave][f][2], s_carry[wave][f][3]};
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) io[i] = M.A[i][0] * ci[0] + M.A[i][1] * ci[1] + M.A[i][2] * ci[2] + M.A[i][3] * ci[3] + M.b[i];
+      }
       double facs = wave_sum(facp);
       __builtin_amdgcn_wave_barrier();
       if (lane == 63) {
@@ -377,6 +404,9 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
 #undef GRT_XFER_CASE
   return hipErrorInvalidValue;
 }

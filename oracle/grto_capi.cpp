@@ -72,6 +72,11 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
     else polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);
     for (int c = 0; c < 4; ++c) w.jraw[4 * i + c] = e[c];
     for (int c = 0; c < 7; ++c) w.Kraw[7 * i + c] = S.coefindx[c] ? e[4 + c] : 0.0;
+    if (S.nvals == 1) {   // emis.f90:566-569: j = K(:,1), K = K(:,5) only, coefindx not applied
+      for (int c = 1; c < 4; ++c) w.jraw[4 * i + c] = 0.0;
+      w.Kraw[7 * i] = e[4];
+      for (int c = 1; c < 7; ++c) w.Kraw[7 * i + c] = 0.0;
+    }
   }
   if (n > 1) {
     for (int i = 0; i < n; ++i) fac += w.jraw[4 * i] * (w.g.lam[0] - w.g.lam[i]);
@@ -81,6 +86,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
   if (!(fac / 1e16 > 0.0)) return;
   for (int i = 0; i < n; ++i) {
     double s2 = w.s2xi[i], c2 = w.c2xi[i], g = w.rshift[i];
+    if (S.nvals == 1) { s2 = 0.0; c2 = 1.0; }   // rotate_emis only for neq==4 (grtrans_driver.f90:201)
     double jq = w.jraw[4 * i + 1], ju = w.jraw[4 * i + 2], aq = w.Kraw[7 * i + 1], au = w.Kraw[7 * i + 2];
     double rq = w.Kraw[7 * i + 4], ru = w.Kraw[7 * i + 5];
     double jj[4] = {w.jraw[4 * i], c2 * jq - s2 * ju, s2 * jq + c2 * ju, w.jraw[4 * i + 3]};
@@ -98,7 +104,12 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
     for (int i = 0; i < n; ++i) absa[i] = std::fabs(w.K[7 * i]);
     tsum(n, w.g.lam.data(), absa.data(), w.tau.data());
     for (int i = 0; i < n; ++i) w.tau[i] = -w.tau[i];
-    if (S.iflag == 1) integrate_delo(n, w.g.lam.data(), w.tau.data(), w.j.data(), w.K.data(), w.I.data());
+    if (S.nvals == 1) {   // radtrans_integrate_quadrature, radtrans_integrate.f90:878-882
+      std::vector<double> f(n), out(n);
+      for (int i = 0; i < n; ++i) f[i] = w.j[4 * i] * std::exp(-w.tau[i]);
+      tsum(n, w.g.lam.data(), f.data(), out.data());
+      for (int i = 0; i < n; ++i) w.I[4 * i] = -out[i];
+    } else if (S.iflag == 1) integrate_delo(n, w.g.lam.data(), w.tau.data(), w.j.data(), w.K.data(), w.I.data());
     else integrate_formal(n, w.g.lam.data(), w.j.data(), w.K.data(), w.I.data());
     for (size_t q = 0; q < w.I.size(); ++q) w.I[q] = w.I[q] * fac * LBH;
     for (int c = 0; c < 4; ++c) pix[c] = w.I[4 * (n - 1) + c];

@@ -204,6 +204,23 @@ def test_harm_loader_refuses_wrong_spin(dev, harm_dir):
         dev.load_harm(os.path.join(harm_dir, "dump"), os.path.join(harm_dir, "dump040"), 40, 0.5)
 
 
+def test_nvals1_quadrature_vs_reference_golden(dev):
+    # nvals=1: Stokes I only, quadrature integrator whatever iname says (radtrans_integrate.f90:176-189)
+    from grtrans_amd import capi
+    g = np.load(os.path.join(G, "nvals1_32x32x100.npz"))
+    dev.load_sphacc()
+    for iname in ("formal", "delo"):
+        cam = capi.make_camera(1, (-40., 20., -20., 40.), (32, 32, 100), 0.998, 0.906, 0.01, -0.5)
+        em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+        pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "FFJET", em, [FREQ], iname, nvals=1)
+        assert pix.shape == (1, 1024, 1) and np.array_equal(status, g["ffjet_npts"])
+        assert stokes_err(pix, g["ffjet_ivals"]) < STOKES_TOL
+        cam = capi.make_camera(1, (-25., 25., -25., 25.), (32, 32, 100), 0.0, 0.5, 0.04, -0.5)
+        em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+        pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "SPHACC", em, [FREQ_SPHACC], iname, nvals=1)
+        assert np.array_equal(status, g["sphacc_npts"]) and stokes_err(pix, g["sphacc_ivals"]) < STOKES_TOL
+
+
 def test_library_refuses_unsupported(dev):
     from grtrans_amd import capi
     cam = capi.make_camera(1, (-40., 20., -20., 40.), (8, 8, 50), 0.998, 0.906, 0.01, -0.5)

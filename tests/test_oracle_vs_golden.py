@@ -189,3 +189,15 @@ def test_harm_polsynchth_image_and_rays(harm_dir):
                        ("ncgs", 1e-6), ("bcgs", 1e-6), ("tcgs", 1e-6), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6),
                        ("Kraw", 1e-6), ("I", 1e-6)):
             assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
+
+
+def test_nvals1_quadrature():
+    # nvals=1 (unpolarized): j_I, alpha_I only and the quadrature integrator for either iname
+    g = load("nvals1_32x32x100.npz")
+    for key, kw, fr in (("ffjet", {}, 3.45e11), ("sphacc", SPHACC, 2.41e11)):
+        for iname in ("formal", "delo"):
+            o = O.Oracle(nn=(32, 32, 100), iname=iname, nvals=1, **kw)
+            pix, npts, _ = o.trace(1, 1024, [fr], nthreads=8)
+            assert pix.shape == (1, 1024, 1) and np.array_equal(npts, g[key + "_npts"])
+            ref = g[key + "_ivals"].astype(float)
+            assert np.abs(pix - ref).max() / np.abs(ref).max() < 1e-6

@@ -172,6 +172,16 @@ def harm(nx, nup, nzone=64):
     np.savez_compressed(os.path.join(G, "harm_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, nzone=nzone, **rays)
 
 
+def nvals1():
+    # nvals=1: emissivity/absorption of Stokes I only and the quadrature integrator (radtrans_integrate.f90:878)
+    out = {}
+    r = R.Ref(nn=(32, 32, 100), iname="formal", nvals=1, **FFJET)
+    out["ffjet_ivals"], out["ffjet_npts"], _ = r.trace(1, 1024, [FREQ], nthreads=8)
+    r = R.Ref(nn=(32, 32, 100), iname="delo", nvals=1, **SPHACC)
+    out["sphacc_ivals"], out["sphacc_npts"], _ = r.trace(1, 1024, [FREQ_SPHACC], nthreads=1)
+    np.savez_compressed(os.path.join(G, "nvals1_32x32x100.npz"), **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -183,4 +193,5 @@ if __name__ == "__main__":
     ffjet(32, 100)
     sphacc(64, 200)
     harm(48, 200)
+    nvals1()
     print("golden fixtures written to", os.path.abspath(G))
