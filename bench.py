@@ -64,11 +64,13 @@ def _cpu_baseline(nx, ny, nup, budget_s):
         from oracle import orabind
         eng, kind = orabind.Oracle(**kw), "port"
     centre = (nx // 2) * ny + 1
-    probe = max(cores * 8, 64)
-    _, npts, sec = eng.trace(centre, centre + probe - 1, [FREQ], nthreads=cores)
-    rate = max(float(np.abs(npts).sum()) / max(sec, 1e-6), 1.0)
-    nrays = int(min(max(budget_s * rate / (nup * 1.1), probe), 200000, nx * ny - centre))
-    _, npts, sec = eng.trace(centre, centre + nrays - 1, [FREQ], nthreads=cores)
+    nrays = max(cores * 8, 64)
+    # grow the sample until it costs about budget_s of wall time on this host (bounded by 200k rays)
+    while True:
+        _, npts, sec = eng.trace(centre, centre + nrays - 1, [FREQ], nthreads=cores)
+        if sec >= 0.5 * budget_s or nrays >= min(200000, nx * ny - centre):
+            break
+        nrays = int(min(max(nrays * min(budget_s / max(sec, 1e-3), 16.0), nrays * 2), 200000, nx * ny - centre))
     steps = int(np.abs(npts).sum())
     return {"value": steps / sec, "unit": "ray-steps/s", "cores": cores, "kind": kind,
             "sample": "%d contiguous pixels from the image centre of the same %dx%dx%d FFJET camera, "

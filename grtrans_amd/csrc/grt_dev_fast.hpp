@@ -16,6 +16,9 @@
 // (tests/test_hostsim_fast.py, tests/test_gpu_parity.py).
 #pragma once
 #include "grt_dev_ray.hpp"
+#ifndef GRT_RJ95
+#define GRT_RJ95 0
+#endif
 
 namespace grtd {
 
@@ -27,18 +30,38 @@ GRT_HD double rc7(double x, double y) {
   if (y > 0.0) {
     xt = x; yt = y; w = 1.0;
   } else {
-    xt = x - y; yt = -y; w = sqrt(x) / sqrt(xt);
+    xt = x - y; yt = -y; w = fdiv(fsqrt(x), fsqrt(xt));
   }
   do {
-    double alamb = 2.0 * sqrt(xt) * sqrt(yt) + yt;
+    double alamb = 2.0 * fsqrt(xt) * fsqrt(yt) + yt;
     xt = .25 * (xt + alamb);
     yt = .25 * (yt + alamb);
     ave = (1.0 / 3.0) * (xt + yt + yt);
     s = yt - ave;
   } while (fabs(s) > 0.009 * ave);
-  s = s / ave;
-  return w * (1.0 + s * s * (0.3 + s * (1.0 / 7.0 + s * (0.375 + s * (9.0 / 22.0 + s * (159.0 / 208.0 + s * (9.0 / 8.0))))))) /
-         sqrt(ave);
+  s = fdiv(s, ave);
+  return w * (1.0 + s * s * (0.3 + s * (1.0 / 7.0 + s * (0.375 + s * (9.0 / 22.0 + s * (159.0 / 208.0 + s * (9.0 / 8.0))))))) *
+         frcp(fsqrt(ave));
+}
+
+// R_C(1, 1+e) in closed form; b = 1+e is passed separately because the caller can form it without
+// cancellation.  |e| shrinks 64x per duplication step, so after the first step or two only the
+// alternating series is evaluated.
+GRT_HD double rc1p(double e, double b) {
+  if (fabs(e) < 0.03) {
+    double s = 1.0 / 25.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 11; k >= 0; --k) s = 1.0 / (2 * k + 1) - e * s;
+    return s;
+  }
+  if (e > 0.0) {
+    double r = fsqrt(e);
+    return fdiv(atan(r), r);
+  }
+  double r = fsqrt(-e);
+  return fdiv(log(fdiv((1.0 + r) * (1.0 + r), b)), 2.0 * r);
 }
 
 // R_F, R_D(x,y,z) and NJ x R_J(x,y,z,p_k) with ONE shared duplication sequence (three square roots
@@ -50,7 +73,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
   const double TOL = 0.015;
   constexpr int NA = NJ > 0 ? NJ : 1;
   double xt = x, yt = y, zt = z, fac = 1.0, sumd = 0.0;
-  double pt[NA], sumj[NA], aa[NA], bb[NA], rcx[NA];
+  double pt[NA], sumj[NA], aa[NA], bb[NA], rcx[NA], delta[NA];
   bool neg[NA];
   // R_J with p<=0: Carlson's transformation (geokerr_wrapper.f:3723-3733); x,y,z enter symmetrically
   double xs = dmin(x, dmin(y, z)), zs = dmax(x, dmax(y, z)), ys = x + y + z - xs - zs;
@@ -61,28 +84,45 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     sumj[k] = 0.0;
     neg[k] = !(p[k] > 0.0);
     if (neg[k]) {
-      aa[k] = 1.0 / (ys - p[k]);
+      aa[k] = frcp(ys - p[k]);
       bb[k] = aa[k] * (zs - ys) * (ys - xs);
       pt[k] = ys + bb[k];
-      rcx[k] = rc7(xs * zs / ys, p[k] * pt[k] / ys);
+      { double iys = frcp(ys); rcx[k] = rc7(xs * zs * iys, p[k] * pt[k] * iys); }
     } else {
       aa[k] = 0.0; bb[k] = 0.0; rcx[k] = 0.0;
       pt[k] = p[k];
     }
+    delta[k] = (pt[k] - x) * (pt[k] - y) * (pt[k] - z);
   }
   double avef, aved, avej[NA];
   bool more;
+#ifdef GRT_COUNT
+  g_calls[NJ]++;
+#endif
   do {
-    double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+#ifdef GRT_COUNT
+    g_it[NJ]++;
+#endif
+    double sx = fsqrt(xt), sy = fsqrt(yt), sz = fsqrt(zt);
     double alamb = sx * (sy + sz) + sy * sz;
-    sumd = sumd + fac / (sz * (zt + alamb));
+    sumd = sumd + fac * frcp(sz * (zt + alamb));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < NJ; ++k) {
+#if GRT_RJ95
+      // Carlson (1995) form of the R_J step: one square root, one R_C(1,1+e_m) in closed form
+      // (the reference's 1979 form, geokerr_wrapper.f:3735-3746, needs a full R_C duplication here)
+      double sp = fsqrt(pt[k]);
+      double d = (sp + sx) * (sp + sy) * (sp + sz), id = frcp(d);
+      double e = fac * fac * fac * delta[k] * id * id;
+      double b = 2.0 * sp * (pt[k] + alamb) * id;
+      sumj[k] = sumj[k] + fac * id * rc1p(e, b);
+#else
       double t = pt[k] * (sx + sy + sz) + sx * sy * sz;
       double t2 = pt[k] + alamb;
-      sumj[k] = sumj[k] + fac * rc7(t * t, pt[k] * (t2 * t2));
+      sumj[k] = sumj[k] + 0.5 * fac * rc7(t * t, pt[k] * (t2 * t2));
+#endif
       pt[k] = .25 * (pt[k] + alamb);
     }
     fac = .25 * fac;
@@ -103,30 +143,30 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     }
   } while (more);
   {  // R_F (DLMF 19.36.1)
-    double inv = 1.0 / avef, X = (avef - xt) * inv, Y = (avef - yt) * inv, Z = -X - Y;
+    double inv = frcp(avef), X = (avef - xt) * inv, Y = (avef - yt) * inv, Z = -X - Y;
     double E2 = X * Y - Z * Z, E3 = X * Y * Z;
-    orf = (1.0 - E2 / 10.0 + E3 / 14.0 + E2 * E2 / 24.0 - 3.0 * E2 * E3 / 44.0 - 5.0 / 208.0 * E2 * E2 * E2 +
-           3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 / 16.0) * sqrt(inv);
+    orf = (1.0 - E2 * (1.0 / 10.0) + E3 * (1.0 / 14.0) + E2 * E2 * (1.0 / 24.0) - (3.0 / 44.0) * E2 * E3 - 5.0 / 208.0 * E2 * E2 * E2 +
+           3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 * (1.0 / 16.0)) * fsqrt(inv);
   }
   {  // R_D (DLMF 19.36.2 with the elementary symmetric functions of X,Y,Z,Z,Z)
-    double inv = 1.0 / aved, X = (aved - xt) * inv, Y = (aved - yt) * inv, Z = -(X + Y) / 3.0;
+    double inv = frcp(aved), X = (aved - xt) * inv, Y = (aved - yt) * inv, Z = -(X + Y) * (1.0 / 3.0);
     double E2 = X * Y - 6.0 * Z * Z, E3 = (3.0 * X * Y - 8.0 * Z * Z) * Z, E4 = 3.0 * (X * Y - Z * Z) * Z * Z, E5 = X * Y * Z * Z * Z;
-    double ser = 1.0 - 3.0 / 14.0 * E2 + E3 / 6.0 + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
-                 E2 * E2 * E2 / 16.0 + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
+    double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
+                 E2 * E2 * E2 * (1.0 / 16.0) + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
                  9.0 / 68.0 * (E3 * E4 + E2 * E5);
-    ord = 3.0 * sumd + fac * ser * inv * sqrt(inv);
+    ord = 3.0 * sumd + fac * ser * inv * fsqrt(inv);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
   for (int k = 0; k < NJ; ++k) {  // R_J (DLMF 19.36.2 with X,Y,Z,P,P)
-    double inv = 1.0 / avej[k], X = (avej[k] - xt) * inv, Y = (avej[k] - yt) * inv, Z = (avej[k] - zt) * inv, P = -(X + Y + Z) / 2.0;
+    double inv = frcp(avej[k]), X = (avej[k] - xt) * inv, Y = (avej[k] - yt) * inv, Z = (avej[k] - zt) * inv, P = -(X + Y + Z) / 2.0;
     double E2 = X * Y + X * Z + Y * Z - 3.0 * P * P, E3 = X * Y * Z + 2.0 * E2 * P + 4.0 * P * P * P,
            E4 = (2.0 * X * Y * Z + E2 * P + 3.0 * P * P * P) * P, E5 = X * Y * Z * P * P;
-    double ser = 1.0 - 3.0 / 14.0 * E2 + E3 / 6.0 + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
-                 E2 * E2 * E2 / 16.0 + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
+    double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
+                 E2 * E2 * E2 * (1.0 / 16.0) + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
                  9.0 / 68.0 * (E3 * E4 + E2 * E5);
-    double r = 3.0 * sumj[k] + fac * ser * inv * sqrt(inv);
+    double r = 6.0 * sumj[k] + fac * ser * inv * fsqrt(inv);
     if (neg[k]) r = aa[k] * (bb[k] * r + 3.0 * (rcx[k] - orf));
     orj[k] = r;
   }
@@ -144,6 +184,7 @@ struct RealRay {
   double r12, r13, r25i, r35i;
   double wk[3], pk[3], jk[3], cI2, cI1, cA4, cRD;   // products of the d_ij used per point (2.35, 2.48)
   double sqee, ur, cA, cB, cC, cD, cP, cQ;
+  double siu0m, siu0e, isqee, ii3mu, id15[3], imuplus, imposneg, ifac2facm;   // reciprocals of per-ray constants used per point
   double iu0, tu0, phiu0, tu01;                  // u0-side pieces (cached by the set-up kernel)
   double jfac, m1u, sqmee;                       // geor (Table 2 rows 7/8)
   // M(mu)
@@ -151,6 +192,7 @@ struct RealRay {
   double mneg, mpos, muplus, muminus, mposR, muplusR;
   double facm, facmR, m1m, akm, nn, fac2, i1mu, i3mu, rfc, rdc, rjc, tmu1, tmu3, phimu1, phimu3;
   double sgna_pi;
+  AgmLadder agm_mu, agm_u;         // Landen ladders of the two Jacobi inversions (moduli m1m, m1u are per-ray constants)
 };
 
 GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
@@ -230,6 +272,12 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   K.i1mu = R.i1mu; K.i3mu = R.i3mu; K.rfc = R.rffmu3; K.rdc = R.rdc; K.rjc = R.rjc;
   K.tmu1 = R.tmu1; K.tmu3 = R.tmu3; K.phimu1 = R.phimu1; K.phimu3 = R.phimu3;
   K.sgna_pi = fsign(1.0, a) * 3.141592653589793;
+  K.siu0m = K.su * K.iu0 / K.sqmee; K.siu0e = K.su * K.iu0 / K.sqee;
+  K.isqee = 1.0 / K.sqee; K.ii3mu = 1.0 / K.i3mu; K.imuplus = 1.0 / K.muplus; K.imposneg = 1.0 / (K.mpos - K.mneg);
+  K.ifac2facm = 1.0 / K.fac2 / K.facm;
+  for (int k = 0; k < 3; ++k) K.id15[k] = 1.0 / K.d15[k];
+  agm_ladder(K.m1m, K.agm_mu);
+  agm_ladder(K.m1u, K.agm_u);
 }
 
 // u end-point: I_u1 and the four uf-side integrals of Eq. 47-49 for the pair (uf, root).
@@ -247,9 +295,9 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0;
   if (uf == root) return;
   const double y = c7 ? uf : K.u3, x = c7 ? K.u2 : uf, sg = c7 ? 1.0 : -1.0;
-  double X1 = sqrt(K.a1 + K.b1 * x), X2 = sqrt(K.a2 + K.b2 * x), X3 = sqrt(K.a3 + K.b3 * x), X4 = sqrt(K.a4 + K.b4 * x);
-  double Y1 = sqrt(K.a1 + K.b1 * y), Y2 = sqrt(K.a2 + K.b2 * y), Y3 = sqrt(K.a3 + K.b3 * y), Y4 = sqrt(K.a4 + K.b4 * y);
-  double idxy = 1.0 / (x - y);
+  double X1 = fsqrt(K.a1 + K.b1 * x), X2 = fsqrt(K.a2 + K.b2 * x), X3 = fsqrt(K.a3 + K.b3 * x), X4 = fsqrt(K.a4 + K.b4 * x);
+  double Y1 = fsqrt(K.a1 + K.b1 * y), Y2 = fsqrt(K.a2 + K.b2 * y), Y3 = fsqrt(K.a3 + K.b3 * y), Y4 = fsqrt(K.a4 + K.b4 * y);
+  double idxy = frcp(x - y);
   double U122 = sq((X1 * X2 * Y3 * Y4 + Y1 * Y2 * X3 * X4) * idxy);
   double U132 = sq((X1 * X3 * Y2 * Y4 + Y1 * Y3 * X2 * X4) * idxy);
   double U14 = (X1 * X4 * Y2 * Y3 + Y1 * Y4 * X2 * X3) * idxy;
@@ -257,27 +305,38 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   constexpr int NJ = PHI ? 2 : 0;
   double W22[2], rj2[2], rff, rdd;
   W22[0] = U122 - K.wk[0]; W22[1] = U122 - K.wk[1];
+  // everything that needs the eight square roots is formed BEFORE the duplication loop, so that they are
+  // dead while it runs (the loop is where the register allocator was spilling)
+  const double tI2 = two * X1 * Y1 * frcp(X4 * Y4 * fabs(U14));
+  const double A111m1m2 = X1 * X2 * X3 * frcp(X4 * x) - Y1 * Y2 * Y3 * frcp(Y4 * y);
+  double P22[2], Q22[2];
+  if (PHI) {
+    const double ixy1 = frcp(sq(X1 * Y1));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 2; ++k) {
+      double X52 = K.a5[k] + K.b5[k] * x, Y52 = K.a5[k] + K.b5[k] * y;
+      Q22[k] = X52 * Y52 * ixy1 * W22[k];
+      P22[k] = Q22[k] + K.pk[k];
+    }
+  }
   carlson_bundle<NJ>(U122, U132, U142, W22, rff, rdd, rj2);
   double I1 = two * rff;
   o.iu1 = sg * I1;
   // GEOPHITIME skips the end-point terms when uf sits on the turning point (:2200, :2258)
   if (c7 ? !(fabs(uf - K.u2) > 1e-12) : false) return;
   // [-1,-1,-1,-1,-4] with (a5,b5)=(0,1), Carlson (1988) 2.48
-  double I2 = K.cRD * rdd + two * X1 * Y1 / (X4 * Y4 * fabs(U14));
-  double A111m1m2 = X1 * X2 * X3 / (X4 * x) - Y1 * Y2 * Y3 / (Y4 * y);
+  double I2 = K.cRD * rdd + tI2;
   o.tu11 = sg * (K.cI2 * I2 + K.cI1 * I1 - K.cA4 * A111m1m2);
   if (PHI) {
     double v[2];
-    double ixy1 = 1.0 / sq(X1 * Y1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < 2; ++k) {   // [-1,-1,-1,-1,-2], Carlson (1988) 2.35
-      double X52 = K.a5[k] + K.b5[k] * x, Y52 = K.a5[k] + K.b5[k] * y;
-      double Q22 = X52 * Y52 * ixy1 * W22[k];
-      double P22 = Q22 + K.pk[k];
-      double I3 = K.jk[k] * rj2[k] + two * rc7(P22, Q22);
-      v[k] = sg * (K.b5[k] * I3 - K.b1 * I1) / K.d15[k];
+      double I3 = K.jk[k] * rj2[k] + two * rc7(P22[k], Q22[k]);
+      v[k] = sg * (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
     }
     o.phiu1 = -K.cP * v[0] + K.cQ * v[1];
   }
@@ -291,11 +350,11 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
   double sf;
   bool past;     // phi_f > pi/2  <=>  tan(phi_f) < 0  (phi_f = acos(muf/muplus) in [0,pi])
   if (K.sym) {
-    double c = muf / K.muplus;
-    sf = sqrt((1.0 - c) * (1.0 + c));      // sin(acos(c))
+    double c = muf * K.imuplus;
+    sf = fsqrt((1.0 - c) * (1.0 + c));      // sin(acos(c))
     past = c < 0.0;
   } else {
-    sf = sqrt((K.mpos - muf * muf) / (K.mpos - K.mneg));
+    sf = fsqrt((K.mpos - muf * muf) * K.imposneg);
     past = false;
   }
   double qf = (1.0 - sf * K.akm) * (1.0 + sf * K.akm);
@@ -307,28 +366,28 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
     double fac = forgeor ? K.facmR : K.facm;
     bool pastg = past;
     if (forgeor && K.muplusR != K.muplus) {   // GEOR's own (unclamped) muplus: redo the F piece consistently
-      double cr = muf / K.muplusR, sfr = sqrt((1.0 - cr) * (1.0 + cr)), qfr = (1.0 - sfr * K.akm) * (1.0 + sfr * K.akm);
+      double cr = fdiv(muf, K.muplusR), sfr = fsqrt((1.0 - cr) * (1.0 + cr)), qfr = (1.0 - sfr * K.akm) * (1.0 + sfr * K.akm);
       imuf = sfr * rf(1.0 - sfr * sfr, qfr, 1.0);
       pastg = cr < 0.0;
     }
     if (pastg) imuf = K.i3mu * fac - imuf;
-    o.i2mu = imuf / fac;
+    o.i2mu = fdiv(imuf, fac);
   } else {
-    o.i2mu = imuf / (forgeor ? K.facmR : K.facm);
+    o.i2mu = fdiv(imuf, forgeor ? K.facmR : K.facm);
   }
   // E and Pi pieces (ellphitmu, :2571-2588)
-  double ellef = sf * (rff - sq(sf * K.akm) * rdf / 3.0), ellpif = 0.0;
-  if (PHI && K.nn != 1.0) ellpif = sf * (rff + K.nn * sf * sf * rjf[0] / 3.0);
+  double ellef = sf * (rff - sq(sf * K.akm) * rdf * (1.0 / 3.0)), ellpif = 0.0;
+  if (PHI && K.nn != 1.0) ellpif = sf * (rff + K.nn * sf * sf * rjf[0] * (1.0 / 3.0));
   if (past) {
-    double ellec = 2.0 * (K.rfc - K.akm * K.akm * K.rdc / 3.0);
+    double ellec = 2.0 * (K.rfc - K.akm * K.akm * K.rdc * (1.0 / 3.0));
     ellef = ellec - ellef;
     if (PHI) {
-      double ellpic = 2.0 * (K.rfc + K.nn * K.rjc / 3.0);
+      double ellpic = 2.0 * (K.rfc + K.nn * K.rjc * (1.0 / 3.0));
       ellpif = ellpic - ellpif;
     }
   }
   o.tmuf = K.facm * ellef;
-  o.phimuf = PHI ? ellpif / K.fac2 / K.facm : 0.0;
+  o.phimuf = PHI ? ellpif * K.ifac2facm : 0.0;
 }
 
 // Stored point idx of a real-quartic ray (same contract as ray_point).
@@ -354,21 +413,21 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
     }
     if (c7 ? (un > root) : (un < root)) un = root;        // geokerr_wrapper.f:1079,1089
     real_upart<PHI>(K, un, U);
-    iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) / K.sqee;
+    iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
     // mu_f from I_u (Eq. 30-42)
-    double a1 = K.sm, r1 = (iu - K.i1mu) / K.i3mu;
+    double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
     if (K.sm == 1) tpm = fint(r1) + (K.sym ? fint((1 + fsign(1.0, r1)) / 2.0) : fint(fabs((1 + fsign(1.0, r1)) / 2.0)));
-    else tpm = fint((iu + K.i1mu) / K.i3mu);
+    else tpm = fint((iu + K.i1mu) * K.ii3mu);
     double a2 = K.sm * powm1(tpm);
     double a3 = two * fint((two * (double)tpm + 3.0 - K.sm) / 4.0) - one;
-    double iarg = fabs(K.a) / a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
+    double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);   // a2 = +-1: 1/a2 == a2
     double sn, cn, dn;
     if (K.sym) {
-      sncndn(sqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn);
+      sncndn_ladder(K.agm_mu, fsqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn);
       mun = K.muminus * cn;
     } else {
-      sncndn(fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
-      mun = K.muminus / dn;
+      sncndn_ladder(K.agm_mu, fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
+      mun = fdiv(K.muminus, dn);
     }
     real_mupart<PHI>(K, mun, M, false);
   } else {
@@ -379,15 +438,15 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
     double imu = b1 * K.i1mu + b2 * M.i2mu + b3 * K.i3mu;
     double sn, cn, dn;
     if (c7) {
-      double arg = imu - K.su * K.iu0 / K.sqmee;
-      sncndn(K.jfac * arg, K.m1u, sn, cn, dn);
-      un = ((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1)) / ((K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
-      tprs = (int)((fsign(1.0, K.su * (imu - K.su * K.iu0 / K.sqee)) + 1.0) / 2.0);
+      double arg = imu - K.siu0m;
+      sncndn_ladder(K.agm_u, K.jfac * arg, K.m1u, sn, cn, dn);
+      un = fdiv((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1), (K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
+      tprs = (int)((fsign(1.0, K.su * (imu - K.siu0e)) + 1.0) / 2.0);
     } else {
-      double arg = imu + K.su * K.iu0 / K.sqmee;
-      sncndn(K.jfac * arg, K.m1u, sn, cn, dn);
-      un = ((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2)) / ((K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
-      tprs = (int)((-fsign(1.0, K.su * (imu + K.su * K.iu0 / K.sqmee)) + 1.0) / 2.0);
+      double arg = imu + K.siu0m;
+      sncndn_ladder(K.agm_u, K.jfac * arg, K.m1u, sn, cn, dn);
+      un = fdiv((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2), (K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
+      tprs = (int)((-fsign(1.0, K.su * (imu + K.siu0m)) + 1.0) / 2.0);
     }
     real_upart<PHI>(K, un, U);
     iu = imu;
@@ -395,14 +454,14 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
   }
   // Eq. 48-49, 45-46 (geokerr_wrapper.f:2229-2234, 2313-2351)
   const double s = powm1(tprs);
-  double lambdau = K.su * (K.tu01 - s * U.tu11) / K.sqee;
+  double lambdau = K.su * (K.tu01 - s * U.tu11) * K.isqee;
   double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
   double tmu;
   if (K.sym) tmu = K.a * K.a * K.mneg * iu + (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
   else tmu = (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
   double dphi = 0.0;
   if (PHI) {
-    double phiu = K.su * (K.phiu0 - s * U.phiu1) / K.sqee * K.ur;
+    double phiu = K.su * (K.phiu0 - s * U.phiu1) * K.isqee * K.ur;
     double phimu = -K.l * iu + K.l * (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3);
     if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
     dphi = phimu + phiu;

@@ -14,6 +14,37 @@
 namespace grtd {
 
 GRT_HD double sq(double x) { return x * x; }
+
+// Per-point division / square root.  hipcc expands an fp64 '/' or sqrt() into the IEEE-exact sequence
+// (div_scale, rcp, 5 fma, div_fmas, div_fixup: ~12 instructions; sqrt ~17 with its denormal scaling);
+// the per-point code needs neither denormal nor overflow handling (all operands are O(1e-30..1e30)),
+// so it uses the seed instruction plus Newton/Goldschmidt refinement: <= 1 ulp, 6-9 instructions.
+// Once-per-ray code keeps the exact forms.  The host build (tests/hostsim) maps them to '/' and sqrt.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_IEEE_DIVSQRT)
+GRT_HD double frcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+GRT_HD double fdiv(double a, double b) {
+  double r = frcp(b), q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+GRT_HD double fsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  g = fma(fma(-g, g, x), h, g);
+  return (x == 0.0) ? 0.0 : g;
+}
+#else
+GRT_HD double frcp(double b) { return 1.0 / b; }
+GRT_HD double fdiv(double a, double b) { return a / b; }
+GRT_HD double fsqrt(double x) { return sqrt(x); }
+#endif
 GRT_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
 GRT_HD double powm1(int n) { return (n & 1) ? -1.0 : 1.0; }
 GRT_HD int fint(double x) { return (int)x; }
@@ -188,6 +219,74 @@ GRT_NI void sncndn(double uu, double emmc, double &sn, double &cn, double &dn) {
     cn = 1.0 / cosh(u);
     dn = cn;
     sn = tanh(u);
+  }
+}
+
+// The descending-Landen ladder of sncndn depends only on the complementary parameter emmc, which is a
+// constant of the ray (M(mu) or U(u) modulus): build it once per ray, run only the ascending recurrence
+// (and one sincos) per point.  Same operations in the same order as sncndn above -> identical values.
+struct AgmLadder {
+  int l, bo;            // l = 0: emmc == 0 (hyperbolic limit), handled by the generic routine
+  double d, c;          // sqrt(1-emmc) for emmc<0 ; final mean (scale of u)
+  double em[13], en[13];
+};
+
+GRT_HD void agm_ladder(double emmc, AgmLadder &L) {
+  const double CA = 3.e-8;
+  double emc = emmc, a = 1.0, c = 0.0;
+  L.l = 0; L.bo = 0; L.d = 1.0; L.c = 0.0;
+  for (int i = 0; i < 13; ++i) { L.em[i] = 0.0; L.en[i] = 0.0; }
+  if (emc == 0.0) return;
+  L.bo = (emc < 0.0);
+  if (L.bo) {
+    double d = 1.0 - emc;
+    emc = -emc / d;
+    L.d = sqrt(d);
+  }
+  int l = 13;
+  for (int i = 1; i <= 13; ++i) {
+    l = i;
+    L.em[i - 1] = a;
+    emc = sqrt(emc);
+    L.en[i - 1] = emc;
+    c = 0.5 * (a + emc);
+    if (fabs(a - emc) <= CA * a) break;
+    emc = a * emc;
+    a = c;
+  }
+  L.l = l; L.c = c;
+}
+
+GRT_HD void sncndn_ladder(const AgmLadder &L, double uu, double emmc, double &sn, double &cn, double &dn) {
+  if (L.l == 0) { sncndn(uu, emmc, sn, cn, dn); return; }
+  double u = L.bo ? L.d * uu : uu;
+  double a, b, c = L.c;
+  dn = 1.0;
+  u = c * u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(u, &sn, &cn);
+#else
+  sn = sin(u); cn = cos(u);
+#endif
+  if (sn != 0.0) {
+    a = fdiv(cn, sn);
+    c = a * c;
+    for (int ii = L.l; ii >= 1; --ii) {
+      b = L.em[ii - 1];
+      a = c * a;
+      c = dn * c;
+      dn = fdiv(L.en[ii - 1] + a, b + a);
+      a = fdiv(c, b);
+    }
+    a = frcp(fsqrt(c * c + 1.0));
+    sn = (sn < 0.0) ? -a : a;
+    cn = c * sn;
+  }
+  if (L.bo) {
+    a = dn;
+    dn = cn;
+    cn = a;
+    sn = fdiv(sn, L.d);
   }
 }
 

@@ -7,6 +7,7 @@ iname = sys.argv[4] if len(sys.argv) > 4 else "formal"
 dev = capi.Device(0); dev.load_ffjet(); dev.load_tables()
 cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
 em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+capi.record_steps(os.environ.get("GRT_RECORD", "0") == "1")
 best = None
 for it in range(3):
     _, _, _, st = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [3.45e11], iname, resident=True)
