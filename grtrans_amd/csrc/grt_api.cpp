@@ -10,6 +10,7 @@
 #include <vector>
 #include "grt_types.h"
 #include "grt_harm_pack.hpp"
+#include "grt_pl_pack.hpp"
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
                                        int *ray_npts, int *live, int *counters, void *rrays);
@@ -224,27 +225,12 @@ int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float 
 
 int grt_upload_polsynchpl_tables(const double *t) {
   if (!C.init) return GRT_E_NOTINIT;
-  // 2020 table values + 6 slope tables (543 + 5*243) computed here once
-  std::vector<double> h(2020 + 543 + 5 * 243);
-  std::memcpy(h.data(), t, 2020 * sizeof(double));
+  std::vector<double> h;
+  grt_pl_pack_tables(t, h);          // 2020 table values + 6 slope tables (543 + 5*243)
   std::memcpy(C.h_tables, t, 2020 * sizeof(double));
-  auto slopes = [&](int xo, int nx, int yo, int so) {
-    for (int iy = 0; iy < 3; ++iy)
-      for (int i = 0; i < nx; ++i) {
-        int j = (i < nx - 1) ? i : nx - 2;
-        h[so + iy * nx + i] = (h[yo + iy * nx + j + 1] - h[yo + iy * nx + j]) / (h[xo + j + 1] - h[xo + j]);
-      }
-  };
-  slopes(0, 181, 181, 2020);
-  const int yo[5] = {805, 1048, 1291, 1534, 1777};
-  for (int k = 0; k < 5; ++k) slopes(724, 81, yo[k], 2020 + 543 + k * 243);
   if (!C.d_tables) HIPCHK(hipMalloc((void **)&C.d_tables, h.size() * sizeof(double)));
   HIPCHK(hipMemcpy(C.d_tables, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-  double *d = C.d_tables;
-  C.tables.gx = d; C.tables.gy = d + 181; C.tables.xv = d + 724; C.tables.ya = d + 805;
-  C.tables.yp = d + 1048; C.tables.yv = d + 1291; C.tables.yap = d + 1534; C.tables.yav = d + 1777;
-  C.tables.sgy = d + 2020; C.tables.sya = d + 2563; C.tables.syp = d + 2806; C.tables.syv = d + 3049;
-  C.tables.syap = d + 3292; C.tables.syav = d + 3535;
+  grt_pl_point_tables(C.d_tables, C.tables);
   C.have_tables = true;
   return 0;
 }
@@ -334,18 +320,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields;
   const long long fstride = (long long)nrays * maxpts;
   GrtPLConst plc{};
-  {   // constant factors of polsynchpl (polsynchemis.f90:557-591)
-    const double p = em->p1, gmin = em->gmin, gmax = em->gmax, al = (p - 1.0) / 2.0;
-    plc.p = p; plc.gmin = gmin; plc.gmax = gmax; plc.alpha = al;
-    plc.A0 = (p - 1.0) / (std::pow(gmin, 1.0 - p) - std::pow(gmax, 1.0 - p));
-    plc.lmin = std::log(1.5 * gmin * gmin); plc.lmax = std::log(1.5 * gmax * gmax);
-    plc.kq = std::pow(gmin, -2.0 * al + 1.0) / (al - 0.5);
-    plc.kv = 2.0 * (al + 1.5) / (al + 1.0) * std::log(gmin) * std::pow(gmin, -2.0 * (al + 1.0));
-    plc.l2g = 2.0 * std::log(gmin);
-    plc.gx0 = C.h_tables[0]; plc.gxs = 181.0 / (C.h_tables[180] - C.h_tables[0]);
-    plc.xv0 = C.h_tables[724]; plc.xvs = 81.0 / (C.h_tables[804] - C.h_tables[724]);
-    plc.iy = (p < 5.0) ? ((p > 3.2) ? 1 : 0) : 2;      // find_inds_gxp, polsynchemis.f90:74
-  }
+  grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
   HIPCHK(hipMemcpyAsync(C.d_freqs, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));

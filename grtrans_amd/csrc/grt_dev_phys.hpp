@@ -32,20 +32,22 @@ GRT_HD float logf_cr(float x) { return (float)log((double)x); }
 
 struct Metric { double g[10]; };   // slots 1,4,5,8,10 (0-based 0,3,4,7,9) non-zero
 
-GRT_HD Metric blmetric_cov(double r, double th, double a) {
+// kerr.f90:381 with sin(th), cos(th) supplied (the kernel forms them once per point with one sincos)
+GRT_HD Metric blmetric_cov_sc(double r, double sth, double cth, double a) {
   Metric m;
   for (int i = 0; i < 10; ++i) m.g[i] = 0.0;
-  double cth = cos(th), sth = sin(th);
   double delta = r * r - 2.0 * r + a * a;
   double rho2 = r * r + a * a * cth * cth;
   double sigma = sq(r * r + a * a) - a * a * delta * sth * sth;
-  m.g[0] = -(delta - a * a * sth * sth) / rho2;
-  m.g[3] = -2.0 * a * r * sth * sth / rho2;
-  m.g[4] = rho2 / delta;
+  double irho2 = frcp(rho2);
+  m.g[0] = -(delta - a * a * sth * sth) * irho2;
+  m.g[3] = -2.0 * a * r * sth * sth * irho2;
+  m.g[4] = fdiv(rho2, delta);
   m.g[7] = rho2;
-  m.g[9] = sigma / rho2 * sth * sth;
+  m.g[9] = sigma * irho2 * sth * sth;
   return m;
 }
+GRT_HD Metric blmetric_cov(double r, double th, double a) { return blmetric_cov_sc(r, sin(th), cos(th), a); }
 
 // single-precision metric, promoted to double slots (blmetric_cov_real + assign_metric_real)
 GRT_HD Metric blmetric_cov_real(float r, float th, float a) {
@@ -66,29 +68,32 @@ GRT_HD Metric blmetric_cov_real(float r, float th, float a) {
 }
 
 // a*b with a's metric: lower(a) . b   (class_four_vector.f90:115-135)
+// Only g_tt, g_tphi, g_rr, g_thth, g_phph of the Boyer-Lindquist metric are non-zero; the other five slots
+// of the reference's 10-slot form contribute exact zeros (x*0 + y == y), so they are left out.
 GRT_HD double dot4(const double *a, const Metric &m, const double *b) {
   const double *g = m.g;
-  double d0 = g[0] * a[0] + g[1] * a[1] + g[2] * a[2] + g[3] * a[3];
-  double d1 = g[1] * a[0] + g[4] * a[1] + g[5] * a[2] + g[6] * a[3];
-  double d2 = g[2] * a[0] + g[5] * a[1] + g[7] * a[2] + g[8] * a[3];
-  double d3 = g[3] * a[0] + g[6] * a[1] + g[8] * a[2] + g[9] * a[3];
+  double d0 = g[0] * a[0] + g[3] * a[3];
+  double d1 = g[4] * a[1];
+  double d2 = g[7] * a[2];
+  double d3 = g[3] * a[0] + g[9] * a[3];
   return d0 * b[0] + d1 * b[1] + d2 * b[2] + d3 * b[3];   // dot_product: sequential sum
 }
 
 // kerr.f90:255 with rcomp and thcomp present
 GRT_HD void calc_nullp(double q2, double l, double a, double r, double mu, double su, double smu, double *k) {
-  double u = 1.0 / r;
-  double rho2 = r * r + a * a * mu * mu;
-  double delta = r * r - 2.0 * r + a * a;
+  double u = frcp(r);
+  double rho2 = r * r + a * a * mu * mu, irho2 = frcp(rho2);
+  double delta = r * r - 2.0 * r + a * a, idelta = frcp(delta);
   double Mfunc = q2 + (a * a - q2 - l * l) * mu * mu - a * a * mu * mu * mu * mu;
   if (!(Mfunc > 0.0)) Mfunc = 0.0;
-  double pmu = 1.0 / rho2 * smu * sqrt(Mfunc / (1.0 - mu * mu));
+  double ism2 = frcp(1.0 - mu * mu);
+  double pmu = irho2 * smu * fsqrt(Mfunc * ism2);
   double Ufunc = 1.0 + (a * a - q2 - l * l) * u * u + 2.0 * (sq(a - l) + q2) * u * u * u - a * a * q2 * u * u * u * u;
   if (!(Ufunc > 0.0)) Ufunc = 0.0;
-  double Rfunc = r * r * sqrt(Ufunc);
-  double pu = su * Rfunc / rho2;
-  double pt = (-a * (a * (1.0 - mu * mu) - l) + (r * r + a * a) / delta * (r * r + a * a - a * l)) / rho2;
-  double pphi = (-a + l / (1.0 - mu * mu) + a / delta * (r * r + a * a - a * l)) / rho2;
+  double Rfunc = r * r * fsqrt(Ufunc);
+  double pu = su * Rfunc * irho2;
+  double pt = (-a * (a * (1.0 - mu * mu) - l) + (r * r + a * a) * idelta * (r * r + a * a - a * l)) * irho2;
+  double pphi = (-a + l * ism2 + a * idelta * (r * r + a * a - a * l)) * irho2;
   k[0] = pt; k[1] = pu; k[2] = pmu; k[3] = pphi;
 }
 
@@ -113,10 +118,9 @@ GRT_HD void lnrf_frame_inv_real(float vr, float vt, float omega, float r, float 
 }
 
 // kerr.f90:502
-GRT_HD void transport_perpk(const double *k, double r, double th, double a, const Metric &m, double Kap1,
+GRT_HD void transport_perpk(const double *k, double r, double sth, double cth, double a, const Metric &m, double Kap1,
                             double Kap2, double &f1, double &f2, double &f3) {
   double g03 = m.g[3], g11 = m.g[4], g22 = m.g[7], g33 = m.g[9];
-  double cth = cos(th), sth = sin(th);
   double k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
   double gam1 = a * cth * k0 - a * a * cth * sth * sth * k3;
   double gam2 = r * (r * r + a * a) * sth * k3 - a * r * sth * k0;
@@ -129,14 +133,13 @@ GRT_HD void transport_perpk(const double *k, double r, double th, double a, cons
   f1 = (gam2 * Kap1 - del2 * Kap2) * (g33 * k3 + g03 * k0) - g22 * k2 * (gam3 * Kap1 - del3 * Kap2);
   f2 = (del1 * Kap2 - gam1 * Kap1) * (g33 * k3 + g03 * k0) + g11 * k1 * (gam3 * Kap1 - del3 * Kap2);
   f3 = g22 * k2 * (gam1 * Kap1 - del1 * Kap2) - g11 * k1 * (gam2 * Kap1 - del2 * Kap2);
-  if (fabs(denom) > 0.0) { f1 /= denom; f2 /= denom; f3 /= denom; }
+  if (fabs(denom) > 0.0) { double id = frcp(denom); f1 *= id; f2 *= id; f3 *= id; }
 }
 
 // kerr.f90:586.  u,b,k: contravariant BL components (t,r,th,phi).
-GRT_NI void comoving_ortho(double r, double th, double a, double alpha, double beta, double mus, const double *u,
-                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang,
-                           double &g, double &cosne) {
-  Metric m = blmetric_cov(r, th, a);
+GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double alpha, double beta, double mus, const double *u,
+                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang, double &g) {
+  Metric m = blmetric_cov_sc(r, sth, cth, a);
   double gtt = m.g[0], gtp = m.g[3], grr = m.g[4], gmm = m.g[7], gpp = m.g[9];
   double ut = u[0], ur = u[1], um = u[2], up = u[3];
   double utc = gtt * ut + gtp * up, upc = gpp * up + gtp * ut, urc = grr * ur, umc = um * gmm;
@@ -144,39 +147,43 @@ GRT_NI void comoving_ortho(double r, double th, double a, double alpha, double b
   double Kap2 = -beta;
   double al1, al2, al3;
   if (Kap1 != 0.0 || Kap2 != 0.0) {
-    transport_perpk(k, r, th, a, m, Kap1, Kap2, al1, al2, al3);
+    transport_perpk(k, r, sth, cth, a, m, Kap1, Kap2, al1, al2, al3);
   } else {
-    al1 = 0.0; al2 = 0.0; al3 = 1.0 / sqrt(m.g[9]);
+    al1 = 0.0; al2 = 0.0; al3 = frcp(fsqrt(m.g[9]));
   }
   double aa[4] = {0.0, al1, al2, al3};
   double delta = r * r + a * a - 2.0 * r;
   double nr2 = -grr * (utc * ut + upc * up) * (1.0 + umc * um);
   double nm2 = gmm * (1.0 + umc * um);
-  double np2 = -(utc * ut + upc * up) * delta * sin(th) * sin(th);
+  double np2 = -(utc * ut + upc * up) * delta * sth * sth;
+  // x / sqrt(n): one reciprocal square root per tetrad leg instead of a division per component
+  const double inr = frcp(fsqrt(nr2)), inm = frcp(fsqrt(nm2)), inp = frcp(fsqrt(np2));
   double ekt[4] = {-1.0 * u[0], -1.0 * u[1], -1.0 * u[2], -1.0 * u[3]};
-  double ekr[4] = {(urc * ut) / sqrt(nr2), -(utc * ut + upc * up) / sqrt(nr2), 0.0, (urc * up) / sqrt(nr2)};
-  double ekm[4] = {(umc * ut) / sqrt(nm2), (umc * ur) / sqrt(nm2), (1 + umc * um) / sqrt(nm2),
-                   (umc * up) / sqrt(nm2)};
-  double ekp[4] = {upc / sqrt(np2), 0.0, 0.0, -utc / sqrt(np2)};
+  double ekr[4] = {(urc * ut) * inr, -(utc * ut + upc * up) * inr, 0.0, (urc * up) * inr};
+  double ekm[4] = {(umc * ut) * inm, (umc * ur) * inm, (1 + umc * um) * inm, (umc * up) * inm};
+  double ekp[4] = {upc * inp, 0.0, 0.0, -utc * inp};
   double bhatr = dot4(ekr, m, b), bhatm = dot4(ekm, m, b), bhatp = dot4(ekp, m, b);
   double khatt = dot4(ekt, m, k), khatr = dot4(ekr, m, k), khatm = dot4(ekm, m, k), khatp = dot4(ekp, m, k);
   double ahatt = dot4(ekt, m, aa), ahatr = dot4(ekr, m, aa), ahatm = dot4(ekm, m, aa), ahatp = dot4(ekp, m, aa);
   double bdotb = dot4(b, m, b);
-  double aahat1 = ahatr - khatr * ahatt / khatt;
-  double aahat2 = ahatm - khatm * ahatt / khatt;
-  double aahat3 = ahatp - khatp * ahatt / khatt;
+  const double ikt = frcp(khatt);
+  double aahat1 = ahatr - khatr * ahatt * ikt;
+  double aahat2 = ahatm - khatm * ahatt * ikt;
+  double aahat3 = ahatp - khatp * ahatt * ikt;
   double knorm = khatr * khatr + khatm * khatm + khatp * khatp;
-  double bb1 = -(aahat2 * khatp - aahat3 * khatm) / sqrt(knorm);
-  double bb2 = -(aahat3 * khatr - aahat1 * khatp) / sqrt(knorm);
-  double bb3 = -(aahat1 * khatm - aahat2 * khatr) / sqrt(knorm);
+  const double ikn = frcp(fsqrt(knorm));
+  double bb1 = -(aahat2 * khatp - aahat3 * khatm) * ikn;
+  double bb2 = -(aahat3 * khatr - aahat1 * khatp) * ikn;
+  double bb3 = -(aahat1 * khatm - aahat2 * khatr) * ikn;
   double bdotk = bhatr * khatr + bhatm * khatm + bhatp * khatp;
   double angnorm;
   if (bdotb > 0.0) {
     double aadotbp = bhatr * aahat1 + bhatm * aahat2 + bhatp * aahat3;
     double bpdotbb = bhatr * bb1 + bhatm * bb2 + bhatp * bb3;
-    s2xi = -2.0 * aadotbp * bpdotbb / (aadotbp * aadotbp + bpdotbb * bpdotbb);
-    c2xi = (bpdotbb * bpdotbb - aadotbp * aadotbp) / (aadotbp * aadotbp + bpdotbb * bpdotbb);
-    angnorm = bdotk / sqrt(knorm) / sqrt(bdotb);
+    const double inn = frcp(aadotbp * aadotbp + bpdotbb * bpdotbb);
+    s2xi = -2.0 * aadotbp * bpdotbb * inn;
+    c2xi = (bpdotbb * bpdotbb - aadotbp * aadotbp) * inn;
+    angnorm = bdotk * ikn * frcp(fsqrt(bdotb));
   } else {
     s2xi = 0.0; c2xi = 1.0; angnorm = 0.5;
   }
@@ -184,8 +191,7 @@ GRT_NI void comoving_ortho(double r, double th, double a, double alpha, double b
   double t = (angnorm <= angmax) ? angnorm : angmax;
   t = (angnorm >= angmin) ? t : angmin;
   ang = acos(t);
-  g = 1.0 / khatt;
-  cosne = g * sqrt(beta * beta + mus * mus * (alpha * alpha - a * a)) / r;
+  g = ikt;
 }
 
 // phys_constants.f90
@@ -283,11 +289,16 @@ GRT_HD double interp_fast(double lx, int ix, int iy, const double *xv, int nx, c
 GRT_HD void polsynchpl_fast(const GrtTables &T, const GrtPLConst &C, double nu, double nnth, double B, double th, double *e) {
   const double nufloor = 1e-10, thsafe = 1e-10;
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
-  double s0 = sin(th), c0 = cos(th);
-  double tanth = s0 / c0 + fsign(1.0, c0) * thsafe;
+  double s0, c0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(th, &s0, &c0);
+#else
+  s0 = sin(th); c0 = cos(th);
+#endif
+  double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe, itanth = frcp(tanth);
   double sinth = s0 + thsafe;
   double nubperp = ec * B / m / c / 2.0 / pi * sinth + nufloor;
-  double x = nubperp / nu, lx = log(x);
+  double x = fdiv(nubperp, nu), lx = log(x);
   double lxmin = -lx - C.lmin, lxmax = -lx - C.lmax;      // log(nu/nucmin), log(nu/nucmax)
   double A = C.A0 * nnth;
   int ix1, ix2;
@@ -302,22 +313,22 @@ GRT_HD void polsynchpl_fast(const GrtTables &T, const GrtPLConst &C, double nu, 
   double gvfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yv, T.syv) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yv, T.syv);
   double gavfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yav, T.syav) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yav, T.syav);
   const double l15 = 0.4054651081081644;                   // log(1.5)
-  double x15 = 1.5 * x, sq15 = sqrt(x15);
+  double x15 = 1.5 * x, sq15 = fsqrt(x15);
   double pw = exp(C.alpha * (lx + l15));                   // (3 nub/2 nu)^((p-1)/2)
-  double jfac = A * ec * ec / c * sqrt(3.0) / 4.0 * pw * nubperp;
+  double jfac = A * (ec * ec / c * 1.7320508075688772 / 4.0) * pw * nubperp;
   double ji = jfac * gxfac;
   double jq = jfac * gpfac;
-  double jv = jfac * 4.0 / 3.0 / tanth * sq15 * gvfac;
-  double kperp = A * ec * ec / m / c / nubperp;
+  double jv = jfac * (4.0 / 3.0) * itanth * sq15 * gvfac;
+  double kperp = A * (ec * ec / m / c) * frcp(nubperp);
   double kstarq = kperp * (x * x * x) * C.kq * (1.0 - exp((C.alpha - 0.5) * (lx + C.l2g)));
-  double kstarv = C.kv * kperp * (x * x) / tanth;
+  double kstarv = C.kv * kperp * (x * x) * itanth;
   double omega0 = nubperp * 2.0 * pi, omega = nu * 2.0 * pi;
   // (2w/3w0)^(-p/2) = (1.5 x)^(p/2) = pw * sqrt(1.5 x)
-  double afac = (2.0 * pi) * (2.0 * pi) * (2.0 * pi) * A * ec * ec * sqrt(3.0) * omega0 * (C.p + 2.0) / 32.0 / (pi * pi) / m / c /
-                (omega * omega) * (pw * sq15);
+  double afac = (2.0 * pi) * (2.0 * pi) * (2.0 * pi) * A * (ec * ec * 1.7320508075688772 / 32.0 / (pi * pi) / m / c) * omega0 * (C.p + 2.0) *
+                frcp(omega * omega) * (pw * sq15);
   double ai = afac * gafac;
   double aq = afac * gapfac;
-  double av = afac * 4.0 / 3.0 / tanth * gavfac * sq15;
+  double av = afac * (4.0 / 3.0) * itanth * gavfac * sq15;
   e[0] = ji; e[1] = jq; e[2] = 0.0; e[3] = jv;
   e[4] = ai; e[5] = aq; e[6] = 0.0; e[7] = av;
   e[8] = kstarq; e[9] = 0.0; e[10] = kstarv;
@@ -440,8 +451,9 @@ GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]
     return;
   }
   double ap = aq * rhoq + au * rhou + av * rhov;
-  double lam1 = sqrt(sqrt(sq(a2 - p2) / 4.0 + ap * ap) + (a2 - p2) / 2.0);
-  double lam2 = sqrt(sqrt(sq(a2 - p2) / 4.0 + ap * ap) - (a2 - p2) / 2.0);
+  const double rt = fsqrt(sq(a2 - p2) / 4.0 + ap * ap);
+  double lam1 = fsqrt(rt + (a2 - p2) / 2.0);
+  double lam2 = fsqrt(rt - (a2 - p2) / 2.0);
   double theta = lam1 * lam1 + lam2 * lam2;
   double sig = fsign(1.0, ap);
   double M2[4][4], M3[4][4], M4[4][4];
@@ -457,17 +469,23 @@ GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]
   M4[0][1] = av * rhou - au * rhov; M4[1][1] = aq * aq + rhoq * rhoq - (a2 + p2) / 2.0; M4[2][1] = aq * au + rhoq * rhou; M4[3][1] = av * aq + rhov * rhoq;
   M4[0][2] = aq * rhov - av * rhoq; M4[1][2] = aq * au + rhoq * rhou; M4[2][2] = au * au + rhou * rhou - (a2 + p2) / 2.0; M4[3][2] = au * av + rhou * rhov;
   M4[0][3] = au * rhoq - aq * rhou; M4[1][3] = av * aq + rhov * rhoq; M4[2][3] = au * av + rhou * rhov; M4[3][3] = av * av + rhov * rhov - (a2 + p2) / 2.0;
-  double ep = exp(lam1 * dx), em = 1.0 / ep;
+  double ep = exp(lam1 * dx), em = frcp(ep);
   double ch = 0.5 * (ep + em), zz = lam1 * dx;
   double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz / 6.0 * (1.0 + zz * zz / 20.0)) : 0.5 * (ep - em);
-  double co = cos(lam2 * dx);
+  double co, si;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(lam2 * dx, &si, &co);
+#else
+  si = sin(lam2 * dx); co = cos(lam2 * dx);
+#endif
   double c1 = 1.0 / 2.0 * (ch + co);
-  double c2 = sin(lam2 * dx), c3 = sh;
+  double c2 = si, c3 = sh;
   double c4 = 1.0 / 2.0 * (ch - co);
+  const double ith = frcp(theta);
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
       double m1 = (i == j) ? 1.0 : 0.0;
-      double m2 = 1.0 / theta * M2[i][j], m3 = 1.0 / theta * M3[i][j], m4 = 2.0 / theta * M4[i][j];
+      double m2 = ith * M2[i][j], m3 = ith * M3[i][j], m4 = 2.0 * ith * M4[i][j];
       O[i][j] = onopol * (c1 * m1 - c2 * m2 - c3 * m3 + c4 * m4);
     }
 }

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     GeoPoint P;
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
     if (valid) {
-      if (FAST) ray_point_real<PHI>(cam, *Rp, *Kp, idx, P);
+      if (FAST && PHI) ray_point_real<true>(cam, *Rp, *Kp, idx, P);
+      else if (FAST) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
       else ray_point(cam, *Rp, idx, P);
     }
     if (base == n) LamN = __shfl(P.lam, 0);
@@ -194,16 +195,17 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_tr
     const double th = sp0[GRT_F_TH * field_stride + ic];
     const double lam_i = sp0[GRT_F_LAM * field_stride + ic];
     const int fl8 = fp0[ic];
-    double kv[4];
-    calc_nullp(q2, l, cam.a, r, cos(th), su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
+    double kv[4], sth, cth;
+    sincos(th, &sth, &cth);
+    calc_nullp(q2, l, cam.a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
     sumr += valid ? r : 0.0;
     // fluid + frame (grtrans_driver.f90:126-130)
     FluidPoint fl;
     if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
     else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
     else if (FLUID == GRT_FLUID_HARM) harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl);
-    double s2xi, c2xi, ang, g, cosne;
-    comoving_ortho(r, th, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g, cosne);
+    double s2xi, c2xi, ang, g;
+    comoving_ortho(r, sth, cth, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g);
     // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC)
     double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
     if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }

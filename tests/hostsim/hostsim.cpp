@@ -4,6 +4,7 @@
 // a machine without a GPU.  Not part of the product: libgrtrans_amd.so has no CPU path.
 #include "grt_dev_fast.hpp"
 #include "grt_harm_pack.hpp"
+#include "grt_pl_pack.hpp"
 #include <vector>
 #include <cstring>
 using namespace grtd;
@@ -58,7 +59,7 @@ int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, dou
   realray_init(*cam, R, K);
   for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
     GeoPoint P;
-    ray_point_real<false>(*cam, R, K, idx, P);
+    ray_point_real_branchy<false>(*cam, R, K, idx, P);   // the form the image-only kernel runs
     u[idx - 1] = P.u; mu[idx - 1] = P.mu; lam[idx - 1] = P.lam; tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
   }
   return R.npts;
@@ -105,5 +106,29 @@ void hs_harm_point(double r, double th, double a, double mbh, double mdot, doubl
   out14[0] = f.rho; out14[1] = f.p; out14[2] = f.bmag;
   for (int i = 0; i < 4; ++i) { out14[3 + i] = f.u[i]; out14[7 + i] = f.b[i]; }
   harm_convert(f, mbh, mdot, muval, gminval, out14[11], out14[12], out14[13]);
+}
+
+// transfer-side per-point functions: photon momentum, comoving frame, power-law coefficients, one formal step
+static std::vector<double> g_pl;
+static GrtTables g_T;
+static GrtPLConst g_plc;
+void hs_pl_setup(const double *tables2020, double p, double gmin, double gmax) {
+  grt_pl_pack_tables(tables2020, g_pl);
+  grt_pl_point_tables(g_pl.data(), g_T);
+  grt_pl_const(tables2020, p, gmin, gmax, g_plc);
+}
+// out: k[4], s2xi, c2xi, ang, g, e[11]
+void hs_frame_and_coeffs(double r, double th, double a, double alpha, double beta, double mu0, double q2, double l, double su,
+                         double sm, int tpm, int tpr, const double *u, const double *b, double nu_obs, double nnth, double B,
+                         double *out) {
+  double sth = sin(th), cth = cos(th);
+  calc_nullp(q2, l, a, r, cth, su * powm1(tpr), sm * powm1(tpm), out);
+  comoving_ortho(r, sth, cth, a, alpha, beta, mu0, u, b, out, out[4], out[5], out[6], out[7]);
+  polsynchpl_fast(g_T, g_plc, nu_obs / out[7], nnth, B, out[6], out + 8);
+}
+void hs_formal_step(const double *j4, const double *K7, double dx, const double *Iin, double *Iout) {
+  Affine M;
+  formal_map(j4, K7, dx, M);
+  for (int i = 0; i < 4; ++i) Iout[i] = M.A[i][0] * Iin[0] + M.A[i][1] * Iin[1] + M.A[i][2] * Iin[2] + M.A[i][3] * Iin[3] + M.b[i];
 }
 }

@@ -118,3 +118,44 @@ def test_harm_loader_sampler_and_units_match_oracle(L, tmp_path):
             with np.errstate(all="ignore"):
                 err = np.abs(out - want) / np.abs(want)
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
+
+
+def test_frame_coefficients_and_formal_step_match_oracle(L):
+    # photon momentum, comoving tetrad (sparse-metric dots, shared reciprocals), folded polsynchpl and one
+    # formal (Landi Degl'Innocenti) step of the product, compiled for the host, against the oracle's FFJET dumps
+    nn = (32, 32, 100)
+    o = O.Oracle(nn=nn, iname="formal")
+    cam = o.camera()
+    t = np.fromfile(os.path.join(ROOT, "grtrans_amd", "data", "polsynchpl_tables.bin"))
+    L.hs_pl_setup.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    L.hs_pl_setup(t.ctypes.data, 3.5, 100.0, 1e5)
+    L.hs_frame_and_coeffs.argtypes = [C.c_double] * 10 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_double] * 3 + [C.c_void_p]
+    L.hs_formal_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    freq = 3.45e11
+    for i in (7, 300, 528, 529, 1000):
+        d = o.ray_dump(i, freq)
+        n = d["npts"]
+        for k in range(0, n, 3):
+            out = np.zeros(19)
+            u = np.ascontiguousarray(d["u"][k]); b = np.ascontiguousarray(d["b"][k])
+            L.hs_frame_and_coeffs(float(d["x"][k, 1]), float(d["x"][k, 2]), 0.998, float(cam["alpha"][i - 1]), float(cam["beta"][i - 1]),
+                                  0.906, float(cam["q2"][i - 1]), float(cam["l"][i - 1]), float(cam["su"][i - 1]), float(cam["sm"][i - 1]),
+                                  int(d["tpm"][k]), int(d["tpr"][k]), u.ctypes.data, b.ctypes.data, freq,
+                                  float(d["ncgsnth"][k]), float(d["bcgs"][k]), out.ctypes.data)
+            assert np.allclose(out[:4], d["k"][k], rtol=1e-11, atol=1e-13 * np.abs(d["k"][k]).max())
+            assert abs(out[4] - d["s2xi"][k]) < 1e-9 and abs(out[5] - d["c2xi"][k]) < 1e-9
+            assert abs(out[6] - d["ang"][k]) < 1e-10 and abs(out[7] / d["rshift"][k] - 1) < 1e-12
+            want = np.concatenate([d["jraw"][k], d["Kraw"][k]])
+            scale = np.array([abs(want[0])] * 4 + [abs(want[4])] * 4 + [abs(want[8]) + abs(want[10])] * 3) + 1e-300
+            assert np.all(np.abs(out[8:] - want) / scale < 1e-9), (i, k, out[8:], want)
+        # formal steps along the ray reproduce the oracle's running intensity
+        I = np.zeros(4)
+        lam = d["lam"]
+        for k in range(n - 2, -1, -1):
+            nxt = np.zeros(4)
+            jj = np.ascontiguousarray(d["j"][k]); KK = np.ascontiguousarray(d["K"][k])
+            L.hs_formal_step(jj.ctypes.data, KK.ctypes.data, float(lam[k] - lam[k + 1]), I.ctypes.data, nxt.ctypes.data)
+            I = nxt
+        if d["fac"] > 0:
+            want = d["I"][n - 1] / (d["fac"] * 6.67e-8 * 3.4e9 * 1.998e33 / 2.99792458e10 ** 2)
+            assert np.abs(I - want).max() <= 1e-9 * np.abs(want).max(), (i, I, want)
