@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--nn", type=int, nargs=3, default=[1024, 1024, 400])
     ap.add_argument("--iname", default="formal")
     ap.add_argument("--workload", default="ffjet", choices=sorted(WORKLOADS))
+    ap.add_argument("--nfreq", type=int, default=1, help="BASELINE config 5 uses 25 log-spaced frequencies 2.41e10..6.31e14")
     ap.add_argument("--no-steps-record", action="store_true", help="do not write the per-step SoA record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -126,8 +127,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    freqs = [W["freq"]] if args.nfreq == 1 else list(2.41e10 * np.exp(np.arange(args.nfreq) * np.log(6.31e14 / 2.41e10) / (args.nfreq - 1)))
+
     def one_step():
-        _, _, _, st = capi.trace_tile(cam, i1, i2, W["fname"], em, [W["freq"]], args.iname, resident=True)
+        _, _, _, st = capi.trace_tile(cam, i1, i2, W["fname"], em, freqs, args.iname, resident=True)
         return st
 
     # secondary figure: image-only mode (no per-step record, azimuth integrals skipped), untimed region
@@ -162,7 +165,7 @@ def main():
         # assemble ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the fp32 tiles over xGMI
         import ctypes as C
         from grtrans_amd.tiling import gather_tiles
-        tile = torch.empty((1, nx * ny, 4), dtype=torch.float32, device="cuda")
+        tile = torch.empty((args.nfreq, nx * ny, 4), dtype=torch.float32, device="cuda")
         capi.check(capi.lib().grt_copy_resident_pixvals(C.c_void_p(tile.data_ptr()), C.c_int64(tile.numel())),
                    "grt_copy_resident_pixvals")
         torch.cuda.synchronize()
@@ -200,12 +203,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "deterministic: BL09 FFJET table shipped with the reference (no RNG in the path)",
-            "config": {"workload": "%s %s nvals=4 spin=%g mu0=%g nn=[%d,%d,%d] per GPU, nfreq=1 (%g Hz), iname=%s, "
-                                   "gridvals=%s, uout=%g" % (W["fname"], W["ename"], W["spin"], W["mu0"], nx, ny, nup,
-                                                             W["freq"], args.iname, list(W["gridvals"]), W["uout"]),
+            "config": {"workload": "%s %s nvals=4 spin=%g mu0=%g nn=[%d,%d,%d] per GPU, nfreq=%d (%g Hz), iname=%s, "
+                                   "gridvals=%s, uout=%g" % (W["fname"], W["ename"], W["spin"], W["mu0"], nx, ny, nup, args.nfreq,
+                                                             freqs[0], args.iname, list(W["gridvals"]), W["uout"]),
                        "pixels_per_gpu": nx * ny, "ray_steps_per_step_per_gpu": ray_steps // args.steps,
                        "parallelism": "pixel strips i1..i2 per GPU, 1 process/GPU, RCCL gather of fp32 tiles",
-                       "per_step_record_written": not args.no_steps_record,
+                       "per_step_record_written": not args.no_steps_record, "nfreq": args.nfreq,
+                       "ray_step_frequencies_per_s": value * args.nfreq,
                        "gather_ms": gather_ms, "setup_kernel_ms": ms_setup / args.steps,
                        "geo_kernel_ms": ms_geo / args.steps, "transfer_kernel_ms": ms_xfer / args.steps,
                        "image_only_mode": image_only},

@@ -310,7 +310,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
-  if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)nfreq))) return rc;
+  if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   // per-step record in HBM: [field][ray][maxpts] fp64, fields r,theta,lambda always (they carry the
   // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
   const long long maxpts = cam->nup + cam->next;
@@ -321,7 +321,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const long long fstride = (long long)nrays * maxpts;
   GrtPLConst plc{};
   grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
-  HIPCHK(hipMemcpyAsync(C.d_freqs, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
+  double hfreq[64];
+  for (int f = 0; f < nfreq; ++f) { hfreq[f] = freqs[f]; hfreq[nfreq + f] = std::log(freqs[f]); }
+  HIPCHK(hipMemcpyAsync(C.d_freqs, hfreq, 2 * nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));   // hfreq is on this frame
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
   HIPCHK(hipMemsetAsync(C.d_pixvals, 0, (size_t)nrays * nfreq * (nvals + nextra) * sizeof(float), C.stream));

@@ -286,7 +286,10 @@ GRT_HD double interp_fast(double lx, int ix, int iy, const double *xv, int nx, c
   return exp(yv[indx - 1] + sv[indx - 1] * (lx - xv[ix - 1]));
 }
 
-GRT_HD void polsynchpl_fast(const GrtTables &T, const GrtPLConst &C, double nu, double nnth, double B, double th, double *e) {
+// The frequency-independent half of polsynchpl_fast, computed once per point and shared by all frequencies
+struct PLPoint { double itanth, nubperp, lnub, A, kperp, omega0; };
+
+GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P) {
   const double nufloor = 1e-10, thsafe = 1e-10;
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
   double s0, c0;
@@ -295,12 +298,21 @@ GRT_HD void polsynchpl_fast(const GrtTables &T, const GrtPLConst &C, double nu, 
 #else
   s0 = sin(th); c0 = cos(th);
 #endif
-  double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe, itanth = frcp(tanth);
+  double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe;
+  P.itanth = frcp(tanth);
   double sinth = s0 + thsafe;
-  double nubperp = ec * B / m / c / 2.0 / pi * sinth + nufloor;
-  double x = fdiv(nubperp, nu), lx = log(x);
+  P.nubperp = ec * B / m / c / 2.0 / pi * sinth + nufloor;
+  P.lnub = log(P.nubperp);
+  P.A = C.A0 * nnth;
+  P.kperp = P.A * (ec * ec / m / c) * frcp(P.nubperp);
+  P.omega0 = P.nubperp * 2.0 * pi;
+}
+
+// lnu = log(nu): log x = log(nub/nu) = lnub - lnu, so a frequency costs exponentials only
+GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoint &P, double nu, double lnu, double *e) {
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
+  double lx = P.lnub - lnu, x = exp(lx);
   double lxmin = -lx - C.lmin, lxmax = -lx - C.lmax;      // log(nu/nucmin), log(nu/nucmax)
-  double A = C.A0 * nnth;
   int ix1, ix2;
   ix2 = (int)((lxmax - C.gx0) * C.gxs); ix2 = (ix2 < 180) ? ((ix2 > 1) ? ix2 : 1) : 180;
   ix1 = (int)((lxmin - C.gx0) * C.gxs); ix1 = (ix1 < 180) ? ((ix1 > 1) ? ix1 : 1) : 180;
@@ -313,25 +325,30 @@ GRT_HD void polsynchpl_fast(const GrtTables &T, const GrtPLConst &C, double nu, 
   double gvfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yv, T.syv) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yv, T.syv);
   double gavfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yav, T.syav) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yav, T.syav);
   const double l15 = 0.4054651081081644;                   // log(1.5)
-  double x15 = 1.5 * x, sq15 = fsqrt(x15);
+  double sq15 = exp(0.5 * (lx + l15));                     // sqrt(1.5 x)
   double pw = exp(C.alpha * (lx + l15));                   // (3 nub/2 nu)^((p-1)/2)
-  double jfac = A * (ec * ec / c * 1.7320508075688772 / 4.0) * pw * nubperp;
+  double jfac = P.A * (ec * ec / c * 1.7320508075688772 / 4.0) * pw * P.nubperp;
   double ji = jfac * gxfac;
   double jq = jfac * gpfac;
-  double jv = jfac * (4.0 / 3.0) * itanth * sq15 * gvfac;
-  double kperp = A * (ec * ec / m / c) * frcp(nubperp);
-  double kstarq = kperp * (x * x * x) * C.kq * (1.0 - exp((C.alpha - 0.5) * (lx + C.l2g)));
-  double kstarv = C.kv * kperp * (x * x) * itanth;
-  double omega0 = nubperp * 2.0 * pi, omega = nu * 2.0 * pi;
+  double jv = jfac * (4.0 / 3.0) * P.itanth * sq15 * gvfac;
+  double kstarq = P.kperp * (x * x * x) * C.kq * (1.0 - exp((C.alpha - 0.5) * (lx + C.l2g)));
+  double kstarv = C.kv * P.kperp * (x * x) * P.itanth;
+  double omega = nu * 2.0 * pi;
   // (2w/3w0)^(-p/2) = (1.5 x)^(p/2) = pw * sqrt(1.5 x)
-  double afac = (2.0 * pi) * (2.0 * pi) * (2.0 * pi) * A * (ec * ec * 1.7320508075688772 / 32.0 / (pi * pi) / m / c) * omega0 * (C.p + 2.0) *
+  double afac = (2.0 * pi) * (2.0 * pi) * (2.0 * pi) * P.A * (ec * ec * 1.7320508075688772 / 32.0 / (pi * pi) / m / c) * P.omega0 * (C.p + 2.0) *
                 frcp(omega * omega) * (pw * sq15);
   double ai = afac * gafac;
   double aq = afac * gapfac;
-  double av = afac * (4.0 / 3.0) * itanth * gavfac * sq15;
+  double av = afac * (4.0 / 3.0) * P.itanth * gavfac * sq15;
   e[0] = ji; e[1] = jq; e[2] = 0.0; e[3] = jv;
   e[4] = ai; e[5] = aq; e[6] = 0.0; e[7] = av;
   e[8] = kstarq; e[9] = 0.0; e[10] = kstarv;
+}
+
+GRT_HD void polsynchpl_fast(const GrtTables &T, const GrtPLConst &C, double nu, double nnth, double B, double th, double *e) {
+  PLPoint P;
+  polsynchpl_point(C, nnth, B, th, P);
+  polsynchpl_freq(T, C, P, nu, log(nu), e);
 }
 
 // bessel.f90

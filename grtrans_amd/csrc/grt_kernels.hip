@@ -13,11 +13,10 @@
 //                      geodesic and writes (r, theta, phi, lambda) of the per-step SoA record, lanes =
 //                      consecutive points -> 512-byte coalesced rows, plus one byte of turning-point
 //                      parities.
-//   grt_transfer_kernel : same wave/lane mapping.  Reads (r, theta, lambda) back, samples the fluid,
-//                      builds the comoving tetrad and the synchrotron coefficients and turns the lane's
-//                      transfer step into an affine map I -> A I + b; the 64 maps of a chunk are composed
-//                      with a Kogge-Stone scan of wave shuffles and applied to the intensity carried from
-//                      the previous (farther) chunk; optionally writes (I,Q,U,V) of the record.
+//   grt_transfer_kernel : one LANE per live ray, points walked far end -> camera.  Reads (r, theta, lambda)
+//                      back through LDS tiles (8 steps x 64 rays), samples the fluid, builds the comoving
+//                      tetrad and the synchrotron coefficients and applies the transfer step
+//                      I <- A_k I + b_k in registers; optionally writes (I,Q,U,V) of the record.
 // Splitting the two keeps each kernel's live state small (the fused version needed 512 registers per
 // lane plus scratch); the 24 B/step that cross HBM between them are part of the record anyway.
 #include <hip/hip_runtime.h>
@@ -75,30 +74,6 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   }
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-}
-
-__device__ __forceinline__ void affine_shfl_up(const Affine &m, int d, Affine &e) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e.A[i][j] = __shfl_up(m.A[i][j], d);
-    e.b[i] = __shfl_up(m.b[i], d);
-  }
-}
-
-__device__ __forceinline__ void affine_bcast(const Affine &m, int src, Affine &e) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e.A[i][j] = __shfl(m.A[i][j], src);
-    e.b[i] = __shfl(m.b[i], src);
-  }
-}
-
-
 // field order of the per-step record: r, theta, lambda, phi, I, Q, U, V  (fields 0..2 always exist)
 #define GRT_F_R 0
 #define GRT_F_TH 1
@@ -145,202 +120,237 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
 }
 
-template <int IFLAG, int FLUID, int EMIS>
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_XFER) void grt_transfer_kernel(
+// ---------------------------------------------------------------------------------------------------
+// Transfer kernel: one LANE per live ray, the ray's stored points walked far end -> camera in a loop.
+// The transfer recurrence I <- A_k I + b_k is then a plain in-register matrix-vector update per step: no
+// scan, no idle lanes in the last chunk of a ray, and DELO / quadrature take their neighbour point from the
+// previous loop trip.  The geodesic record is [ray][point] (written coalesced by grt_geo_kernel: lanes =
+// points), so the wave stages it through LDS in tiles of 8 steps x 64 rays: 8 lanes fetch one ray's 64-byte
+// segment, the tile is then read transposed (lane = ray).  The per-step I,Q,U,V record goes back through the
+// same tile buffers (a slot is overwritten only after its own lane has consumed it).
+// Frequencies are processed FB at a time (blockIdx.y = batch): the intensities of a batch live in registers.
+#define GRT_TS 8                 // tile row stride in doubles (8 steps; unpadded: 4 buffers x 8 waves must fit the 160 KB LDS,
+                                 // and the 8-way bank conflict of the transposed read is noise next to ~1e4 cycles of VALU per step)
+#define GRT_XFER_THREADS 256
+template <int IFLAG, int FLUID, int EMIS, int FB>
+__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned char *__restrict__ flags,
     long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
-  __shared__ double s_carry[GRT_WAVES_PER_BLOCK][GRT_MAXF][4];
-  __shared__ double s_fac[GRT_WAVES_PER_BLOCK][GRT_MAXF];
-  constexpr bool NEEDS_NB = (IFLAG == GRT_INT_DELO || IFLAG == GRT_INT_QUAD);   // step couples points idx and idx+1
-  __shared__ double s_nb[NEEDS_NB ? GRT_WAVES_PER_BLOCK : 1][NEEDS_NB ? GRT_MAXF : 1][11];
+  constexpr int NW = GRT_XFER_THREADS / 64;
+  const double *lfreqs = freqs + nfreq;      // log(freqs), appended by the host
+  __shared__ double s_tile[NW][4][64 * GRT_TS];
+  __shared__ unsigned char s_fl[NW][64 * 8];
+  __shared__ int s_ray[NW][64];
+  __shared__ int s_n[NW][64];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ float s_harm[FLUID == GRT_FLUID_HARM ? 2 * GRT_HARM_MAXCOORD : 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (FLUID == GRT_FLUID_HARM) {     // coordinate vectors (x1, r, x2, theta of the zone centres) in LDS
     const int nc = 2 * (fd.hm.nx1 + fd.hm.nx2);
     for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.hm.coords[i];
-    __syncthreads();
   }
   if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches
     for (int i = threadIdx.x; i < GRT_SPHACC_NTAB; i += blockDim.x) s_sphacc[i] = fd.sphacc[i];
-    __syncthreads();
   }
-  int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
-  if (slot >= nlive) return;
-  slot = __builtin_amdgcn_readfirstlane(slot);
-  const int rayidx = live[slot];
+  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_SPHACC) __syncthreads();
+  const int slot = blockIdx.x * GRT_XFER_THREADS + threadIdx.x;
+  const bool has_ray = slot < nlive;
+  const int f0 = blockIdx.y * FB;
+  const int nf = (nfreq - f0 < FB) ? (nfreq - f0) : FB;
+  const bool first_batch = (blockIdx.y == 0);
+  const bool record = (nfields > GRT_F_I) && first_batch;
+  const int rayidx = has_ray ? live[slot] : 0;
+  const int n = has_ray ? rays[rayidx].npts : 0;
+  int nmax = n;
+  for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
+  if (nmax == 0) return;             // whole wave idle (tail of the grid)
+  const long long base = (long long)rayidx * ray_stride;
+  s_ray[wave][lane] = rayidx;
+  s_n[wave][lane] = n;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    for (int e = 0; e < GRT_TS; ++e) s_tile[wave][c][lane * GRT_TS + e] = (c == 0) ? 10.0 : 1.0;   // benign r, theta for idle slots
   const GrtRay &R = rays[rayidx];
-  const int n = R.npts;
   const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
   const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
-  const double *sp0 = steps + (long long)rayidx * ray_stride;
-  const unsigned char *fp0 = flags + (long long)rayidx * ray_stride;
-  const double lam_1 = sp0[GRT_F_LAM * field_stride];   // g%lambda(1)
-
-  for (int f = lane; f < nfreq; f += 64) {
-    s_carry[wave][f][0] = 0.0; s_carry[wave][f][1] = 0.0; s_carry[wave][f][2] = 0.0; s_carry[wave][f][3] = 0.0;
-    s_fac[wave][f] = 0.0;
+  const double lam_1 = has_ray ? steps[GRT_F_LAM * field_stride + base] : 0.0;   // g%lambda(1)
+  double I[FB][4], facs[FB];
+  double jn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][4], Kn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][7];
+#pragma unroll
+  for (int f = 0; f < FB; ++f) {
+    facs[f] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) I[f][c] = 0.0;
   }
-  __builtin_amdgcn_wave_barrier();
+  if (IFLAG != GRT_INT_FORMAL) {
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) jn[f][c] = 0.0;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) Kn[f][c] = 0.0;
+    }
+  }
+  double sumr = 0.0, lam_prev = 0.0;
+  double *tl0 = s_tile[wave][0], *tl1 = s_tile[wave][1], *tl2 = s_tile[wave][2], *tl3 = s_tile[wave][3];
+  unsigned char *tfl = s_fl[wave];
 
-  double sumr = 0.0;
-  double nb_lam = 0.0;            // lambda of the point stored just after this chunk's first one (carry)
-  for (int base = n; base >= 1; base -= 64) {
-    const int idx = base - lane;
-    const bool valid = idx >= 1;
-    const int ic = valid ? idx - 1 : 0;
-    const double r = sp0[GRT_F_R * field_stride + ic];
-    const double th = sp0[GRT_F_TH * field_stride + ic];
-    const double lam_i = sp0[GRT_F_LAM * field_stride + ic];
-    const int fl8 = fp0[ic];
-    double kv[4], sth, cth;
-    sincos(th, &sth, &cth);
-    calc_nullp(q2, l, cam.a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
-    sumr += valid ? r : 0.0;
-    // fluid + frame (grtrans_driver.f90:126-130)
-    FluidPoint fl;
-    if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
-    else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
-    else if (FLUID == GRT_FLUID_HARM) harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl);
-    double s2xi, c2xi, ang, g;
-    comoving_ortho(r, sth, cth, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g);
-    // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC)
-    double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
-    if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }
-    else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
-    else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, em.mbh, em.mdot, em.muval, em.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
-    // neighbour along the integration direction = stored point idx+1 = lane-1 (or previous chunk)
-    double lam_nb = __shfl_up(lam_i, 1);
-    if (lane == 0) lam_nb = nb_lam;
-    const double dx = lam_i - lam_nb;
-    const bool step = valid && (idx < n);
-
-    for (int f = 0; f < nfreq; ++f) {
-      const double nu = freqs[f] / g;
-      double e[11];
-      if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_fast(tb, plc, nu, ncgsnth, bcgs, ang, e);
-      else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth(nu, ncgs, bcgs, tcgs, ang, e);
-      double facp = valid ? e[0] * (lam_1 - lam_i) : 0.0;
-      double io[4];
-      if constexpr (IFLAG == GRT_INT_QUAD) {
-        // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
-        // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end is the scalar affine recurrence
-        // I <- e^{-dtau} I + dx/2 (j_k + j_k+1 e^{-dtau}) over the same neighbour pairs as DELO.
-        const double j0 = e[0] * g * g, K0 = e[4] / g * LBH;
-        double jn = __shfl_up(j0, 1), Kn = __shfl_up(K0, 1);
-        if (lane == 0) { jn = s_nb[wave][f][0]; Kn = s_nb[wave][f][4]; }
-        const double delta = dx * ((fabs(K0) + fabs(Kn)) / 2.0);
-        double a = 1.0, b = 0.0;
-        if (step) {
-          const double E = exp(-delta);
-          a = E;
-          b = 0.5 * dx * (j0 + jn * E);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 63) { s_nb[wave][f][0] = j0; s_nb[wave][f][4] = K0; }
+  for (int t0 = 0; t0 < nmax; t0 += 8) {
+    // ---- stage the next 8 points of each of the wave's 64 rays: lane -> (ray i*8 + lane/8, element lane%8)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const double ea = __shfl_up(a, d), eb = __shfl_up(b, d);
-          if (lane >= d) { b = a * eb + b; a = a * ea; }
-        }
-        io[0] = a * s_carry[wave][f][0] + b;
-        io[1] = 0.0; io[2] = 0.0; io[3] = 0.0;
-      } else {
-  #pragma unroll
-        for (int c = 0; c < 7; ++c)
-          if (!em.coefindx[c]) e[4 + c] = 0.0;
-        // rotate_emis + invariant_emis + cgs scaling (emis.f90:797-838, grtrans_driver.f90:201-217)
-        double jj[4] = {e[0], c2xi * e[1] - s2xi * e[2], s2xi * e[1] + c2xi * e[2], e[3]};
-        double KK[7] = {e[4], c2xi * e[5] - s2xi * e[6], s2xi * e[5] + c2xi * e[6], e[7],
-                        c2xi * e[8] - s2xi * e[9], s2xi * e[8] + c2xi * e[9], e[10]};
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) jj[c] = jj[c] * g * g;
-  #pragma unroll
-        for (int c = 0; c < 7; ++c) KK[c] = KK[c] / g * LBH;
-        Affine M;
-        if (IFLAG == GRT_INT_FORMAL) {
-          if (step) formal_map(jj, KK, dx, M);
-          else affine_identity(M);
-        } else {
-          // DELO couples point idx with idx+1: fetch the neighbour's coefficients (lane-1, or the
-          // previous chunk's last lane, parked in LDS)
-          double jn[4], Kn[7];
-  #pragma unroll
-          for (int c = 0; c < 4; ++c) jn[c] = __shfl_up(jj[c], 1);
-  #pragma unroll
-          for (int c = 0; c < 7; ++c) Kn[c] = __shfl_up(KK[c], 1);
-          if (lane == 0) {
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) jn[c] = s_nb[wave][f][c];
-  #pragma unroll
-            for (int c = 0; c < 7; ++c) Kn[c] = s_nb[wave][f][4 + c];
-          }
-          // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 / math.f90:30-44 is local: dx * mean |alpha_I|
-          double delta = dx * ((fabs(KK[0]) + fabs(Kn[0])) / 2.0);
-          if (step) delo_map(jj, KK, jn, Kn, dx, delta, M);
-          else affine_identity(M);
-          __builtin_amdgcn_wave_barrier();
-          if (lane == 63) {
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) s_nb[wave][f][c] = jj[c];
-  #pragma unroll
-            for (int c = 0; c < 7; ++c) s_nb[wave][f][4 + c] = KK[c];
-          }
-        }
-        // inclusive Kogge-Stone scan: M_l <- M_l o M_{l-1} o ... o M_0
-  #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          Affine E, N;
-          affine_shfl_up(M, d, E);
-          if (lane >= d) {
-            affine_compose(M, E, N);
-            M = N;
-          }
-        }
-        double ci[4] = {s_carry[wave][f][0], s_carry[wave][f][1], s_carry[wave][f][2], s_carry[wave][f][3]};
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) io[i] = M.A[i][0] * ci[0] + M.A[i][1] * ci[1] + M.A[i][2] * ci[2] + M.A[i][3] * ci[3] + M.b[i];
-      }
-      double facs = wave_sum(facp);
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 63) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s_carry[wave][f][i] = io[i];
-      }
-      if (lane == 0) s_fac[wave][f] += facs;
-      __builtin_amdgcn_wave_barrier();
-      if (nfields > GRT_F_I && f == 0 && valid) {
-        double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sp[(GRT_F_I + c) * field_stride] = io[c] * LBH;
+    for (int i = 0; i < 8; ++i) {
+      const int rs = i * 8 + (lane >> 3), e = lane & 7;
+      const int idxm = s_n[wave][rs] - t0 - 8 + e;        // 0-based stored-point index
+      if (idxm >= 0) {
+        const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
+        tl0[rs * GRT_TS + e] = steps[GRT_F_R * field_stride + b];
+        tl1[rs * GRT_TS + e] = steps[GRT_F_TH * field_stride + b];
+        tl2[rs * GRT_TS + e] = steps[GRT_F_LAM * field_stride + b];
+        tfl[rs * 8 + e] = flags[b];
       }
     }
-    nb_lam = __shfl(lam_i, 63);
+    __builtin_amdgcn_wave_barrier();
+#pragma clang loop unroll(disable)
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = n - t0 - jj;                           // 1-based stored point of this lane's ray
+      const bool valid = k >= 1;
+      const int e = 7 - jj;
+      const double r = valid ? tl0[lane * GRT_TS + e] : 10.0;    // idle lanes (shorter rays) keep benign inputs
+      const double th = valid ? tl1[lane * GRT_TS + e] : 1.0;
+      const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
+      const int fl8 = tfl[lane * 8 + e];
+      double kv[4], sth, cth;
+      sincos(th, &sth, &cth);
+      calc_nullp(q2, l, cam.a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
+      sumr += valid ? r : 0.0;
+      // fluid + frame (grtrans_driver.f90:126-130)
+      FluidPoint fl;
+      if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
+      else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
+      else if (FLUID == GRT_FLUID_HARM) harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl);
+      double s2xi, c2xi, ang, g;
+      comoving_ortho(r, sth, cth, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g);
+      // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
+      double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
+      if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }
+      else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
+      else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, em.mbh, em.mdot, em.muval, em.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
+      PLPoint plp;
+      if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_point(plc, ncgsnth, bcgs, ang, plp);
+      const double lg = log(g);
+      const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
+      const bool step = valid && (k < n);
+
+      // not unrolled on purpose: FB copies of the coefficient + propagator code cost more (900 ms against 658 ms
+      // for 25 frequencies at 1024x1024x400) than indexing the per-frequency intensities dynamically
+#pragma clang loop unroll(disable)
+      for (int f = 0; f < FB; ++f) {
+        if (f < nf) {
+          const double nu = freqs[f0 + f] / g;
+          double e11[11];
+          if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_freq(tb, plc, plp, nu, lfreqs[f0 + f] - lg, e11);
+          else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth(nu, ncgs, bcgs, tcgs, ang, e11);
+          facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
+          if constexpr (IFLAG == GRT_INT_QUAD) {
+            // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
+            // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end, is the scalar recurrence
+            // I <- e^{-dtau} I + dx/2 (j_k + j_k+1 e^{-dtau}).
+            const double j0 = e11[0] * g * g, K0 = e11[4] / g * LBH;
+            const double delta = dx * ((fabs(K0) + fabs(Kn[f][0])) / 2.0);
+            if (step) {
+              const double E = exp(-delta);
+              I[f][0] = E * I[f][0] + 0.5 * dx * (j0 + jn[f][0] * E);
+            }
+            if (valid) { jn[f][0] = j0; Kn[f][0] = K0; }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+              if (!em.coefindx[c]) e11[4 + c] = 0.0;
+            // rotate_emis + invariant_emis + cgs scaling (emis.f90:797-838, grtrans_driver.f90:201-217)
+            double jj4[4] = {e11[0], c2xi * e11[1] - s2xi * e11[2], s2xi * e11[1] + c2xi * e11[2], e11[3]};
+            double KK[7] = {e11[4], c2xi * e11[5] - s2xi * e11[6], s2xi * e11[5] + c2xi * e11[6], e11[7],
+                            c2xi * e11[8] - s2xi * e11[9], s2xi * e11[8] + c2xi * e11[9], e11[10]};
+            const double ig = frcp(g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) KK[c] = KK[c] * ig * LBH;
+            if constexpr (IFLAG == GRT_INT_FORMAL) {
+              // I <- O_k (j_k dx_k + I)   (radtrans_integrate.f90:863-871)
+              if (step) {
+                double O[4][4];
+                calc_O(KK, KK + 4, dx, O);
+                const double v0 = jj4[0] * dx + I[f][0], v1 = jj4[1] * dx + I[f][1], v2 = jj4[2] * dx + I[f][2], v3 = jj4[3] * dx + I[f][3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) I[f][c] = O[c][0] * v0 + O[c][1] * v1 + O[c][2] * v2 + O[c][3] * v3;
+              }
+            } else {
+              // DELO couples point k with k+1 = the previous trip (radtrans_integrate.f90:811-837);
+              // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 is local: dx * mean |alpha_I|
+              if (step) {
+                const double delta = dx * ((fabs(KK[0]) + fabs(Kn[f][0])) / 2.0);
+                Affine M;
+                delo_map(jj4, KK, jn[f], Kn[f], dx, delta, M);
+                const double v0 = I[f][0], v1 = I[f][1], v2 = I[f][2], v3 = I[f][3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) I[f][c] = M.A[c][0] * v0 + M.A[c][1] * v1 + M.A[c][2] * v2 + M.A[c][3] * v3 + M.b[c];
+              }
+              if (valid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) jn[f][c] = jj4[c];
+#pragma unroll
+                for (int c = 0; c < 7; ++c) Kn[f][c] = KK[c];
+              }
+            }
+          }
+        }
+      }
+      if (record) {   // running intensity of the first frequency into the consumed tile slot
+        tl0[lane * GRT_TS + e] = I[0][0] * LBH;
+        tl1[lane * GRT_TS + e] = I[0][1] * LBH;
+        tl2[lane * GRT_TS + e] = I[0][2] * LBH;
+        tl3[lane * GRT_TS + e] = I[0][3] * LBH;
+      }
+      if (valid) lam_prev = lam_i;
+    }
+    if (record) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rs = i * 8 + (lane >> 3), e = lane & 7;
+        const int idxm = s_n[wave][rs] - t0 - 8 + e;
+        if (idxm >= 0) {
+          const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
+          steps[(GRT_F_I + 0) * field_stride + b] = tl0[rs * GRT_TS + e];
+          steps[(GRT_F_I + 1) * field_stride + b] = tl1[rs * GRT_TS + e];
+          steps[(GRT_F_I + 2) * field_stride + b] = tl2[rs * GRT_TS + e];
+          steps[(GRT_F_I + 3) * field_stride + b] = tl3[rs * GRT_TS + e];
+        }
+      }
+    }
   }
-  sumr = wave_sum(sumr);
-  __builtin_amdgcn_wave_barrier();
+  if (!has_ray) return;
   const int pixslot = R.pix - (int)i1;
-  for (int f = lane; f < nfreq; f += 64) {
-    double fac = s_fac[wave][f];
-    bool ok = (fac / 1e16 > 0.0) && !(sumr < 0.0);
-    for (int c = 0; c < nvals && c < 4; ++c) {
-      double v = ok ? s_carry[wave][f][c] * LBH : 0.0;
-      pixvals[((long long)f * npix_tile + pixslot) * nvals + c] = (float)v;
-    }
-  }
-  if (nfields > GRT_F_I) {
-    // a ray the reference skips (fac <= 0 or NaN, grtrans_driver.f90:183,314-317) keeps rt%I = 0 in its dump
-    const double fac0 = s_fac[wave][0];
-    if (!((fac0 / 1e16 > 0.0) && !(sumr < 0.0))) {
-      double *spz = steps + (long long)rayidx * ray_stride;
-      for (int i = lane; i < n; i += 64)
+  bool ok0 = true;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) spz[(GRT_F_I + c) * field_stride + i] = 0.0;
+  for (int f = 0; f < FB; ++f) {
+    if (f < nf) {
+      const bool ok = (facs[f] / 1e16 > 0.0) && !(sumr < 0.0);
+      if (f == 0) ok0 = ok;
+      for (int c = 0; c < nvals && c < 4; ++c)
+        pixvals[((long long)(f0 + f) * npix_tile + pixslot) * nvals + c] = (float)(ok ? I[f][c] * LBH : 0.0);
     }
   }
-  if (lane == 0) {
+  if (record && !ok0) {
+    // a ray the reference skips (fac <= 0 or NaN, grtrans_driver.f90:183,314-317) keeps rt%I = 0 in its dump
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) steps[(GRT_F_I + c) * field_stride + base + i] = 0.0;
+  }
+  if (first_batch) {
     if (sumr < 0.0) ray_status[rayidx] = -n;
     atomicAdd(step_counter, (unsigned long long)n);
   }
@@ -375,14 +385,25 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
 }
 
 template <int IFLAG, int FLUID, int EMIS>
-static void launch_transfer_t(hipStream_t s, dim3 g, dim3 b, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
+static void launch_transfer_t(hipStream_t s, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
                               double *steps, const unsigned char *flags, long long ray_stride, long long field_stride,
                               int nfields, unsigned long long *step_counter) {
-  hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS>), g, b, 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq,
-                     freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields,
-                     step_counter);
+  const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
+  if (nfreq == 1) {
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
+                       *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride,
+                       field_stride, nfields, step_counter);
+  } else {
+    // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
+    // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
+    // DELO (which also parks the neighbour's j, K per frequency) 8/13/32 -> 258/281/345 ms at 512^2
+    constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
+                       dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
+                       nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);
+  }
 }
 
 // returns hipErrorInvalidValue for a (fluid, emissivity, integrator) combination that has no kernel
@@ -393,10 +414,9 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const unsigned char *flags, long long ray_stride, long long field_stride,
                                           int nfields, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
-  dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
-    launch_transfer_t<I, F, E>(s, g, b, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals, \
+    launch_transfer_t<I, F, E>(s, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
                                ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);           \
     return hipGetLastError();                                                                                           \
   }

@@ -47,7 +47,7 @@ struct GrtHarm {                // device pointers; one 2-D HARM slice (nt=1), f
   int32_t nx1, nx2;
   float h, pad;
 };
-#define GRT_HARM_MAXCOORD 2048  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats)
+#define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 
 struct GrtFluidDev {            // what the transfer kernel samples; only the selected model's part is read
   GrtFFJet fj;
