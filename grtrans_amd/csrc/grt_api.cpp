@@ -18,7 +18,7 @@ extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, int nlive, double *steps, unsigned char *flags,
                                      long long ray_stride, long long field_stride, int nfields);
-extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, const GrtCam *cam, const GrtRay *rays,
+extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
@@ -291,7 +291,8 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH);
   if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
-  if (cam->standard != 1 || cam->nup < 2 || (nvals != 4 && nvals != 1) || nextra != 0) return GRT_E_UNSUPPORTED;
+  // nextra: 0, or the 19 ray diagnostics of extra=1 for nup>1 (pgrtrans.f90:108-114)
+  if (cam->standard != 1 || cam->nup < 2 || (nvals != 4 && nvals != 1) || (nextra != 0 && nextra != 19)) return GRT_E_UNSUPPORTED;
   // nvals=1: both iname=delo and iname=formal fall through to the quadrature (radtrans_integrate.f90:176-189)
   const int kflag = (nvals == 1) ? 4 /* GRT_INT_QUAD */ : iflag;
   if (fluid_model == GRT_FLUID_FFJET && !C.have_ffjet) return GRT_E_NOFLUID;
@@ -314,7 +315,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   // per-step record in HBM: [field][ray][maxpts] fp64, fields r,theta,lambda always (they carry the
   // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
   const long long maxpts = cam->nup + cam->next;
-  const int nfields = C.record_steps ? 8 : 3;
+  const int nfields = C.record_steps ? 8 : (nextra ? 4 : 3);   // extra=1 weights by phi as well
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nfields * nrays * maxpts))) return rc;
   if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * maxpts))) return rc;
   C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields;
@@ -340,10 +341,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
                         maxpts, fstride, nfields));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
-  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
+  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, maxpts,
                              fstride, nfields, C.d_stepcount));
-  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
+  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
                              C.d_flags, maxpts, fstride, nfields, C.d_stepcount));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));

@@ -22,9 +22,12 @@
 
 namespace grtd {
 
-// R_C by duplication with the 7th-order series of Carlson (1979) (the reference stops at 5th order with
-// ERRTOL=0.0012, geokerr_wrapper.f:3608-3645; two more terms allow |s|<=0.009, ~1.5 fewer iterations,
-// same value to rounding).
+// R_C by duplication with a 12th-order series (the reference stops at 5th order with ERRTOL=0.0012,
+// geokerr_wrapper.f:3608-3645).  Two changes against a literal translation: the convergence test comes
+// BEFORE the first duplication (inside the R_J loop the two arguments are already within a few per cent of
+// each other after the first step, so most calls need no duplication at all), and the longer series allows
+// |s| <= 0.045 (remainder 31 s^13 ~ 1e-16), about 1.2 fewer duplications (2 square roots each) otherwise.
+// Coefficients: Taylor series of R_C(1-2s, 1+s) (1, 0, 3/10, 1/7, 3/8, 9/22, 159/208, 9/8, 4275/2176, ...).
 GRT_HD double rc7(double x, double y) {
   double xt, yt, w, ave, s;
   if (y > 0.0) {
@@ -32,16 +35,20 @@ GRT_HD double rc7(double x, double y) {
   } else {
     xt = x - y; yt = -y; w = fdiv(fsqrt(x), fsqrt(xt));
   }
-  do {
+  ave = (1.0 / 3.0) * (xt + yt + yt);
+  s = yt - ave;
+  while (fabs(s) > 0.045 * ave) {
     double alamb = 2.0 * fsqrt(xt) * fsqrt(yt) + yt;
     xt = .25 * (xt + alamb);
     yt = .25 * (yt + alamb);
     ave = (1.0 / 3.0) * (xt + yt + yt);
     s = yt - ave;
-  } while (fabs(s) > 0.009 * ave);
-  s = fdiv(s, ave);
-  return w * (1.0 + s * s * (0.3 + s * (1.0 / 7.0 + s * (0.375 + s * (9.0 / 22.0 + s * (159.0 / 208.0 + s * (9.0 / 8.0))))))) *
-         frcp(fsqrt(ave));
+  }
+  const double ia = frcp(ave);
+  s = s * ia;
+  const double poly = 0.3 + s * (1.0 / 7.0 + s * (0.375 + s * (9.0 / 22.0 + s * (159.0 / 208.0 + s * (9.0 / 8.0 + s * (4275.0 / 2176.0 +
+                      s * (985.0 / 304.0 + s * (1449.0 / 256.0 + s * (28875.0 / 2944.0 + s * (445039.0 / 25600.0))))))))));
+  return w * (1.0 + s * s * poly) * fsqrt(ia);
 }
 
 // R_C(1, 1+e) in closed form; b = 1+e is passed separately because the caller can form it without

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 #define GRT_TS 8                 // tile row stride in doubles (8 steps; unpadded: 4 buffers x 8 waves must fit the 160 KB LDS,
                                  // and the 8-way bank conflict of the transposed read is noise next to ~1e4 cycles of VALU per step)
 #define GRT_XFER_THREADS 256
-template <int IFLAG, int FLUID, int EMIS, int FB>
+// EXTRA (FB = 1 only): the 19 ray diagnostics of EXTRA_QUANTS=1 (grtrans_driver.f90:230-292) as running sums of
+// the same far-end -> camera walk: six optical depths, emission-weighted means through the attenuated-sum
+// recurrence S <- e^{-dtau} S + dx/2 (w_k + w_k+1 e^{-dtau}), and the LP-increment-weighted means.
+template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
 __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
@@ -193,6 +196,14 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       for (int c = 0; c < 7; ++c) Kn[f][c] = 0.0;
     }
   }
+  // EXTRA accumulators (dead code otherwise)
+  double xT[6], xKp[6], xS[9], xWp[9], xD[6], xLPp = 0.0;
+  if (EXTRA) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { xT[c] = 0.0; xKp[c] = 0.0; xD[c] = 0.0; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { xS[c] = 0.0; xWp[c] = 0.0; }
+  }
   double sumr = 0.0, lam_prev = 0.0;
   double *tl0 = s_tile[wave][0], *tl1 = s_tile[wave][1], *tl2 = s_tile[wave][2], *tl3 = s_tile[wave][3];
   unsigned char *tfl = s_fl[wave];
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
         tl0[rs * GRT_TS + e] = steps[GRT_F_R * field_stride + b];
         tl1[rs * GRT_TS + e] = steps[GRT_F_TH * field_stride + b];
         tl2[rs * GRT_TS + e] = steps[GRT_F_LAM * field_stride + b];
+        if (EXTRA) tl3[rs * GRT_TS + e] = steps[GRT_F_PHI * field_stride + b];
         tfl[rs * 8 + e] = flags[b];
       }
     }
@@ -222,6 +234,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       const double th = valid ? tl1[lane * GRT_TS + e] : 1.0;
       const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
       const int fl8 = tfl[lane * 8 + e];
+      const double phi_i = EXTRA ? tl3[lane * GRT_TS + e] : 0.0;
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);
       calc_nullp(q2, l, cam.a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       const double lg = log(g);
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
+      double xJK[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // EXTRA: j_I and K(1:7) of the first frequency after rotate/invariant/cgs
 
       // not unrolled on purpose: FB copies of the coefficient + propagator code cost more (900 ms against 658 ms
       // for 25 frequencies at 1024x1024x400) than indexing the per-frequency intensities dynamically
@@ -259,6 +273,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
             // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end, is the scalar recurrence
             // I <- e^{-dtau} I + dx/2 (j_k + j_k+1 e^{-dtau}).
             const double j0 = e11[0] * g * g, K0 = e11[4] / g * LBH;
+            if (EXTRA && f == 0) { xJK[0] = j0; xJK[1] = K0; }
             const double delta = dx * ((fabs(K0) + fabs(Kn[f][0])) / 2.0);
             if (step) {
               const double E = exp(-delta);
@@ -278,6 +293,11 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
             for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g;
 #pragma unroll
             for (int c = 0; c < 7; ++c) KK[c] = KK[c] * ig * LBH;
+            if (EXTRA && f == 0) {
+              xJK[0] = jj4[0];
+#pragma unroll
+              for (int c = 0; c < 7; ++c) xJK[1 + c] = KK[c];
+            }
             if constexpr (IFLAG == GRT_INT_FORMAL) {
               // I <- O_k (j_k dx_k + I)   (radtrans_integrate.f90:863-871)
               if (step) {
@@ -307,6 +327,30 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
             }
           }
         }
+      }
+      if (EXTRA && valid) {
+        // scaled coefficients of this point (first frequency): j_I g^2 and |K| columns alpha_I,Q,U,V, rho_Q, rho_V
+        const double jI = xJK[0];
+        const double Kc[6] = {fabs(xJK[1]), fabs(xJK[2]), fabs(xJK[3]), fabs(xJK[4]), fabs(xJK[5]), fabs(xJK[7])};
+        const double beta_p = (double)(fl.p * 2.f / powf(fl.bmag, 2.f));          // f%p*2./f%bmag**2. in REAL(4)
+        const double qv[9] = {1.0, r, th, phi_i, ncgs, tcgs, bcgs, beta_p, (cth < 0.0) ? -1.0 : 1.0};
+        if (step) {
+          const double dtau = dx * ((Kc[0] + xKp[0]) / 2.0);
+          const double E = exp(-dtau);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) xT[c] += dx * ((Kc[c] + xKp[c]) / 2.0);
+#pragma unroll
+          for (int c = 0; c < 9; ++c) xS[c] = E * xS[c] + 0.5 * dx * (jI * qv[c] + xWp[c] * E);
+          // LP increment between stored points k and k+1 (the running intensity after this step is point k's)
+          const double LP = sqrt(I[0][0] * I[0][0] + I[0][1] * I[0][1]);
+          const double dlp = (IFLAG == GRT_INT_QUAD) ? 0.0 : LP - xLPp;
+          xD[0] += dlp; xD[1] += dlp * r; xD[2] += dlp * th; xD[3] += dlp * xT[4]; xD[4] += dlp * xT[5]; xD[5] += dlp * qv[8];
+          xLPp = LP;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xKp[c] = Kc[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xWp[c] = jI * qv[c];
       }
       if (record) {   // running intensity of the first frequency into the consumed tile slot
         tl0[lane * GRT_TS + e] = I[0][0] * LBH;
@@ -340,9 +384,25 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
     if (f < nf) {
       const bool ok = (facs[f] / 1e16 > 0.0) && !(sumr < 0.0);
       if (f == 0) ok0 = ok;
-      for (int c = 0; c < nvals && c < 4; ++c)
-        pixvals[((long long)(f0 + f) * npix_tile + pixslot) * nvals + c] = (float)(ok ? I[f][c] * LBH : 0.0);
+      if (!EXTRA)
+        for (int c = 0; c < nvals && c < 4; ++c)
+          pixvals[((long long)(f0 + f) * npix_tile + pixslot) * nvals + c] = (float)(ok ? I[f][c] * LBH : 0.0);
     }
+  }
+  if (EXTRA) {
+    const int nx = nvals, ns = nvals - 19;      // the launcher passes the full row width nvals+nextra as `nvals`
+    float *o = pixvals + ((long long)f0 * npix_tile + pixslot) * nx;
+    for (int c = 0; c < ns && c < 4; ++c) o[c] = (float)(ok0 ? I[0][c] * LBH : 0.0);
+    double xt[19];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xt[c] = xT[c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xt[6 + c] = 1.0 / xS[0] * xS[1 + c];
+    // tau_arr(k,5:6) is counted from the camera: total minus the far-side running sum used in the loop
+    xt[14] = xD[1] / xD[0]; xt[15] = xD[2] / xD[0];
+    xt[16] = (xT[4] * xD[0] - xD[3]) / xD[0]; xt[17] = (xT[5] * xD[0] - xD[4]) / xD[0];
+    xt[18] = xD[5] / xD[0];
+    for (int c = 0; c < 19; ++c) o[ns + c] = (float)(ok0 ? xt[c] : 0.0);
   }
   if (record && !ok0) {
     // a ray the reference skips (fac <= 0 or NaN, grtrans_driver.f90:183,314-317) keeps rt%I = 0 in its dump
@@ -385,14 +445,18 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
 }
 
 template <int IFLAG, int FLUID, int EMIS>
-static void launch_transfer_t(hipStream_t s, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
+static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
                               double *steps, const unsigned char *flags, long long ray_stride, long long field_stride,
                               int nfields, unsigned long long *step_counter) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
-  if (nfreq == 1) {
-    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
+  if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
+                       rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags,
+                       ray_stride, field_stride, nfields, step_counter);
+  } else if (nfreq == 1) {
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
                        *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride,
                        field_stride, nfields, step_counter);
   } else {
@@ -400,14 +464,14 @@ static void launch_transfer_t(hipStream_t s, const GrtCam *cam, const GrtRay *ra
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
     // DELO (which also parks the neighbour's j, K per frequency) 8/13/32 -> 258/281/345 ms at 512^2
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
-    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
                        dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
                        nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);
   }
 }
 
 // returns hipErrorInvalidValue for a (fluid, emissivity, integrator) combination that has no kernel
-extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, const GrtCam *cam, const GrtRay *rays,
+extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
@@ -416,7 +480,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   if (nlive <= 0) return hipSuccess;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
-    launch_transfer_t<I, F, E>(s, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
+    launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
                                ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);           \
     return hipGetLastError();                                                                                           \
   }

@@ -122,8 +122,9 @@ class grtrans:
     def run_pgrtrans(self, device=0, **kwargs):
         """Same kwargs as write_grtrans_inputs; fills ivals(nvals,npix,ncams), ab(2,npix), nu."""
         inp = self.inputs = grtrans_inputs(**kwargs)
-        if inp.nt != 1 or inp.nload != 1 or inp.extra != 0:
-            raise capi.GrtError("nt/nload > 1 and extra=1 are not on the device yet")
+        if inp.nt != 1 or inp.nload != 1:
+            raise capi.GrtError("nt/nload > 1 are not on the device yet")
+        nextra = 19 if int(inp.extra) == 1 else 0           # pgrtrans.f90:108-114 (nup > 1)
         nfreq, nmu, nmdot = int(inp.nfreq), int(inp.nmu), int(inp.nmdot)
         freqs = np.array([inp.fmin]) if nfreq == 1 else inp.fmin * np.exp(np.arange(nfreq) * np.log(inp.fmax / inp.fmin) / (nfreq - 1))
         mu0 = np.array([inp.mumin]) if nmu == 1 else inp.mumin + (inp.mumax - inp.mumin) / (nmu - 1) * np.arange(nmu)
@@ -141,7 +142,7 @@ class grtrans:
                 if int(inp.fnt) != 1:
                     raise capi.GrtError("HARM with hnt > 1 (time-dependent) is not on the device yet")
                 dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
-            ivals = np.zeros((inp.nvals, npix, ncams))
+            ivals = np.zeros((inp.nvals + nextra, npix, ncams))
             ab = np.zeros((2, npix))
             for j in range(nmu):
                 cam = capi.make_camera(inp.standard, inp.gridvals, inp.nn, inp.spin, float(mu0[j]), inp.uout, inp.phi0)
@@ -150,7 +151,7 @@ class grtrans:
                     em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
                                         inp.muval, inp.epcoefindx, mdot=float(mdot))
                     pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
-                                                           nvals=inp.nvals)
+                                                           nvals=inp.nvals, nextra=nextra)
                     for k in range(nfreq):
                         c = (j * nfreq * nmdot) + m * nfreq + k          # grtrans_driver.f90:324
                         ivals[:, inp.i1 - 1:inp.i2, c] = pix[k].T
@@ -158,7 +159,7 @@ class grtrans:
         finally:
             dev.close()
         self.ivals, self.ab, self.nu = ivals, ab, freqs
-        self.nx, self.ny, self.nvals = int(inp.nn[0]), int(inp.nn[1]), int(inp.nvals)
+        self.nx, self.ny, self.nvals = int(inp.nn[0]), int(inp.nn[1]), int(inp.nvals) + nextra
 
     def read_grtrans_output(self, bin=1):
         """cflag=0 binary file (camera.f90:321-340): Fortran sequential records per camera."""

@@ -84,7 +84,8 @@ contains
     ! ---- what this build can put on the device; everything else stops loudly (no CPU path) ----
     if (.not. use_geokerr) call die('use_geokerr=F is not supported')
     if (nt /= 1 .or. nload /= 1) call die('time-dependent runs (nt,nload > 1) are not supported yet')
-    if (extra /= 0 .or. debug /= 0) call die('extra=1 / debug=1 are not supported yet')
+    if (debug /= 0) call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps')
+    if (extra == 1 .and. nup <= 1) call die('extra=1 with nup=1 is not supported yet')
     select case (trim(fname))
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
     case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC

@@ -37,7 +37,8 @@ struct RayWork {
 
 // One pixel / one frequency, stages kept for dumping.  Returns pixel Stokes (double, before
 // the fp32 cast), fac and npts.
-void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
+void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, double *extra = nullptr) {
+  if (extra) for (int c = 0; c < 19; ++c) extra[c] = 0.0;
   Pixel px = camera_pixel(S.cam, ii);
   make_geodesic(S.cam, px, S.phi0, 0.0, w.g);
   const int n = w.g.npts;
@@ -113,6 +114,59 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac) {
     else integrate_formal(n, w.g.lam.data(), w.j.data(), w.K.data(), w.I.data());
     for (size_t q = 0; q < w.I.size(); ++q) w.I[q] = w.I[q] * fac * LBH;
     for (int c = 0; c < 4; ++c) pix[c] = w.I[4 * (n - 1) + c];
+    if (extra) {   // EXTRA_QUANTS=1, grtrans_driver.f90:230-292
+      std::vector<double> s(n), y(n), t(n), tw(n), dm(n);
+      for (int i = 0; i < n; ++i) s[i] = w.g.lam[0] - w.g.lam[i];
+      const int cols[6] = {0, 1, 2, 3, 4, 6};
+      std::vector<std::vector<double>> tau_arr(6, std::vector<double>(n));
+      for (int c = 0; c < 6; ++c) {
+        for (int i = 0; i < n; ++i) y[i] = std::fabs(w.K[7 * i + cols[c]]);
+        tsum(n, s.data(), y.data(), tau_arr[c].data());
+      }
+      int taudex = 0;
+      double best = 1e300, mn = 1e300;
+      for (int i = 0; i < n; ++i) {
+        double d = std::fabs(w.tau[i] - 1.0);
+        if (d < best) { best = d; taudex = i; }
+        mn = std::min(mn, w.tau[i]);
+      }
+      if (mn < 1.0) taudex = n - 1;
+      if (taudex == 0) taudex = 1;
+      for (int c = 0; c < 6; ++c) extra[c] = tau_arr[c][taudex];
+      for (int i = 0; i < n; ++i) dm[i] = w.j[4 * i] * std::exp(-w.tau[i]);
+      tsum(n, w.g.lam.data(), dm.data(), tw.data());
+      for (int m = 7; m <= 14; ++m) {
+        for (int i = 0; i < n; ++i) {
+          double q;
+          switch (m) {
+            case 7: q = w.g.x[4 * i + 1]; break;
+            case 8: q = w.g.x[4 * i + 2]; break;
+            case 9: q = w.g.x[4 * i + 3]; break;
+            case 10: q = w.ncgs[i]; break;
+            case 11: q = w.tcgs[i]; break;
+            case 12: q = w.bcgs[i]; break;
+            case 13: q = (double)(w.f[i].p * 2.f / std::pow(w.f[i].bmag, 2.f)); break;   // f%p*2./f%bmag**2. in REAL(4)
+            default: q = std::copysign(1.0, std::cos(w.g.x[4 * i + 2]));
+          }
+          y[i] = dm[i] * q;
+        }
+        tsum(n, w.g.lam.data(), y.data(), t.data());
+        extra[m - 1] = 1.0 / tw[taudex] * t[taudex];
+      }
+      std::vector<double> lp(n);
+      for (int i = 0; i < n; ++i) {   // w.I is in integration order: row n-1-i is stored point i (0-based)
+        const double *Ip = &w.I[4 * (n - 1 - i)];
+        lp[i] = (S.nvals == 4) ? std::sqrt(Ip[0] * Ip[0] + Ip[1] * Ip[1]) : 0.0;
+      }
+      double sd = 0, a15 = 0, a16 = 0, a17 = 0, a18 = 0, a19 = 0;
+      for (int i = 0; i < n - 1; ++i) {
+        double d = (S.nvals == 4) ? lp[i] - lp[i + 1] : 0.0;
+        sd += d; a15 += d * w.g.x[4 * i + 1]; a16 += d * w.g.x[4 * i + 2];
+        a17 += d * tau_arr[4][i]; a18 += d * tau_arr[5][i];
+        a19 += d * std::copysign(1.0, std::cos(w.g.x[4 * i + 2]));
+      }
+      extra[14] = a15 / sd; extra[15] = a16 / sd; extra[16] = a17 / sd; extra[17] = a18 / sd; extra[18] = a19 / sd;
+    }
   } else {
     for (int c = 0; c < 4; ++c) pix[c] = w.j[c];
   }
@@ -222,6 +276,26 @@ void grto_trace(int i1, int i2, int nfreq, const double *freqs, int nthreads, fl
     }
   }
   *seconds = omp_get_wtime() - t0;
+}
+
+// extra=1: [npix_range][nvals+19] fp32 for one frequency
+void grto_trace_extra(int i1, int i2, double freq, int nthreads, float *pixvals, int *raynpts) {
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  const int nv = S.nvals + 19;
+#pragma omp parallel
+  {
+    RayWork w;
+#pragma omp for schedule(static, 1)
+    for (int i = i1; i <= i2; ++i) {
+      double pix[4], fac, ex[19];
+      ray_stages(i, freq, w, pix, fac, ex);
+      float *o = pixvals + (size_t)(i - i1) * nv;
+      for (int c = 0; c < S.nvals; ++c) o[c] = (float)pix[c];
+      const bool live = (w.g.status == 1 && w.g.npts > 1);
+      for (int c = 0; c < 19; ++c) o[S.nvals + c] = live ? (float)ex[c] : 0.f;
+      raynpts[i - i1] = (w.g.status == 1) ? w.g.npts : -w.g.npts;
+    }
+  }
 }
 
 void grto_polsynchpl(int n, const double *nu, const double *nnth, const double *b, const double *th, const double *p,

@@ -32,6 +32,7 @@ module grt_ref_driver
   use polsynchemis, only: polsynchpl, polsynchth, initialize_polsynchpl, gxvals, gyvals, xvals, &
        yavals, ypvals, yvvals, yapvals, yavvals
   use phys_constants, only: GC => G, C2, MSUN
+  use math, only: tsum
   implicit none
 
   type (geokerr_args), save :: gargs
@@ -345,6 +346,127 @@ contains
 !$omp end parallel do
     seconds = omp_get_wtime() - t0
   end subroutine ref_trace
+
+  ! One pixel, one frequency, EXTRA_QUANTS=1 and npts>1: the 19 ray diagnostics of grtrans_driver.f90:230-292
+  ! appended to the Stokes values.  Sequencing restated (grtrans_driver.f90 cannot be compiled here, see header);
+  ! every cumulative integral is the reference's own calc_opt_depth / tsum.
+  subroutine trace_pixel_extra(i, freq, pix, nptsout)
+    integer, intent(in) :: i
+    real(8), intent(in) :: freq
+    real(4), intent(out) :: pix(nvals_s + 19)
+    integer, intent(out) :: nptsout
+    real(8), allocatable :: s2xi(:), c2xi(:), rshift(:), ang(:), nu(:), cosne(:), tau(:)
+    real(8), allocatable :: tau_arr(:,:), w(:), q(:), tq(:), tw(:), dlp(:), lp(:)
+    type (source_params) :: sp
+    type (emis_params) :: ep
+    real(8) :: LBH, fac, xt(19), sd
+    integer :: n, st, ii, taudex, m
+    integer, parameter :: cols(6) = (/1, 2, 3, 4, 5, 7/)
+    pix = 0.
+    ep = eparams0
+    call initialize_geodesic(ge, gargs, i, st)
+    n = ge%npts; nptsout = n
+    if (st /= 1) nptsout = -n
+    if (st == 1 .and. n > 1) then
+       allocate(nu(n), s2xi(n), c2xi(n), rshift(n), ang(n), cosne(n), tau(n))
+       s2xi = 0d0; c2xi = 0d0
+       call initialize_fluid_model(fl, fname_s, gargs%a, n)
+       call select_emissivity_values(em, ename_s)
+       call get_fluid_vars(ge%x, ge%k, ge%gk%a, fl)
+       call comoving_ortho(ge%x%data(2), ge%x%data(3), ge%gk%a, ge%gk%alpha(1), ge%gk%beta(1), &
+            ge%gk%mu0, fl%u, fl%b, ge%k, s2xi, c2xi, ang, rshift, cosne)
+       call initialize_rad_trans(rt, iname_s, n, nvals_s, 1)
+       call init_radtrans_integrate_data(rt%iflag, rt%neq, n, rt%npts)
+       sp = sparams0
+       call initialize_source_params(sp, n)
+       call initialize_emis_params(ep, n)
+       call initialize_emissivity(em, n, fl%nfreq, rshift, ang, cosne, fl%nrelbin, fl%bingammamin, fl%bingammamax)
+       LBH = GC*sp%mbh*MSUN/C2
+       call convert_model_ref(sp)
+       ep%gmin = sp%gmin; ep%mu = sp%mu
+       call emis_model(em, ep)
+       nu = freq/rshift
+       call calc_emissivity(nu, em, ep)
+       fac = sum(em%j(:,1)*(ge%lambda(1)-ge%lambda(1:n)))
+       xt = 0d0
+       if (fac/1d16 > 0d0) then
+          if (em%neq == 4) call rotate_emis(em, s2xi, c2xi)
+          call invariant_emis(em, rshift)
+          em%j = em%j/fac; em%K = em%K*LBH
+          call calc_opt_depth(ge%lambda(1:n), em, tau, 1)
+          tau = -tau
+          call integrate(ge%lambda(1:n), em%j, em%K, tau, rt%npts)
+          rt%I(1:rt%neq,1:rt%npts) = intensity(1:rt%neq,1:rt%npts)
+          rt%I = rt%I*fac*LBH
+          ! --- :230-292 ---
+          allocate(tau_arr(n,6), w(n), q(n), tq(n), tw(n), dlp(n-1), lp(n))
+          do ii = 1, 6
+             call calc_opt_depth(ge%lambda(1)-ge%lambda(1:n), em, tq, cols(ii))
+             tau_arr(:,ii) = tq
+          end do
+          taudex = minloc(abs(tau-1d0), 1)
+          if (minval(tau) < 1d0) taudex = n
+          if (taudex == 1) taudex = 2
+          xt(1:6) = tau_arr(taudex,:)
+          w = em%j(:,1)*exp(-tau(1:n))
+          tw = tsum(ge%lambda, w)
+          do m = 7, 14
+             select case (m)
+             case (7);  q = ge%x%data(2)
+             case (8);  q = ge%x%data(3)
+             case (9);  q = ge%x%data(4)
+             case (10); q = em%ncgs
+             case (11); q = em%tcgs
+             case (12); q = em%bcgs
+             case (13); q = fl%p*2./fl%bmag**2.
+             case (14); q = sign(1d0, cos(ge%x%data(3)))
+             end select
+             tq = tsum(ge%lambda, w*q)
+             xt(m) = 1d0/tw(taudex)*tq(taudex)
+          end do
+          if (rt%neq == 4) then
+             do m = 1, n      ! rt%I is stored in integration order: column n+1-m is stored point m
+                lp(m) = sqrt(rt%I(1,n+1-m)**2. + rt%I(2,n+1-m)**2.)
+             end do
+             dlp = lp(1:n-1) - lp(2:n)
+          else
+             dlp = 0.
+          end if
+          sd = sum(dlp)
+          xt(15) = sum(dlp*ge%x(1:n-1)%data(2))/sd
+          xt(16) = sum(dlp*ge%x(1:n-1)%data(3))/sd
+          xt(17) = sum(dlp*tau_arr(1:n-1,5))/sd
+          xt(18) = sum(dlp*tau_arr(1:n-1,6))/sd
+          xt(19) = sum(dlp*sign(1d0, cos(ge%x(1:n-1)%data(3))))/sd
+          deallocate(tau_arr, w, q, tq, tw, dlp, lp)
+       else
+          rt%I(:,:) = 0d0; rt%npts = 1
+       end if
+       pix(1:rt%neq) = real(rt%I(:,rt%npts))
+       pix(nvals_s+1:nvals_s+19) = real(xt)
+       call del_source_params(sp); call del_emis_params(ep); call del_emissivity(em)
+       call del_rad_trans(rt); call del_radtrans_integrate_data(); call del_fluid_model(fl)
+       deallocate(nu, s2xi, c2xi, rshift, ang, cosne, tau)
+    end if
+    call del_geodesic(ge)
+  end subroutine trace_pixel_extra
+
+  subroutine ref_trace_extra(i1, i2, freq, nthreads, pixvals, raynpts) bind(C, name='ref_trace_extra')
+    integer(c_int), value :: i1, i2, nthreads
+    real(c_double), value :: freq
+    real(c_float), intent(out) :: pixvals(nvals_s + 19, i2-i1+1)
+    integer(c_int), intent(out) :: raynpts(i2-i1+1)
+    real(4) :: pix(nvals_s + 19)
+    integer :: i, np
+    if (nthreads > 0) call omp_set_num_threads(nthreads)
+!$omp parallel do schedule(static,1) private(i,pix,np)
+    do i = i1, i2
+       call trace_pixel_extra(i, freq, pix, np)
+       pixvals(:, i-i1+1) = pix
+       raynpts(i-i1+1) = np
+    end do
+!$omp end parallel do
+  end subroutine ref_trace_extra
 
   ! ---------------- leaf probes ----------------
   function ref_rf(x, y, z) bind(C, name='ref_rf') result(v)

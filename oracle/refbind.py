@@ -134,6 +134,14 @@ class Ref:
             out[k] = dump[c, :max(n, 0)].T.copy() if isinstance(c, slice) else dump[c, :max(n, 0)].copy()
         return out
 
+    def trace_extra(self, i1, i2, freq, nthreads=0):
+        """extra=1: (nvals+19) values per pixel for one frequency (grtrans_driver.f90:230-292)."""
+        n = i2 - i1 + 1
+        pix = np.zeros((n, self.nvals + 19), dtype=np.float32)
+        npts = np.zeros(n, dtype=np.int32)
+        lib().ref_trace_extra(C.c_int(i1), C.c_int(i2), C.c_double(freq), C.c_int(nthreads), _fp(pix), _ip(npts))
+        return pix, npts
+
     def trace(self, i1, i2, freqs, nthreads=0):
         freqs = np.ascontiguousarray(freqs, dtype=np.float64)
         nf = len(freqs)

@@ -221,6 +221,40 @@ def test_nvals1_quadrature_vs_reference_golden(dev):
         assert np.array_equal(status, g["sphacc_npts"]) and stokes_err(pix, g["sphacc_ivals"]) < STOKES_TOL
 
 
+def test_extra_ray_diagnostics_vs_reference(dev):
+    # extra=1: the 19 per-ray diagnostics (optical depths, emission- and LP-weighted means) accumulated in the
+    # transfer kernel's walk; golden = compiled reference routines through oracle/ref_driver.f90
+    from grtrans_amd import capi
+    g = np.load(os.path.join(G, "extra_32x32x100.npz"))
+    dev.load_sphacc()
+
+    # column tolerances (fraction of the column's largest magnitude): Stokes and optical depths 1e-5; the
+    # emission-weighted means 5e-5 (ratios of two attenuated sums; beta goes through REAL(4) pow); the LP-increment
+    # weighted means 1e-4: their weights are differences of neighbouring sqrt(I^2+Q^2), which amplify the few-1e-7
+    # differences of the fp32 fluid islands
+    tolc = np.array([1e-5] * 4 + [1e-5] * 6 + [5e-5] * 8 + [1e-4] * 5)
+
+    def check(vals, ref, tol):
+        a = np.asarray(vals, float); b = np.asarray(ref, float)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        a = np.nan_to_num(a); b = np.nan_to_num(b)
+        err = np.abs(a - b).max(axis=0) / (np.abs(b).max(axis=0) + 1e-300)
+        assert np.all(err < tolc), err
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (32, 32, 100), 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "FFJET", em, [FREQ], "formal", nvals=4, nextra=19)
+    assert pix.shape == (1, 1024, 23) and np.array_equal(status, g["ffjet_npts"])
+    check(pix[0], g["ffjet_vals"], 2e-5)
+    # two frequencies: each camera carries its own diagnostics
+    pix2, _, _, _ = capi.trace_tile(cam, 1, 1024, "FFJET", em, [2.3e11, FREQ], "formal", nvals=4, nextra=19)
+    assert np.array_equal(pix2[1], pix[0])
+    cam = capi.make_camera(1, (-25., 25., -25., 25.), (32, 32, 100), 0.0, 0.5, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "SPHACC", em, [FREQ_SPHACC], "formal", nvals=4, nextra=19)
+    assert np.array_equal(status, g["sphacc_npts"])
+    check(pix[0], g["sphacc_vals"], 2e-5)
+
+
 def test_library_refuses_unsupported(dev):
     from grtrans_amd import capi
     cam = capi.make_camera(1, (-40., 20., -20., 40.), (8, 8, 50), 0.998, 0.906, 0.01, -0.5)
@@ -258,3 +292,31 @@ def test_fortran_host_exe_and_harness_end_to_end(tmp_path, monkeypatch):
     y.calc_spec_pgrtrans(1)
     x.calc_spec(1)
     assert np.allclose(y.spec[:, 0], x.spec[:, 0], rtol=1e-6)
+
+
+def test_fortran_host_sphacc_extra_end_to_end(tmp_path, monkeypatch):
+    # ./grtrans with fname=SPHACC, ename=POLSYNCHTH, extra=1: 4 Stokes + 19 diagnostics per pixel in the output file,
+    # identical through the Fortran host and the Python harness, and equal to the reference-driver golden
+    import subprocess
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "extra_32x32x100.npz"))
+    kw = dict(fname='SPHACC', nfreq=1, nmu=1, fmin=FREQ_SPHACC, fmax=FREQ_SPHACC, ename='POLSYNCHTH', nvals=4, spin=0., mbh=10.,
+              standard=1, nn=[32, 32, 100], uout=0.04, mumin=.5, mumax=.5, gridvals=[-25, 25, -25, 25], iname='formal',
+              cflag=0, extra=1)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (1024, 23, 1)
+    ref = np.nan_to_num(g["sphacc_vals"].astype(float))
+    got = np.nan_to_num(x.ivals[:, :, 0].astype(float))
+    err = np.abs(got - ref).max(axis=0) / (np.abs(ref).max(axis=0) + 1e-300)
+    assert err.max() < 1e-4, err
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert y.ivals.shape == (23, 1024, 1)
+    assert np.array_equal(np.nan_to_num(y.ivals[:, :, 0].T).astype(np.float32), np.nan_to_num(x.ivals[:, :, 0]).astype(np.float32))

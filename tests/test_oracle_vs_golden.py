@@ -201,3 +201,21 @@ def test_nvals1_quadrature():
             assert pix.shape == (1, 1024, 1) and np.array_equal(npts, g[key + "_npts"])
             ref = g[key + "_ivals"].astype(float)
             assert np.abs(pix - ref).max() / np.abs(ref).max() < 1e-6
+
+
+def extra_err(vals, ref):
+    """extra=1 rows: per-column max error relative to the column's largest magnitude; NaNs must coincide."""
+    a = np.asarray(vals, float); b = np.asarray(ref, float)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    a = np.nan_to_num(a); b = np.nan_to_num(b)
+    return (np.abs(a - b).max(axis=0) / (np.abs(b).max(axis=0) + 1e-300)).max()
+
+
+def test_extra_ray_diagnostics():
+    # extra=1 (SURVEY 8f rank 1): 19 diagnostics per ray next to the Stokes values
+    g = load("extra_32x32x100.npz")
+    for key, kw, fr in (("ffjet", {}, 3.45e11), ("sphacc", SPHACC, 2.41e11)):
+        o = O.Oracle(nn=(32, 32, 100), iname="formal", **kw)
+        vals, npts = o.trace_extra(1, 1024, fr, nthreads=8)
+        assert vals.shape == (1024, 23) and np.array_equal(npts, g[key + "_npts"])
+        assert extra_err(vals, g[key + "_vals"]) < 1e-6

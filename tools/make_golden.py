@@ -182,6 +182,16 @@ def nvals1():
     np.savez_compressed(os.path.join(G, "nvals1_32x32x100.npz"), **out)
 
 
+def extra():
+    # extra=1: Stokes + the 19 ray diagnostics (grtrans_driver.f90:230-292) through oracle/ref_driver.f90:trace_pixel_extra
+    out = {}
+    r = R.Ref(nn=(32, 32, 100), iname="formal", **FFJET)
+    out["ffjet_vals"], out["ffjet_npts"] = r.trace_extra(1, 1024, FREQ, nthreads=8)
+    r = R.Ref(nn=(32, 32, 100), iname="formal", **SPHACC)
+    out["sphacc_vals"], out["sphacc_npts"] = r.trace_extra(1, 1024, FREQ_SPHACC, nthreads=1)
+    np.savez_compressed(os.path.join(G, "extra_32x32x100.npz"), **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -194,4 +204,5 @@ if __name__ == "__main__":
     sphacc(64, 200)
     harm(48, 200)
     nvals1()
+    extra()
     print("golden fixtures written to", os.path.abspath(G))
