@@ -320,3 +320,34 @@ def test_fortran_host_sphacc_extra_end_to_end(tmp_path, monkeypatch):
     y.run_pgrtrans(**kw)
     assert y.ivals.shape == (23, 1024, 1)
     assert np.array_equal(np.nan_to_num(y.ivals[:, :, 0].T).astype(np.float32), np.nan_to_num(x.ivals[:, :, 0]).astype(np.float32))
+
+
+def test_edge_cases_single_pixel_dead_tile_small_nup_and_max_nfreq():
+    from grtrans_amd import capi
+    from oracle import orabind
+    dev = capi.Device(0)        # (the harness tests above end with grt_free: bring the context up again)
+    dev.load_ffjet(); dev.load_tables(); dev.load_sphacc()
+    # (a) a one-pixel tile equals that pixel of the full image
+    full, _, sfull, _ = run((32, 32, 100), "formal")
+    one, _, sone, _ = run((32, 32, 100), "formal", 517, 517)
+    assert np.array_equal(one[0, 0], full[0, 516]) and sone[0] == sfull[516]
+    # (b) a tile in which no ray ever enters r < 1/uout (image corner of the SPHACC camera): zero pixels, status 0,
+    #     nothing launched for it (grtrans_driver.f90:452-462)
+    cam = capi.make_camera(1, (-25., 25., -25., 25.), (64, 64, 200), 0.0, 0.5, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+    pix, _, status, st = capi.trace_tile(cam, 1, 4, "SPHACC", em, [FREQ_SPHACC], "formal")
+    assert not pix.any() and not status.any() and st.ray_steps == 0 and st.rays_dead == 4
+    # (c) short rays: nup=10 (kext=1, next=2, 10 stored points for turning rays) against the oracle
+    nn = (16, 16, 10)
+    o = orabind.Oracle(nn=nn, iname="delo")
+    ref, rn, _ = o.trace(1, 256, [FREQ], nthreads=0)
+    pix, _, status, _ = run(nn, "delo")
+    assert np.array_equal(status, rn) and stokes_err(pix, ref) < STOKES_TOL
+    # (d) the ABI's frequency limit (32) and one past it
+    freqs = list(2.41e10 * np.exp(np.arange(32) * np.log(6.31e14 / 2.41e10) / 31))
+    multi, _, _, _ = run((12, 12, 60), "formal", freqs=freqs)
+    single, _, _, _ = run((12, 12, 60), "formal", freqs=[freqs[17]])
+    assert multi.shape == (32, 144, 4) and np.array_equal(multi[17], single[0])
+    with pytest.raises(capi.GrtError):
+        run((12, 12, 60), "formal", freqs=freqs + [1e15])
+    dev.close()
