@@ -16,13 +16,13 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
                                        int *ray_npts, int *live, int *counters, void *rrays);
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
-                                     const int *live, int nlive, double *steps, unsigned char *flags,
+                                     const int *live, int nlive, double *steps, unsigned long long *flags,
                                      long long ray_stride, long long field_stride, int nfields);
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
-                                          const unsigned char *flags, long long ray_stride, long long field_stride,
+                                          const unsigned long long *flags, long long ray_stride, long long field_stride,
                                           int nfields, unsigned long long *step_counter);
 
 namespace {
@@ -52,7 +52,8 @@ struct Ctx {
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
-  unsigned char *d_flags = nullptr;
+  unsigned long long *d_flags = nullptr;
+  long long steps_stride = 0;
   size_t cap_flags = 0;
   int steps_fields = 0;
   hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -315,11 +316,12 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   // per-step record in HBM: [field][ray][maxpts] fp64, fields r,theta,lambda always (they carry the
   // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
   const long long maxpts = cam->nup + cam->next;
+  const long long rstride = (maxpts + 63) / 64 * 64;      // internal ray stride: 512-byte aligned chunk rows
   const int nfields = C.record_steps ? 8 : (nextra ? 4 : 3);   // extra=1 weights by phi as well
-  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nfields * nrays * maxpts))) return rc;
-  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * maxpts))) return rc;
-  C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields;
-  const long long fstride = (long long)nrays * maxpts;
+  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nfields * nrays * rstride))) return rc;
+  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * (rstride / 64) * 2))) return rc;
+  C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride;
+  const long long fstride = (long long)nrays * rstride;
   GrtPLConst plc{};
   grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
   double hfreq[64];
@@ -337,16 +339,16 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const int nlive = ncls[0] + ncls[1];
   HIPCHK(hipEventRecord(C.ev[1], C.stream));
   // class 0 (four real roots, fast path) sits at the front of live[], class 1 (generic) at the back
-  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, maxpts, fstride, nfields));
+  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields));
   HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
-                        maxpts, fstride, nfields));
+                        rstride, fstride, nfields));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
   HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
-                             C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, maxpts,
+                             C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, rstride,
                              fstride, nfields, C.d_stepcount));
   HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
-                             C.d_flags, maxpts, fstride, nfields, C.d_stepcount));
+                             C.d_flags, rstride, fstride, nfields, C.d_stepcount));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
   if (st) {
@@ -425,8 +427,9 @@ int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
   if (ray0 < 0 || ray0 + nrays > C.steps_rays || maxpts != C.steps_maxpts) return GRT_E_BADARG;
   static const int src[8] = {0, 1, 3, 2, 4, 5, 6, 7};   // public r,theta,phi,lambda,I,Q,U,V <- internal order
   for (int f = 0; f < 8; ++f)
-    HIPCHK(hipMemcpy(out + (size_t)f * nrays * maxpts, C.d_steps + ((size_t)src[f] * C.steps_rays + ray0) * maxpts,
-                     (size_t)nrays * maxpts * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(out + (size_t)f * nrays * maxpts, (size_t)maxpts * sizeof(double),
+                       C.d_steps + ((size_t)src[f] * C.steps_rays + ray0) * C.steps_stride, (size_t)C.steps_stride * sizeof(double),
+                       (size_t)maxpts * sizeof(double), (size_t)nrays, hipMemcpyDeviceToHost));
   return 0;
 }
 

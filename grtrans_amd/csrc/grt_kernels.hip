@@ -11,8 +11,8 @@
 //                      wave-uniform (scalar loads), so the root-case and segment branches of geokerr
 //                      are wave-uniform instead of divergent.  Each lane evaluates its point of the
 //                      geodesic and writes (r, theta, phi, lambda) of the per-step SoA record, lanes =
-//                      consecutive points -> 512-byte coalesced rows, plus one byte of turning-point
-//                      parities.
+//                      consecutive points -> 512-byte aligned coalesced rows, plus two 64-bit lane masks of
+//                      turning-point parities per chunk.
 //   grt_transfer_kernel : one LANE per live ray, points walked far end -> camera.  Reads (r, theta, lambda)
 //                      back through LDS tiles (8 steps x 64 rays), samples the fluid, builds the comoving
 //                      tetrad and the synchrotron coefficients and applies the transfer step
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
 template <bool FAST, bool PHI>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const RealRay *__restrict__ rrays, const int *__restrict__ live,
-    int nlive, double *__restrict__ steps, unsigned char *__restrict__ flags, long long ray_stride,
+    int nlive, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
     long long field_stride, int nfields) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
@@ -94,13 +94,15 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const GrtRay *Rp = rays + rayidx;
   const RealRay *Kp = rrays + (FAST ? rayidx : 0);
   const int n = Rp->npts;
-  double LamN = 0.0;
-  for (int base = n; base >= 1; base -= 64) {
+  const int nchunk = (int)(ray_stride >> 6);      // ray_stride is a multiple of 64 points: every chunk row is a
+  double LamN = 0.0;                              // 512-byte aligned, fully used run of four 128-byte lines
+  // chunk c holds stored points 64c+1 .. 64c+64; the top (partial) chunk first: it owns Lambda(npts)
+  for (int c = (n - 1) >> 6; c >= 0; --c) {
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
     asm volatile("" : "+s"(Rp), "+s"(Kp));
-    const int idx = base - lane;
-    const bool valid = idx >= 1;
+    const int idx = 64 * c + lane + 1;
+    const bool valid = idx <= n;
     GeoPoint P;
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
     if (valid) {
@@ -108,14 +110,19 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       else if (FAST) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
       else ray_point(cam, *Rp, idx, P);
     }
-    if (base == n) LamN = __shfl(P.lam, 0);
+    if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
     if (valid) {   // geodesics.f90:333-347
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
       sp[GRT_F_R * field_stride] = 1.0 / P.u;
       sp[GRT_F_TH * field_stride] = acos(P.mu);
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
       if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = cam.phi0 - P.dphi;
-      flags[(long long)rayidx * ray_stride + (idx - 1)] = (unsigned char)((P.tpm & 1) | ((P.tpr & 1) << 1));
+    }
+    // turning-point parities of the chunk as two 64-bit lane masks (tpm, tpr): 0.25 bit-pairs per byte instead of a byte per point
+    const unsigned long long mm = __ballot(valid && (P.tpm & 1)), mr = __ballot(valid && (P.tpr & 1));
+    if (lane == 0) {
+      unsigned long long *fp = flags + ((long long)rayidx * nchunk + c) * 2;
+      fp[0] = mm; fp[1] = mr;
     }
   }
 }
@@ -139,12 +146,11 @@ template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
 __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
-    int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned char *__restrict__ flags,
+    int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned long long *__restrict__ flags,
     long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
   constexpr int NW = GRT_XFER_THREADS / 64;
   const double *lfreqs = freqs + nfreq;      // log(freqs), appended by the host
   __shared__ double s_tile[NW][4][64 * GRT_TS];
-  __shared__ unsigned char s_fl[NW][64 * 8];
   __shared__ int s_ray[NW][64];
   __shared__ int s_n[NW][64];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
@@ -206,34 +212,45 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
   }
   double sumr = 0.0, lam_prev = 0.0;
   double *tl0 = s_tile[wave][0], *tl1 = s_tile[wave][1], *tl2 = s_tile[wave][2], *tl3 = s_tile[wave][3];
-  unsigned char *tfl = s_fl[wave];
+  // the ray is walked in tiles of 8 points aligned to 8 (64-byte segments that never straddle a 128-byte line);
+  // tile m holds 0-based points 8m..8m+7, the top tile mt may be partial
+  const int mt = (n - 1) >> 3;
+  const int nchunk = (int)(ray_stride >> 6);
+  unsigned long long fmm = 0ull, fmr = 0ull;     // parity masks of the current 64-point chunk
 
-  for (int t0 = 0; t0 < nmax; t0 += 8) {
+  const int ntile = ((nmax - 1) >> 3) + 1;
+  for (int t = 0; t < ntile; ++t) {
     // ---- stage the next 8 points of each of the wave's 64 rays: lane -> (ray i*8 + lane/8, element lane%8)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rs = i * 8 + (lane >> 3), e = lane & 7;
-      const int idxm = s_n[wave][rs] - t0 - 8 + e;        // 0-based stored-point index
-      if (idxm >= 0) {
+      const int nr = s_n[wave][rs];
+      const int idxm = (((nr - 1) >> 3) - t) * 8 + e;     // 0-based stored-point index
+      if (idxm >= 0 && idxm < nr) {
         const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
         tl0[rs * GRT_TS + e] = steps[GRT_F_R * field_stride + b];
         tl1[rs * GRT_TS + e] = steps[GRT_F_TH * field_stride + b];
         tl2[rs * GRT_TS + e] = steps[GRT_F_LAM * field_stride + b];
         if (EXTRA) tl3[rs * GRT_TS + e] = steps[GRT_F_PHI * field_stride + b];
-        tfl[rs * 8 + e] = flags[b];
       }
     }
     __builtin_amdgcn_wave_barrier();
+    const int m = mt - t;                                  // this lane's tile (negative: ray already finished)
 #pragma clang loop unroll(disable)
     for (int jj = 0; jj < 8; ++jj) {
-      const int k = n - t0 - jj;                           // 1-based stored point of this lane's ray
-      const bool valid = k >= 1;
       const int e = 7 - jj;
+      const int ip = 8 * m + e;                            // 0-based stored point of this lane's ray
+      const bool valid = has_ray && m >= 0 && ip < n;
+      const int k = ip + 1;
+      if (valid && ((ip & 63) == 63 || ip == n - 1)) {     // entering a new 64-point chunk (walking downwards)
+        const unsigned long long *fp = flags + ((long long)rayidx * nchunk + (ip >> 6)) * 2;
+        fmm = fp[0]; fmr = fp[1];
+      }
       const double r = valid ? tl0[lane * GRT_TS + e] : 10.0;    // idle lanes (shorter rays) keep benign inputs
       const double th = valid ? tl1[lane * GRT_TS + e] : 1.0;
       const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
-      const int fl8 = tfl[lane * 8 + e];
+      const int fl8 = (int)((fmm >> (ip & 63)) & 1ull) | ((int)((fmr >> (ip & 63)) & 1ull) << 1);
       const double phi_i = EXTRA ? tl3[lane * GRT_TS + e] : 0.0;
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);
@@ -365,8 +382,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rs = i * 8 + (lane >> 3), e = lane & 7;
-        const int idxm = s_n[wave][rs] - t0 - 8 + e;
-        if (idxm >= 0) {
+        const int nr = s_n[wave][rs];
+        const int idxm = (((nr - 1) >> 3) - t) * 8 + e;
+        if (idxm >= 0 && idxm < nr) {
           const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
           steps[(GRT_F_I + 0) * field_stride + b] = tl0[rs * GRT_TS + e];
           steps[(GRT_F_I + 1) * field_stride + b] = tl1[rs * GRT_TS + e];
@@ -428,7 +446,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 }
 
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
-                                     const int *live, int nlive, double *steps, unsigned char *flags,
+                                     const int *live, int nlive, double *steps, unsigned long long *flags,
                                      long long ray_stride, long long field_stride, int nfields) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
@@ -448,7 +466,7 @@ template <int IFLAG, int FLUID, int EMIS>
 static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
-                              double *steps, const unsigned char *flags, long long ray_stride, long long field_stride,
+                              double *steps, const unsigned long long *flags, long long ray_stride, long long field_stride,
                               int nfields, unsigned long long *step_counter) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
@@ -475,7 +493,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
-                                          const unsigned char *flags, long long ray_stride, long long field_stride,
+                                          const unsigned long long *flags, long long ray_stride, long long field_stride,
                                           int nfields, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
