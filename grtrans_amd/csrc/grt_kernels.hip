@@ -20,7 +20,7 @@
 // Splitting the two keeps each kernel's live state small (the fused version needed 512 registers per
 // lane plus scratch); the 24 B/step that cross HBM between them are part of the record anyway.
 #include <hip/hip_runtime.h>
-#include "grt_dev_fast.hpp"
+#include "grt_dev_cubic.hpp"
 
 using namespace grtd;
 
@@ -32,11 +32,12 @@ using namespace grtd;
 #define GRT_WPE_XFER 2
 #endif
 #define GRT_MAXF 32
+#define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
 #define GRT_INT_QUAD 4    // internal: nvals=1 quadrature (radtrans_integrate.f90:878-882), chosen for either iname
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
-                                                         int *__restrict__ counters, RealRay *__restrict__ rrays) {
+                                                         int *__restrict__ counters, char *__restrict__ rrays) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
   GrtRay R;
@@ -51,12 +52,19 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   // class 1: every other root structure (generic path), filled from the back.
   const int lane = threadIdx.x & 63;
   const bool alive = inr && R.npts > 0;
-  const bool fastc = alive && (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12;
+  // fast class: four distinct real roots (a != 0), or the three real roots of a Schwarzschild camera (a == 0)
+  const bool quart = alive && (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool cubic = alive && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
-  if (fastc) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
+  if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
     RealRay K;
     realray_init(cam, R, K);
-    rrays[tid] = K;
+    *reinterpret_cast<RealRay *>(rrays + (size_t)tid * GRT_RR_STRIDE) = K;
+  } else if (cubic) {
+    CubRay K;
+    cubray_init(cam, R, K);
+    *reinterpret_cast<CubRay *>(rrays + (size_t)tid * GRT_RR_STRIDE) = K;
   }
   {
     unsigned long long mask = __ballot(fastc);
@@ -81,9 +89,10 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
 #define GRT_F_PHI 3
 #define GRT_F_I 4
 
-template <bool FAST, bool PHI>
+// FAST: 0 generic (every root case), 1 four real roots, 2 Schwarzschild cubic
+template <int FAST, bool PHI>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
-    GrtCam cam, const GrtRay *__restrict__ rays, const RealRay *__restrict__ rrays, const int *__restrict__ live,
+    GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     int nlive, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
     long long field_stride, int nfields) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -92,7 +101,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   slot = __builtin_amdgcn_readfirstlane(slot);
   const int rayidx = live[slot];
   const GrtRay *Rp = rays + rayidx;
-  const RealRay *Kp = rrays + (FAST ? rayidx : 0);
+  const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)(FAST ? rayidx : 0) * GRT_RR_STRIDE);
+  const CubRay *Cp = reinterpret_cast<const CubRay *>(Kp);
   const int n = Rp->npts;
   const int nchunk = (int)(ray_stride >> 6);      // ray_stride is a multiple of 64 points: every chunk row is a
   double LamN = 0.0;                              // 512-byte aligned, fully used run of four 128-byte lines
@@ -100,14 +110,15 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   for (int c = (n - 1) >> 6; c >= 0; --c) {
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
-    asm volatile("" : "+s"(Rp), "+s"(Kp));
+    asm volatile("" : "+s"(Rp), "+s"(Kp), "+s"(Cp));
     const int idx = 64 * c + lane + 1;
     const bool valid = idx <= n;
     GeoPoint P;
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
     if (valid) {
-      if (FAST && PHI) ray_point_real<true>(cam, *Rp, *Kp, idx, P);
-      else if (FAST) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
+      if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
+      else if (FAST == 1 && PHI) ray_point_real<true>(cam, *Rp, *Kp, idx, P);
+      else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
       else ray_point(cam, *Rp, idx, P);
     }
     if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
@@ -435,13 +446,13 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
 }
 
 // ---- host-side launch helpers (called from grt_api.cpp) ----
-extern "C" size_t grt_sizeof_realray(void) { return sizeof(RealRay); }
+extern "C" size_t grt_sizeof_realray(void) { return GRT_RR_STRIDE; }
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
                                        int *ray_npts, int *live, int *counters, void *rrays) {
   int blocks = (nrays + 255) / 256;
   hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
-                     (RealRay *)rrays);
+                     (char *)rrays);
   return hipGetLastError();
 }
 
@@ -450,15 +461,14 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
                                      long long ray_stride, long long field_stride, int nfields) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
-  if (fast && nfields > GRT_F_PHI)
-    hipLaunchKernelGGL((grt_geo_kernel<true, true>), g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps, flags,
-                       ray_stride, field_stride, nfields);
-  else if (fast)
-    hipLaunchKernelGGL((grt_geo_kernel<true, false>), g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps,
-                       flags, ray_stride, field_stride, nfields);
-  else
-    hipLaunchKernelGGL((grt_geo_kernel<false, true>), g, b, 0, s, *cam, rays, (const RealRay *)rrays, live, nlive, steps,
-                       flags, ray_stride, field_stride, nfields);
+  const char *rr = (const char *)rrays;
+  const bool phi = nfields > GRT_F_PHI;
+  const int kind = !fast ? 0 : (cam->a == 0.0 ? 2 : 1);
+#define GRT_GEO_CASE(F, P)                                                                                              \
+  if (kind == F && phi == P)                                                                                            \
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive, steps, flags, ray_stride, field_stride, nfields);
+  GRT_GEO_CASE(1, true) GRT_GEO_CASE(1, false) GRT_GEO_CASE(2, true) GRT_GEO_CASE(2, false) GRT_GEO_CASE(0, true) GRT_GEO_CASE(0, false)
+#undef GRT_GEO_CASE
   return hipGetLastError();
 }
 

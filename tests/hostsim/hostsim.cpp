@@ -2,7 +2,7 @@
 // Compiles the product's per-lane device functions (grtrans_amd/csrc/grt_dev_*.hpp) for the HOST
 // with g++ so that the per-ray set-up and per-point evaluation can be compared with the oracle on
 // a machine without a GPU.  Not part of the product: libgrtrans_amd.so has no CPU path.
-#include "grt_dev_fast.hpp"
+#include "grt_dev_cubic.hpp"
 #include "grt_harm_pack.hpp"
 #include "grt_pl_pack.hpp"
 #include <vector>
@@ -61,6 +61,25 @@ int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, dou
     GeoPoint P;
     ray_point_real_branchy<false>(*cam, R, K, idx, P);   // the form the image-only kernel runs
     u[idx - 1] = P.u; mu[idx - 1] = P.mu; lam[idx - 1] = P.lam; tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
+  }
+  return R.npts;
+}
+
+// Schwarzschild cubic fast path; returns -npts when the ray is not in that class
+int hs_ray_points_cubic(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *dt, double *dphi, double *lam,
+                        int *tpm, int *tpr, int *ncase) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  *ncase = R.ncase;
+  const bool cubic = R.npts > 0 && cam->a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+  if (!cubic) return -R.npts;
+  CubRay K;
+  cubray_init(*cam, R, K);
+  for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
+    GeoPoint P;
+    ray_point_cubic<true>(*cam, R, K, idx, P);
+    u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
+    tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
   }
   return R.npts;
 }

@@ -159,3 +159,32 @@ def test_frame_coefficients_and_formal_step_match_oracle(L):
         if d["fac"] > 0:
             want = d["I"][n - 1] / (d["fac"] * 6.67e-8 * 3.4e9 * 1.998e33 / 2.99792458e10 ** 2)
             assert np.abs(I - want).max() <= 1e-9 * np.abs(want).max(), (i, I, want)
+
+
+def test_schwarzschild_cubic_fast_path_matches_sequential_oracle(L):
+    # a = 0 camera (BASELINE config 2): the cubic fast path (one R_F/R_D loop, closed-form polar motion) against the
+    # oracle's literal GEOKERR; integers exact, u/mu/dphi/lambda to 1e-10 of scale
+    spin, mu0, gv, nn, uout = 0.0, 0.5, (-25., 25., -25., 25.), (64, 64, 200), 0.04
+    cam = (C.c_char * L.hs_sizeof_cam())()
+    gva = np.array(gv, dtype=float); nna = np.array(nn, dtype=np.int32)
+    L.hs_make_cam(cam, 1, gva.ctypes.data_as(C.POINTER(C.c_double)), nna.ctypes.data_as(C.POINTER(C.c_int)),
+                  C.c_double(spin), C.c_double(mu0), C.c_double(uout), C.c_double(-0.5))
+    o = O.Oracle(nn=nn, spin=spin, mu0=mu0, gridvals=gv, uout=uout, fname="SPHACC", ename="POLSYNCHTH", mbh=10.0)
+    maxn = nn[2] * 2 + 64
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    ncub = 0
+    for i in range(1, nn[0] * nn[1] + 1, 7):
+        g = o.geokerr_ray(i)
+        d = [np.zeros(maxn) for _ in range(5)]
+        tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
+        n = L.hs_ray_points_cubic(cam, i, maxn, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc))
+        if n <= 0:
+            continue
+        ncub += 1
+        assert n == g["n"] and nc.value == g["ncase"]
+        assert np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"])
+        for k, key in enumerate(("u", "mu", "dt", "dphi", "lam")):
+            if key != "dt":
+                assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, key)
+    assert ncub > 300
