@@ -96,10 +96,19 @@ def main():
     n_gpus = args.gpus
     dist = None
     import torch
+    # test hooks (single-GPU boxes): GRT_BENCH_BACKEND=gloo runs the N>1 code path with CPU collectives,
+    # GRT_BENCH_DEVICE pins every rank to one HIP ordinal.  The driver's runs use neither (nccl = RCCL, one GPU per rank).
+    backend = os.environ.get("GRT_BENCH_BACKEND", "nccl")
+    if "GRT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["GRT_BENCH_DEVICE"])
+    cdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     from grtrans_amd import capi
 
     nx, ny, nup = args.nn
@@ -169,13 +178,15 @@ def main():
         capi.check(capi.lib().grt_copy_resident_pixvals(C.c_void_p(tile.data_ptr()), C.c_int64(tile.numel())),
                    "grt_copy_resident_pixvals")
         torch.cuda.synchronize()
+        if cdev == "cpu":
+            tile = tile.cpu()
         tg = time.perf_counter()
         full = gather_tiles(tile, dist, 0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
             assert full.shape[1] == nx * ny * world
-        tmax = torch.tensor([dt, float(ray_steps), ms_trace], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt, float(ray_steps), ms_trace], dtype=torch.float64, device=cdev)
         tsum = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -193,7 +204,10 @@ def main():
         achieved = BYTES_PER_STEP * (ray_steps / args.steps) / t_kernel / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        # the PMC passes were collected on the default workload only (tools/profile_round.sh)
+        same_as_profiled = (args.workload == "ffjet" and [nx, ny, nup] == [1024, 1024, 400] and args.nfreq == 1
+                            and args.iname == "formal" and not args.no_steps_record)
+        if os.path.exists(tfile) and same_as_profiled:
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
