@@ -455,6 +455,58 @@ GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, do
   e[8] = rhoq; e[9] = rhou; e[10] = rhov;
 }
 
+// polsynchth for the kernel: the same formulas (polsynchemis.f90:700-863) with the shared pieces formed once --
+// one sincos, a cube root instead of two pow(), every x^c as exp(c log x) over two logs, the constant
+// 2^(-1/3) 3^(-23/6) pi 1e4 folded, K_0 and K_1 evaluated once (K_2 = K_0 + 2 theta_e K_1) -- and the per-point
+// seed+Newton division.  Values agree with the literal routine to rounding (tests/test_hostsim_fast.py).
+GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double theta, double *e) {
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
+  const double nucminval = 1.0, thetaemin = 1e-10, s3 = 1.7320508075688772;
+  double sth, cth;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(theta, &sth, &cth);
+#else
+  sth = sin(theta); cth = cos(theta);
+#endif
+  const double thetae = k * T / m / c / c + thetaemin, th2 = thetae * thetae;
+  const double nuc = 3.0 * ec * B * sth / 4.0 / pi / m / c * th2 + nucminval;
+  const double xm = fdiv(nu, nuc);
+  const double x13 = cbrt(xm), x23 = x13 * x13;
+  const double i13 = frcp(x13), i23 = i13 * i13, ixm = i23 * i13;
+  const double ex = exp(-1.8899 * x13);
+  const double iix = 2.5651 * (1.0 + 1.92 * i13 + .9977 * i23) * ex;
+  const double iqx = 2.5651 * (1.0 + .93193 * i13 + .499873 * i23) * ex;
+  const double ivx = (1.81384 * ixm + 3.42319 * i23 + 0.0292545 * frcp(fsqrt(xm)) + 2.03773 * i13) * ex;
+  const double jfac = (ec * ec / c / s3 / 2.0) * n * frcp(th2) * nu;
+  const double ji = jfac * iix, jq = jfac * iqx;
+  const double jv = (4.0 * (ec * ec) / c / 3.0 / s3) * fdiv(cth, sth) * n / 2.0 * frcp(th2 * thetae) * nu * ivx;
+  const double ibn = frcp(bnu(T, nu));
+  const double ai = ji * ibn, aq = jq * ibn, av = jv * ibn;
+  const double wp2 = 4.0 * pi * n * (ec * ec) / m;
+  const double omega0 = ec * B / m / c;
+  const double x = thetae * fsqrt(1.4142135623730951 * sth * (1e3 * omega0 / 2.0 / pi) * frcp(nu));
+  // jffunc, shgmfunc (polsynchemis.f90:799-822)
+  const double lx = log(x), lxe = log(x + 1e-16);
+  const double e472 = exp(-x / 47.2);
+  const double extraterm = (.011 * e472 - 369.69342869090826 * exp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh((lx - 4.787491742782046) / 0.1));
+  const double jff = 2.011 * exp(-exp(1.035 * lx) / 4.7) - cos(x / 2.0) * exp(-exp(1.2 * lx) / 2.73) - .011 * e472 + extraterm;
+  const double w = 2.0 * pi * nu, iw = frcp(w), iw3 = iw * iw * iw;
+  double eps11m22, eps12;
+  if (thetae > 1e-2) {
+    const double it = frcp(thetae);
+    const double k0 = besselk0(it), k1 = besselk1(it), k2 = k0 + 2.0 * thetae * k1, ik2 = frcp(k2);     // besselk(2, 1/thetae)
+    const double shgm = (double)0.43793091f * log(1.0 + (double)0.00185777f * exp((double)1.50316886f * lx));
+    eps11m22 = jff * wp2 * (omega0 * omega0) * (iw3 * iw) * (k1 * ik2 + 6.0 * thetae) * (sth * sth);
+    const double step = 0.5 + 0.5 * tanh((thetae - 1.0) / 0.05);
+    eps12 = wp2 * omega0 * iw3 * (k0 - step * shgm) * ik2 * cth;
+  } else {
+    eps11m22 = jff * wp2 * (omega0 * omega0) * (iw3 * iw) * (1.0 + 6.0 * thetae) * (sth * sth);
+    eps12 = wp2 * omega0 * iw3 * cth;
+  }
+  e[0] = ji; e[1] = jq; e[2] = 0.0; e[3] = jv; e[4] = ai; e[5] = aq; e[6] = 0.0 * ibn; e[7] = av;
+  e[8] = w / 2.0 / c * eps11m22; e[9] = 0.0 * ibn; e[10] = w / c * eps12;
+}
+
 // ------------------------------------------------------------------ integrators
 // calc_O  radtrans_integrate.f90:615   O[i][j] row i col j
 GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]) {

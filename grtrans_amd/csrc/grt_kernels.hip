@@ -294,7 +294,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
           const double nu = freqs[f0 + f] / g;
           double e11[11];
           if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_freq(tb, plc, plp, nu, lfreqs[f0 + f] - lg, e11);
-          else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
           if constexpr (IFLAG == GRT_INT_QUAD) {
             // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
