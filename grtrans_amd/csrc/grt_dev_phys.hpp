@@ -685,7 +685,11 @@ GRT_HD void sphacc_sample(const float *tab, double r, FluidPoint &f) {
   GRT_NO_CONTRACT
   const float gamma = (float)(5.0 / 3.0), alpha = 0.25f, ninf = 1.f, Tinf = (float).917e-9, us = (float).94;
   const float u = (float)(1.0 / r);
-  const float n = (float)((double)(ninf * alpha / 4.f / us) * pow((double)(2 * gamma * Tinf), -1.5) * pow(2.0 * (double)u, 1.5));
+  // ninf*alpha/4./us*(2*gamma*Tinf)**(-1.5d0) is a constant: 0.0664893612 (REAL(4)) * 5917359014296.9004 (glibc pow of the
+  // REAL(4) product); (2u)**1.5d0 = 2u sqrt(2u)
+  const double t2u = 2.0 * (double)u;
+  const float n = (float)(393441421008.81982 * (t2u * sqrt(t2u)));
+  (void)gamma; (void)alpha; (void)ninf; (void)Tinf; (void)us;
   const float T = sphacc_lookup(tab + 2 * GRT_SPHACC_NU, tab + 2 * GRT_SPHACC_NU + GRT_SPHACC_NT, GRT_SPHACC_NT, u);
   const float B = (float)sqrt(8.0 * PH_pi * (double)n * 1.67262158e-24 / 2.0 * PH_c2 * (double)u);
   const float ur = sphacc_lookup(tab, tab + GRT_SPHACC_NU, GRT_SPHACC_NU, u);

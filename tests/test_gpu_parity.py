@@ -351,3 +351,30 @@ def test_edge_cases_single_pixel_dead_tile_small_nup_and_max_nfreq():
     with pytest.raises(capi.GrtError):
         run((12, 12, 60), "formal", freqs=freqs + [1e15])
     dev.close()
+
+
+def test_fortran_host_harm_end_to_end(tmp_path, monkeypatch, harm_dir):
+    # ./grtrans with fname=HARM: the namelist's hdfile/hhfile/hindf reach grt_load_harm_files through the Fortran host;
+    # golden = compiled reference on the same synthetic dump
+    import shutil
+    import subprocess
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "harm_48x48x200.npz"))
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(harm_dir, "dump040"), tmp_path / "dump040")      # relative names, as the reference expects
+    kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375,
+              standard=1, nn=[48, 48, 200], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428,
+              mumax=.6428, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='delo', cflag=0, hdfile='dump',
+              hhfile='dump040', hindf=40, hnt=1)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (48 * 48, 4, 1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_delo"]) < STOKES_TOL
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
