@@ -81,6 +81,17 @@ def test_multi_frequency_matches_single(dev):
         assert np.array_equal(multi[k], single[0])
 
 
+@pytest.mark.parametrize("iname,nf", [("formal", 15), ("delo", 10)])
+def test_frequency_batches_match_single_runs(dev, iname, nf):
+    # more frequencies than one batch of the transfer kernel holds (13 formal / 8 DELO): every camera equals its own run
+    nn = (16, 16, 80)
+    freqs = list(2.41e10 * np.exp(np.arange(nf) * np.log(6.31e14 / 2.41e10) / (nf - 1)))
+    multi, _, _, _ = run(nn, iname, freqs=freqs)
+    for k in (0, 7, 8, nf - 3, nf - 1):
+        single, _, _, _ = run(nn, iname, freqs=[freqs[k]])
+        assert np.array_equal(multi[k], single[0]), k
+
+
 def test_per_step_record_matches_reference_dump(dev):
     from grtrans_amd import capi
     g = np.load(os.path.join(G, "ffjet_rays_32x32x100.npz"))
