@@ -82,6 +82,9 @@ class Device:
         check(lib().grt_load_harm_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin)),
               "grt_load_harm_files")
 
+    def set_thindisk(self, mdot, rin, rout):
+        check(lib().grt_set_thindisk(C.c_double(mdot), C.c_double(rin), C.c_double(rout)), "grt_set_thindisk")
+
     def load_tables(self, path=None):
         path = path or os.path.join(DATA, "polsynchpl_tables.bin")
         check(lib().grt_load_polsynchpl_tables_file(path.encode()), "grt_load_polsynchpl_tables_file")

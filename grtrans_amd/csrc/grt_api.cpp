@@ -25,6 +25,10 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
                                           int nfields, unsigned long long *step_counter);
 
+extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mbh, float mdot, float rin, float rout, long long i1,
+                                      int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
+                                      unsigned long long *step_counter);
+
 namespace {
 
 struct Ctx {
@@ -40,6 +44,8 @@ struct Ctx {
   float *d_harm_cells = nullptr, *d_harm_coords = nullptr;
   GrtHarm harm{};
   bool have_harm = false;
+  float disk_mdot = 0.f, disk_rin = -1.f, disk_rout = 1e8f;
+  bool have_disk = false;
   double *d_tables = nullptr;
   GrtTables tables{};
   double h_tables[2020] = {0};
@@ -224,6 +230,13 @@ int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float 
   return 0;
 }
 
+int grt_set_thindisk(double mdot, double rin, double rout) {
+  if (!C.init) return GRT_E_NOTINIT;
+  C.disk_mdot = (float)mdot; C.disk_rin = (float)rin; C.disk_rout = (float)rout;   // init_thindisk takes REAL(4)
+  C.have_disk = true;
+  return 0;
+}
+
 int grt_upload_polsynchpl_tables(const double *t) {
   if (!C.init) return GRT_E_NOTINIT;
   std::vector<double> h;
@@ -286,6 +299,34 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (!C.init) return GRT_E_NOTINIT;
   if (!cam || !em || !freqs || nfreq < 1 || nfreq > 32 || i2 < i1 || i1 < 1) return GRT_E_BADARG;
   if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
+  if (cam->standard == 2) {
+    // the one standard=2 problem on the device: one point per ray on a thin disk (BASELINE config 1)
+    if (cam->nup != 1 || fluid_model != GRT_FLUID_THINDISK || em->type != GRT_EMIS_BB || nvals != 1 || nextra != 0)
+      return GRT_E_UNSUPPORTED;
+    if (!C.have_disk) return GRT_E_NOFLUID;
+    HIPCHK(hipSetDevice(C.device));
+    const int nrays = (int)(i2 - i1 + 1);
+    int rc;
+    if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
+    if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq))) return rc;
+    if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;
+    HIPCHK(hipMemcpyAsync(C.d_freqs, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
+    HIPCHK(hipEventRecord(C.ev[1], C.stream));
+    HIPCHK(grt_launch_disk(C.stream, cam, (float)em->mbh, C.disk_mdot, C.disk_rin, C.disk_rout, (long long)i1, nrays, nfreq,
+                           C.d_freqs, C.d_pixvals, C.d_npts, C.d_stepcount));
+    HIPCHK(hipEventRecord(C.ev[2], C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    if (st) {
+      unsigned long long steps_done = 0;
+      HIPCHK(hipMemcpy(&steps_done, C.d_stepcount, sizeof(steps_done), hipMemcpyDeviceToHost));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, C.ev[1], C.ev[2]));
+      st->ray_steps = (int64_t)steps_done; st->rays_live = (int64_t)steps_done; st->rays_dead = nrays - (int64_t)steps_done;
+      st->ms_trace = ms; st->ms_geo = ms; st->ms_transfer = 0.0;
+    }
+    return 0;
+  }
   // (fluid, emissivity) pairs that have a kernel; everything else is refused, never emulated
   const bool pair_ok = (fluid_model == GRT_FLUID_FFJET && em->type == GRT_EMIS_POLSYNCHPL) ||
                        (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH) ||

@@ -21,6 +21,7 @@
 // lane plus scratch); the 24 B/step that cross HBM between them are part of the record anyway.
 #include <hip/hip_runtime.h>
 #include "grt_dev_cubic.hpp"
+#include "grt_dev_disk.hpp"
 
 using namespace grtd;
 
@@ -443,6 +444,27 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
     if (sumr < 0.0) ray_status[rayidx] = -n;
     atomicAdd(step_counter, (unsigned long long)n);
   }
+}
+
+// standard=2 / nup=1 / THINDISK / BB: one lane per pixel, one point per ray (grt_dev_disk.hpp)
+__global__ __launch_bounds__(256) void grt_disk_kernel(GrtCam cam, GrtDisk disk, long long i1, int nrays, int nfreq,
+                                                       const double *__restrict__ freqs, float *__restrict__ pixvals,
+                                                       int *__restrict__ ray_status, unsigned long long *__restrict__ step_counter) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= nrays) return;
+  const int st = disk_pixel(cam, disk, (int)(i1 + tid), nfreq, freqs, pixvals + tid, nrays);
+  ray_status[tid] = st;
+  if (st > 0) atomicAdd(step_counter, 1ull);
+}
+
+extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mbh, float mdot, float rin, float rout, long long i1,
+                                      int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
+                                      unsigned long long *step_counter) {
+  GrtDisk d;
+  d.mbh = mbh; d.mdot = mdot; d.rin = rin; d.rout = rout;
+  hipLaunchKernelGGL(grt_disk_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, d, i1, nrays, nfreq, freqs, pixvals,
+                     ray_status, step_counter);
+  return hipGetLastError();
 }
 
 // ---- host-side launch helpers (called from grt_api.cpp) ----

@@ -138,6 +138,8 @@ class grtrans:
                 dev.load_ffjet(path)
             elif inp.fname == 'SPHACC':
                 dev.load_sphacc()
+            elif inp.fname == 'THINDISK':
+                dev.set_thindisk(float(inp.tmdot), float(inp.srin), float(inp.srout))   # fmdot, frin, frout of the namelist
             elif inp.fname == 'HARM':
                 if int(inp.fnt) != 1:
                     raise capi.GrtError("HARM with hnt > 1 (time-dependent) is not on the device yet")

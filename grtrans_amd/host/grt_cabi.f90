@@ -53,6 +53,11 @@ module grt_cabi
        real(c_double), value :: spin
        integer(c_int) :: rc
      end function grt_load_harm_files
+     function grt_set_thindisk(mdot, rin, rout) bind(C, name='grt_set_thindisk') result(rc)
+       import :: c_int, c_double
+       real(c_double), value :: mdot, rin, rout
+       integer(c_int) :: rc
+     end function grt_set_thindisk
      function grt_load_sphacc_tables_file(path) bind(C, name='grt_load_sphacc_tables_file') result(rc)
        import :: c_int, c_char
        character(kind=c_char), dimension(*), intent(in) :: path

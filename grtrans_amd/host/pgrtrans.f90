@@ -90,18 +90,22 @@ contains
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
     case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC
     case ('HARM'); fluid_id = GRT_FLUID_HARM
+    case ('THINDISK'); fluid_id = GRT_FLUID_THINDISK
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
     select case (trim(ename))
     case ('POLSYNCHPL'); emis_id = GRT_EMIS_POLSYNCHPL
     case ('POLSYNCHTH'); emis_id = GRT_EMIS_POLSYNCHTH
+    case ('BB'); emis_id = GRT_EMIS_BB
     case default; call die('emissivity '//trim(ename)//' is not on the device yet')
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37
     case ('delo'); iflag = 1
     case ('formal'); iflag = 2
     case ('lsoda', 'lsodasph')
-       call die('iname='//trim(iname)//': LSODA has no device implementation, use formal or delo')
+       iflag = 0
+       ! one stored point per ray: no integrator runs (grtrans_driver.f90:296-300), so the name is immaterial
+       if (nup /= 1) call die('iname='//trim(iname)//': LSODA has no device implementation, use formal or delo')
     case default; call die('unknown iname '//trim(iname))
     end select
 
@@ -126,6 +130,9 @@ contains
        if (fnt /= 1) call die('HARM with fnt > 1 (time-dependent) is not supported yet')
        rc = grt_load_harm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc)
+    else if (fluid_id == GRT_FLUID_THINDISK) then
+       ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
+       rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) call die_rc('grt_set_thindisk', rc)
     else if (fluid_id == GRT_FLUID_SPHACC) then
        ! the reference holds these tables as DATA statements (fluid_model_sphacc.f90:40-448)
        path = trim(datadir)//'/sphacc_tables.bin'

@@ -91,6 +91,11 @@ int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float 
  * refuses a spin that differs from the dump's by more than 1e-4 as the reference does (:435-438). */
 int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin);
 
+/* replaces init_thindisk(a, ifile, mdot, mbh, rin, rout) (fluid_model_thindisk.f90:31-49, called from
+ * fluid.f90:226-227 with fargs%mdot, %rin, %rout; the mass comes with grt_emis.mbh).  Only the reference's
+ * harm.in.dist problem is on the device for this model: standard=2 camera, nup=1, ename BB, nvals=1. */
+int grt_set_thindisk(double mdot, double rin, double rout);
+
 /* replaces initialize_polsynchpl (polsynchemis.f90:107-525): 2020 doubles,
  * gxvals[181] gyvals[543] xvals[81] yavals[243] ypvals[243] yvvals[243] yapvals[243] yavvals[243] */
 int grt_upload_polsynchpl_tables(const double *tables2020);

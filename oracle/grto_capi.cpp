@@ -23,6 +23,7 @@ struct Setup {
   FFJetTable ffjet;
   SphaccTable sphacc;
   HarmTable harm;
+  ThinDisk disk;
   double mdot = 0, muval = 0;
   PLTables pl;
   bool ok = false;
@@ -56,6 +57,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
     const double *x = &w.g.x[4 * i], *k = &w.g.k[4 * i];
     if (S.fluid == 13) ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 1) sphacc_point(S.sphacc, x[1], w.f[i]);
+    else if (S.fluid == 2) thindisk_point(S.disk, x, (float)S.cam.a, w.f[i]);
     else harm_vals(S.harm, x, (float)S.cam.a, w.f[i]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
@@ -66,10 +68,13 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       w.bcgs[i] = w.f[i].bmag * S.bfac;
     } else if (S.fluid == 1) {              // fluid.f90:1249-1259
       w.ncgs[i] = w.f[i].rho; w.bcgs[i] = w.f[i].bmag; w.tcgs[i] = w.f[i].p;
+    } else if (S.fluid == 2) {              // fluid.f90:1190-1196
+      w.tcgs[i] = w.f[i].rho; w.ncgs[i] = 1.0;
     } else {                                // fluid.f90:957-973
       harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
     if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    else if (S.emis == 8) { for (int c = 0; c < 11; ++c) e[c] = 0.0; e[0] = bnu(w.tcgs[i], nu); }   // bbemis, emis.f90:162-168
     else polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);
     for (int c = 0; c < 4; ++c) w.jraw[4 * i + c] = e[c];
     for (int c = 0; c < 7; ++c) w.Kraw[7 * i + c] = S.coefindx[c] ? e[4 + c] : 0.0;
@@ -186,15 +191,19 @@ void grto_sncndn(double u, double emmc, double *sn, double *cn, double *dn) { sn
 int grto_setup(int standard, double mu0, double phi0, double spin, double uout, const double *gridvals,
                const int *nn, const char *fname, const char *ename, const char *iname, const char *dfile,
                const char *pltab, double mbh, double gmin, double gmax, double p1, double ftscl, double frscl,
-               const int *coefindx, int nvals, const char *hfile, int indf, double mdot, double muval) {
+               const int *coefindx, int nvals, const char *hfile, int indf, double mdot, double muval, double fmdot) {
   S = Setup();
   camera_init(S.cam, standard, gridvals[0], gridvals[1], gridvals[2], gridvals[3], nn[0], nn[1], nn[2], spin, mu0, uout);
   S.phi0 = phi0; S.spin = spin; S.nvals = nvals;
   std::string fn(fname), en(ename), in(iname);
-  if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else if (fn == "HARM") S.fluid = 12; else return -1;
+  if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else if (fn == "HARM") S.fluid = 12;
+  else if (fn == "THINDISK") { S.fluid = 2; S.disk = ThinDisk(); S.disk.mbh = (float)mbh; S.disk.mdot = (float)fmdot; }
+  else return -1;
   S.mdot = mdot; S.muval = muval;
-  if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else return -2;
-  if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2; else return -3;
+  if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8; else return -2;
+  if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2;
+  else if (in == "lsoda" && nn[2] == 1) S.iflag = 0;     // one point per ray: no integrator runs (grtrans_driver.f90:296-300)
+  else return -3;
   S.mbh = mbh; S.nfac = ftscl; S.bfac = frscl; S.gmin = gmin; S.gmax = gmax; S.p1 = p1;
   for (int i = 0; i < 7; ++i) S.coefindx[i] = coefindx[i];
   if (S.fluid == 13 && !ffjet_load(dfile, S.ffjet)) return -4;

@@ -179,6 +179,71 @@ inline void sphacc_point(const SphaccTable &t, double r, FluidPoint &f) {
   f.rho = n; f.p = T; f.bmag = B;
 }
 
+// ------------------------------------------------------------------ THINDISK (Novikov-Thorne disk, REAL(4))
+// thindisk_vals fluid_model_thindisk.f90:51-92 ; calc_rms, krolikc, ledd kerr.f90:94-129 ;
+// get_thindisk_fluidvars fluid.f90:586-620 (the polarisation vector f%b is not needed for nvals=1 / BB: left zero)
+struct ThinDisk { float mbh = 10.f, mdot = 0.1f, rin = -1.f, rout = 1e8f; };
+
+inline float calc_rms_f(float a) {
+  float third = 1.f / 3.f;
+  float z1 = 1.f + std::pow(1.f - a * a, third) * (std::pow(1.f + a, third) + std::pow(1.f - a, third));
+  float z2 = std::sqrt(3.f * a * a + z1 * z1);
+  return 3.f + z2 - std::copysign(std::sqrt((3.f - z1) * (3.f + z1 + 2.f * z2)), a);
+}
+
+inline float krolikc_f(float r, float a) {
+  float pi = std::acos(-1.f);
+  float rms = calc_rms_f(a);
+  float y = std::sqrt(r), yms = std::sqrt(rms);
+  float third = 1.f / 3.f;
+  float y1 = (float)(2.0 * (double)std::cos(third * (std::acos(a) - pi)));
+  float y2 = (float)(2.0 * (double)std::cos(third * (std::acos(a) + pi)));
+  float y3 = (float)(-2.0 * (double)std::cos(third * std::acos(a)));
+  float arg1 = (float)((double)(3.f * a) / (2.0 * (double)y));
+  auto argk = [&](float ya, float yb, float yc) {
+    return (float)((double)3.f * std::pow((double)(ya - a), 2.0) / (double)(y * ya * (ya - yb) * (ya - yc)));
+  };
+  float arg2 = argk(y1, y2, y3), arg3 = argk(y2, y1, y3), arg4 = argk(y3, y1, y2);
+  return 1.f - yms / y - arg1 * std::log(y / yms) - arg2 * std::log((y - y1) / (yms - y1)) -
+         arg3 * std::log((y - y2) / (yms - y2)) - arg4 * std::log((y - y3) / (yms - y3));
+}
+
+inline void thindisk_vals(ThinDisk &d, float r, float th, float a, float &T, float &omega) {
+  const double G = PH_G, c2 = PH_c2, msun = PH_msun, sigb = 5.6704e-5, mp = 1.67262158e-24, c = PH_c, sigt = 6.6523e-25;
+  float lbh = (float)((double)d.mbh * msun * G / c2);
+  float b = 1.f - 3.f / r + 2.f * a / std::pow(r, 3.f / 2.f);
+  float rms = calc_rms_f(a);
+  d.rin = std::max(rms, d.rin);
+  float kc = krolikc_f(r, a);
+  float dd = r * r - 2.f * r + a * a;
+  float lc = (rms * rms - 2.f * a * std::sqrt(rms) + a * a) / (std::pow(rms, 1.5f) - 2.f * std::sqrt(rms) + a);
+  float hc = (2.f * r - a * lc) / dd;
+  float t1 = r * r + a * a, sth = std::sin(th);
+  float ar = std::pow(t1, 2.f) - a * a * dd * std::pow(sth, 2.f);
+  float om = 2.f * a * r / ar;
+  float Mdotedd = (float)(4.0 * PH_pi * G * (double)d.mbh * msun * mp * c / sigt / c2);   // ledd(MBH)/c2 ; 4.*pi: REAL(4) 4. times double pi
+  float T0 = (float)std::pow(3.0 / 8.0 / PH_pi * G * (double)d.mbh * msun * (double)d.mdot * (double)Mdotedd / (double)lbh / (double)lbh /
+                                 (double)lbh / sigb, (double).25f);
+  if (r > rms) omega = std::max(1.f / (std::pow(r, 3.f / 2.f) + a), om);
+  else omega = std::max((lc + a * hc) / (r * r + 2.f * r * (1.f + hc)), om);
+  if (r > d.rin && r < d.rout) T = T0 * std::pow(kc / b / std::pow(r, 3.f), 1.f / 4.f);
+  else T = (float)((double)T0 / 1e5);
+}
+
+inline void thindisk_point(ThinDisk &d, const double *x, float a, FluidPoint &f) {
+  float T, omega;
+  thindisk_vals(d, (float)x[1], (float)x[2], a, T, omega);
+  f.rho = T; f.p = 0.f; f.bmag = 0.f;
+  Metric ms = blmetric_cov_real((float)x[1], (float)x[2], a);
+  for (int i = 0; i < 4; ++i) { f.u[i] = 0.0; f.b[i] = 0.0; }
+  // f%u%data(1)=sqrt(-1./(metric(:,1)+2d0*metric(:,4)*omega+metric(:,10)*omega*omega)): REAL(4) metric and omega,
+  // the 2d0 factor promotes the middle term to double; the result lands in a REAL(8) component
+  float g1 = (float)ms.g[0], g4 = (float)ms.g[3], g10 = (float)ms.g[9];
+  double den = (double)g1 + 2.0 * (double)g4 * (double)omega + (double)(g10 * omega * omega);
+  f.u[0] = std::sqrt(-1.0 / den);
+  f.u[3] = (double)omega * f.u[0];
+}
+
 // ------------------------------------------------------------------ emissivity
 struct PLTables {   // polsynchemis.f90:107-525 (values dumped from the compiled reference)
   std::vector<double> gx, gy, xv, ya, yp, yv, yap, yav;

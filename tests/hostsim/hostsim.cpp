@@ -3,6 +3,7 @@
 // with g++ so that the per-ray set-up and per-point evaluation can be compared with the oracle on
 // a machine without a GPU.  Not part of the product: libgrtrans_amd.so has no CPU path.
 #include "grt_dev_cubic.hpp"
+#include "grt_dev_disk.hpp"
 #include "grt_harm_pack.hpp"
 #include "grt_pl_pack.hpp"
 #include <vector>
@@ -24,6 +25,7 @@ void hs_make_cam(GrtCam *cam, int standard, const double *gridvals, const int *n
   cam->a = a;
   cam->phi0 = (double)(acosf(-1.f)) * phi0;
   cam->usegeor = 0; cam->phit = 1;
+  if (standard == 2) { cam->usegeor = 1; if (cam->nup == 1) cam->offset = 0.0; return; }   // geodesics.f90:93-99, geokerr_wrapper.f:225
   if (cam->nup > 1) { cam->mufill = 1; cam->kext = (int)ceil(3.0 * cam->nup / 400.0); cam->next = (int)ceil(60.0 * cam->nup / 400.0); }
 }
 
@@ -149,5 +151,11 @@ void hs_formal_step(const double *j4, const double *K7, double dx, const double 
   Affine M;
   formal_map(j4, K7, dx, M);
   for (int i = 0; i < 4; ++i) Iout[i] = M.A[i][0] * Iin[0] + M.A[i][1] * Iin[1] + M.A[i][2] * Iin[2] + M.A[i][3] * Iin[3] + M.b[i];
+}
+
+// standard=2 / nup=1 thin-disk pixel (BASELINE config 1)
+int hs_disk_pixel(const GrtCam *cam, float mbh, float mdot, float rin, float rout, int ii, double freq, float *pix) {
+  GrtDisk d; d.mbh = mbh; d.mdot = mdot; d.rin = rin; d.rout = rout;
+  return disk_pixel(*cam, d, ii, 1, &freq, pix, 1);
 }
 }

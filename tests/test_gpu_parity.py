@@ -266,6 +266,26 @@ def test_extra_ray_diagnostics_vs_reference(dev):
     check(pix[0], g["sphacc_vals"], 2e-5)
 
 
+def test_thindisk_bb_config1_vs_reference_golden(dev):
+    # BASELINE config 1 (harm.in.dist): standard=2 camera, one point per ray on a Novikov-Thorne disk, blackbody, nvals=1
+    from grtrans_amd import capi
+    g = np.load(os.path.join(G, "thindisk_100x100x1.npz"))
+    dev.set_thindisk(0.1, -1.0, 1e8)
+    em = capi.make_emis("BB", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+    for mu0 in (0.1, 0.7):
+        cam = capi.make_camera(2, (-25., 25., -25., 25.), (100, 100, 1), 0.998, mu0, 1e-4, -0.5)
+        pix, _, status, st = capi.trace_tile(cam, 1, 10000, "THINDISK", em, [1e17], "lsoda", nvals=1)
+        tag = "mu%02d" % int(mu0 * 10)
+        assert np.array_equal(status, g["npts_" + tag])
+        ref = g["ivals_" + tag].astype(float)
+        assert np.abs(pix[0] - ref).max() / ref.max() < STOKES_TOL
+        assert st.ray_steps == int((status > 0).sum())
+    # anything else with standard=2 is refused
+    cam = capi.make_camera(2, (-25., 25., -25., 25.), (10, 10, 50), 0.998, 0.5, 1e-4, -0.5)
+    with pytest.raises(capi.GrtError):
+        capi.trace_tile(cam, 1, 100, "THINDISK", em, [1e17], "formal", nvals=1)
+
+
 def test_library_refuses_unsupported(dev):
     from grtrans_amd import capi
     cam = capi.make_camera(1, (-40., 20., -20., 40.), (8, 8, 50), 0.998, 0.906, 0.01, -0.5)
@@ -389,3 +409,30 @@ def test_fortran_host_harm_end_to_end(tmp_path, monkeypatch, harm_dir):
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
+
+
+def test_fortran_host_config1_thindisk_ten_inclinations(tmp_path, monkeypatch):
+    # the reference's harm.in.dist (BASELINE config 1) through ./grtrans: ten cameras (nmu=10, mu0 = 0.1..1.0), one per
+    # inclination, THINDISK + BB, standard=2, nn=[100,100,1], iname='lsoda' (no integrator runs for one point per ray)
+    import subprocess
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "thindisk_100x100x1.npz"))
+    kw = dict(standard=2, spin=0.998, mumin=0.1, mumax=1.0, nmu=10, gridvals=[-25., 25., -25., 25.], nn=[100, 100, 1],
+              fname='THINDISK', ename='BB', nfreq=1, fmin=1e17, fmax=1e17, mbh=10., tmdot=0.1, nvals=1, iname='lsoda',
+              cflag=0, uout=1e-4)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (10000, 1, 10)
+    for cam, tag in ((0, "mu01"), (6, "mu07")):           # mu0 = 0.1 + 0.1*k
+        ref = g["ivals_" + tag].astype(float)
+        assert np.abs(x.ivals[:, :, cam] - ref).max() / ref.max() < STOKES_TOL, tag
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert y.ivals.shape == (1, 10000, 10)
+    assert np.array_equal(y.ivals[0].astype(np.float32), x.ivals[:, 0, :].astype(np.float32))

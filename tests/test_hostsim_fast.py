@@ -188,3 +188,24 @@ def test_schwarzschild_cubic_fast_path_matches_sequential_oracle(L):
             if key != "dt":
                 assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, key)
     assert ncub > 300
+
+
+def test_thindisk_single_point_pixels_match_oracle(L):
+    # BASELINE config 1 (harm.in.dist): standard=2 camera, nup=1, THINDISK + BB, nvals=1; device function compiled for the host
+    kw = dict(standard=2, spin=0.998, uout=1e-4, gridvals=(-25., 25., -25., 25.), nn=(40, 40, 1), fname="THINDISK", ename="BB",
+              nvals=1, iname="lsoda", mbh=10., fmdot=0.1)
+    L.hs_disk_pixel.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_double, C.c_void_p]
+    for mu0 in (0.1, 0.7):
+        o = O.Oracle(mu0=mu0, **kw)
+        ref, rn, _ = o.trace(1, 1600, [1e17], nthreads=8)
+        cam = (C.c_char * L.hs_sizeof_cam())()
+        gva = np.array(kw["gridvals"], dtype=float); nna = np.array(kw["nn"], dtype=np.int32)
+        L.hs_make_cam(cam, 2, gva.ctypes.data_as(C.POINTER(C.c_double)), nna.ctypes.data_as(C.POINTER(C.c_int)),
+                      C.c_double(0.998), C.c_double(mu0), C.c_double(1e-4), C.c_double(-0.5))
+        got = np.zeros(1600, dtype=np.float32); st = np.zeros(1600, dtype=np.int32)
+        for i in range(1600):
+            p = np.zeros(1, dtype=np.float32)
+            st[i] = L.hs_disk_pixel(cam, 10.0, 0.1, -1.0, 1e8, i + 1, 1e17, p.ctypes.data)
+            got[i] = p[0]
+        assert np.array_equal(st, rn)
+        assert np.abs(got - ref[0, :, 0]).max() <= 1e-5 * ref.max()

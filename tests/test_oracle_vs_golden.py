@@ -219,3 +219,18 @@ def test_extra_ray_diagnostics():
         vals, npts = o.trace_extra(1, 1024, fr, nthreads=8)
         assert vals.shape == (1024, 23) and np.array_equal(npts, g[key + "_npts"])
         assert extra_err(vals, g[key + "_vals"]) < 1e-6
+
+
+def test_thindisk_bb_single_point_config1():
+    # BASELINE config 1 (reference's harm.in.dist): standard=2 / usegeor, nup=1, THINDISK + BB, nvals=1.  The disk
+    # temperature is REAL(4) in the reference; the restatement reproduces it to 1 ulp (94 % of pixels bit-equal)
+    g = load("thindisk_100x100x1.npz")
+    kw = dict(standard=2, spin=0.998, uout=1e-4, gridvals=(-25., 25., -25., 25.), nn=(100, 100, 1), fname="THINDISK",
+              ename="BB", nvals=1, iname="lsoda", mbh=10., fmdot=0.1)
+    for mu0 in (0.1, 0.7):
+        o = O.Oracle(mu0=mu0, **kw)
+        pix, npts, _ = o.trace(1, 10000, [1e17], nthreads=8)
+        tag = "mu%02d" % int(mu0 * 10)
+        assert np.array_equal(npts, g["npts_" + tag])          # 1 = hits the plane, -1 = no crossing (status -1)
+        ref = g["ivals_" + tag].astype(float)
+        assert np.abs(pix[0] - ref).max() / ref.max() < 1e-6

@@ -192,6 +192,20 @@ def extra():
     np.savez_compressed(os.path.join(G, "extra_32x32x100.npz"), **out)
 
 
+def thindisk():
+    # BASELINE config 1 = the reference's harm.in.dist problem: standard=2, nn=[100,100,1], THINDISK + BB, nvals=1, fmin=1e17,
+    # mbh=10, fmdot=0.1 (iname is irrelevant: one point per ray, no integrator runs); two of its ten mu0 values
+    out = {}
+    kw = dict(standard=2, spin=0.998, uout=1e-4, gridvals=(-25., 25., -25., 25.), nn=(100, 100, 1), fname="THINDISK",
+              ename="BB", nvals=1, iname="lsoda", mbh=10., fmdot=0.1)
+    for mu0 in (0.1, 0.7):
+        r = R.Ref(mu0=mu0, **kw)
+        pix, npts, _ = r.trace(1, 10000, [1e17], nthreads=8)
+        out["ivals_mu%02d" % int(mu0 * 10)] = pix[0]
+        out["npts_mu%02d" % int(mu0 * 10)] = npts
+    np.savez_compressed(os.path.join(G, "thindisk_100x100x1.npz"), **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -205,4 +219,5 @@ if __name__ == "__main__":
     harm(48, 200)
     nvals1()
     extra()
+    thindisk()
     print("golden fixtures written to", os.path.abspath(G))
