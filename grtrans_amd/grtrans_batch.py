@@ -122,14 +122,15 @@ class grtrans:
     def run_pgrtrans(self, device=0, **kwargs):
         """Same kwargs as write_grtrans_inputs; fills ivals(nvals,npix,ncams), ab(2,npix), nu."""
         inp = self.inputs = grtrans_inputs(**kwargs)
-        if inp.nt != 1 or inp.nload != 1:
-            raise capi.GrtError("nt/nload > 1 are not on the device yet")
+        if inp.nload != 1:
+            raise capi.GrtError("slow light (nload > 1) is not on the device yet")
+        nt = int(inp.nt)
         nextra = 19 if int(inp.extra) == 1 else 0           # pgrtrans.f90:108-114 (nup > 1)
         nfreq, nmu, nmdot = int(inp.nfreq), int(inp.nmu), int(inp.nmdot)
         freqs = np.array([inp.fmin]) if nfreq == 1 else inp.fmin * np.exp(np.arange(nfreq) * np.log(inp.fmax / inp.fmin) / (nfreq - 1))
         mu0 = np.array([inp.mumin]) if nmu == 1 else inp.mumin + (inp.mumax - inp.mumin) / (nmu - 1) * np.arange(nmu)
         npix = inp.nn[0] * inp.nn[1]
-        ncams = nmdot * nfreq * nmu
+        ncams = nmdot * nfreq * nmu * nt
         dev = capi.Device(device)
         try:
             dev.load_tables()
@@ -146,18 +147,29 @@ class grtrans:
                 dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
             ivals = np.zeros((inp.nvals + nextra, npix, ncams))
             ab = np.zeros((2, npix))
+            harm_indf, harm_toffset, harm_tstep = int(inp.findf), np.float32(0.), np.float32(20.)
             for j in range(nmu):
                 cam = capi.make_camera(inp.standard, inp.gridvals, inp.nn, inp.spin, float(mu0[j]), inp.uout, inp.phi0)
-                for m in range(nmdot):
-                    mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
-                    em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
-                                        inp.muval, inp.epcoefindx, mdot=float(mdot))
-                    pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
-                                                           nvals=inp.nvals, nextra=nextra)
-                    for k in range(nfreq):
-                        c = (j * nfreq * nmdot) + m * nfreq + k          # grtrans_driver.f90:324
-                        ivals[:, inp.i1 - 1:inp.i2, c] = pix[k].T
-                    ab[:, inp.i1 - 1:inp.i2] = loc.T
+                for l in range(nt):
+                    if l > 0 and inp.fname == 'HARM':
+                        # advance_harm_timestep (fluid_model_harm.f90:511-521): REAL(4) tstep, toffset kept across frames
+                        nupdate = int(np.floor(float(inp.dt) / float(harm_tstep)))
+                        harm_toffset = np.float32(float(harm_toffset) + float(inp.dt) - float(harm_tstep) * nupdate)
+                        nupdate += int(np.floor(harm_toffset / harm_tstep))
+                        harm_toffset = np.float32(harm_toffset - np.float32(np.floor(harm_toffset / harm_tstep)) * harm_tstep)
+                        harm_indf += nupdate
+                        if nupdate > 0:
+                            dev.load_harm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
+                    for m in range(nmdot):
+                        mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
+                        em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
+                                            inp.muval, inp.epcoefindx, mdot=float(mdot))
+                        pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
+                                                               nvals=inp.nvals, nextra=nextra)
+                        for k in range(nfreq):
+                            c = ((j * nt + l) * nfreq * nmdot) + m * nfreq + k      # grtrans_driver.f90:324 with l -> (j-1)*nt+l
+                            ivals[:, inp.i1 - 1:inp.i2, c] = pix[k].T
+                        ab[:, inp.i1 - 1:inp.i2] = loc.T
         finally:
             dev.close()
         self.ivals, self.ab, self.nu = ivals, ab, freqs

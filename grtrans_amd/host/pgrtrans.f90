@@ -13,6 +13,11 @@ module pgrtrans
   real(8), allocatable, dimension(:,:) :: ab
   real(8), allocatable, dimension(:) :: freqs
   real(8) :: last_ray_steps = 0d0, last_kernel_ms = 0d0    ! extra: what the tracer reported
+  ! HARM time-stepping state (module variables of fluid_model_harm.f90:12-16)
+  integer, save :: cur_fluid = 0, harm_indf = 0
+  real, save :: harm_tstep = 20., harm_toffset = 0.
+  real(8), save :: harm_spin = 0d0
+  character(len=256), save :: harm_dfile = ' ', harm_hfile = ' ' 
 
 contains
 
@@ -83,7 +88,7 @@ contains
 
     ! ---- what this build can put on the device; everything else stops loudly (no CPU path) ----
     if (.not. use_geokerr) call die('use_geokerr=F is not supported')
-    if (nt /= 1 .or. nload /= 1) call die('time-dependent runs (nt,nload > 1) are not supported yet')
+    if (nload /= 1) call die('slow light (nload > 1) is not supported yet')
     if (debug /= 0) call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps')
     if (extra == 1 .and. nup <= 1) call die('extra=1 with nup=1 is not supported yet')
     select case (trim(fname))
@@ -93,6 +98,7 @@ contains
     case ('THINDISK'); fluid_id = GRT_FLUID_THINDISK
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
+    cur_fluid = fluid_id
     select case (trim(ename))
     case ('POLSYNCHPL'); emis_id = GRT_EMIS_POLSYNCHPL
     case ('POLSYNCHTH'); emis_id = GRT_EMIS_POLSYNCHTH
@@ -130,6 +136,7 @@ contains
        if (fnt /= 1) call die('HARM with fnt > 1 (time-dependent) is not supported yet')
        rc = grt_load_harm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
     else if (fluid_id == GRT_FLUID_THINDISK) then
        ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
        rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) call die_rc('grt_set_thindisk', rc)
@@ -150,6 +157,7 @@ contains
        if (rc /= 0) call die_rc('grt_make_camera', rc)
        wtime = omp_get_wtime()
        do l = 1, nt
+          if (l > 1) call advance_fluid_timestep(dt)             ! pgrtrans.f90:211 (after frame l-1)
           do m = 1, nmdot
              em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
              em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
@@ -210,6 +218,26 @@ contains
     if (allocated(ab)) deallocate(ab)
     if (allocated(freqs)) deallocate(freqs)
   end subroutine del_pgrtrans_data
+
+  ! advance_fluid_timestep (fluid.f90:246-262) for one loaded slice: only HARM steps (advance_harm_timestep,
+  ! fluid_model_harm.f90:511-521, REAL(4) tstep=20. and toffset kept across calls); the other device models are static
+  subroutine advance_fluid_timestep(dtobs)
+    use grt_cabi
+    real(8), intent(in) :: dtobs
+    integer :: nupdate, rc
+    if (cur_fluid /= GRT_FLUID_HARM) return
+    nupdate = floor(dtobs / harm_tstep)
+    harm_toffset = harm_toffset + dtobs - harm_tstep*nupdate
+    nupdate = nupdate + floor(harm_toffset/harm_tstep)
+    harm_toffset = harm_toffset - floor(harm_toffset/harm_tstep)*harm_tstep
+    harm_indf = harm_indf + nupdate
+    write(6,*) 'advance harm timestep: ', dtobs, harm_tstep, harm_toffset, harm_indf, nupdate
+    ! nupdate = 0 leaves the slice as it is (update_harm_data(0) loads nothing)
+    if (nupdate > 0) then
+       rc = grt_load_harm_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
+       if (rc /= 0) call die_rc('grt_load_harm_files (advance) '//trim(harm_dfile), rc)
+    end if
+  end subroutine advance_fluid_timestep
 
   subroutine die(msg)
     character(len=*), intent(in) :: msg

@@ -108,6 +108,12 @@ contains
     is_setup = .true.
   end subroutine ref_setup
 
+  ! advance_fluid_timestep(fname,dt) between movie frames (pgrtrans.f90:211): for HARM it re-loads dumps
+  subroutine ref_advance_timestep(dt) bind(C, name='ref_advance_timestep')
+    real(c_double), value :: dt
+    call advance_fluid_timestep(fname_s, dt)
+  end subroutine ref_advance_timestep
+
   subroutine ref_teardown() bind(C, name='ref_teardown')
     if (.not. is_setup) return
     call del_geokerr_args(gargs)

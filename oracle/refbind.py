@@ -134,6 +134,15 @@ class Ref:
             out[k] = dump[c, :max(n, 0)].T.copy() if isinstance(c, slice) else dump[c, :max(n, 0)].copy()
         return out
 
+    def advance_timestep(self, dt):
+        """advance_fluid_timestep between movie frames (HARM: re-loads dumps; relative paths -> run in datadir)."""
+        cwd = os.getcwd()
+        os.chdir(self.p.get("datadir", DATA))
+        try:
+            lib().ref_advance_timestep(C.c_double(dt))
+        finally:
+            os.chdir(cwd)
+
     def trace_extra(self, i1, i2, freq, nthreads=0):
         """extra=1: (nvals+19) values per pixel for one frequency (grtrans_driver.f90:230-292)."""
         n = i2 - i1 + 1

@@ -436,3 +436,36 @@ def test_fortran_host_config1_thindisk_ten_inclinations(tmp_path, monkeypatch):
     y.run_pgrtrans(**kw)
     assert y.ivals.shape == (1, 10000, 10)
     assert np.array_equal(y.ivals[0].astype(np.float32), x.ivals[:, 0, :].astype(np.float32))
+
+
+def test_harm_movie_frames_through_both_hosts(tmp_path, monkeypatch):
+    # nt=3, dt=30 with one loaded slice: advance_harm_timestep walks the dump index 40 -> 41 -> 43 (tstep=20, the
+    # left-over 10 M accumulates); golden frames = compiled reference with advance_fluid_timestep between traces
+    import hashlib
+    import subprocess
+    import sys
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "harm_movie_32x32x100.npz"))
+    monkeypatch.chdir(tmp_path)
+    paths = make_golden.write_movie_dumps(str(tmp_path))
+    assert [hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)] == list(g["dump_sha256"])
+    kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375,
+              standard=1, nn=[32, 32, 100], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428,
+              mumax=.6428, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', cflag=0, hdfile='dump',
+              hhfile='dump040', hindf=40, hnt=1, nt=3, dt=30.)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (1024, 4, 3)
+    for l in range(3):
+        assert stokes_err(x.ivals[:, :, l], g["ivals"][l]) < STOKES_TOL, l
+    assert stokes_err(x.ivals[:, :, 1], g["ivals"][0]) > 1e-4          # the frames do differ
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(np.transpose(y.ivals, (1, 0, 2)).astype(np.float32), x.ivals.astype(np.float32))

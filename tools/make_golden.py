@@ -206,6 +206,34 @@ def thindisk():
     np.savez_compressed(os.path.join(G, "thindisk_100x100x1.npz"), **out)
 
 
+MOVIE_SEEDS = {40: 20261002, 41: 20261003, 43: 20261005}
+
+
+def write_movie_dumps(outdir, nzone=64):
+    import make_harm_dump
+    return {k: make_harm_dump.write(outdir, n=nzone, name="dump%03d" % k, seed=s) for k, s in MOVIE_SEEDS.items()}
+
+
+def harm_movie():
+    # nt=3 movie frames, dt=30 with HARM's default tstep=20 (one slice loaded): advance_harm_timestep
+    # (fluid_model_harm.f90:511-521) steps the dump index 40 -> 41 -> 43 (the 10 M left over accumulates)
+    import hashlib
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_movie_dumps(td)
+        out["dump_sha256"] = np.array([hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)])
+        r = R.Ref(nn=(32, 32, 100), iname="formal", datadir=td, **HARM)
+        frames = []
+        for l in range(3):
+            pix, npts, _ = r.trace(1, 1024, [FREQ_HARM], nthreads=8)
+            frames.append(pix[0])
+            if l < 2:
+                r.advance_timestep(30.0)
+        out["ivals"] = np.stack(frames); out["npts"] = npts
+    np.savez_compressed(os.path.join(G, "harm_movie_32x32x100.npz"), freq=FREQ_HARM, dt=30.0, **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -220,4 +248,5 @@ if __name__ == "__main__":
     nvals1()
     extra()
     thindisk()
+    harm_movie()
     print("golden fixtures written to", os.path.abspath(G))
