@@ -373,7 +373,11 @@ GRT_HD void geomu(double &u0, double &uf, double mu0, double &muf, double a, dou
 GRT_HD void geophitime(double u0, double uf, double mu0, double muf, double a, double l, double l2,
                        double q2, int tpm, int tpr, double su, double sm, double iu, GKCache &c,
                        double &phimu, double &tmu, double &phiu, double &tu, double &lambda,
-                       bool firstpt) {
+                       bool firstpt, int want = 3) {
+  // want: bit 0 = coordinate time, bit 1 = azimuth.  The per-point callers of the complex-root cases (5, 6) drop
+  // the integrals that feed only an output nobody reads (t is never stored; phi only with the per-step record);
+  // first-point calls keep everything (they fill the caches).
+  const bool want_t = (want & 1) != 0, want_phi = (want & 2) != 0;
   const double one = 1.0, two = 2.0;
   const double pi = acos(-one);
   int p[5] = {-1, -1, -1, 0, 0};
@@ -548,9 +552,11 @@ GRT_HD void geophitime(double u0, double uf, double mu0, double muf, double a, d
       p[4] = -4;
       tu1 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, 0.0, one, f, g, h, c.rffu0, lo, hi);
       p[4] = -2;
-      tu2 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, 0.0, one, f, g, h, c.rffu0, lo, hi);
-      tu3 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, one, -one / uplus, f, g, h, c.rffu0, lo, hi);
-      tu4 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, one, -umi, f, g, h, c.rffu0, lo, hi);
+      if (want_t) tu2 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, 0.0, one, f, g, h, c.rffu0, lo, hi);
+      if (want_t || want_phi) {
+        tu3 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, one, -one / uplus, f, g, h, c.rffu0, lo, hi);
+        tu4 = sg * ellquarticcomplex(p, -c.u1, one, c.u4 * qs, -one * qs, one, -umi, f, g, h, c.rffu0, lo, hi);
+      }
       tu = su * ur / sqrt(-qs * ee) * (cA * tu1 + cB * tu2 - cC * tu3 + cD * tu4);
       lambdau = su * tu1 / sqrt(fabs(ee));
       phiu0 = -tu3; phiu1 = -tu4;
@@ -569,9 +575,11 @@ GRT_HD void geophitime(double u0, double uf, double mu0, double muf, double a, d
       p[4] = -4;
       tu1 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, 0.0, one, c.rffu0, lo, hi);
       p[4] = -2;
-      tu2 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, 0.0, one, c.rffu0, lo, hi);
-      tu3 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, one, -one / uplus, c.rffu0, lo, hi);
-      tu4 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, one, -umi, c.rffu0, lo, hi);
+      if (want_t) tu2 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, 0.0, one, c.rffu0, lo, hi);
+      if (want_t || want_phi) {
+        tu3 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, one, -one / uplus, c.rffu0, lo, hi);
+        tu4 = sg * elldoublecomplex(p, f1, g1, c.h1, f2, g2, h2, one, -umi, c.rffu0, lo, hi);
+      }
       phiu0 = -tu3; phiu1 = -tu4;
       tu = su * ur / sqrt(-qs * ee) * (cA * tu1 + cB * tu2 - cC * tu3 + cD * tu4);
       phiu = su * ur / sqrt(-qs * ee) * (cP * phiu0 - cQ * phiu1);

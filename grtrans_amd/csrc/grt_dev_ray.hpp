@@ -125,8 +125,8 @@ struct GeoPoint {
   int tpm, tpr;
 };
 
-// Stored point idx (1..npts) of ray R.
-GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P) {
+// Stored point idx (1..npts) of ray R.  want: see geophitime (3 = everything).
+GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P, int want = 3) {
   const double two = 2.0;
   const double a = cam.a, mu0 = cam.mu0, uout = cam.uout, offset = cam.offset, l = R.l, q2 = R.q2, su = R.su, sm = R.sm;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
@@ -141,7 +141,7 @@ GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P) 
     double u0 = cam.u0;
     un = uout + (idx - offset) * R.du;
     geomu(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tpr1, su, sm, c, true, false);
-    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tpr1, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false);
+    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tpr1, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false, want);
     tprp = 0;
   } else if (fill && idx <= lo + next) {
     int k = idx - lo, tprs = R.tpr;
@@ -149,7 +149,7 @@ GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P) 
     indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, sm, k, next, offset, mun, tpm);
     un = 0.0;
     geor(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tprs, su, sm, c, true, false);
-    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tprs, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false);
+    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tprs, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false, want);
     tprp = tprs;
   } else {
     int K = fill ? (idx - (next - 2 * kext)) : idx;
@@ -157,7 +157,7 @@ GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P) 
     double u0 = R.uf;
     un = two * R.ub - (uout + (K - offset) * R.du);
     geomu(u0, un, mu0, mun, a, l, l2, q2, iu, tpm, tprs, su, sm, c, true, false);
-    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tprs, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false);
+    geophitime(u0, un, mu0, mun, a, l, l2, q2, tpm, tprs, su, sm, iu, c, phimu, tmu, phiu, tu, lambda, false, want);
     tprp = 1;
   }
   P.u = un; P.mu = mun; P.dt = tmu + tu; P.dphi = phimu + phiu; P.lam = lambda; P.tpm = tpm; P.tpr = tprp;

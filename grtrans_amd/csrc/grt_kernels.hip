@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
       else if (FAST == 1 && PHI) ray_point_real<true>(cam, *Rp, *Kp, idx, P);
       else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
-      else ray_point(cam, *Rp, idx, P);
+      else ray_point(cam, *Rp, idx, P, PHI ? 2 : 0);
     }
     if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
     if (valid) {   // geodesics.f90:333-347
