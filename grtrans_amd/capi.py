@@ -78,9 +78,9 @@ class Device:
         path = path or os.path.join(DATA, "sphacc_tables.bin")
         check(lib().grt_load_sphacc_tables_file(path.encode()), "grt_load_sphacc_tables_file")
 
-    def load_harm(self, dfile, hfile, indf, spin):
-        check(lib().grt_load_harm_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin)),
-              "grt_load_harm_files")
+    def load_harm(self, dfile, hfile, indf, spin, nt=1):
+        check(lib().grt_load_harm_files_nt(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_int(nt), C.c_double(spin)),
+              "grt_load_harm_files_nt")
 
     def set_thindisk(self, mdot, rin, rout):
         check(lib().grt_set_thindisk(C.c_double(mdot), C.c_double(rin), C.c_double(rout)), "grt_set_thindisk")

@@ -13,17 +13,17 @@
 #include "grt_pl_pack.hpp"
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters, void *rrays);
+                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time);
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, int nlive, double *steps, unsigned long long *flags,
-                                     long long ray_stride, long long field_stride, int nfields);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield);
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
-                                          int nfields, unsigned long long *step_counter);
+                                          int nfields, int tfield, unsigned long long *step_counter);
 
 extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mbh, float mdot, float rin, float rout, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
@@ -207,17 +207,16 @@ int grt_load_sphacc_tables_file(const char *path) {
   return grt_upload_sphacc(t.data(), t.data() + 498, t.data() + 996, t.data() + 1457);
 }
 
-int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
-                    const float *p, const float *b0, const float *br, const float *bth, const float *bph,
-                    const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+int grt_upload_harm_slices(int nx1, int nx2, int nt, float tstep, float h, const float *x1_arr, const float *x2_arr,
+                           const float *rho, const float *p, const float *b0, const float *br, const float *bth,
+                           const float *bph, const float *u0, const float *vrl, const float *vtl, const float *vpl) {
   if (!C.init) return GRT_E_NOTINIT;
-  if (nx1 < 2 || nx2 < 2 || nx1 + nx2 > GRT_HARM_MAXCOORD || !x1_arr || !x2_arr) return GRT_E_BADARG;
-  const size_t n = (size_t)nx1 * nx2;
+  if (nx1 < 2 || nx2 < 2 || nt < 1 || nx1 + nx2 > GRT_HARM_MAXCOORD || !x1_arr || !x2_arr) return GRT_E_BADARG;
   const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
   for (const float *q : src)
     if (!q) return GRT_E_BADARG;
   std::vector<float> cells, crd;
-  grt_harm_pack(nx1, nx2, h, x1_arr, x2_arr, src, cells, crd);
+  grt_harm_pack(nx1, nx2, h, x1_arr, x2_arr, src, cells, crd, nt);
   if (C.d_harm_cells) { (void)hipFree(C.d_harm_cells); C.d_harm_cells = nullptr; }
   if (C.d_harm_coords) { (void)hipFree(C.d_harm_coords); C.d_harm_coords = nullptr; }
   HIPCHK(hipMalloc((void **)&C.d_harm_cells, cells.size() * sizeof(float)));
@@ -225,9 +224,15 @@ int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float 
   HIPCHK(hipMemcpy(C.d_harm_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(C.d_harm_coords, crd.data(), crd.size() * sizeof(float), hipMemcpyHostToDevice));
   C.harm.cells = C.d_harm_cells; C.harm.coords = C.d_harm_coords;
-  C.harm.nx1 = nx1; C.harm.nx2 = nx2; C.harm.h = h;
+  C.harm.nx1 = nx1; C.harm.nx2 = nx2; C.harm.h = h; C.harm.nt = nt; C.harm.tstep = tstep;
   C.have_harm = true;
   return 0;
+}
+
+int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
+                    const float *p, const float *b0, const float *br, const float *bth, const float *bph,
+                    const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+  return grt_upload_harm_slices(nx1, nx2, 1, 20.f, h, x1_arr, x2_arr, rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl);
 }
 
 int grt_set_thindisk(double mdot, double rin, double rout) {
@@ -359,7 +364,12 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const long long maxpts = cam->nup + cam->next;
   const long long rstride = (maxpts + 63) / 64 * 64;      // internal ray stride: 512-byte aligned chunk rows
   const int nfields = C.record_steps ? 8 : (nextra ? 4 : 3);   // extra=1 weights by phi as well
-  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nfields * nrays * rstride))) return rc;
+  // several HARM slices loaded ("slow light"): every point also carries its coordinate time, one more field
+  const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1);
+  if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;
+  const int tfield = need_time ? nfields : -1;
+  const int nalloc = nfields + (need_time ? 1 : 0);
+  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * nrays * rstride))) return rc;
   if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * (rstride / 64) * 2))) return rc;
   C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride;
   const long long fstride = (long long)nrays * rstride;
@@ -373,23 +383,23 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
   HIPCHK(hipMemsetAsync(C.d_pixvals, 0, (size_t)nrays * nfreq * (nvals + nextra) * sizeof(float), C.stream));
   HIPCHK(hipEventRecord(C.ev[0], C.stream));
-  HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1, nrays, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays));
+  HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1, nrays, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, need_time ? 1 : 0));
   int ncls[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
   const int nlive = ncls[0] + ncls[1];
   HIPCHK(hipEventRecord(C.ev[1], C.stream));
   // class 0 (four real roots, fast path) sits at the front of live[], class 1 (generic) at the back
-  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields));
+  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield));
   HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
-                        rstride, fstride, nfields));
+                        rstride, fstride, nfields, tfield));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
   HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, rstride,
-                             fstride, nfields, C.d_stepcount));
+                             fstride, nfields, tfield, C.d_stepcount));
   HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
-                             C.d_flags, rstride, fstride, nfields, C.d_stepcount));
+                             C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
   if (st) {

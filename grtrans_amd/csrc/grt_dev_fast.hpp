@@ -288,18 +288,20 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
 }
 
 // u end-point: I_u1 and the four uf-side integrals of Eq. 47-49 for the pair (uf, root).
-struct UPart { double iu1, phiu1, tu11; };
+struct UPart { double iu1, phiu1, tu11, tu1; };   // tu1: Eq. 47 combination (only with the coordinate time)
 
 // PHI=false drops the two R_J integrals that only feed the azimuth (Eq. 48): a stationary axisymmetric
 // fluid never reads phi, so they are evaluated only when the per-step record is requested.  The
 // coordinate-time integral (Eq. 47, one more R_J) is never evaluated: t is not an output of this path
 // for nt=nload=1 (grtrans_driver.f90 uses x(1) only through time-dependent fluid models).
-template <bool PHI>
+// NPH: 0 = neither, 2 = the two azimuth integrals (Eq. 48), 3 = azimuth + the third [-2] integral, (a5,b5) = (0,1),
+// that only the coordinate time needs (Eq. 47; slow-light fluid models read t)
+template <int NPH>
 GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   const double two = 2.0;
   const bool c7 = (K.ncase == 7);
   const double root = c7 ? K.u2 : K.u3;
-  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0;
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
   if (uf == root) return;
   const double y = c7 ? uf : K.u3, x = c7 ? K.u2 : uf, sg = c7 ? 1.0 : -1.0;
   double X1 = fsqrt(K.a1 + K.b1 * x), X2 = fsqrt(K.a2 + K.b2 * x), X3 = fsqrt(K.a3 + K.b3 * x), X4 = fsqrt(K.a4 + K.b4 * x);
@@ -309,20 +311,24 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   double U132 = sq((X1 * X3 * Y2 * Y4 + Y1 * Y3 * X2 * X4) * idxy);
   double U14 = (X1 * X4 * Y2 * Y3 + Y1 * Y4 * X2 * X3) * idxy;
   double U142 = sq(U14);
-  constexpr int NJ = PHI ? 2 : 0;
-  double W22[2], rj2[2], rff, rdd;
-  W22[0] = U122 - K.wk[0]; W22[1] = U122 - K.wk[1];
+  constexpr int NJ = NPH;
+  constexpr int NA = NPH > 0 ? NPH : 1;
+  double W22[NA], rj2[NA], rff, rdd;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < NPH; ++k) W22[k] = U122 - K.wk[k];
   // everything that needs the eight square roots is formed BEFORE the duplication loop, so that they are
   // dead while it runs (the loop is where the register allocator was spilling)
   const double tI2 = two * X1 * Y1 * frcp(X4 * Y4 * fabs(U14));
   const double A111m1m2 = X1 * X2 * X3 * frcp(X4 * x) - Y1 * Y2 * Y3 * frcp(Y4 * y);
-  double P22[2], Q22[2];
-  if (PHI) {
+  double P22[NA], Q22[NA];
+  if (NPH > 0) {
     const double ixy1 = frcp(sq(X1 * Y1));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NPH; ++k) {
       double X52 = K.a5[k] + K.b5[k] * x, Y52 = K.a5[k] + K.b5[k] * y;
       Q22[k] = X52 * Y52 * ixy1 * W22[k];
       P22[k] = Q22[k] + K.pk[k];
@@ -336,16 +342,17 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   // [-1,-1,-1,-1,-4] with (a5,b5)=(0,1), Carlson (1988) 2.48
   double I2 = K.cRD * rdd + tI2;
   o.tu11 = sg * (K.cI2 * I2 + K.cI1 * I1 - K.cA4 * A111m1m2);
-  if (PHI) {
-    double v[2];
+  if (NPH > 0) {
+    double v[NA];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 2; ++k) {   // [-1,-1,-1,-1,-2], Carlson (1988) 2.35
+    for (int k = 0; k < NPH; ++k) {   // [-1,-1,-1,-1,-2], Carlson (1988) 2.35
       double I3 = K.jk[k] * rj2[k] + two * rc7(P22[k], Q22[k]);
       v[k] = sg * (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
     }
     o.phiu1 = -K.cP * v[0] + K.cQ * v[1];
+    if (NPH == 3) o.tu1 = K.cA * o.tu11 + K.cB * v[2] - K.cC * v[0] + K.cD * v[1];   // :2215-2219
   }
 }
 
@@ -404,8 +411,9 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
 // two "integral" stages around one inversion, so the function is written as a two-pass loop whose body holds
 // ONE copy of each stage (the earlier if/else form inlined every stage twice: twice the code, and the register
 // allocator spilled inside the duplication loops).
-template <bool PHI>
+template <int NPH>
 GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P) {
+  constexpr bool PHI = NPH > 0;
   const double one = 1.0, two = 2.0;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
   const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
@@ -415,7 +423,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
   const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
   double un = 0.0, mun = 0.0, iu = 0.0, jarg = 0.0;
   int tpm = 0, tprs = 0, tprp = 0;
-  UPart U; U.iu1 = 0.0; U.phiu1 = 0.0; U.tu11 = 0.0;
+  UPart U; U.iu1 = 0.0; U.phiu1 = 0.0; U.tu11 = 0.0; U.tu1 = 0.0;
   MuPart M; M.i2mu = 0.0; M.tmuf = 0.0; M.phimuf = 0.0;
   if (!isfill) {
     if (idx <= lo || R.tpr == 0) {
@@ -433,7 +441,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 #endif
   for (int pass = 0; pass < 2; ++pass) {
     const bool doU = (pass == 0) != isfill;
-    if (doU) real_upart<PHI>(K, un, U);
+    if (doU) real_upart<NPH>(K, un, U);
     else real_mupart<PHI>(K, mun, M, isfill);
     if (pass == 0) {
       // argument of the Jacobi inversion
@@ -491,7 +499,9 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
     if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
     dphi = phimu + phiu;
   }
-  P.u = un; P.mu = mun; P.dt = 0.0; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
+  double dt = 0.0;
+  if (NPH == 3) dt = K.su * (K.tu0 - s * U.tu1) * K.isqee * K.ur + tmu;      // DTI = tu + tmu (:2220, :2351)
+  P.u = un; P.mu = mun; P.dt = dt; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
 }
 
 // Branch-per-segment form of ray_point_real (each stage inlined once per segment type).  Kept for the
@@ -518,7 +528,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
     }
     if (c7 ? (un > root) : (un < root)) un = root;        // geokerr_wrapper.f:1079,1089
-    real_upart<PHI>(K, un, U);
+    real_upart<(PHI ? 2 : 0)>(K, un, U);
     iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
     // mu_f from I_u (Eq. 30-42)
     double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
@@ -554,7 +564,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       un = fdiv((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2), (K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
       tprs = (int)((-fsign(1.0, K.su * (imu + K.siu0m)) + 1.0) / 2.0);
     }
-    real_upart<PHI>(K, un, U);
+    real_upart<(PHI ? 2 : 0)>(K, un, U);
     iu = imu;
     tprp = tprs;
   }

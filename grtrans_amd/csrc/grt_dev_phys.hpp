@@ -746,7 +746,22 @@ GRT_HD double zbrent_x2(const HarmX2 &func, double x1, double x2, double tol) {
 }
 
 // crd = [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2] (LDS in the kernel)
-GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_d, float a, FluidPoint &f) {
+// Kerr-Schild look-back time of a point relative to the ray's first stored point -> slice index (harm_vals :134-137,
+// :175-186; REAL(4) tt and tstep; the time WEIGHT is zero in the reference, so this selects, it does not blend)
+GRT_HD double bl2ks_time(double r, double x, double a) {      // kerr.f90:147-154
+  const double sq1 = sqrt(1. - a * a);
+  return x + log(r * r - 2 * r + a * a) + 1. / (2.0 * sq1) * log((r - 1. - sq1) / (r - 1 + sq1));
+}
+GRT_HD int harm_time_index(const GrtHarm &t, double r, double tcoord, double r1, float a) {
+  if (t.nt <= 1) return 0;
+  float tt = (float)(bl2ks_time((double)(float)r, (double)(float)tcoord, (double)a) - bl2ks_time((double)(float)r1, 0.0, (double)a));
+  tt = (float)(-(double)tt + 1e-8);
+  const int fl = (int)floorf(tt / t.tstep);
+  int tindx = (fl <= t.nt - 2) ? fl : t.nt - 1;
+  return tindx < 0 ? 0 : tindx;                         // (negative: out of bounds in the reference)
+}
+
+GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_d, float a, FluidPoint &f, int tindx = 0) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2;
@@ -767,8 +782,9 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
   float rd = (zr - uniqr[lx1c - 1]) / (uniqr[ux1c - 1] - uniqr[lx1c - 1]);
   const float rh = 1.f + sqrtf(1.f - a * a);
   if (uniqr[lx1c - 1] <= rh) rd = 1.f;                                                     // :165-167
-  const float *c00 = t.cells + (size_t)((lx1c - 1) * nx2 + (lx2c - 1)) * 12;   // (x1l, x2l)
-  const float *c01 = t.cells + (size_t)((lx1c - 1) * nx2 + (ux2 - 1)) * 12;    // (x1l, x2u)
+  const float *slice = t.cells + (size_t)tindx * nx1 * nx2 * 12;
+  const float *c00 = slice + (size_t)((lx1c - 1) * nx2 + (lx2c - 1)) * 12;   // (x1l, x2l)
+  const float *c01 = slice + (size_t)((lx1c - 1) * nx2 + (ux2 - 1)) * 12;    // (x1l, x2u)
   const float *c10 = c00 + (size_t)nx2 * 12, *c11 = c01 + (size_t)nx2 * 12;    // x1u
   float q[10];
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -80,8 +80,8 @@ void lnrf_real(float vr, float vt, float omega, float r, float a, float th, floa
 
 }  // namespace
 
-extern "C" int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin) {
-  if (!dfile || !hfile) return GRT_E_BADARG;
+extern "C" int grt_load_harm_files_nt(const char *dfile, const char *hfile, int indf, int nt, double spin) {
+  if (!dfile || !hfile || nt < 1) return GRT_E_BADARG;
   const size_t nhead = 26, dlen = 34;
   std::vector<double> head;
   if (!slurp_numbers(hfile, nhead, head)) return GRT_E_IO;
@@ -92,23 +92,33 @@ extern "C" int grt_load_harm_files(const char *dfile, const char *hfile, int ind
     std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
     return GRT_E_BADARG;
   }
-  char suffix[16];
-  std::snprintf(suffix, sizeof suffix, "%03d", indf);      // write(append, fmt='(I3.3)') indf  (:463)
-  const size_t n = (size_t)nx1 * nx2;
-  std::vector<double> all;
-  if (!slurp_numbers(std::string(dfile) + suffix, nhead + n * dlen, all)) return GRT_E_IO;
-  const double *z = all.data() + nhead;
-  std::vector<float> x1(n), x2(n), rho(n), p(n), u0(n), vrl(n), vtl(n), vpl(n), b0(n), br(n), bth(n), bph(n);
-  for (size_t i = 0; i < n; ++i, z += dlen) {
-    x1[i] = (float)z[0]; x2[i] = (float)z[1];
-    const float r = (float)z[2], th = (float)z[3];
-    const Zone4 u = mks_to_bl(z + 13, r, x2[i], h, asim), b = mks_to_bl(z + 21, r, x2[i], h, asim);
-    lnrf_real((float)(u.r / u.t), (float)(u.th / u.t), (float)(u.ph / u.t), r, asim, th, vrl[i], vtl[i], vpl[i]);
-    rho[i] = (float)z[4];
-    p[i] = (float)(z[5] * (double)(gam - 1.f));            // internal energy -> pressure (:477)
-    u0[i] = (float)u.t;
-    b0[i] = (float)b.t; br[i] = (float)b.r; bth[i] = (float)b.th; bph[i] = (float)b.ph;
+  const size_t n = (size_t)nx1 * nx2, ntot = n * (size_t)nt;
+  std::vector<float> x1(n), x2(n), rho(ntot), p(ntot), u0(ntot), vrl(ntot), vtl(ntot), vpl(ntot), b0(ntot), br(ntot), bth(ntot),
+      bph(ntot), tdump((size_t)nt);
+  for (int ks = 0; ks < nt; ++ks) {                // load_harm_data: slice k <- file indf-(k-1) (:461-465)
+    char suffix[16];
+    std::snprintf(suffix, sizeof suffix, "%03d", indf - ks);      // write(append, fmt='(I3.3)')
+    std::vector<double> all;
+    if (!slurp_numbers(std::string(dfile) + suffix, nhead + n * dlen, all)) return GRT_E_IO;
+    tdump[ks] = (float)all[0];
+    const double *z = all.data() + nhead;
+    const size_t o = (size_t)ks * n;
+    for (size_t i = 0; i < n; ++i, z += dlen) {
+      x1[i] = (float)z[0]; x2[i] = (float)z[1];
+      const float r = (float)z[2], th = (float)z[3];
+      const Zone4 u = mks_to_bl(z + 13, r, x2[i], h, asim), b = mks_to_bl(z + 21, r, x2[i], h, asim);
+      lnrf_real((float)(u.r / u.t), (float)(u.th / u.t), (float)(u.ph / u.t), r, asim, th, vrl[o + i], vtl[o + i], vpl[o + i]);
+      rho[o + i] = (float)z[4];
+      p[o + i] = (float)(z[5] * (double)(gam - 1.f));            // internal energy -> pressure (:477)
+      u0[o + i] = (float)u.t;
+      b0[o + i] = (float)b.t; br[o + i] = (float)b.r; bth[o + i] = (float)b.th; bph[o + i] = (float)b.ph;
+    }
   }
-  return grt_upload_harm(nx1, nx2, h, x1.data(), x2.data(), rho.data(), p.data(), b0.data(), br.data(), bth.data(),
-                         bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data());
+  const float tstep = (nt > 1) ? (tdump[0] - tdump[1]) : 20.f;    // :493-500 (module default 20. for one slice)
+  return grt_upload_harm_slices(nx1, nx2, nt, tstep, h, x1.data(), x2.data(), rho.data(), p.data(), b0.data(), br.data(), bth.data(),
+                                bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data());
+}
+
+extern "C" int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin) {
+  return grt_load_harm_files_nt(dfile, hfile, indf, 1, spin);
 }

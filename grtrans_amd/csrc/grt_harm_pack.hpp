@@ -7,9 +7,10 @@
 // cells: [nx1*nx2][12] zone-interleaved (x2 fastest) so the four corners of a sample are two pairs of
 // adjacent 48-byte records; crd: [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2], the per-call vectors of
 // harm_vals (fluid_model_harm.f90:126-129) built once.
+// nt time slices: the ten arrays hold nt*n values, slice-major as in the reference (fluid_model_harm.f90:471-490)
 inline void grt_harm_pack(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *const src[10],
-                          std::vector<float> &cells, std::vector<float> &crd) {
-  const size_t n = (size_t)nx1 * nx2;
+                          std::vector<float> &cells, std::vector<float> &crd, int nt = 1) {
+  const size_t n = (size_t)nx1 * nx2 * (size_t)nt;
   cells.assign(n * 12, 0.f);
   crd.assign((size_t)2 * (nx1 + nx2), 0.f);
   for (size_t i = 0; i < n; ++i)

@@ -38,7 +38,7 @@ using namespace grtd;
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
-                                                         int *__restrict__ counters, char *__restrict__ rrays) {
+                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
   GrtRay R;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   const bool alive = inr && R.npts > 0;
   // fast class: four distinct real roots (a != 0), or the three real roots of a Schwarzschild camera (a == 0)
   const bool quart = alive && (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12;
-  const bool cubic = alive && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool cubic = alive && !need_time && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
@@ -91,11 +91,13 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
 #define GRT_F_I 4
 
 // FAST: 0 generic (every root case), 1 four real roots, 2 Schwarzschild cubic
-template <int FAST, bool PHI>
+// NPH : 0 no azimuth, 2 azimuth (per-step record / extra=1), 3 azimuth + coordinate time (slow-light fluid models)
+template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     int nlive, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
-    long long field_stride, int nfields) {
+    long long field_stride, int nfields, int tfield) {
+  constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
   if (slot >= nlive) return;   // whole wave leaves together
@@ -118,9 +120,10 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
     if (valid) {
       if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
-      else if (FAST == 1 && PHI) ray_point_real<true>(cam, *Rp, *Kp, idx, P);
+      else if (FAST == 1 && NPH == 3) ray_point_real<3>(cam, *Rp, *Kp, idx, P);
+      else if (FAST == 1 && NPH == 2) ray_point_real<2>(cam, *Rp, *Kp, idx, P);
       else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
-      else ray_point(cam, *Rp, idx, P, PHI ? 2 : 0);
+      else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
     }
     if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
     if (valid) {   // geodesics.f90:333-347
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       sp[GRT_F_TH * field_stride] = acos(P.mu);
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
       if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = cam.phi0 - P.dphi;
+      if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt;     // x%data(1) = DTI(1)-DTI(i)-t0, t0 = 0 (geodesics.f90:345)
     }
     // turning-point parities of the chunk as two 64-bit lane masks (tpm, tpr): 0.25 bit-pairs per byte instead of a byte per point
     const unsigned long long mm = __ballot(valid && (P.tpm & 1)), mr = __ballot(valid && (P.tpr & 1));
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned long long *__restrict__ flags,
-    long long ray_stride, long long field_stride, int nfields, unsigned long long *__restrict__ step_counter) {
+    long long ray_stride, long long field_stride, int nfields, int tfield, unsigned long long *__restrict__ step_counter) {
   constexpr int NW = GRT_XFER_THREADS / 64;
   const double *lfreqs = freqs + nfreq;      // log(freqs), appended by the host
   __shared__ double s_tile[NW][4][64 * GRT_TS];
@@ -197,6 +201,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
   const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
   const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
   const double lam_1 = has_ray ? steps[GRT_F_LAM * field_stride + base] : 0.0;   // g%lambda(1)
+  const bool slowlight = (FLUID == GRT_FLUID_HARM) && !EXTRA && tfield >= 0;    // several HARM slices: the point's time picks one
+  const double r_1 = (slowlight && has_ray) ? steps[GRT_F_R * field_stride + base] : 10.0;
   double I[FB][4], facs[FB];
   double jn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][4], Kn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][7];
 #pragma unroll
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
         tl1[rs * GRT_TS + e] = steps[GRT_F_TH * field_stride + b];
         tl2[rs * GRT_TS + e] = steps[GRT_F_LAM * field_stride + b];
         if (EXTRA) tl3[rs * GRT_TS + e] = steps[GRT_F_PHI * field_stride + b];
+        else if (slowlight) tl3[rs * GRT_TS + e] = steps[(long long)tfield * field_stride + b];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
       const int fl8 = (int)((fmm >> (ip & 63)) & 1ull) | ((int)((fmr >> (ip & 63)) & 1ull) << 1);
       const double phi_i = EXTRA ? tl3[lane * GRT_TS + e] : 0.0;
+      const double t_i = (slowlight && valid) ? tl3[lane * GRT_TS + e] : 0.0;
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);
       calc_nullp(q2, l, cam.a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
@@ -272,7 +280,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       FluidPoint fl;
       if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
       else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
-      else if (FLUID == GRT_FLUID_HARM) harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl);
+      else if (FLUID == GRT_FLUID_HARM)
+        harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl, slowlight ? harm_time_index(fd.hm, r, t_i, r_1, (float)cam.a) : 0);
       double s2xi, c2xi, ang, g;
       comoving_ortho(r, sth, cth, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
@@ -471,25 +480,26 @@ extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mb
 extern "C" size_t grt_sizeof_realray(void) { return GRT_RR_STRIDE; }
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters, void *rrays) {
+                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time) {
   int blocks = (nrays + 255) / 256;
   hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
-                     (char *)rrays);
+                     (char *)rrays, need_time);
   return hipGetLastError();
 }
 
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, int nlive, double *steps, unsigned long long *flags,
-                                     long long ray_stride, long long field_stride, int nfields) {
+                                     long long ray_stride, long long field_stride, int nfields, int tfield) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
   const char *rr = (const char *)rrays;
-  const bool phi = nfields > GRT_F_PHI;
+  // the time field needs the azimuth integrals anyway (Eq. 47 shares them), so NPH = 3 also when phi is not stored
+  const int nph = (tfield >= 0) ? 3 : ((nfields > GRT_F_PHI) ? 2 : 0);
   const int kind = !fast ? 0 : (cam->a == 0.0 ? 2 : 1);
 #define GRT_GEO_CASE(F, P)                                                                                              \
-  if (kind == F && phi == P)                                                                                            \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive, steps, flags, ray_stride, field_stride, nfields);
-  GRT_GEO_CASE(1, true) GRT_GEO_CASE(1, false) GRT_GEO_CASE(2, true) GRT_GEO_CASE(2, false) GRT_GEO_CASE(0, true) GRT_GEO_CASE(0, false)
+  if (kind == F && nph == P)                                                                                            \
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive, steps, flags, ray_stride, field_stride, nfields, tfield);
+  GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE
   return hipGetLastError();
 }
@@ -499,16 +509,16 @@ static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
                               double *steps, const unsigned long long *flags, long long ray_stride, long long field_stride,
-                              int nfields, unsigned long long *step_counter) {
+                              int nfields, int tfield, unsigned long long *step_counter) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
                        rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags,
-                       ray_stride, field_stride, nfields, step_counter);
+                       ray_stride, field_stride, nfields, tfield, step_counter);
   } else if (nfreq == 1) {
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
                        *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride,
-                       field_stride, nfields, step_counter);
+                       field_stride, nfields, tfield, step_counter);
   } else {
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
@@ -516,7 +526,7 @@ static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
                        dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
-                       nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);
+                       nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter);
   }
 }
 
@@ -526,12 +536,12 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
-                                          int nfields, unsigned long long *step_counter) {
+                                          int nfields, int tfield, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
     launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
-                               ray_status, i1, steps, flags, ray_stride, field_stride, nfields, step_counter);           \
+                               ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter);   \
     return hipGetLastError();                                                                                           \
   }
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)

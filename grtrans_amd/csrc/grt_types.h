@@ -41,11 +41,12 @@ struct GrtFFJet {               // device pointers; cell-interleaved copy of the
   int32_t nx1, pad;
 };
 
-struct GrtHarm {                // device pointers; one 2-D HARM slice (nt=1), fluid_model_harm.f90:15-21
+struct GrtHarm {                // device pointers; nt 2-D HARM slices, fluid_model_harm.f90:15-21
   const float *cells;           // [nx1*nx2][12], x2 fastest: rho,p,b0,br,bth,bph,u0,vrl,vtl,vpl,pad,pad
   const float *coords;          // [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2] (staged in LDS by the kernel)
   int32_t nx1, nx2;
-  float h, pad;
+  float h, tstep;               // tstep: time between loaded slices (t(1)-t(2); module default 20. when nt = 1)
+  int32_t nt, pad;              // loaded time slices: slice k = dump indf-(k-1), cells [nt][nx1*nx2][12]
 };
 #define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 

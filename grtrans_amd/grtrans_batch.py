@@ -142,9 +142,9 @@ class grtrans:
             elif inp.fname == 'THINDISK':
                 dev.set_thindisk(float(inp.tmdot), float(inp.srin), float(inp.srout))   # fmdot, frin, frout of the namelist
             elif inp.fname == 'HARM':
-                if int(inp.fnt) != 1:
-                    raise capi.GrtError("HARM with hnt > 1 (time-dependent) is not on the device yet")
-                dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
+                if int(inp.fnt) > 1 and nextra:
+                    raise capi.GrtError("extra=1 with several HARM slices (hnt > 1) is not on the device yet")
+                dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), nt=int(inp.fnt))
             ivals = np.zeros((inp.nvals + nextra, npix, ncams))
             ab = np.zeros((2, npix))
             harm_indf, harm_toffset, harm_tstep = int(inp.findf), np.float32(0.), np.float32(20.)
@@ -159,7 +159,7 @@ class grtrans:
                         harm_toffset = np.float32(harm_toffset - np.float32(np.floor(harm_toffset / harm_tstep)) * harm_tstep)
                         harm_indf += nupdate
                         if nupdate > 0:
-                            dev.load_harm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
+                            dev.load_harm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin), nt=int(inp.fnt))
                     for m in range(nmdot):
                         mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
                         em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,

@@ -58,6 +58,13 @@ module grt_cabi
        real(c_double), value :: mdot, rin, rout
        integer(c_int) :: rc
      end function grt_set_thindisk
+     function grt_load_harm_files_nt(dfile, hfile, indf, nt, spin) bind(C, name='grt_load_harm_files_nt') result(rc)
+       import :: c_int, c_char, c_double
+       character(kind=c_char), dimension(*), intent(in) :: dfile, hfile
+       integer(c_int), value :: indf, nt
+       real(c_double), value :: spin
+       integer(c_int) :: rc
+     end function grt_load_harm_files_nt
      function grt_load_sphacc_tables_file(path) bind(C, name='grt_load_sphacc_tables_file') result(rc)
        import :: c_int, c_char
        character(kind=c_char), dimension(*), intent(in) :: path

@@ -14,7 +14,7 @@ module pgrtrans
   real(8), allocatable, dimension(:) :: freqs
   real(8) :: last_ray_steps = 0d0, last_kernel_ms = 0d0    ! extra: what the tracer reported
   ! HARM time-stepping state (module variables of fluid_model_harm.f90:12-16)
-  integer, save :: cur_fluid = 0, harm_indf = 0
+  integer, save :: cur_fluid = 0, harm_indf = 0, harm_nt = 1
   real, save :: harm_tstep = 20., harm_toffset = 0.
   real(8), save :: harm_spin = 0d0
   character(len=256), save :: harm_dfile = ' ', harm_hfile = ' ' 
@@ -133,10 +133,12 @@ contains
        if (rc /= 0) call die_rc('grt_load_ffjet_file '//trim(fdfile), rc)
     else if (fluid_id == GRT_FLUID_HARM) then
        ! initialize_harm_model(a,ifile,fdfile,fhfile,fnt,findf), fluid.f90:193-194
-       if (fnt /= 1) call die('HARM with fnt > 1 (time-dependent) is not supported yet')
-       rc = grt_load_harm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
+       ! fnt > 1: that many time slices are loaded and each point reads the one its look-back time selects (slow light)
+       if (fnt > 1 .and. extra /= 0) call die('extra=1 with several HARM slices (fnt > 1) is not supported')
+       rc = grt_load_harm_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(fnt, c_int), spin)
        if (rc /= 0) call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc)
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
+       harm_nt = fnt
     else if (fluid_id == GRT_FLUID_THINDISK) then
        ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
        rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) call die_rc('grt_set_thindisk', rc)
@@ -234,7 +236,7 @@ contains
     write(6,*) 'advance harm timestep: ', dtobs, harm_tstep, harm_toffset, harm_indf, nupdate
     ! nupdate = 0 leaves the slice as it is (update_harm_data(0) loads nothing)
     if (nupdate > 0) then
-       rc = grt_load_harm_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
+       rc = grt_load_harm_files_nt(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), int(harm_nt, c_int), harm_spin)
        if (rc /= 0) call die_rc('grt_load_harm_files (advance) '//trim(harm_dfile), rc)
     end if
   end subroutine advance_fluid_timestep

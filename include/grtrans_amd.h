@@ -87,9 +87,17 @@ int grt_load_sphacc_tables_file(const char *path);
 int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
                     const float *p, const float *b0, const float *br, const float *bth, const float *bph,
                     const float *u0, const float *vrl, const float *vtl, const float *vpl);
+/* the same with nt loaded time slices ("slow light"): the ten arrays hold nt*n values, slice k (1-based) =
+ * dump indf-(k-1) (fluid_model_harm.f90:461-490); tstep = t(1)-t(2) (:493-500).  A point then reads the slice its
+ * Kerr-Schild look-back time selects (:134-137, :175-186). */
+int grt_upload_harm_slices(int nx1, int nx2, int nt, float tstep, float h, const float *x1_arr, const float *x2_arr,
+                           const float *rho, const float *p, const float *b0, const float *br, const float *bth,
+                           const float *bph, const float *u0, const float *vrl, const float *vtl, const float *vpl);
 /* replaces initialize_harm_model (fluid_model_harm.f90:275-427): header file + text dump `dfile`//I3.3(indf);
  * refuses a spin that differs from the dump's by more than 1e-4 as the reference does (:435-438). */
 int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin);
+/* nt slices: dumps indf, indf-1, ..., indf-nt+1 */
+int grt_load_harm_files_nt(const char *dfile, const char *hfile, int indf, int nt, double spin);
 
 /* replaces init_thindisk(a, ifile, mdot, mbh, rin, rout) (fluid_model_thindisk.f90:31-49, called from
  * fluid.f90:226-227 with fargs%mdot, %rin, %rout; the mass comes with grt_emis.mbh).  Only the reference's

@@ -58,7 +58,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
     if (S.fluid == 13) ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 1) sphacc_point(S.sphacc, x[1], w.f[i]);
     else if (S.fluid == 2) thindisk_point(S.disk, x, (float)S.cam.a, w.f[i]);
-    else harm_vals(S.harm, x, (float)S.cam.a, w.f[i]);
+    else harm_vals(S.harm, x, (float)S.cam.a, w.f[i], w.g.x[1]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
     double nu = freq / w.rshift[i];
@@ -191,7 +191,7 @@ void grto_sncndn(double u, double emmc, double *sn, double *cn, double *dn) { sn
 int grto_setup(int standard, double mu0, double phi0, double spin, double uout, const double *gridvals,
                const int *nn, const char *fname, const char *ename, const char *iname, const char *dfile,
                const char *pltab, double mbh, double gmin, double gmax, double p1, double ftscl, double frscl,
-               const int *coefindx, int nvals, const char *hfile, int indf, double mdot, double muval, double fmdot) {
+               const int *coefindx, int nvals, const char *hfile, int indf, double mdot, double muval, double fmdot, int fnt) {
   S = Setup();
   camera_init(S.cam, standard, gridvals[0], gridvals[1], gridvals[2], gridvals[3], nn[0], nn[1], nn[2], spin, mu0, uout);
   S.phi0 = phi0; S.spin = spin; S.nvals = nvals;
@@ -208,7 +208,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   for (int i = 0; i < 7; ++i) S.coefindx[i] = coefindx[i];
   if (S.fluid == 13 && !ffjet_load(dfile, S.ffjet)) return -4;
   if (S.fluid == 1 && !sphacc_load(dfile, S.sphacc)) return -4;
-  if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm) != 0) return -4;
+  if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm, fnt > 0 ? fnt : 1) != 0) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;

@@ -4,15 +4,17 @@
 //   umksh2uks     fluid_model_harm.f90:72-98 ; uks2ubl kerr.f90:131-144 ; lnrf_frame_real kerr.f90:427-449
 //   harm_vals     fluid_model_harm.f90:100-265 ; transformbl2mksh :58-71 ; zbrent math.f90:56-135
 //   convert       fluid.f90:957-973 (scale_sim_units :765-790, monika_e :870-892)
-// nt = 1 only: the reference zeroes the time weight (rttd=0., :199) and with one slice both time indices
-// fold onto the same dump (:187-190), so the coordinate time of the ray does not enter.
+// Several loaded slices (nt > 1, "slow light"): slice k holds dump indf-(k-1) (:461-465); a point reads the slice
+// tindx = floor(tt/tstep) of its Kerr-Schild look-back time tt relative to the ray's first point, clamped to the
+// oldest slice (:175-186).  The reference zeroes the time WEIGHT (rttd=0., :199): nearest-older slice, no blending.
 #pragma once
 #include "grto_physics.hpp"
 
 namespace grto {
 
 struct HarmTable {
-  int nx1 = 0, nx2 = 0;
+  int nx1 = 0, nx2 = 0, nt = 1;
+  float tstep = 20.f;                                                  // module default (:14); t(1)-t(2) when nt > 1
   float h = 0, asim = 0, gam = 0;
   std::vector<float> x1, x2, r, th;                                   // [n], x2 fastest
   std::vector<float> rho, p, u0, vrl, vpl, vtl, b0, br, bth, bph;     // [n]
@@ -72,7 +74,7 @@ inline void lnrf_frame_real(float vr, float vt, float omega, float r, float a, f
 }
 
 // returns 0 ok, -1 io, -2 spin mismatch
-inline int harm_load(const char *dfile, const char *hfile, int indf, double a, HarmTable &t) {
+inline int harm_load(const char *dfile, const char *hfile, int indf, double a, HarmTable &t, int nt = 1) {
   const int nhead = 26, dlen = 34;
   FILE *f = std::fopen(hfile, "r");
   if (!f) return -1;
@@ -84,44 +86,51 @@ inline int harm_load(const char *dfile, const char *hfile, int indf, double a, H
   t.asim = (float)header[9]; t.gam = (float)header[10]; t.h = (float)header[nhead - 2];
   if (std::fabs((double)t.asim - a) > 1e-4) return -2;
   const int n = t.nx1 * t.nx2;
-  char name[512];
-  std::snprintf(name, sizeof name, "%s%03d", dfile, indf);
-  f = std::fopen(name, "r");
-  if (!f) return -1;
-  for (int i = 0; i < nhead; ++i)
-    if (std::fscanf(f, "%lf", &header[i]) != 1) { std::fclose(f); return -1; }
-  std::vector<double> data((size_t)n * dlen);
-  for (size_t i = 0; i < data.size(); ++i)
-    if (std::fscanf(f, "%lf", &data[i]) != 1) { std::fclose(f); return -1; }
-  std::fclose(f);
+  t.nt = nt;
   const int rhopos = 4, ppos = 5, vpos = 13, bpos = 21;
-  for (auto *v : {&t.x1, &t.x2, &t.r, &t.th, &t.rho, &t.p, &t.u0, &t.vrl, &t.vpl, &t.vtl, &t.b0, &t.br, &t.bth, &t.bph})
-    v->resize(n);
+  for (auto *v : {&t.x1, &t.x2, &t.r, &t.th}) v->resize(n);
+  for (auto *v : {&t.rho, &t.p, &t.u0, &t.vrl, &t.vpl, &t.vtl, &t.b0, &t.br, &t.bth, &t.bph}) v->resize((size_t)n * nt);
   const double as = (double)t.asim;
-  for (int i = 0; i < n; ++i) {
-    const double *row = &data[(size_t)i * dlen];
-    t.x1[i] = (float)row[0]; t.x2[i] = (float)row[1]; t.r[i] = (float)row[2]; t.th[i] = (float)row[3];
-    double u[4] = {row[vpos], row[vpos + 1], row[vpos + 2], row[vpos + 3]};
-    double b[4] = {row[bpos], row[bpos + 1], row[bpos + 2], row[bpos + 3]};
-    // umksh2uks (:72): ur = r u^1 ; uth = u^2 dth/dx2, the derivative stored in single precision
-    float dthdx2 = (float)(PH_pi * (1.0 + (double)(1.f - t.h) * std::cos(2.0 * PH_pi * (double)t.x2[i])));
-    const double rd = (double)t.r[i];
-    auto to_bl = [&](double *w) {
-      w[1] = rd * w[1];
-      w[2] = w[2] * (double)dthdx2;
-      double delta = rd * rd - 2.0 * rd + as * as;          // uks2ubl, kerr.f90:139-143
-      double w0 = w[0] - 2.0 * rd / delta * w[1];
-      double w3 = w[3] - as / delta * w[1];
-      w[0] = w0; w[3] = w3;
-    };
-    to_bl(u); to_bl(b);
-    lnrf_frame_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), t.r[i], t.asim, t.th[i],
-                    t.vrl[i], t.vtl[i], t.vpl[i]);
-    t.rho[i] = (float)row[rhopos];
-    t.p[i] = (float)(row[ppos] * (double)(t.gam - 1.f));     // p_arr = p*(gam-1.)
-    t.b0[i] = (float)b[0]; t.br[i] = (float)b[1]; t.bth[i] = (float)b[2]; t.bph[i] = (float)b[3];
-    t.u0[i] = (float)u[0];
+  std::vector<float> tdump(nt);
+  for (int ks = 0; ks < nt; ++ks) {          // load_harm_data: slice k <- file indf-(k-1)
+    char name[512];
+    std::snprintf(name, sizeof name, "%s%03d", dfile, indf - ks);
+    f = std::fopen(name, "r");
+    if (!f) return -1;
+    for (int i = 0; i < nhead; ++i)
+      if (std::fscanf(f, "%lf", &header[i]) != 1) { std::fclose(f); return -1; }
+    tdump[ks] = (float)header[0];
+    std::vector<double> data((size_t)n * dlen);
+    for (size_t i = 0; i < data.size(); ++i)
+      if (std::fscanf(f, "%lf", &data[i]) != 1) { std::fclose(f); return -1; }
+    std::fclose(f);
+    const size_t o = (size_t)ks * n;
+    for (int i = 0; i < n; ++i) {
+      const double *row = &data[(size_t)i * dlen];
+      t.x1[i] = (float)row[0]; t.x2[i] = (float)row[1]; t.r[i] = (float)row[2]; t.th[i] = (float)row[3];
+      double u[4] = {row[vpos], row[vpos + 1], row[vpos + 2], row[vpos + 3]};
+      double b[4] = {row[bpos], row[bpos + 1], row[bpos + 2], row[bpos + 3]};
+      // umksh2uks (:72): ur = r u^1 ; uth = u^2 dth/dx2, the derivative stored in single precision
+      float dthdx2 = (float)(PH_pi * (1.0 + (double)(1.f - t.h) * std::cos(2.0 * PH_pi * (double)t.x2[i])));
+      const double rd = (double)t.r[i];
+      auto to_bl = [&](double *w) {
+        w[1] = rd * w[1];
+        w[2] = w[2] * (double)dthdx2;
+        double delta = rd * rd - 2.0 * rd + as * as;          // uks2ubl, kerr.f90:139-143
+        double w0 = w[0] - 2.0 * rd / delta * w[1];
+        double w3 = w[3] - as / delta * w[1];
+        w[0] = w0; w[3] = w3;
+      };
+      to_bl(u); to_bl(b);
+      lnrf_frame_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), t.r[i], t.asim, t.th[i],
+                      t.vrl[o + i], t.vtl[o + i], t.vpl[o + i]);
+      t.rho[o + i] = (float)row[rhopos];
+      t.p[o + i] = (float)(row[ppos] * (double)(t.gam - 1.f));     // p_arr = p*(gam-1.)
+      t.b0[o + i] = (float)b[0]; t.br[o + i] = (float)b[1]; t.bth[o + i] = (float)b[2]; t.bph[o + i] = (float)b[3];
+      t.u0[o + i] = (float)u[0];
+    }
   }
+  t.tstep = (nt > 1) ? (tdump[0] - tdump[1]) : 20.f;            // :493-500
   // harm_vals:126-130 (recomputed per call in the reference)
   t.uniqx2.assign(t.x2.begin(), t.x2.begin() + t.nx2);
   t.uniqx1.resize(t.nx1); t.uniqr.resize(t.nx1); t.uniqth.resize(t.nx2);
@@ -132,8 +141,25 @@ inline int harm_load(const char *dfile, const char *hfile, int indf, double a, H
 }
 
 // fluid_model_harm.f90:100.  x = (t,r,th,phi) double; a single precision.
-inline void harm_vals(const HarmTable &t, const double *x, float a, FluidPoint &f) {
+inline double bl2ks_time(double r, double x, double a) {      // kerr.f90:147-154
+  return x + std::log(r * r - 2 * r + a * a) +
+         1. / (2.0 * std::sqrt(1. - a * a)) * std::log((r - 1. - std::sqrt(1. - a * a)) / (r - 1 + std::sqrt(1. - a * a)));
+}
+
+// r1 = r of the ray's first stored point (zr(1) of the array call)
+inline void harm_vals(const HarmTable &t, const double *x, float a, FluidPoint &f, double r1 = 0.0) {
   const int nx1 = t.nx1, nx2 = t.nx2;
+  int tindx = 0;
+  if (t.nt > 1) {
+    float zt = (float)x[0];
+    float tt = (float)(bl2ks_time((double)(float)x[1], (double)zt, (double)a) - bl2ks_time((double)(float)r1, 0.0, (double)a));
+    tt = (float)(-(double)tt + 1e-8);
+    const int maxtindx = t.nt - 2;
+    const int fl = (int)std::floor(tt / t.tstep);
+    tindx = (fl <= maxtindx) ? fl : maxtindx + 1;
+    if (tindx < 0) tindx = 0;                                  // (out-of-bounds in the reference)
+  }
+  const size_t toff = (size_t)tindx * ((size_t)nx1 * nx2);
   float theta = (float)x[2], zr = (float)x[1];
   float x1 = std::log(zr);
   // transformbl2mksh: args are REAL(4) widened to double
@@ -158,9 +184,9 @@ inline void harm_vals(const HarmTable &t, const double *x, float a, FluidPoint &
   int x2l = lx2c - 1, x2u = ux2 - 1, x1l = (lx1c - 1) * nx2, x1u = (ux1c - 1) * nx2;
   int idx[4] = {x1l + x2l, x1l + x2u, x1u + x2l, x1u + x2u};
   auto g = [&](const std::vector<float> &arr) {
-    // trilininterp(vv, xd=0, yd=rd, zd=td) with both time slices equal (interpolate.f90:185-203)
-    float i1 = arr[idx[0]] * (1.f - td) + arr[idx[1]] * td;
-    float i2 = arr[idx[2]] * (1.f - td) + arr[idx[3]] * td;
+    // trilininterp(vv, xd=0, yd=rd, zd=td): zero time weight, only slice tindx contributes (interpolate.f90:185-203)
+    float i1 = arr[toff + idx[0]] * (1.f - td) + arr[toff + idx[1]] * td;
+    float i2 = arr[toff + idx[2]] * (1.f - td) + arr[toff + idx[3]] * td;
     float w1 = i1 * (1.f - rd) + i2 * rd;
     return w1 * (1.f - 0.f) + w1 * 0.f;
   };

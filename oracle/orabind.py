@@ -45,7 +45,7 @@ DEFAULTS = dict(standard=1, mu0=0.906, phi0=-0.5, spin=0.998, uout=0.01,
                 dfile=os.path.join(DATA, "m87bl09rfp10xi5a998fluidvars.bin"),
                 pltab=os.path.join(DATA, "polsynchpl_tables.bin"),
                 mbh=3.4e9, gmin=100., gmax=1e5, p1=3.5, ftscl=2.0, frscl=70.0,
-                coefindx=(1,) * 7, nvals=4, hfile="dump040", findf=40, mdot=1.57e15, muval=0.25, datadir=None, fmdot=0.1)
+                coefindx=(1,) * 7, nvals=4, hfile="dump040", findf=40, mdot=1.57e15, muval=0.25, datadir=None, fmdot=0.1, fnt=1)
 
 
 class Oracle:
@@ -72,7 +72,7 @@ class Oracle:
                               C.c_double(p["gmin"]), C.c_double(p["gmax"]), C.c_double(p["p1"]),
                               C.c_double(p["ftscl"]), C.c_double(p["frscl"]), _ip(ci), C.c_int(p["nvals"]),
                               p["hfile"].encode(), C.c_int(p["findf"]), C.c_double(p["mdot"]), C.c_double(p["muval"]),
-                              C.c_double(p["fmdot"]))
+                              C.c_double(p["fmdot"]), C.c_int(p["fnt"]))
         if rc != 0:
             raise RuntimeError("grto_setup failed rc=%d" % rc)
         self.npix = int(nn[0]) * int(nn[1])

@@ -44,7 +44,7 @@ int hs_ray_points_fast(const GrtCam *cam, int ii, int maxn, double *u, double *m
   if (fast) realray_init(*cam, R, K);
   for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
     GeoPoint P;
-    if (fast) ray_point_real<true>(*cam, R, K, idx, P); else ray_point(*cam, R, idx, P);
+    if (fast) ray_point_real<3>(*cam, R, K, idx, P); else ray_point(*cam, R, idx, P);   // 3: azimuth + coordinate time
     u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
     tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
   }
@@ -113,13 +113,23 @@ void hs_polsynchth(double nu, double n, double B, double T, double th, double *e
 // to grt_upload_harm; here that entry point is a capture stub that packs them exactly as grt_api.cpp does.
 static GrtHarm g_harm;
 static std::vector<float> g_cells, g_crd;
-int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float *x2_arr, const float *rho,
-                    const float *p, const float *b0, const float *br, const float *bth, const float *bph,
-                    const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+int grt_upload_harm_slices(int nx1, int nx2, int nt, float tstep, float h, const float *x1_arr, const float *x2_arr,
+                           const float *rho, const float *p, const float *b0, const float *br, const float *bth,
+                           const float *bph, const float *u0, const float *vrl, const float *vtl, const float *vpl) {
   const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
-  grt_harm_pack(nx1, nx2, h, x1_arr, x2_arr, src, g_cells, g_crd);
+  grt_harm_pack(nx1, nx2, h, x1_arr, x2_arr, src, g_cells, g_crd, nt);
   g_harm.cells = g_cells.data(); g_harm.coords = g_crd.data(); g_harm.nx1 = nx1; g_harm.nx2 = nx2; g_harm.h = h;
+  g_harm.nt = nt; g_harm.tstep = tstep;
   return 0;
+}
+// t, r1: coordinate time of the point and radius of the ray's first point (slice selection when nt > 1)
+void hs_harm_point_t(double r, double th, double t, double r1, double a, double mbh, double mdot, double muval, double gminval,
+                     double *out14) {
+  FluidPoint f;
+  harm_sample(g_harm, g_crd.data(), r, th, (float)a, f, harm_time_index(g_harm, r, t, r1, (float)a));
+  out14[0] = f.rho; out14[1] = f.p; out14[2] = f.bmag;
+  for (int i = 0; i < 4; ++i) { out14[3 + i] = f.u[i]; out14[7 + i] = f.b[i]; }
+  harm_convert(f, mbh, mdot, muval, gminval, out14[11], out14[12], out14[13]);
 }
 void hs_harm_point(double r, double th, double a, double mbh, double mdot, double muval, double gminval, double *out14) {
   FluidPoint f;

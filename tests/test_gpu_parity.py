@@ -469,3 +469,43 @@ def test_harm_movie_frames_through_both_hosts(tmp_path, monkeypatch):
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(np.transpose(y.ivals, (1, 0, 2)).astype(np.float32), x.ivals.astype(np.float32))
+
+
+def test_harm_slow_light_three_slices_device_and_fortran_host(tmp_path, monkeypatch):
+    # fnt=3 (hnt=3): three dumps resident, every point reads the slice its Kerr-Schild look-back time selects; the
+    # geo kernels carry the coordinate time (fast path: third [-2] integral), golden = compiled reference
+    import hashlib
+    import subprocess
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "harm_slowlight_32x32x100.npz"))
+    monkeypatch.chdir(tmp_path)
+    paths = make_golden.write_slow_dumps(str(tmp_path))
+    assert [hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)] == list(g["dump_sha256"])
+    dev = capi.Device(0)
+    dev.load_tables()
+    dev.load_harm("dump", "dump041", 41, 0.9375, nt=3)
+    cam = capi.make_camera(1, (-13., 13., -13., 13.), (32, 32, 100), 0.9375, 0.6428, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5, muval=0.25, mdot=1.57e15)
+    for iname in ("formal", "delo"):
+        for rec in (False, True):
+            capi.record_steps(rec)
+            pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], iname)
+            assert np.array_equal(status, g["npts"])
+            assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL, (iname, rec)
+    capi.record_steps(False)
+    dev.close()
+    kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375,
+              standard=1, nn=[32, 32, 100], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428,
+              mumax=.6428, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', cflag=0, hdfile='dump',
+              hhfile='dump041', hindf=41, hnt=3)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal"]) < STOKES_TOL

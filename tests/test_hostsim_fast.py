@@ -51,7 +51,7 @@ def test_per_point_paths_match_sequential_oracle(L, spin, mu0, gv, nn, uout, str
             n = abs(fn(cam, i, maxn, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc)))
             assert n == g["n"] and nc.value == g["ncase"]
             assert np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"])
-            keys = ("u", "mu", "dt", "dphi", "lam") if fn is L.hs_ray_points else ("u", "mu", "dphi", "lam")
+            keys = ("u", "mu", "dt", "dphi", "lam")     # the fast path is run with its coordinate-time option too
             for k, key in enumerate(("u", "mu", "dt", "dphi", "lam")):
                 if key in keys and n:
                     assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, key)
@@ -209,3 +209,34 @@ def test_thindisk_single_point_pixels_match_oracle(L):
             got[i] = p[0]
         assert np.array_equal(st, rn)
         assert np.abs(got - ref[0, :, 0]).max() <= 1e-5 * ref.max()
+
+
+def test_harm_slow_light_slice_selection_matches_oracle(L, tmp_path):
+    # three loaded slices (dumps 41, 40, 39, 20 M apart): the product's loader + time-index + sampler against the oracle
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_harm_dump
+    for k, (seed, t) in {41: (20261003, 2040.0), 40: (20261002, 2020.0), 39: (20261001, 2000.0)}.items():
+        make_harm_dump.write(str(tmp_path), n=64, name="dump%03d" % k, seed=seed, time=t)
+    kw = dict(fname="HARM", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1.57e15, mu0=0.6428,
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=1., dfile="dump", hfile="dump041", findf=41, fnt=3, nn=(32, 32, 100))
+    o = O.Oracle(iname="formal", datadir=str(tmp_path), **kw)
+    L.grt_load_harm_files_nt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double]
+    assert L.grt_load_harm_files_nt(str(tmp_path / "dump").encode(), str(tmp_path / "dump041").encode(), 41, 3, 0.9375) == 0
+    L.hs_harm_point_t.argtypes = [C.c_double] * 9 + [C.c_void_p]
+    seen = set()
+    for i in (510, 300, 720):
+        d = o.ray_dump(i, 2.3e11)
+        r1 = float(d["x"][0, 1])
+        for k in range(0, d["npts"], 3):
+            out = np.zeros(14)
+            L.hs_harm_point_t(float(d["x"][k, 1]), float(d["x"][k, 2]), float(d["x"][k, 0]), r1, 0.9375, 4e6, 1.57e15, 0.25, 1.0,
+                              out.ctypes.data)
+            want = np.concatenate([[d["rho"][k], d["p"][k], d["bmag"][k]], d["u"][k], d["b"][k],
+                                   [d["ncgs"][k], d["bcgs"][k], d["tcgs"][k]]])
+            tol = np.full(14, 1e-12); tol[2:7] = 3e-7; tol[12] = 3e-7
+            with np.errstate(all="ignore"):
+                err = np.abs(out - want) / np.abs(want)
+            assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
+            seen.add(int(np.floor((-d["x"][k, 0]) / 20.0)))
+    assert len(seen) >= 2          # the rays really cross slice boundaries

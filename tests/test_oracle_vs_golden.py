@@ -234,3 +234,23 @@ def test_thindisk_bb_single_point_config1():
         assert np.array_equal(npts, g["npts_" + tag])          # 1 = hits the plane, -1 = no crossing (status -1)
         ref = g["ivals_" + tag].astype(float)
         assert np.abs(pix[0] - ref).max() / ref.max() < 1e-6
+
+
+def test_harm_slow_light_three_slices(tmp_path):
+    # fnt=3: slice selection by Kerr-Schild look-back time (fluid_model_harm.f90:134-137,175-190); golden = compiled reference
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    g = load("harm_slowlight_32x32x100.npz")
+    paths = make_golden.write_slow_dumps(str(tmp_path))
+    assert [hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)] == list(g["dump_sha256"])
+    kw = dict(HARM); kw.update(hfile="dump041", findf=41, fnt=3)
+    for iname in ("formal", "delo"):
+        o = O.Oracle(nn=(32, 32, 100), iname=iname, datadir=str(tmp_path), **kw)
+        pix, npts, _ = o.trace(1, 1024, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g["npts"])
+        ref = g["ivals_" + iname].astype(float)
+        assert (np.abs(pix[0] - ref).max(axis=0) / np.abs(ref).max(axis=0)).max() < 1e-6
+    # and it is not the single-slice image
+    assert np.abs(g["ivals_formal"] - g["ivals_formal_fastlight"]).max() / np.abs(g["ivals_formal"]).max() > 1e-4

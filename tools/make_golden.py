@@ -234,6 +234,33 @@ def harm_movie():
     np.savez_compressed(os.path.join(G, "harm_movie_32x32x100.npz"), freq=FREQ_HARM, dt=30.0, **out)
 
 
+SLOW_DUMPS = {41: (20261003, 2040.0), 40: (20261002, 2020.0), 39: (20261001, 2000.0)}
+
+
+def write_slow_dumps(outdir, nzone=64):
+    import make_harm_dump
+    return {k: make_harm_dump.write(outdir, n=nzone, name="dump%03d" % k, seed=s, time=t) for k, (s, t) in SLOW_DUMPS.items()}
+
+
+def harm_slowlight():
+    # three loaded slices 20 M apart (fnt=3, findf=41): each point reads the dump its Kerr-Schild look-back time selects
+    import hashlib
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_slow_dumps(td)
+        out["dump_sha256"] = np.array([hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)])
+        kw = dict(HARM); kw.update(hfile="dump041", findf=41, fnt=3)
+        for iname in ("formal", "delo"):
+            r = R.Ref(nn=(32, 32, 100), iname=iname, datadir=td, **kw)
+            pix, npts, _ = r.trace(1, 1024, [FREQ_HARM], nthreads=8)
+            out["ivals_" + iname] = pix[0]; out["npts"] = npts
+        kw1 = dict(kw); kw1["fnt"] = 1
+        r = R.Ref(nn=(32, 32, 100), iname="formal", datadir=td, **kw1)
+        out["ivals_formal_fastlight"] = r.trace(1, 1024, [FREQ_HARM], nthreads=8)[0][0]
+    np.savez_compressed(os.path.join(G, "harm_slowlight_32x32x100.npz"), freq=FREQ_HARM, **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -249,4 +276,5 @@ if __name__ == "__main__":
     extra()
     thindisk()
     harm_movie()
+    harm_slowlight()
     print("golden fixtures written to", os.path.abspath(G))

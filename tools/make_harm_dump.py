@@ -35,7 +35,7 @@ def ks_metric(r, th, a):
     return g
 
 
-def make(n=256, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED):
+def make(n=256, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED, time=2000.0):
     rh = 1.0 + np.sqrt(1.0 - a * a)
     rin = 0.98 * rh
     startx1, startx2 = np.log(rin), 0.0
@@ -98,7 +98,7 @@ def make(n=256, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED):
     cols[..., 25:29] = bcov
     cols[..., 33] = gdet
     header = np.zeros(26)
-    header[0] = 2000.0
+    header[0] = time          # dump time (M): consecutive dumps of a slow-light set differ by the time step
     header[1], header[2] = n, n
     header[3], header[4], header[5], header[6] = startx1, startx2, dx1, dx2
     header[7] = 2000.0
