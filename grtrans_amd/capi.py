@@ -134,6 +134,28 @@ def trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=4, nextra=0, resident
     return pix, loc, status, st
 
 
+def compute_t0(cam, i1, i2):
+    """Raw per-ray time origins (nload > 1, geodesics.f90:113-128); normalise with normalise_t0, then set_t0."""
+    t0 = np.zeros(i2 - i1 + 1)
+    check(lib().grt_compute_t0(C.byref(cam), C.c_int64(i1), C.c_int64(i2), t0.ctypes.data_as(C.POINTER(C.c_double))),
+          "grt_compute_t0")
+    return t0
+
+
+def normalise_t0(t0):
+    """pgrtrans.f90:183-188"""
+    t0 = np.where(t0 > 0.0, t0 - t0.max(), 0.0)
+    return t0 - t0.min()
+
+
+def set_t0(t0):
+    if t0 is None:
+        check(lib().grt_set_t0(None, C.c_int64(0)), "grt_set_t0")
+    else:
+        t0 = np.ascontiguousarray(t0, dtype=np.float64)
+        check(lib().grt_set_t0(t0.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(t0.size)), "grt_set_t0")
+
+
 def record_steps(enable):
     check(lib().grt_set_record_steps(C.c_int(1 if enable else 0)), "grt_set_record_steps")
 

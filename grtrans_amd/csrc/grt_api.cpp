@@ -17,7 +17,8 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, int nlive, double *steps, unsigned long long *flags,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0);
+extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long i1, int nrays, double *t0);
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
@@ -44,6 +45,9 @@ struct Ctx {
   float *d_harm_cells = nullptr, *d_harm_coords = nullptr;
   GrtHarm harm{};
   bool have_harm = false;
+  double *d_t0 = nullptr;        // per-ray time origin of the current tile (nload > 1), or unset
+  size_t cap_t0 = 0;
+  long long t0_n = 0;
   float disk_mdot = 0.f, disk_rin = -1.f, disk_rout = 1e8f;
   bool have_disk = false;
   double *d_tables = nullptr;
@@ -116,7 +120,7 @@ int grt_free(void) {
   (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -233,6 +237,30 @@ int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float 
                     const float *p, const float *b0, const float *br, const float *bth, const float *bph,
                     const float *u0, const float *vrl, const float *vtl, const float *vpl) {
   return grt_upload_harm_slices(nx1, nx2, 1, 20.f, h, x1_arr, x2_arr, rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl);
+}
+
+int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_host) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!cam || !t0_host || i2 < i1 || i1 < 1 || i2 > (int64_t)cam->nro * cam->nphi || cam->standard != 1) return GRT_E_BADARG;
+  HIPCHK(hipSetDevice(C.device));
+  const int nrays = (int)(i2 - i1 + 1);
+  int rc;
+  if ((rc = grow(C.d_t0, C.cap_t0, (size_t)nrays))) return rc;
+  C.t0_n = 0;
+  HIPCHK(grt_launch_t0(C.stream, cam, (long long)i1, nrays, C.d_t0));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  HIPCHK(hipMemcpy(t0_host, C.d_t0, (size_t)nrays * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int grt_set_t0(const double *t0_host, int64_t n) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!t0_host || n <= 0) { C.t0_n = 0; return 0; }
+  int rc;
+  if ((rc = grow(C.d_t0, C.cap_t0, (size_t)n))) return rc;
+  HIPCHK(hipMemcpy(C.d_t0, t0_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  C.t0_n = n;
+  return 0;
 }
 
 int grt_set_thindisk(double mdot, double rin, double rout) {
@@ -368,6 +396,8 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1);
   if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;
   const int tfield = need_time ? nfields : -1;
+  if (need_time && C.t0_n != 0 && C.t0_n != (long long)(i2 - i1 + 1)) return GRT_E_BADARG;   // t0 table of another tile
+  const double *d_t0 = (need_time && C.t0_n != 0) ? C.d_t0 : nullptr;
   const int nalloc = nfields + (need_time ? 1 : 0);
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * nrays * rstride))) return rc;
   if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * (rstride / 64) * 2))) return rc;
@@ -390,9 +420,9 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const int nlive = ncls[0] + ncls[1];
   HIPCHK(hipEventRecord(C.ev[1], C.stream));
   // class 0 (four real roots, fast path) sits at the front of live[], class 1 (generic) at the back
-  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield));
+  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield, d_t0));
   HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
-                        rstride, fstride, nfields, tfield));
+                        rstride, fstride, nfields, tfield, d_t0));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
   HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, rstride,

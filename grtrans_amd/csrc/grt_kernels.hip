@@ -90,13 +90,30 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
 #define GRT_F_PHI 3
 #define GRT_F_I 4
 
+// nload > 1 (pgrtrans.f90:172-189 -> initialize_geo_tabs, geodesics.f90:113-128): the time origin of a ray is the
+// coordinate time of the single point of its nup=1, no-mu-fill geodesic = the first-point dt the set-up caches.
+__global__ __launch_bounds__(256) void grt_t0_kernel(GrtCam cam, long long i1, int nrays, double *__restrict__ t0) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= nrays) return;
+  GrtCam c1 = cam;
+  c1.nup = 1; c1.mufill = 0; c1.kext = 0; c1.next = 0;
+  GrtRay R;
+  setup_ray(c1, (int)(i1 + tid), R);
+  t0[tid] = (R.npts > 0) ? R.dt1 : 0.0;      // get_geo_tabs: t0 = 0 for a ray with no points
+}
+
+extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long i1, int nrays, double *t0) {
+  hipLaunchKernelGGL(grt_t0_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, i1, nrays, t0);
+  return hipGetLastError();
+}
+
 // FAST: 0 generic (every root case), 1 four real roots, 2 Schwarzschild cubic
 // NPH : 0 no azimuth, 2 azimuth (per-step record / extra=1), 3 azimuth + coordinate time (slow-light fluid models)
 template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     int nlive, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
-    long long field_stride, int nfields, int tfield) {
+    long long field_stride, int nfields, int tfield, const double *__restrict__ t0) {
   constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       sp[GRT_F_TH * field_stride] = acos(P.mu);
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
       if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = cam.phi0 - P.dphi;
-      if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt;     // x%data(1) = DTI(1)-DTI(i)-t0, t0 = 0 (geodesics.f90:345)
+      if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)
     }
     // turning-point parities of the chunk as two 64-bit lane masks (tpm, tpr): 0.25 bit-pairs per byte instead of a byte per point
     const unsigned long long mm = __ballot(valid && (P.tpm & 1)), mr = __ballot(valid && (P.tpr & 1));
@@ -489,7 +506,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, int nlive, double *steps, unsigned long long *flags,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield) {
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0) {
   if (nlive <= 0) return hipSuccess;
   dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
   const char *rr = (const char *)rrays;
@@ -498,7 +515,7 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   const int kind = !fast ? 0 : (cam->a == 0.0 ? 2 : 1);
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P)                                                                                            \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive, steps, flags, ray_stride, field_stride, nfields, tfield);
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive, steps, flags, ray_stride, field_stride, nfields, tfield, t0);
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE
   return hipGetLastError();

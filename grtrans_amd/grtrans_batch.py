@@ -122,8 +122,6 @@ class grtrans:
     def run_pgrtrans(self, device=0, **kwargs):
         """Same kwargs as write_grtrans_inputs; fills ivals(nvals,npix,ncams), ab(2,npix), nu."""
         inp = self.inputs = grtrans_inputs(**kwargs)
-        if inp.nload != 1:
-            raise capi.GrtError("slow light (nload > 1) is not on the device yet")
         nt = int(inp.nt)
         nextra = 19 if int(inp.extra) == 1 else 0           # pgrtrans.f90:108-114 (nup > 1)
         nfreq, nmu, nmdot = int(inp.nfreq), int(inp.nmu), int(inp.nmdot)
@@ -150,6 +148,13 @@ class grtrans:
             harm_indf, harm_toffset, harm_tstep = int(inp.findf), np.float32(0.), np.float32(20.)
             for j in range(nmu):
                 cam = capi.make_camera(inp.standard, inp.gridvals, inp.nn, inp.spin, float(mu0[j]), inp.uout, inp.phi0)
+                if int(inp.nload) > 1:
+                    # pgrtrans.f90:172-189: per-ray time origins from one-point geodesics, normalised over the image;
+                    # initialize_geo_tabs leaves the mu-fill segment switched off for the traces that follow
+                    cam.mufill, cam.kext, cam.next = 0, 0, 0
+                    capi.set_t0(capi.normalise_t0(capi.compute_t0(cam, inp.i1, inp.i2)))
+                else:
+                    capi.set_t0(None)
                 for l in range(nt):
                     if l > 0 and inp.fname == 'HARM':
                         # advance_harm_timestep (fluid_model_harm.f90:511-521): REAL(4) tstep, toffset kept across frames

@@ -53,6 +53,19 @@ module grt_cabi
        real(c_double), value :: spin
        integer(c_int) :: rc
      end function grt_load_harm_files
+     function grt_compute_t0(cam, i1, i2, t0) bind(C, name='grt_compute_t0') result(rc)
+       import :: c_int, c_int64_t, c_double, grt_camera
+       type(grt_camera), intent(in) :: cam
+       integer(c_int64_t), value :: i1, i2
+       real(c_double), intent(out) :: t0(*)
+       integer(c_int) :: rc
+     end function grt_compute_t0
+     function grt_set_t0(t0, n) bind(C, name='grt_set_t0') result(rc)
+       import :: c_int, c_int64_t, c_double
+       real(c_double), intent(in) :: t0(*)
+       integer(c_int64_t), value :: n
+       integer(c_int) :: rc
+     end function grt_set_t0
      function grt_set_thindisk(mdot, rin, rout) bind(C, name='grt_set_thindisk') result(rc)
        import :: c_int, c_double
        real(c_double), value :: mdot, rin, rout

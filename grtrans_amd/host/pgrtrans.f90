@@ -48,7 +48,7 @@ contains
     integer, dimension(7), intent(in) :: epcoefindx
 
     integer :: nro, nphi, nup, ncams, nextra, j, l, m, k, cam_index, rc, fluid_id, emis_id, iflag, npix, ntile, dev
-    real(8), allocatable :: mdots(:), mu0(:)
+    real(8), allocatable :: mdots(:), mu0(:), t0tab(:)
     real(c_float), allocatable :: pixvals(:), pixloc(:)
     integer(c_int32_t), allocatable :: status(:)
     type(grt_camera) :: cam
@@ -88,7 +88,6 @@ contains
 
     ! ---- what this build can put on the device; everything else stops loudly (no CPU path) ----
     if (.not. use_geokerr) call die('use_geokerr=F is not supported')
-    if (nload /= 1) call die('slow light (nload > 1) is not supported yet')
     if (debug /= 0) call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps')
     if (extra == 1 .and. nup <= 1) call die('extra=1 with nup=1 is not supported yet')
     select case (trim(fname))
@@ -157,6 +156,21 @@ contains
     do j = 1, nmu
        rc = grt_make_camera(cam, int(standard, c_int), gridvals, int(nn, c_int), spin, mu0(j), uout, phi0)
        if (rc /= 0) call die_rc('grt_make_camera', rc)
+       if (nload > 1) then
+          ! pgrtrans.f90:172-189: time origin of every ray from a one-point geodesic, normalised over the image;
+          ! initialize_geo_tabs (geodesics.f90:120) leaves the mu-fill segment switched off for what follows
+          cam%mufill = 0; cam%kext = 0; cam%next = 0
+          allocate(t0tab(ntile))
+          rc = grt_compute_t0(cam, int(i1, c_int64_t), int(i2, c_int64_t), t0tab); if (rc /= 0) call die_rc('grt_compute_t0', rc)
+          where (t0tab > 0.)
+             t0tab = t0tab - maxval(t0tab)
+          elsewhere
+             t0tab = 0.
+          end where
+          t0tab = t0tab - minval(t0tab)
+          rc = grt_set_t0(t0tab, int(ntile, c_int64_t)); if (rc /= 0) call die_rc('grt_set_t0', rc)
+          deallocate(t0tab)
+       end if
        wtime = omp_get_wtime()
        do l = 1, nt
           if (l > 1) call advance_fluid_timestep(dt)             ! pgrtrans.f90:211 (after frame l-1)

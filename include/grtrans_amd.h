@@ -113,6 +113,14 @@ int grt_load_polsynchpl_tables_file(const char *path);
 int grt_make_camera(grt_camera *cam, int standard, const double gridvals[4], const int nn[3], double spin,
                     double mu0, double uout, double phi0);
 
+/* nload > 1 (pgrtrans.f90:172-189): grt_compute_t0 replaces the loop over initialize_geo_tabs (geodesics.f90:113-128)
+ * and returns the RAW per-ray time origins of pixels i1..i2; the caller normalises them over the image exactly as
+ * pgrtrans does (where(t0>0) t0=t0-max(t0) elsewhere 0; t0=t0-min(t0)) and hands the table for the NEXT traces of
+ * the same tile to grt_set_t0 (NULL clears it).  As in the reference, the caller also clears mufill/kext/next of the
+ * camera for those traces.  The table only matters with several HARM slices loaded. */
+int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_host);
+int grt_set_t0(const double *t0_host, int64_t n);
+
 /* replaces the i=i1..i2 loop over grtrans_driver (pgrtrans.f90:200-207).
  *   i1,i2     1-based inclusive pixel range, reference semantics (read_inputs.f90:8-9)
  *   pixvals   HOST out, [nfreq][i2-i1+1][nvals+nextra] REAL(4): c(cam)%pixvals(:,i) (camera.f90:35)

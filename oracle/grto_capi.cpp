@@ -24,6 +24,7 @@ struct Setup {
   SphaccTable sphacc;
   HarmTable harm;
   ThinDisk disk;
+  std::vector<double> t0;     // per-ray time origin (nload > 1), empty = zero
   double mdot = 0, muval = 0;
   PLTables pl;
   bool ok = false;
@@ -41,7 +42,7 @@ struct RayWork {
 void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, double *extra = nullptr) {
   if (extra) for (int c = 0; c < 19; ++c) extra[c] = 0.0;
   Pixel px = camera_pixel(S.cam, ii);
-  make_geodesic(S.cam, px, S.phi0, 0.0, w.g);
+  make_geodesic(S.cam, px, S.phi0, S.t0.empty() ? 0.0 : S.t0[ii - 1], w.g);
   const int n = w.g.npts;
   for (int c = 0; c < 4; ++c) pix[c] = 0.0;
   fac = 0.0;
@@ -285,6 +286,29 @@ void grto_trace(int i1, int i2, int nfreq, const double *freqs, int nthreads, fl
     }
   }
   *seconds = omp_get_wtime() - t0;
+}
+
+// nload > 1 (pgrtrans.f90:172-189, geodesics.f90:113-145): time origin of every ray from a one-point geodesic
+// (nup=1, no mu-fill), normalised over the image; initialize_geo_tabs also leaves the mu-fill segment switched off.
+void grto_nload_t0(int i1, int i2, double *t0out) {
+  const int npix = S.cam.nro * S.cam.nphi;
+  S.t0.assign(npix, 0.0);
+  S.cam.kext = 0; S.cam.next = 0; S.cam.mufill = 0;
+  Camera c1 = S.cam;
+  c1.nup = 1;
+  for (int i = i1; i <= i2; ++i) {
+    Pixel px = camera_pixel(c1, i);
+    Geodesic g;
+    make_geodesic(c1, px, S.phi0, 0.0, g);
+    S.t0[i - 1] = (g.npts == 0) ? 0.0 : g.x[0];
+  }
+  double mx = -1e300;
+  for (double v : S.t0) mx = std::max(mx, v);
+  for (double &v : S.t0) v = (v > 0.0) ? v - mx : 0.0;
+  double mn = 1e300;
+  for (double v : S.t0) mn = std::min(mn, v);
+  for (double &v : S.t0) v -= mn;
+  for (int i = 0; i < npix; ++i) t0out[i] = S.t0[i];
 }
 
 // extra=1: [npix_range][nvals+19] fp32 for one frequency

@@ -116,6 +116,11 @@ class Oracle:
             out[k] = dump[c, :max(n, 0)].T.copy() if isinstance(c, slice) else dump[c, :max(n, 0)].copy()
         return out
 
+    def nload_t0(self, i1=None, i2=None):
+        t0 = np.zeros(self.npix)
+        lib().grto_nload_t0(C.c_int(i1 or 1), C.c_int(i2 or self.npix), _dp(t0))
+        return t0
+
     def trace_extra(self, i1, i2, freq, nthreads=0):
         n = i2 - i1 + 1
         pix = np.zeros((n, self.nvals + 19), dtype=np.float32)

@@ -108,6 +108,27 @@ contains
     is_setup = .true.
   end subroutine ref_setup
 
+  ! nload > 1 (pgrtrans.f90:172-189): the look-back time origin t0 of every ray from a one-point geodesic, normalised
+  ! over the image.  initialize_geo_tabs also switches the mu-fill segment off for everything that follows.
+  subroutine ref_nload_t0(i1, i2, t0out) bind(C, name='ref_nload_t0')
+    integer(c_int), value :: i1, i2
+    real(c_double), intent(out) :: t0out(npix_s)
+    integer :: i
+    gargs%t0 = 0d0
+    gargs%nup = 1
+    do i = i1, i2
+       call initialize_geo_tabs(gargs, i)
+    end do
+    where (gargs%t0 > 0.)
+       gargs%t0 = gargs%t0 - maxval(gargs%t0)
+    elsewhere
+       gargs%t0 = 0.
+    end where
+    gargs%t0 = gargs%t0 - minval(gargs%t0)
+    gargs%nup = nup_s
+    t0out = gargs%t0
+  end subroutine ref_nload_t0
+
   ! advance_fluid_timestep(fname,dt) between movie frames (pgrtrans.f90:211): for HARM it re-loads dumps
   subroutine ref_advance_timestep(dt) bind(C, name='ref_advance_timestep')
     real(c_double), value :: dt

@@ -134,6 +134,12 @@ class Ref:
             out[k] = dump[c, :max(n, 0)].T.copy() if isinstance(c, slice) else dump[c, :max(n, 0)].copy()
         return out
 
+    def nload_t0(self, i1=None, i2=None):
+        """pgrtrans.f90:172-189 (nload > 1): per-ray time origin, normalised; also turns the mu-fill segment off."""
+        t0 = np.zeros(self.npix)
+        lib().ref_nload_t0(C.c_int(i1 or 1), C.c_int(i2 or self.npix), _dp(t0))
+        return t0
+
     def advance_timestep(self, dt):
         """advance_fluid_timestep between movie frames (HARM: re-loads dumps; relative paths -> run in datadir)."""
         cwd = os.getcwd()

@@ -499,6 +499,16 @@ def test_harm_slow_light_three_slices_device_and_fortran_host(tmp_path, monkeypa
             assert np.array_equal(status, g["npts"])
             assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL, (iname, rec)
     capi.record_steps(False)
+    # nload > 1: time-origin table (raw from the device, normalised as pgrtrans does), mu-fill off
+    cam.mufill, cam.kext, cam.next = 0, 0, 0
+    t0 = capi.normalise_t0(capi.compute_t0(cam, 1, 1024))
+    assert np.abs(t0 - g["t0_nload"]).max() < 1e-6
+    capi.set_t0(t0)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], "formal")
+    assert np.array_equal(status, g["npts_nload"]) and stokes_err(pix[0], g["ivals_formal_nload"]) < STOKES_TOL
+    with pytest.raises(capi.GrtError):
+        capi.trace_tile(cam, 1, 512, "HARM", em, [FREQ_HARM], "formal")          # the table belongs to another tile
+    capi.set_t0(None)
     dev.close()
     kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375,
               standard=1, nn=[32, 32, 100], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428,
@@ -509,3 +519,13 @@ def test_harm_slow_light_three_slices_device_and_fortran_host(tmp_path, monkeypa
     x.run_grtrans()
     x.read_grtrans_output(bin=1)
     assert stokes_err(x.ivals[:, :, 0], g["ivals_formal"]) < STOKES_TOL
+    # the same with nload=3 through the Fortran host and the harness
+    kw["nload"] = 3
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_nload"]) < STOKES_TOL
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))

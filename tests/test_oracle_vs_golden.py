@@ -254,3 +254,11 @@ def test_harm_slow_light_three_slices(tmp_path):
         assert (np.abs(pix[0] - ref).max(axis=0) / np.abs(ref).max(axis=0)).max() < 1e-6
     # and it is not the single-slice image
     assert np.abs(g["ivals_formal"] - g["ivals_formal_fastlight"]).max() / np.abs(g["ivals_formal"]).max() > 1e-4
+    # nload > 1: the per-ray time origin table (and no mu-fill segment afterwards)
+    o = O.Oracle(nn=(32, 32, 100), iname="formal", datadir=str(tmp_path), **kw)
+    t0 = o.nload_t0()
+    assert np.abs(t0 - g["t0_nload"]).max() < 1e-6          # differences of ~1e8 M elapsed times
+    pix, npts, _ = o.trace(1, 1024, [float(g["freq"])], nthreads=8)
+    assert np.array_equal(npts, g["npts_nload"]) and set(np.unique(npts)) == {100}
+    ref = g["ivals_formal_nload"].astype(float)
+    assert (np.abs(pix[0] - ref).max(axis=0) / np.abs(ref).max(axis=0)).max() < 1e-6

@@ -258,6 +258,11 @@ def harm_slowlight():
         kw1 = dict(kw); kw1["fnt"] = 1
         r = R.Ref(nn=(32, 32, 100), iname="formal", datadir=td, **kw1)
         out["ivals_formal_fastlight"] = r.trace(1, 1024, [FREQ_HARM], nthreads=8)[0][0]
+        # nload > 1: per-ray time origin table + mu-fill off (pgrtrans.f90:172-189)
+        r = R.Ref(nn=(32, 32, 100), iname="formal", datadir=td, **kw)
+        out["t0_nload"] = r.nload_t0()
+        pix, npts, _ = r.trace(1, 1024, [FREQ_HARM], nthreads=8)
+        out["ivals_formal_nload"] = pix[0]; out["npts_nload"] = npts
     np.savez_compressed(os.path.join(G, "harm_slowlight_32x32x100.npz"), freq=FREQ_HARM, **out)
 
 
