@@ -99,6 +99,46 @@ class grtrans_inputs:
         nm.write_namelist(fname, names, args, vals, nargs)
 
 
+def read_fits(path):
+    """Minimal FITS reader (no astropy in this image): [(cards, data)] per HDU, cards = [(keyword, value string)],
+    data = flat big-endian array converted to native float32/float64/int."""
+    out = []
+    with open(path, 'rb') as f:
+        raw = f.read()
+    pos = 0
+    while pos < len(raw):
+        cards, end = [], False
+        while not end:
+            block = raw[pos:pos + 2880]
+            if len(block) < 2880:
+                return out
+            pos += 2880
+            for i in range(36):
+                c = block[80 * i:80 * (i + 1)].decode('ascii', 'replace')
+                if c.startswith('END') and c[3:].strip() == '':
+                    end = True
+                    break
+                if c.strip() == '':
+                    continue
+                if c.startswith('HIERARCH'):
+                    k, _, v = c[8:].partition('=')
+                else:
+                    k, v = c[:8], c[10:] if c[8:10] == '= ' else ''
+                v = v.split(' / ')[0].strip()
+                cards.append((k.strip(), v.strip("' ").strip() if v.startswith("'") else v))
+        hd = dict(cards)
+        bitpix = int(hd.get('BITPIX', 8)); naxis = int(hd.get('NAXIS', 0))
+        n = 1 if naxis else 0
+        for a in range(1, naxis + 1):
+            n *= int(hd['NAXIS%d' % a])
+        dt = {-32: '>f4', -64: '>f8', 16: '>i2', 32: '>i4', 64: '>i8', 8: 'u1'}[bitpix]
+        nbytes = n * abs(bitpix) // 8
+        data = np.frombuffer(raw, dtype=dt, count=n, offset=pos).astype(dt[1:]) if n else np.zeros(0)
+        pos += (nbytes + 2879) // 2880 * 2880
+        out.append((cards, data))
+    return out
+
+
 class grtrans:
     """run & analyze grtrans on the MI355X path (same methods as the reference's class grtrans)"""
 
@@ -183,7 +223,19 @@ class grtrans:
     def read_grtrans_output(self, bin=1):
         """cflag=0 binary file (camera.f90:321-340): Fortran sequential records per camera."""
         if bin == 0:
-            raise capi.GrtError("FITS output (cflag=1) needs cfitsio; write cflag=0 and read with bin=1")
+            # FITS (cflag=1): primary HDU = pixloc, one IMAGE extension per camera; nx, ny, nu are the three cards after
+            # the six mandatory ones (the reference reads them by position: hdu.header.get(6..8), grtrans_batch.py:431-434)
+            hdus = read_fits(self.ofile)
+            ab = hdus[0][1].reshape(-1, 2)
+            nx = int(float(hdus[1][0][6][1])); ny = int(float(hdus[1][0][7][1]))
+            nus = [float(h[0][8][1]) for h in hdus[1:]]
+            nvals = hdus[1][1].size // (nx * ny)
+            self.ab = ab
+            self.ivals = np.stack([h[1].reshape(nx * ny, nvals) for h in hdus[1:]], axis=2).astype(np.float64)
+            self.nu = np.array(nus)
+            self.nx, self.ny, self.nvals = nx, ny, nvals
+            self.calc_spec(len(nus))
+            return
         ivals, nus = [], []
         with open(self.ofile, 'rb') as f:
             def rec(dtype):

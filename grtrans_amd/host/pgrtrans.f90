@@ -30,6 +30,7 @@ contains
        fwmin,fwmax,ffmin,ffmax,frmax,fsigt,ffcol,fmdot,fnscl,fnnthscl,fnnthp,fbeta, &
        fbl06,fnp,ftp,frin,frout,fthin,fthout,fphiin,fphiout,fscalefac,sigcut,epcoefindx,epotherargs,nepotherargs)
     use grt_cabi
+    use fits_min
     use omp_lib
     integer, intent(in) :: standard,nrotype,nvals,nfreq,nmu,cflag,nt,nmdot,nload,extra,i1,i2,nepotherargs,debug
     logical, intent(in) :: use_geokerr
@@ -195,9 +196,41 @@ contains
        write(6,*) 'ray-steps: ', last_ray_steps, ' device ms: ', last_kernel_ms
     end do
     ab(:, i1:i2) = reshape(dble(pixloc), (/2, ntile/))      ! c(1)%pixloc (pgrtrans.f90:227)
-    if (len_trim(outfile) > 0) then
+    if (len_trim(outfile) > 0 .and. cflag /= 1) then
        do m = 1, ncams
           call write_camera(trim(outfile), m, nro, nphi, nvals+nextra, freqs(1+mod(m-1,nfreq)), ab, ivals(:,:,m), cflag)
+       end do
+    else if (len_trim(outfile) > 0) then
+       ! cflag=1: the FITS layout of kwrite_raytrace_camera (camera.f90:185-319) through the built-in emitter
+       do m = 1, ncams
+          if (m == 1) then
+             call fits_open_new(12, trim(outfile))
+             call fits_primary(12, real(reshape(ab, (/2*npix/))))
+          else
+             call fits_open_append(12, trim(outfile))
+          end if
+          call fits_image_begin(npix*(nvals+nextra))
+          call fits_key_d('nx', dble(real(nro)), '# x pixels')
+          call fits_key_d('ny', dble(real(nphi)), '# y pixels')
+          call fits_key_d('nu', dble(real(freqs(1+mod(m-1,nfreq)))), 'Frequency (Hz)')
+          call fits_key_i('standard', standard, 'standard'); call fits_key_d('mumin', mumin, 'mumin')
+          call fits_key_d('mumax', mumax, 'mumax'); call fits_key_i('nmu', nmu, 'nmu'); call fits_key_d('phi0', phi0, 'phi0')
+          call fits_key_d('spin', spin, 'spin'); call fits_key_d('uout', uout, 'uout'); call fits_key_d('uin', uin, 'uin')
+          call fits_key_d('rcut', rcut, 'rcut'); call fits_key_i('nrotype', nrotype, 'nrotype')
+          call fits_key_d('gridvals(1)', gridvals(1), 'gridvals(1)'); call fits_key_d('gridvals(2)', gridvals(2), 'gridvals(2)')
+          call fits_key_d('gridvals(3)', gridvals(3), 'gridvals(3)'); call fits_key_d('gridvals(4)', gridvals(4), 'gridvals(4)')
+          call fits_key_i('nn(1)', nn(1), 'nn(1)'); call fits_key_i('nn(2)', nn(2), 'nn(2)'); call fits_key_i('nn(3)', nn(3), 'nn(3)')
+          call fits_key_s('fname', trim(fname), 'fname'); call fits_key_d('dt', dt, 'dt'); call fits_key_i('nt', nt, 'nt')
+          call fits_key_i('nload', nload, 'nload'); call fits_key_i('nmdot', nmdot, 'nmdot')
+          call fits_key_d('mdotmin', mdotmin, 'mdotmin'); call fits_key_d('mdotmax', mdotmax, 'mdotmax')
+          call fits_key_s('ename', trim(ename), 'ename'); call fits_key_d('mbh', mbh, 'mbh'); call fits_key_i('nfreq', nfreq, 'nfreq')
+          call fits_key_d('fmin', fmin, 'fmin'); call fits_key_d('fmax', fmax, 'fmax'); call fits_key_d('muval', muval, 'muval')
+          call fits_key_d('gmin', gmin, 'gmin'); call fits_key_d('gmax', gmax, 'gmax'); call fits_key_d('p1', p1, 'p1')
+          call fits_key_d('p2', p2, 'p2'); call fits_key_d('jetalpha', jetalpha, 'jetalpha'); call fits_key_s('stype', trim(stype), 'stype')
+          call fits_key_s('use_geokerr', merge('T', 'F', use_geokerr), 'use_geokerr'); call fits_key_i('nvals', nvals, 'nvals')
+          call fits_key_s('iname', trim(iname), 'iname'); call fits_key_i('cflag', cflag, 'cflag'); call fits_key_i('extra', extra, 'extra')
+          call fits_image_end(12, real(reshape(ivals(:,:,m), (/npix*(nvals+nextra)/))))
+          call fits_close(12)
        end do
     end if
     deallocate(pixvals, pixloc, status, mu0, mdots)
@@ -212,7 +245,6 @@ contains
     real(8), intent(in) :: freq, abv(:,:), iv(:,:)
     integer :: k
     real(4) :: kvals(3)
-    if (cflag == 1) call die('cflag=1 (FITS) needs cfitsio, which this build does not link; use cflag=0')
     if (cnum == 1) then
        open(unit=12, file=outfile, form='unformatted', status='replace')
     else

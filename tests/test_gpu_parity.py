@@ -529,3 +529,31 @@ def test_harm_slow_light_three_slices_device_and_fortran_host(tmp_path, monkeypa
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
+
+
+def test_fits_output_cflag1_through_fortran_host(tmp_path, monkeypatch):
+    # cflag=1: the reference's default on-disk format.  The host writes FITS with its own emitter (no cfitsio here),
+    # the harness reads it back without astropy; nx, ny, nu sit at header positions 6, 7, 8 as the reference's reader
+    # expects.  (Format parity with cfitsio's output is unpinned: neither cfitsio nor astropy exists in this image.)
+    import subprocess
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "ffjet_32x32x100.npz"))
+    kw = dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=2, nmu=1, fmin=FREQ, fmax=2 * FREQ,
+              ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1, nn=[32, 32, 100], uout=0.01, mbh=3.4e9,
+              mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], ntscl=2., nrscl=70., iname='formal', cflag=1)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.fits', **kw)
+    x.run_grtrans()
+    raw = open('grtrans.fits', 'rb').read()
+    assert len(raw) % 2880 == 0 and raw[:30].decode() == "SIMPLE  =                    T"
+    hdus = gb.read_fits('grtrans.fits')
+    assert len(hdus) == 3 and [k for k, _ in hdus[1][0][:9]] == ['XTENSION', 'BITPIX', 'NAXIS', 'NAXIS1', 'PCOUNT', 'GCOUNT', 'NX', 'NY', 'NU']
+    assert dict(hdus[1][0])['gridvals(3)'].startswith('-2.0') and dict(hdus[2][0])['FNAME'] == 'FFJET'
+    x.read_grtrans_output(bin=0)
+    assert x.ivals.shape == (1024, 4, 2) and np.allclose(x.nu, [FREQ, 2 * FREQ], rtol=1e-6)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal"]) < STOKES_TOL
+    assert np.array_equal(x.ab[:, 0], g["cam_alpha"].astype(np.float32))
