@@ -62,6 +62,32 @@ def test_ffjet_vs_oracle_other_camera(dev):
     assert stokes_err(pix, ref) < STOKES_TOL
 
 
+CAMERA_SWEEP = [(0.1, 0.95, (-20., 20., -20., 20.), 0.02), (0.7, 0.0, (-15., 15., -15., 15.), 0.03),
+                (0.998, 1.0, (-20., 20., -20., 20.), 0.02), (0.9, -0.8, (-30., 10., -10., 30.), 0.015),
+                (0.3, 0.2, (-12., 12., -12., 12.), 0.05), (0.0, -0.4, (-18., 18., -18., 18.), 0.03)]
+
+
+@pytest.mark.parametrize("spin,mu0,gv,uout", CAMERA_SWEEP)
+def test_camera_sweep_vs_oracle(dev, spin, mu0, gv, uout):
+    # slow and fast rotators, equatorial (mu0=0), pole-on (mu0=1), southern (mu0<0) and Schwarzschild cameras: the
+    # fast classes, the generic path and the mu-fill logic against the oracle (itself equal to the compiled reference
+    # on these cameras to <1e-8 of peak, checked with oracle/refbind.py)
+    from grtrans_amd import capi
+    from oracle import orabind
+    nn = (24, 24, 80)
+    for iname in ("formal", "delo"):
+        o = orabind.Oracle(nn=nn, iname=iname, spin=spin, mu0=mu0, gridvals=gv, uout=uout)
+        ref, rn, _ = o.trace(1, nn[0] * nn[1], [FREQ], nthreads=0)
+        cam = capi.make_camera(1, gv, nn, spin, mu0, uout, -0.5)
+        em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+        for rec in (False, True):
+            capi.record_steps(rec)
+            pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [FREQ], iname)
+            assert np.array_equal(status, rn)
+            assert stokes_err(pix, ref) < STOKES_TOL, (iname, rec)
+    capi.record_steps(False)
+
+
 def test_tiles_equal_full_image(dev):
     # i1..i2 semantics (read_inputs.f90:8-9): a tile reproduces exactly those pixels of the full run
     nn = (32, 32, 100)
