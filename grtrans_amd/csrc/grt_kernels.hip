@@ -175,6 +175,27 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 // EXTRA (FB = 1 only): the 19 ray diagnostics of EXTRA_QUANTS=1 (grtrans_driver.f90:230-292) as running sums of
 // the same far-end -> camera walk: six optical depths, emission-weighted means through the attenuated-sum
 // recurrence S <- e^{-dtau} S + dx/2 (w_k + w_k+1 e^{-dtau}), and the LP-increment-weighted means.
+// The by-value argument structs (camera, emissivity, power-law constants: ~100 SGPRs) do not fit beside the table
+// pointers and literal constants of the step loop; held for the whole kernel they are parked in VGPR lanes and
+// every use costs a v_readlane on the vector pipe.  Re-reading them from the kernarg segment inside the loop
+// (scalar loads from the constant cache, issued on the scalar pipe) keeps them live only where they are used.
+#define GRT_AS4 __attribute__((address_space(4)))
+struct XferKargHead { GrtCam cam; const GrtRay *rays; const int *live; int nlive; GrtFluidDev fd; GrtTables tb; GrtEmis em; GrtPLConst plc; };
+__device__ __forceinline__ const char GRT_AS4 *karg_fresh() {     // a kernarg pointer the optimiser cannot hoist loads through
+  const char GRT_AS4 *p = (const char GRT_AS4 *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 *base, size_t off) {
+  static_assert(sizeof(T) % 4 == 0, "dword-sized arguments only");
+  T out;
+  unsigned *o = reinterpret_cast<unsigned *>(&out);
+  const unsigned GRT_AS4 *q = reinterpret_cast<const unsigned GRT_AS4 *>(base + off);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
+  return out;
+}
+
 template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
 __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
@@ -188,7 +209,31 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
   __shared__ int s_n[NW][64];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
   __shared__ float s_harm[FLUID == GRT_FLUID_HARM ? 2 * GRT_HARM_MAXCOORD : 1];
+  // polsynchpl: the p-bin's row of every log-G table and slope table (3 x 181 + 11 x 81 doubles = 11.2 KB) lives in
+  // LDS: 36 look-ups per step and frequency become ds_reads and the 14 table pointers leave the SGPR file
+  constexpr int PLG = 181, PLX = 81, PLN = 3 * PLG + 11 * PLX;
+  __shared__ double s_pl[EMIS == GRT_EMIS_POLSYNCHPL ? PLN : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  GrtTables tbl = tb;
+  if (EMIS == GRT_EMIS_POLSYNCHPL) {
+    const int iy = plc.iy;
+    for (int i = threadIdx.x; i < PLG; i += blockDim.x) {
+      s_pl[i] = tb.gx[i]; s_pl[PLG + i] = tb.gy[iy * PLG + i]; s_pl[2 * PLG + i] = tb.sgy[iy * PLG + i];
+    }
+    double *x = s_pl + 3 * PLG;
+    for (int i = threadIdx.x; i < PLX; i += blockDim.x) {
+      x[i] = tb.xv[i];
+      x[1 * PLX + i] = tb.ya[iy * PLX + i];  x[2 * PLX + i] = tb.sya[iy * PLX + i];
+      x[3 * PLX + i] = tb.yp[iy * PLX + i];  x[4 * PLX + i] = tb.syp[iy * PLX + i];
+      x[5 * PLX + i] = tb.yv[iy * PLX + i];  x[6 * PLX + i] = tb.syv[iy * PLX + i];
+      x[7 * PLX + i] = tb.yap[iy * PLX + i]; x[8 * PLX + i] = tb.syap[iy * PLX + i];
+      x[9 * PLX + i] = tb.yav[iy * PLX + i]; x[10 * PLX + i] = tb.syav[iy * PLX + i];
+    }
+    tbl.gx = s_pl; tbl.gy = s_pl + PLG; tbl.sgy = s_pl + 2 * PLG;
+    tbl.xv = x; tbl.ya = x + PLX; tbl.sya = x + 2 * PLX; tbl.yp = x + 3 * PLX; tbl.syp = x + 4 * PLX;
+    tbl.yv = x + 5 * PLX; tbl.syv = x + 6 * PLX; tbl.yap = x + 7 * PLX; tbl.syap = x + 8 * PLX;
+    tbl.yav = x + 9 * PLX; tbl.syav = x + 10 * PLX;
+  }
   if (FLUID == GRT_FLUID_HARM) {     // coordinate vectors (x1, r, x2, theta of the zone centres) in LDS
     const int nc = 2 * (fd.hm.nx1 + fd.hm.nx2);
     for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.hm.coords[i];
@@ -196,7 +241,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
   if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches
     for (int i = threadIdx.x; i < GRT_SPHACC_NTAB; i += blockDim.x) s_sphacc[i] = fd.sphacc[i];
   }
-  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_SPHACC) __syncthreads();
+  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_SPHACC || EMIS == GRT_EMIS_POLSYNCHPL) __syncthreads();
   const int slot = blockIdx.x * GRT_XFER_THREADS + threadIdx.x;
   const bool has_ray = slot < nlive;
   const int f0 = blockIdx.y * FB;
@@ -276,6 +321,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
 #pragma clang loop unroll(disable)
     for (int jj = 0; jj < 8; ++jj) {
       const int e = 7 - jj;
+      const double cam_a = karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, a));
       const int ip = 8 * m + e;                            // 0-based stored point of this lane's ray
       const bool valid = has_ray && m >= 0 && ip < n;
       const int k = ip + 1;
@@ -291,23 +337,24 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       const double t_i = (slowlight && valid) ? tl3[lane * GRT_TS + e] : 0.0;
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);
-      calc_nullp(q2, l, cam.a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
+      calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
       sumr += valid ? r : 0.0;
       // fluid + frame (grtrans_driver.f90:126-130)
       FluidPoint fl;
-      if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
+      if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam_a, fl);
       else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
       else if (FLUID == GRT_FLUID_HARM)
-        harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl, slowlight ? harm_time_index(fd.hm, r, t_i, r_1, (float)cam.a) : 0);
+        harm_sample(fd.hm, s_harm, r, th, (float)cam_a, fl, slowlight ? harm_time_index(fd.hm, r, t_i, r_1, (float)cam_a) : 0);
       double s2xi, c2xi, ang, g;
-      comoving_ortho(r, sth, cth, cam.a, alpha, beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g);
+      comoving_ortho(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
       double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
-      if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }
+      const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
+      if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * emk.nfac; bcgs = (double)fl.bmag * emk.bfac; }
       else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
-      else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, em.mbh, em.mdot, em.muval, em.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
+      else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
       PLPoint plp;
-      if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_point(plc, ncgsnth, bcgs, ang, plp);
+      if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp);
       const double lg = log(g);
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
@@ -320,7 +367,11 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
         if (f < nf) {
           const double nu = freqs[f0 + f] / g;
           double e11[11];
-          if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_freq(tb, plc, plp, nu, lfreqs[f0 + f] - lg, e11);
+          if (EMIS == GRT_EMIS_POLSYNCHPL) {
+            GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
+            plck.iy = 0;                                   // the LDS copy holds the p-bin's row only
+            polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
+          }
           else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
           if constexpr (IFLAG == GRT_INT_QUAD) {
@@ -336,9 +387,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
             }
             if (valid) { jn[f][0] = j0; Kn[f][0] = K0; }
           } else {
+            const GrtEmis emf = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
 #pragma unroll
             for (int c = 0; c < 7; ++c)
-              if (!em.coefindx[c]) e11[4 + c] = 0.0;
+              if (!emf.coefindx[c]) e11[4 + c] = 0.0;
             // rotate_emis + invariant_emis + cgs scaling (emis.f90:797-838, grtrans_driver.f90:201-217)
             double jj4[4] = {e11[0], c2xi * e11[1] - s2xi * e11[2], s2xi * e11[1] + c2xi * e11[2], e11[3]};
             double KK[7] = {e11[4], c2xi * e11[5] - s2xi * e11[6], s2xi * e11[5] + c2xi * e11[6], e11[7],
