@@ -30,6 +30,7 @@ using namespace grtd;
 #define GRT_WPE_GEO 2     // waves per SIMD the register allocator must make room for
 #endif
 #ifndef GRT_WPE_XFER
+#define GRT_AS4 __attribute__((address_space(4)))
 #define GRT_WPE_XFER 2
 #endif
 #define GRT_MAXF 32
@@ -130,7 +131,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   for (int c = (n - 1) >> 6; c >= 0; --c) {
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
-    asm volatile("" : "+s"(Rp), "+s"(Kp), "+s"(Cp));
+    {
+      // (constant address space: the loads below become scalar loads of the wave's ray; see grt_fresh)
+      const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rp;
+      const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kp;
+      asm volatile("" : "+s"(r_), "+s"(k_));
+      Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
+    }
     const int idx = 64 * c + lane + 1;
     const bool valid = idx <= n;
     GeoPoint P;
@@ -139,7 +146,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
       else if (FAST == 1 && NPH == 3) ray_point_real<3>(cam, *Rp, *Kp, idx, P);
       else if (FAST == 1 && NPH == 2) ray_point_real<2>(cam, *Rp, *Kp, idx, P);
+#if defined(GRT_GEO0_TWOPASS)
+      else if (FAST == 1) ray_point_real<0>(cam, *Rp, *Kp, idx, P);
+#else
       else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
+#endif
       else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
     }
     if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
@@ -179,7 +190,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 // pointers and literal constants of the step loop; held for the whole kernel they are parked in VGPR lanes and
 // every use costs a v_readlane on the vector pipe.  Re-reading them from the kernarg segment inside the loop
 // (scalar loads from the constant cache, issued on the scalar pipe) keeps them live only where they are used.
-#define GRT_AS4 __attribute__((address_space(4)))
 struct XferKargHead { GrtCam cam; const GrtRay *rays; const int *live; int nlive; GrtFluidDev fd; GrtTables tb; GrtEmis em; GrtPLConst plc; };
 __device__ __forceinline__ const char GRT_AS4 *karg_fresh() {     // a kernarg pointer the optimiser cannot hoist loads through
   const char GRT_AS4 *p = (const char GRT_AS4 *)__builtin_amdgcn_kernarg_segment_ptr();

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/pmc.sh [args of tools/time_kernels.py]: separate rocprofv3 --pmc passes (no tracing domains), CSV under gpurun_out/pmc/
-R=$PWD
+R=$PWD; mkdir -p $R/gpurun_out/pmc
 export TMPDIR=/tmp
 cd /tmp
 i=0
