@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB = os.environ.get("GRTRANS_AMD_LIB", os.path.join(PKG, "libgrtrans_amd.so"))
 DATA = os.path.join(PKG, "data")
 
-FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13}       # fluid.f90:40-43
+FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13, "HARM3D": 19}       # fluid.f90:40-43
 EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8}    # emis.f90:11-18
 INTEG = {"lsoda": 0, "delo": 1, "formal": 2, "lsodasph": 3}          # rad_trans.f90:29-37
 
@@ -28,6 +28,7 @@ class GrtEmis(C.Structure):
     _fields_ = [("mbh", C.c_double), ("nfac", C.c_double), ("bfac", C.c_double),
                 ("gmin", C.c_double), ("gmax", C.c_double), ("p1", C.c_double), ("muval", C.c_double),
                 ("mdot", C.c_double), ("gminval", C.c_double),
+                ("jetalpha", C.c_double), ("sigcut", C.c_double),
                 ("type", C.c_int32), ("coefindx", C.c_int32 * 7)]
 
 
@@ -82,6 +83,9 @@ class Device:
         check(lib().grt_load_harm_files_nt(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_int(nt), C.c_double(spin)),
               "grt_load_harm_files_nt")
 
+    def load_harm3d(self, dfile, hfile, indf, spin):
+        check(lib().grt_load_harm3d_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin)), "grt_load_harm3d_files")
+
     def set_thindisk(self, mdot, rin, rout):
         check(lib().grt_set_thindisk(C.c_double(mdot), C.c_double(rin), C.c_double(rout)), "grt_set_thindisk")
 
@@ -102,12 +106,13 @@ def make_camera(standard, gridvals, nn, spin, mu0, uout, phi0=-0.5):
     return cam
 
 
-def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7, mdot=0.0):
+def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7, mdot=0.0, jetalpha=0.02, sigcut=1e10):
     em = GrtEmis()
     em.mbh, em.nfac, em.bfac = mbh, nfac, bfac
     em.gmin, em.gmax, em.p1 = _f32(gmin), _f32(gmax), _f32(p1)   # REAL(4) in emis_params (emis.f90:32-39)
     em.muval = muval
     em.mdot, em.gminval = mdot, gmin                             # REAL(8) in source_params (fluid.f90:67-74)
+    em.jetalpha, em.sigcut = jetalpha, sigcut
     em.type = EMIS[ename]
     for i in range(7):
         em.coefindx[i] = int(coefindx[i])

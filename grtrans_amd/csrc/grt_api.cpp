@@ -45,6 +45,9 @@ struct Ctx {
   float *d_harm_cells = nullptr, *d_harm_coords = nullptr;
   GrtHarm harm{};
   bool have_harm = false;
+  float *d_h3_cells = nullptr, *d_h3_coords = nullptr;
+  GrtHarm3d harm3d{};
+  bool have_harm3d = false;
   double *d_t0 = nullptr;        // per-ray time origin of the current tile (nload > 1), or unset
   size_t cap_t0 = 0;
   long long t0_n = 0;
@@ -120,7 +123,7 @@ int grt_free(void) {
   (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords, C.d_t0};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -237,6 +240,29 @@ int grt_upload_harm(int nx1, int nx2, float h, const float *x1_arr, const float 
                     const float *p, const float *b0, const float *br, const float *bth, const float *bph,
                     const float *u0, const float *vrl, const float *vtl, const float *vpl) {
   return grt_upload_harm_slices(nx1, nx2, 1, 20.f, h, x1_arr, x2_arr, rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl);
+}
+
+int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const float *x2_arr, const float *x3_arr,
+                      const float *rho, const float *p, const float *b0, const float *br, const float *bth,
+                      const float *bph, const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (nx1 < 2 || nx2 < 2 || nx3 < 2 || nx1 > nx2 || 2 * (nx1 + nx2) + nx3 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr)
+    return GRT_E_BADARG;
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  for (const float *q : src)
+    if (!q) return GRT_E_BADARG;
+  std::vector<float> cells, crd;
+  grt_harm3d_pack(nx1, nx2, nx3, x1_arr, x2_arr, x3_arr, src, cells, crd);
+  if (C.d_h3_cells) { (void)hipFree(C.d_h3_cells); C.d_h3_cells = nullptr; }
+  if (C.d_h3_coords) { (void)hipFree(C.d_h3_coords); C.d_h3_coords = nullptr; }
+  HIPCHK(hipMalloc((void **)&C.d_h3_cells, cells.size() * sizeof(float)));
+  HIPCHK(hipMalloc((void **)&C.d_h3_coords, crd.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(C.d_h3_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(C.d_h3_coords, crd.data(), crd.size() * sizeof(float), hipMemcpyHostToDevice));
+  C.harm3d.cells = C.d_h3_cells; C.harm3d.coords = C.d_h3_coords;
+  C.harm3d.nx1 = nx1; C.harm3d.nx2 = nx2; C.harm3d.nx3 = nx3;
+  C.have_harm3d = true;
+  return 0;
 }
 
 int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_host) {
@@ -363,7 +389,8 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   // (fluid, emissivity) pairs that have a kernel; everything else is refused, never emulated
   const bool pair_ok = (fluid_model == GRT_FLUID_FFJET && em->type == GRT_EMIS_POLSYNCHPL) ||
                        (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH) ||
-                       (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH);
+                       (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH) ||
+                       (fluid_model == GRT_FLUID_HARM3D && em->type == GRT_EMIS_POLSYNCHTH);
   if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   // nextra: 0, or the 19 ray diagnostics of extra=1 for nup>1 (pgrtrans.f90:108-114)
@@ -373,11 +400,13 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (fluid_model == GRT_FLUID_FFJET && !C.have_ffjet) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_SPHACC && !C.d_sphacc) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM && !C.have_harm) return GRT_E_NOFLUID;
+  if (fluid_model == GRT_FLUID_HARM3D && !C.have_harm3d) return GRT_E_NOFLUID;
   if (em->type == GRT_EMIS_POLSYNCHPL && !C.have_tables) return GRT_E_NOTABLES;
   GrtFluidDev fd{};
   fd.fj = C.ffjet;
   fd.sphacc = C.d_sphacc;
   fd.hm = C.harm;
+  fd.h3 = C.harm3d;
   HIPCHK(hipSetDevice(C.device));
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
@@ -391,7 +420,8 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
   const long long maxpts = cam->nup + cam->next;
   const long long rstride = (maxpts + 63) / 64 * 64;      // internal ray stride: 512-byte aligned chunk rows
-  const int nfields = C.record_steps ? 8 : (nextra ? 4 : 3);   // extra=1 weights by phi as well
+  // extra=1 weights by phi as well; a 3-D fluid model is sampled at the point's azimuth
+  const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D) ? 4 : 3);
   // several HARM slices loaded ("slow light"): every point also carries its coordinate time, one more field
   const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1);
   if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;

@@ -839,6 +839,124 @@ GRT_HD void harm_convert(const FluidPoint &f, double mbh, double mdotcgs, double
   tcgs = tcgs * trat;
 }
 
+// ------------------------------------------------------------------ 3-D HARM (fluid_model_harm3d.f90)
+GRT_HD double bl2ks_phi(double r, double x, double a) {       // kerr.f90:156-162
+  const double sq1 = sqrt(1. - a * a);
+  return x + a / (2.0 * sq1) * log((r - 1. - sq1) / (r - 1. + sq1));
+}
+
+// harm3d_vals (fluid_model_harm3d.f90:107-327) for one point and one loaded slice: the eight corners (x1l/x1u, x2l/x2u,
+// x3l/x3u) of the zone-centred grid, quadlininterp with the zero time weight the reference sets (:262,
+// interpolate.f90:205-232), periodic in phi, nearest zone in r (and 1e-6 scaled rho, p, |b|) inside the innermost zone
+// centre outside the horizon (:205-213).  REAL(4) throughout, as there; crd = the LDS copy of GrtHarm3d::coords.
+GRT_NI void harm3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f) {
+  GRT_NO_CONTRACT
+  const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
+  const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2, *uniqx3 = crd + 2 * (nx1 + nx2);
+  const float theta = (float)th_d, zr = (float)r, zpp = (float)phi_d;
+  const double twopi = 2. * PH_pi;
+  float zphi = (float)bl2ks_phi((double)zr, (double)zpp, (double)a);
+  zphi = (float)fmod((double)zphi, twopi);
+  if (zphi < 0.f) zphi = (float)((double)zphi + twopi);
+  const float x1 = logf_cr(zr), x3 = zphi, x2 = (float)((double)theta / PH_pi);
+  int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
+  int lx2 = (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
+  int ux2 = lx2 + 1;
+  int lx3 = (int)floorf((x3 - uniqx3[0]) / (uniqx3[nx3 - 1] - uniqx3[0]) * (nx3 - 1)) + 1;
+  int ux3 = lx3 + 1;
+  lx2 = (lx2 >= 1) ? lx2 : 1;
+  lx2 = (lx2 <= nx2 - 1) ? lx2 : nx2 - 1;
+  lx1 = (lx1 >= 1) ? lx1 : 1;
+  ux2 = (ux2 >= 1) ? ux2 : 1;
+  ux2 = (ux2 <= nx2) ? ux2 : nx2;
+  // lx1 has no upper clamp in the reference (beyond the last zone centre it reads outside the table): only addresses are clamped here
+  const int lx1c = lx1 < nx1 - 1 ? lx1 : nx1 - 1, ux1c = lx1c + 1;
+  const float dth = (ux2 != lx2) ? (uniqth[ux2 - 1] - uniqth[lx2 - 1]) : uniqth[0] * 2;     // poles, :185-189
+  float minph;
+  if (ux3 > nx3) ux3 = 1;                                                                    // periodic in phi, :191-198
+  if (lx3 < 1) { lx3 = nx3; minph = (float)((double)uniqx3[lx3 - 1] - twopi); }
+  else minph = uniqx3[lx3 - 1];
+  const float pd = (zphi - minph) / (uniqx3[1] - uniqx3[0]);
+  const float td = fabsf(theta - uniqth[lx2 - 1]) / dth;
+  float rd = (zr - uniqr[lx1c - 1]) / (uniqr[ux1c - 1] - uniqr[lx1c - 1]);
+  const float rh = 1.f + sqrtf(1.f - a * a);
+  double fac = 1.0;
+  if (uniqr[lx1c - 1] <= fmaxf(uniqr[0], rh)) { rd = 1.f; fac = 1e-6; }
+  const size_t row = (size_t)nx3 * 12, plane = (size_t)nx2 * row;
+  const float *b_ll = t.cells + (size_t)(lx1c - 1) * plane + (size_t)(lx2 - 1) * row;     // (x1l, x2l)
+  const float *b_lu = t.cells + (size_t)(lx1c - 1) * plane + (size_t)(ux2 - 1) * row;     // (x1l, x2u)
+  const float *b_ul = b_ll + plane, *b_uu = b_lu + plane;                                   // x1u
+  const size_t o3l = (size_t)(lx3 - 1) * 12, o3u = (size_t)(ux3 - 1) * 12;
+  // the two phi planes one after the other (not unrolled): four corners = 12 dwordx4 loads in flight instead of 24,
+  // which is what keeps this sampler out of scratch
+  float q[10], m1[10];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang loop unroll(disable)
+#endif
+  for (int side = 0; side < 2; ++side) {
+    const size_t o3 = side ? o3u : o3l;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 10; ++k) {
+      float i1 = b_ll[o3 + k] * (1.f - td) + b_lu[o3 + k] * td;
+      float i2 = b_ul[o3 + k] * (1.f - td) + b_uu[o3 + k] * td;
+      float m = i1 * (1.f - rd) + i2 * rd;
+      if (side == 0) m1[k] = m;
+      else {
+        float w1 = m1[k] * (1.f - pd) + m * pd;
+        q[k] = w1 * (1.f - 0.f) + w1 * 0.f;
+      }
+    }
+  }
+  const bool inside = x1 > uniqx1[0];
+  f.rho = (float)((double)q[0] * fac);
+  f.p = (float)((double)q[1] * fac);
+  f.b[0] = (double)(inside ? q[2] : 1.f);
+  f.b[1] = (double)(inside ? q[3] : 1.f);
+  f.b[2] = (double)(inside ? q[4] : 1.f);
+  f.b[3] = (double)(inside ? q[5] : 1.f);
+  f.u[0] = inside ? (double)q[6] : 1.0;
+  const float vrl0 = inside ? q[7] : 0.f;
+  const float vtl0 = inside ? q[8] : 0.f;
+  const float vpl0 = inside ? q[9] : 0.f;
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  float bm = (float)dot4(f.b, ms, f.b);
+  bm = (bm >= 0.f) ? bm : 0.f;
+  f.bmag = (float)((double)sqrtf(bm) * fac);
+  float vr0, vth0, vph0;
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  f.u[1] = f.u[0] * (double)vr0;
+  f.u[2] = f.u[0] * (double)vth0;
+  f.u[3] = f.u[0] * (double)vph0;
+}
+
+// convert_fluidvars_harm3d fluid.f90:975-993 (scale_sim_units :765-790 with mdot = G M / c^3, monika_e :870-892 with
+// rlow = 1/mu - 1, rhigh = gmin (1/mu - 1), T_e = T/(1+trat), nonthermale_b2 :914-923, andrew_sigcut :792-810)
+GRT_HD void harm3d_convert(const FluidPoint &f, double mbh, double mdotcgs, double muval, double gminval, double jetalpha,
+                           double p1, double sigcut, double &ncgs, double &ncgsnth, double &bcgs, double &tcgs) {
+  GRT_NO_CONTRACT
+  const double mp = 1.67262158e-24;
+  const double mdot = PH_G * mbh * PH_msun / (PH_c * PH_c * PH_c);
+  const double lcgs = PH_G * mbh * PH_msun / (PH_c * PH_c), tc = lcgs / PH_c;
+  const double rho = (double)f.rho, p = (double)f.p, bmag = (double)f.bmag;
+  const double rhocgs = mdotcgs / mdot / (lcgs * lcgs * lcgs) * tc * rho;
+  ncgs = rhocgs / mp;
+  const double pcgs = p * rhocgs / rho * (PH_c * PH_c);
+  tcgs = pcgs / ncgs / PH_k;
+  bcgs = bmag * sqrt(rhocgs / rho) * PH_c;
+  bcgs = bcgs * sqrt(4.0 * PH_pi);
+  const double rlow = 1.0 / muval - 1.0, rhigh = gminval * (1.0 / muval - 1.0);
+  const double beta = (double)(f.p / (f.bmag * f.bmag)) / 0.5;
+  const double b2 = beta * beta;
+  const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
+  tcgs = tcgs / (1.0 + trat);
+  const double bmagrho = (bmag * bmag) / rho;
+  ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) / 8.0 / PH_pi / gminval * (p1 - 2.0) / (p1 - 1.0) / 8.2e-7 : 0.0;
+  const double sigmacgs = (bcgs * bcgs) / ((ncgs * mp) * 8.988e20 * 4.0 * PH_pi);
+  if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
+}
+
 // ------------------------------------------------------------------ transfer steps as affine maps
 struct Affine {   // I -> A I + b
   double A[4][4], b[4];

@@ -122,3 +122,58 @@ extern "C" int grt_load_harm_files_nt(const char *dfile, const char *hfile, int 
 extern "C" int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin) {
   return grt_load_harm_files_nt(dfile, hfile, indf, 1, spin);
 }
+
+// 3-D HARM: read_harm3d_data_header / read_harm3d_data / read_harm3d_data_file (BINARY=1 branch) / load_harm3d_data
+// (fluid_model_harm3d.f90:337-368, 516-584, 370-499, 625-686) for one time slice.  The header file holds 15 numbers;
+// the dump `dfile`//I3.3(indf)//'.bin' is one text line followed by REAL(4) data(35, n), x3 (phi) fastest.  The
+// reader's coordinates are x1 = log r, theta = pi x2 (d theta/d x2 = pi in umksh2uks, :77-105), x3 = phi.
+extern "C" int grt_load_harm3d_files(const char *dfile, const char *hfile, int indf, double spin) {
+  if (!dfile || !hfile) return GRT_E_BADARG;
+  const size_t nhead = 15, dlen = 35;
+  std::vector<double> head;
+  if (!slurp_numbers(hfile, nhead, head)) return GRT_E_IO;
+  const int nx1 = (int)head[1], nx2 = (int)head[2], nx3 = (int)head[3];
+  const float asim = (float)head[10], gam = (float)head[11];
+  if (nx1 < 2 || nx2 < 2 || nx3 < 2) return GRT_E_IO;
+  if (std::fabs((double)asim - spin) > 1e-4) {     // fluid_model_harm3d.f90:611-614
+    std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
+    return GRT_E_BADARG;
+  }
+  const size_t n = (size_t)nx1 * nx2 * nx3;
+  char suffix[16];
+  std::snprintf(suffix, sizeof suffix, "%03d", indf);
+  const std::string path = std::string(dfile) + suffix + ".bin";
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) return GRT_E_IO;
+  int ch;
+  while ((ch = std::fgetc(f)) != EOF && ch != '\n') {}     // header bytes up to and including char(10) (:541-546)
+  std::vector<float> data(n * dlen);
+  const size_t got = std::fread(data.data(), sizeof(float), data.size(), f);
+  std::fclose(f);
+  if (got != data.size()) return GRT_E_IO;
+  std::vector<float> x1(n), x2(n), x3(n), rho(n), p(n), u0(n), vrl(n), vtl(n), vpl(n), b0(n), br(n), bth(n), bph(n);
+  const float dthdx2 = (float)kPi;
+  for (size_t i = 0; i < n; ++i) {
+    const float *z = &data[i * dlen];
+    x1[i] = z[3]; x2[i] = z[4]; x3[i] = z[5];                       // grid = data(4:9,:)
+    const float r = std::exp(x1[i]);                                // r_arr = exp(x1_arr)
+    const float th = (float)((double)x2[i] * kPi);                  // th_arr = x2_arr*pi
+    double pp = (double)z[10];
+    if (!(pp > (double)1e-18f)) pp = (double)1e-18f;                // p = merge(p, pmin, p > pmin), pmin = 1e-18 (REAL(4) literal)
+    const double a = (double)asim, rd = (double)r;
+    auto to_bl = [&](const float *w, double o[4]) {                 // umksh2uks + uks2ubl (kerr.f90:131-144)
+      const double wr = rd * (double)w[1], wth = (double)w[2] * (double)dthdx2;
+      const double delta = rd * rd - 2.0 * rd + a * a;
+      o[0] = (double)w[0] - 2.0 * rd / delta * wr; o[1] = wr; o[2] = wth; o[3] = (double)w[3] - a / delta * wr;
+    };
+    double u[4], b[4];
+    to_bl(z + 18, u); to_bl(z + 26, b);
+    lnrf_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r, asim, th, vrl[i], vtl[i], vpl[i]);
+    rho[i] = z[9];
+    p[i] = (float)(pp * (double)(gam - 1.f));                       // internal energy -> pressure (:652)
+    u0[i] = (float)u[0];
+    b0[i] = (float)b[0]; br[i] = (float)b[1]; bth[i] = (float)b[2]; bph[i] = (float)b[3];
+  }
+  return grt_upload_harm3d(nx1, nx2, nx3, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(), br.data(), bth.data(),
+                           bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data());
+}

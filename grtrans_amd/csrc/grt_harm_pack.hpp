@@ -26,3 +26,26 @@ inline void grt_harm_pack(int nx1, int nx2, float h, const float *x1_arr, const 
     crd[2 * nx1 + nx2 + j] = (float)(pi * (double)x2 + (double)((1.f - h) / 2.f) * std::sin(2.0 * pi * (double)x2));   // uniqth
   }
 }
+
+// 3-D: cells [nx1*nx2*nx3][12] zone-interleaved (x3 fastest: the two phi neighbours of a corner pair are adjacent
+// 48-byte records); crd: [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2][uniqx3 nx3], the per-call vectors of
+// harm3d_vals (fluid_model_harm3d.f90:137-143) built once.
+inline void grt_harm3d_pack(int nx1, int nx2, int nx3, const float *x1_arr, const float *x2_arr, const float *x3_arr,
+                            const float *const src[10], std::vector<float> &cells, std::vector<float> &crd) {
+  const size_t n = (size_t)nx1 * nx2 * nx3;
+  cells.assign(n * 12, 0.f);
+  crd.assign((size_t)2 * (nx1 + nx2) + nx3, 0.f);
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 10; ++k) cells[i * 12 + k] = src[k][i];
+  const double pi = std::acos(-1.0);
+  for (int i = 0; i < nx1; ++i) {
+    crd[i] = x1_arr[(size_t)i * nx3 * nx2];       // uniqx1 = x1_arr(1:nx3*(nx2-1)*nx1+1:nx3*nx2)
+    crd[nx1 + i] = std::exp(crd[i]);              // uniqr = exp(uniqx1), REAL(4)
+  }
+  for (int j = 0; j < nx2; ++j) {
+    const float x2 = x2_arr[(size_t)j * nx3];     // uniqx2 = x2_arr(1:nx3*(nx2-1)+1:nx3)
+    crd[2 * nx1 + j] = x2;
+    crd[2 * nx1 + nx2 + j] = (float)(pi * (double)x2);   // uniqth = pi*uniqx2
+  }
+  for (int k = 0; k < nx3; ++k) crd[2 * (nx1 + nx2) + k] = x3_arr[k];   // uniqx3 = x3_arr(1:nx3) = uniqph
+}

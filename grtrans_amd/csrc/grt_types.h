@@ -48,12 +48,18 @@ struct GrtHarm {                // device pointers; nt 2-D HARM slices, fluid_mo
   float h, tstep;               // tstep: time between loaded slices (t(1)-t(2); module default 20. when nt = 1)
   int32_t nt, pad;              // loaded time slices: slice k = dump indf-(k-1), cells [nt][nx1*nx2][12]
 };
+struct GrtHarm3d {              // device pointers; one 3-D HARM slice, fluid_model_harm3d.f90:14-22
+  const float *cells;           // [nx1][nx2][nx3][12], x3 (phi) fastest: rho,p,b0,br,bth,bph,u0,vrl,vtl,vpl,pad,pad
+  const float *coords;          // [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2][uniqx3 nx3] (staged in LDS)
+  int32_t nx1, nx2, nx3, pad;
+};
 #define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 
 struct GrtFluidDev {            // what the transfer kernel samples; only the selected model's part is read
   GrtFFJet fj;
   const float *sphacc;          // [uvals 498][vvals 498][1/rvals 461][tvals 461], fluid_model_sphacc.f90
   GrtHarm hm;
+  GrtHarm3d h3;
 };
 
 struct GrtTables {              // polsynchpl log-G tables (polsynchemis.f90:107-525), device pointers

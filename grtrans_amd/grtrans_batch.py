@@ -183,6 +183,10 @@ class grtrans:
                 if int(inp.fnt) > 1 and nextra:
                     raise capi.GrtError("extra=1 with several HARM slices (hnt > 1) is not on the device yet")
                 dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), nt=int(inp.fnt))
+            elif inp.fname == 'HARM3D':
+                if int(inp.fnt) != 1 or int(inp.nload) != 1:
+                    raise capi.GrtError("HARM3D with several loaded slices (hnt, nload > 1) is not on the device yet")
+                dev.load_harm3d(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
             ivals = np.zeros((inp.nvals + nextra, npix, ncams))
             ab = np.zeros((2, npix))
             harm_indf, harm_toffset, harm_tstep = int(inp.findf), np.float32(0.), np.float32(20.)
@@ -196,19 +200,23 @@ class grtrans:
                 else:
                     capi.set_t0(None)
                 for l in range(nt):
-                    if l > 0 and inp.fname == 'HARM':
-                        # advance_harm_timestep (fluid_model_harm.f90:511-521): REAL(4) tstep, toffset kept across frames
+                    if l > 0 and inp.fname in ('HARM', 'HARM3D'):
+                        # advance_harm_timestep (fluid_model_harm.f90:511-521; the same arithmetic in
+                        # advance_harm3d_timestep, fluid_model_harm3d.f90:688-699): REAL(4) tstep, toffset kept across frames
                         nupdate = int(np.floor(float(inp.dt) / float(harm_tstep)))
                         harm_toffset = np.float32(float(harm_toffset) + float(inp.dt) - float(harm_tstep) * nupdate)
                         nupdate += int(np.floor(harm_toffset / harm_tstep))
                         harm_toffset = np.float32(harm_toffset - np.float32(np.floor(harm_toffset / harm_tstep)) * harm_tstep)
                         harm_indf += nupdate
-                        if nupdate > 0:
+                        if nupdate > 0 and inp.fname == 'HARM':
                             dev.load_harm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin), nt=int(inp.fnt))
+                        elif nupdate > 0:
+                            dev.load_harm3d(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
                     for m in range(nmdot):
                         mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
                         em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
-                                            inp.muval, inp.epcoefindx, mdot=float(mdot))
+                                            inp.muval, inp.epcoefindx, mdot=float(mdot), jetalpha=float(inp.jetalpha),
+                                            sigcut=float(inp.sigcut))
                         pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
                                                                nvals=inp.nvals, nextra=nextra)
                         for k in range(nfreq):

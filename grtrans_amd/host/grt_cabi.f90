@@ -6,7 +6,7 @@ module grt_cabi
   implicit none
 
   integer(c_int), parameter :: GRT_FLUID_FFJET = 13, GRT_FLUID_HARM = 12, GRT_FLUID_SPHACC = 1, &
-       GRT_FLUID_THINDISK = 2
+       GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM3D = 19
   integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
        GRT_EMIS_BB = 8
 
@@ -22,6 +22,7 @@ module grt_cabi
      real(c_double) :: gmin, gmax, p1
      real(c_double) :: muval
      real(c_double) :: mdot, gminval
+     real(c_double) :: jetalpha, sigcut
      integer(c_int32_t) :: etype
      integer(c_int32_t) :: coefindx(7)
   end type grt_emis
@@ -71,6 +72,13 @@ module grt_cabi
        real(c_double), value :: mdot, rin, rout
        integer(c_int) :: rc
      end function grt_set_thindisk
+     function grt_load_harm3d_files(dfile, hfile, indf, spin) bind(C, name='grt_load_harm3d_files') result(rc)
+       import :: c_char, c_int, c_double
+       character(kind=c_char), dimension(*), intent(in) :: dfile, hfile
+       integer(c_int), value :: indf
+       real(c_double), value :: spin
+       integer(c_int) :: rc
+     end function grt_load_harm3d_files
      function grt_load_harm_files_nt(dfile, hfile, indf, nt, spin) bind(C, name='grt_load_harm_files_nt') result(rc)
        import :: c_int, c_char, c_double
        character(kind=c_char), dimension(*), intent(in) :: dfile, hfile

@@ -95,6 +95,7 @@ contains
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
     case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC
     case ('HARM'); fluid_id = GRT_FLUID_HARM
+    case ('HARM3D'); fluid_id = GRT_FLUID_HARM3D
     case ('THINDISK'); fluid_id = GRT_FLUID_THINDISK
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
@@ -139,6 +140,13 @@ contains
        if (rc /= 0) call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc)
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = fnt
+    else if (fluid_id == GRT_FLUID_HARM3D) then
+       ! initialize_harm3d_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:195-196; one loaded slice
+       if (fnt /= 1 .or. nload /= 1) call die('HARM3D with several loaded slices (fnt, nload > 1) is not supported')
+       rc = grt_load_harm3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
+       if (rc /= 0) call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
+       harm_nt = 1
     else if (fluid_id == GRT_FLUID_THINDISK) then
        ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
        rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) call die_rc('grt_set_thindisk', rc)
@@ -179,6 +187,7 @@ contains
              em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
              em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
              em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
+             em%jetalpha = jetalpha; em%sigcut = sigcut               ! sparams%jetalphaval, %sigcut (pgrtrans.f90:129-136)
              em%mdot = mdots(m); em%gminval = gmin                   ! sparams%mdot, %gminval (pgrtrans.f90:127-131)
              rc = grt_trace_tile(cam, int(i1, c_int64_t), int(i2, c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &
                   int(iflag, c_int), int(nvals, c_int), int(nextra, c_int), pixvals, pixloc, status, st)
@@ -273,7 +282,7 @@ contains
     use grt_cabi
     real(8), intent(in) :: dtobs
     integer :: nupdate, rc
-    if (cur_fluid /= GRT_FLUID_HARM) return
+    if (cur_fluid /= GRT_FLUID_HARM .and. cur_fluid /= GRT_FLUID_HARM3D) return
     nupdate = floor(dtobs / harm_tstep)
     harm_toffset = harm_toffset + dtobs - harm_tstep*nupdate
     nupdate = nupdate + floor(harm_toffset/harm_tstep)
@@ -281,7 +290,10 @@ contains
     harm_indf = harm_indf + nupdate
     write(6,*) 'advance harm timestep: ', dtobs, harm_tstep, harm_toffset, harm_indf, nupdate
     ! nupdate = 0 leaves the slice as it is (update_harm_data(0) loads nothing)
-    if (nupdate > 0) then
+    if (nupdate > 0 .and. cur_fluid == GRT_FLUID_HARM3D) then
+       rc = grt_load_harm3d_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
+       if (rc /= 0) call die_rc('grt_load_harm3d_files (advance) '//trim(harm_dfile), rc)
+    else if (nupdate > 0) then
        rc = grt_load_harm_files_nt(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), int(harm_nt, c_int), harm_spin)
        if (rc /= 0) call die_rc('grt_load_harm_files (advance) '//trim(harm_dfile), rc)
     end if

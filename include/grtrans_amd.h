@@ -33,7 +33,7 @@ extern "C" {
 
 /* ids follow the reference so host Fortran can pass its own constants through:
  * fluid.f90:40-43, emis.f90:11-18, rad_trans.f90:29-37 */
-enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13 };
+enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19 };
 enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8 };
 enum { GRT_INT_LSODA = 0, GRT_INT_DELO = 1, GRT_INT_FORMAL = 2 };
 
@@ -53,6 +53,8 @@ typedef struct GrtEmis {
   double muval;
   double mdot, gminval;       /* sparams%mdot (cgs accretion rate) and the unrounded REAL(8) gmin: HARM unit
                                  conversion and electron-temperature model (fluid.f90:957-973) */
+  double jetalpha, sigcut;    /* sparams%jetalphaval, %sigcut: non-thermal fraction and magnetisation cut of the 3-D
+                                 models (fluid.f90:975-993) */
   int32_t type, coefindx[7];
 } grt_emis;
 
@@ -98,6 +100,19 @@ int grt_upload_harm_slices(int nx1, int nx2, int nt, float tstep, float h, const
 int grt_load_harm_files(const char *dfile, const char *hfile, int indf, double spin);
 /* nt slices: dumps indf, indf-1, ..., indf-nt+1 */
 int grt_load_harm_files_nt(const char *dfile, const char *hfile, int indf, int nt, double spin);
+
+/* 3-D HARM (fname HARM3D, fluid.f90:195-196).  replaces init_harm3d_data + load_harm3d_data for one time slice
+ * (fluid_model_harm3d.f90:625-686,725-735): the module arrays after loading, n = nx1*nx2*nx3 zones with x3 (phi)
+ * fastest, then x2, then x1 (:222-240), REAL(4): grid x1_arr, x2_arr, x3_arr and the ten fluid arrays.  The reader's
+ * coordinates are x1 = log r, theta = pi x2, x3 = phi (transformbl2mksh :57-75).  Needs nx1 <= nx2 as the
+ * reference's own slicing of x1_arr does (:139). */
+int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const float *x2_arr, const float *x3_arr,
+                      const float *rho, const float *p, const float *b0, const float *br, const float *bth,
+                      const float *bph, const float *u0, const float *vrl, const float *vtl, const float *vpl);
+/* replaces initialize_harm3d_model (fluid_model_harm3d.f90:586-623): the 15-number header file and the binary
+ * dump `dfile`//I3.3(indf)//'.bin' (one text line, then REAL(4) data(35, n), :516-584); refuses a spin that differs
+ * from the dump's by more than 1e-4 (:611-614). */
+int grt_load_harm3d_files(const char *dfile, const char *hfile, int indf, double spin);
 
 /* replaces init_thindisk(a, ifile, mdot, mbh, rin, rout) (fluid_model_thindisk.f90:31-49, called from
  * fluid.f90:226-227 with fargs%mdot, %rin, %rout; the mass comes with grt_emis.mbh).  Only the reference's

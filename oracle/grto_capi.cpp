@@ -4,6 +4,7 @@
 // on top of the restated stages, exported with a flat C API for tests/ (ctypes) and for
 // bench.py's cpu_baseline leg.  Built by oracle/Makefile into oracle/_build/libgrt_oracle.so.
 #include "grto_harm.hpp"
+#include "grto_harm3d.hpp"
 #include <omp.h>
 #include <string>
 
@@ -23,6 +24,8 @@ struct Setup {
   FFJetTable ffjet;
   SphaccTable sphacc;
   HarmTable harm;
+  Harm3dTable harm3d;
+  double jetalpha = 0.02, sigcut = 1e10;     // source_params the 3-D models read (fluid.f90:975-993)
   ThinDisk disk;
   std::vector<double> t0;     // per-ray time origin (nload > 1), empty = zero
   double mdot = 0, muval = 0;
@@ -59,6 +62,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
     if (S.fluid == 13) ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 1) sphacc_point(S.sphacc, x[1], w.f[i]);
     else if (S.fluid == 2) thindisk_point(S.disk, x, (float)S.cam.a, w.f[i]);
+    else if (S.fluid == 19) harm3d_vals(S.harm3d, x, (float)S.cam.a, w.f[i]);
     else harm_vals(S.harm, x, (float)S.cam.a, w.f[i], w.g.x[1]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
@@ -71,6 +75,8 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       w.ncgs[i] = w.f[i].rho; w.bcgs[i] = w.f[i].bmag; w.tcgs[i] = w.f[i].p;
     } else if (S.fluid == 2) {              // fluid.f90:1190-1196
       w.tcgs[i] = w.f[i].rho; w.ncgs[i] = 1.0;
+    } else if (S.fluid == 19) {             // fluid.f90:975-993
+      harm3d_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, S.jetalpha, S.p1, S.sigcut, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     } else {                                // fluid.f90:957-973
       harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
@@ -198,6 +204,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   S.phi0 = phi0; S.spin = spin; S.nvals = nvals;
   std::string fn(fname), en(ename), in(iname);
   if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else if (fn == "HARM") S.fluid = 12;
+  else if (fn == "HARM3D") S.fluid = 19;
   else if (fn == "THINDISK") { S.fluid = 2; S.disk = ThinDisk(); S.disk.mbh = (float)mbh; S.disk.mdot = (float)fmdot; }
   else return -1;
   S.mdot = mdot; S.muval = muval;
@@ -210,10 +217,14 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   if (S.fluid == 13 && !ffjet_load(dfile, S.ffjet)) return -4;
   if (S.fluid == 1 && !sphacc_load(dfile, S.sphacc)) return -4;
   if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm, fnt > 0 ? fnt : 1) != 0) return -4;
+  if (S.fluid == 19 && harm3d_load(dfile, hfile, indf, spin, S.harm3d, 1) != 0) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;
 }
+
+// source_params beyond grto_setup's list (jetalphaval, sigcut): call after grto_setup
+void grto_set_source_extras(double jetalpha, double sigcut) { S.jetalpha = jetalpha; S.sigcut = sigcut; }
 
 void grto_camera(int npix, double *alpha, double *beta, double *q2, double *l, double *su, double *sm, double *uf,
                  int *tpr, double *scal) {

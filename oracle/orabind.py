@@ -45,7 +45,8 @@ DEFAULTS = dict(standard=1, mu0=0.906, phi0=-0.5, spin=0.998, uout=0.01,
                 dfile=os.path.join(DATA, "m87bl09rfp10xi5a998fluidvars.bin"),
                 pltab=os.path.join(DATA, "polsynchpl_tables.bin"),
                 mbh=3.4e9, gmin=100., gmax=1e5, p1=3.5, ftscl=2.0, frscl=70.0,
-                coefindx=(1,) * 7, nvals=4, hfile="dump040", findf=40, mdot=1.57e15, muval=0.25, datadir=None, fmdot=0.1, fnt=1)
+                coefindx=(1,) * 7, nvals=4, hfile="dump040", findf=40, mdot=1.57e15, muval=0.25, datadir=None, fmdot=0.1, fnt=1,
+                jetalpha=0.02, sigcut=1e10)
 
 
 class Oracle:
@@ -59,7 +60,7 @@ class Oracle:
         p.update({k: v for k, v in kw.items() if k in DEFAULTS})
         if p["fname"] == "SPHACC" and "dfile" not in kw:
             p["dfile"] = os.path.join(DATA, "sphacc_tables.bin")
-        if p["fname"] == "HARM" and p["datadir"]:      # same relative-name convention as the reference
+        if p["fname"] in ("HARM", "HARM3D") and p["datadir"]:      # same relative-name convention as the reference
             p["dfile"] = os.path.join(p["datadir"], p["dfile"]); p["hfile"] = os.path.join(p["datadir"], p["hfile"])
         self.p = p
         gv = np.asarray(p["gridvals"], dtype=np.float64)
@@ -75,6 +76,8 @@ class Oracle:
                               C.c_double(p["fmdot"]), C.c_int(p["fnt"]))
         if rc != 0:
             raise RuntimeError("grto_setup failed rc=%d" % rc)
+        lib().grto_set_source_extras.argtypes = [C.c_double, C.c_double]
+        lib().grto_set_source_extras(p["jetalpha"], p["sigcut"])
         self.npix = int(nn[0]) * int(nn[1])
         self.nup = int(nn[2])
         self.nvals = p["nvals"]

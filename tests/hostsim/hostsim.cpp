@@ -122,6 +122,25 @@ int grt_upload_harm_slices(int nx1, int nx2, int nt, float tstep, float h, const
   g_harm.nt = nt; g_harm.tstep = tstep;
   return 0;
 }
+// 3-D HARM: same capture of the loader's arrays
+static GrtHarm3d g_h3;
+static std::vector<float> g_cells3, g_crd3;
+int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const float *x2_arr, const float *x3_arr,
+                      const float *rho, const float *p, const float *b0, const float *br, const float *bth,
+                      const float *bph, const float *u0, const float *vrl, const float *vtl, const float *vpl) {
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  grt_harm3d_pack(nx1, nx2, nx3, x1_arr, x2_arr, x3_arr, src, g_cells3, g_crd3);
+  g_h3.cells = g_cells3.data(); g_h3.coords = g_crd3.data(); g_h3.nx1 = nx1; g_h3.nx2 = nx2; g_h3.nx3 = nx3;
+  return 0;
+}
+void hs_harm3d_point(double r, double th, double phi, double a, double mbh, double mdot, double muval, double gminval,
+                     double jetalpha, double p1, double sigcut, double *out15) {
+  FluidPoint f;
+  harm3d_sample(g_h3, g_crd3.data(), r, th, phi, (float)a, f);
+  out15[0] = f.rho; out15[1] = f.p; out15[2] = f.bmag;
+  for (int i = 0; i < 4; ++i) { out15[3 + i] = f.u[i]; out15[7 + i] = f.b[i]; }
+  harm3d_convert(f, mbh, mdot, muval, gminval, jetalpha, p1, sigcut, out15[11], out15[14], out15[12], out15[13]);
+}
 // t, r1: coordinate time of the point and radius of the ray's first point (slice selection when nt > 1)
 void hs_harm_point_t(double r, double th, double t, double r1, double a, double mbh, double mdot, double muval, double gminval,
                      double *out14) {

@@ -583,3 +583,69 @@ def test_fits_output_cflag1_through_fortran_host(tmp_path, monkeypatch):
     assert x.ivals.shape == (1024, 4, 2) and np.allclose(x.nu, [FREQ, 2 * FREQ], rtol=1e-6)
     assert stokes_err(x.ivals[:, :, 0], g["ivals_formal"]) < STOKES_TOL
     assert np.array_equal(x.ab[:, 0], g["cam_alpha"].astype(np.float32))
+
+
+def test_harm3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
+    # 3-D HARM (binary dump read by the product's loader; eight-corner fp32 interpolation periodic in
+    # phi sampled at each point's azimuth; fluid.f90:975-993 units, electron model and magnetisation cut); formal, delo,
+    # sigcut, nvals=1, per-step record, then the same problem through ./grtrans (Fortran host) and run_pgrtrans
+    import hashlib
+    import subprocess
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    import make_harm3d_dump
+    g = np.load(os.path.join(G, "harm3d_40x40x200.npz"))
+    monkeypatch.chdir(tmp_path)
+    dfile, hfile = make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
+    assert hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest() == str(g["dump_sha256"])
+    H = make_golden.HARM3D
+    d = capi.Device(0)
+    try:
+        d.load_tables()
+        with pytest.raises(capi.GrtError):
+            d.load_harm3d(dfile, hfile, 40, 0.5)                  # spin check of initialize_harm3d_model
+        d.load_harm3d(dfile, hfile, 40, H["spin"])
+        cam = capi.make_camera(1, H["gridvals"], (40, 40, 200), H["spin"], H["mu0"], H["uout"], -0.5)
+        for iname, key, sig in (("formal", "ivals_formal", 1e10), ("delo", "ivals_delo", 1e10), ("formal", "ivals_formal_sigcut", 1e-3)):
+            em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, H["gmin"], 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], sigcut=sig)
+            pix, _, status, st = capi.trace_tile(cam, 1, 1600, "HARM3D", em, [FREQ_HARM], iname)
+            assert np.array_equal(status, g["npts"])
+            assert stokes_err(pix[0], g[key]) < STOKES_TOL, key
+        # per-step record of the sigcut run against the reference's per-stage dumps
+        r = np.load(os.path.join(G, "harm3d_rays_40x40x200.npz"))
+        capi.record_steps(True)
+        try:
+            capi.trace_tile(cam, 1, 1600, "HARM3D", em, [FREQ_HARM], "formal")
+            for i in r["rays"]:
+                n = int(r["ray%d_npts" % i])
+                rec = capi.download_steps(int(i) - 1, 1, 230)[:, 0, :n]
+                x = r["ray%d_x" % i]
+                assert np.allclose(rec[0], x[:, 1], rtol=1e-9) and np.allclose(rec[2], x[:, 3], rtol=1e-8, atol=1e-9)
+                I = np.nan_to_num(r["ray%d_I" % i])
+                assert np.abs(np.nan_to_num(rec[4:8, ::-1].T[:n]) - I).max() / (np.abs(I).max() + 1e-300) < 1e-5
+        finally:
+            capi.record_steps(False)
+        # nvals=1 (quadrature) runs and agrees with the polarized Stokes I where the medium is thin
+        em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, H["gmin"], 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
+        p1, _, _, _ = capi.trace_tile(cam, 1, 1600, "HARM3D", em, [FREQ_HARM], "formal", nvals=1)
+        assert p1.shape == (1, 1600, 1) and np.isfinite(p1).all() and p1.max() > 0
+    finally:
+        d.close()
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    kw = dict(fname='HARM3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=H["spin"],
+              standard=1, nn=[40, 40, 200], uout=H["uout"], mbh=H["mbh"], mdotmin=H["mdot"], mdotmax=H["mdot"], nmdot=1,
+              mumin=H["mu0"], mumax=H["mu0"], gridvals=list(H["gridvals"]), muval=H["muval"], gmin=H["gmin"], iname='formal',
+              cflag=0, hdfile='dump3d', hhfile='dump3d_header', hindf=40, hnt=1, sigcut=1e-3)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_sigcut"]) < STOKES_TOL
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
+

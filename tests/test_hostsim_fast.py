@@ -120,6 +120,39 @@ def test_harm_loader_sampler_and_units_match_oracle(L, tmp_path):
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
 
 
+def test_harm3d_loader_sampler_and_units_match_oracle(L, tmp_path):
+    # product loader (binary 3-D dump -> BL/LNRF arrays) + device harm3d_sample/harm3d_convert, compiled
+    # for the host, against the oracle's per-stage dump (itself pinned to the compiled reference, tools/make_golden.py)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_harm3d_dump
+    dfile, hfile = make_harm3d_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+    kw = dict(fname="HARM3D", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1e20, mu0=0.5,
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=1., dfile="dump3d", hfile="dump3d_header", findf=40,
+              nn=(24, 24, 200), sigcut=1e-3)
+    o = O.Oracle(iname="formal", datadir=str(tmp_path), **kw)
+    L.grt_load_harm3d_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+    assert L.grt_load_harm3d_files(dfile.encode(), hfile.encode(), 40, 0.9375) == 0
+    assert L.grt_load_harm3d_files(dfile.encode(), hfile.encode(), 40, 0.5) != 0          # spin check
+    assert L.grt_load_harm3d_files(dfile.encode(), hfile.encode(), 39, 0.9375) != 0       # no such dump
+    L.hs_harm3d_point.argtypes = [C.c_double] * 11 + [C.c_void_p]
+    cut = 0
+    for i in (293, 92, 300, 5, 570, 130):
+        d = o.ray_dump(i, 2.3e11)
+        for k in range(0, d["npts"], 3):
+            out = np.zeros(15)
+            L.hs_harm3d_point(float(d["x"][k, 1]), float(d["x"][k, 2]), float(d["x"][k, 3]), 0.9375, 4e6, 1e20, 0.25, 1.0,
+                              0.02, 3.5, 1e-3, out.ctypes.data)
+            want = np.concatenate([[d["rho"][k], d["p"][k], d["bmag"][k]], d["u"][k], d["b"][k],
+                                   [d["ncgs"][k], d["bcgs"][k], d["tcgs"][k], d["ncgsnth"][k]]])
+            cut += int(d["ncgs"][k] == 0.0)
+            tol = np.full(15, 1e-12); tol[2:7] = 3e-7; tol[12] = 3e-7; tol[14] = 6e-7   # bmag, u^mu, B (one fp32 ulp, as for 2-D HARM)
+            with np.errstate(all="ignore"):
+                err = np.abs(out - want) / np.abs(want)
+            assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
+    assert cut > 0          # the magnetisation cut (andrew_sigcut) is exercised
+
+
 def test_frame_coefficients_and_formal_step_match_oracle(L):
     # photon momentum, comoving tetrad (sparse-metric dots, shared reciprocals), folded polsynchpl and one
     # formal (Landi Degl'Innocenti) step of the product, compiled for the host, against the oracle's FFJET dumps

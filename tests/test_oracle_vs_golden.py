@@ -262,3 +262,36 @@ def test_harm_slow_light_three_slices(tmp_path):
     assert np.array_equal(npts, g["npts_nload"]) and set(np.unique(npts)) == {100}
     ref = g["ivals_formal_nload"].astype(float)
     assert (np.abs(pix[0] - ref).max(axis=0) / np.abs(ref).max(axis=0)).max() < 1e-6
+
+
+def test_harm3d_polsynchth_image_rays_and_sigcut(tmp_path):
+    # 3-D HARM sampler (periodic phi, eight-corner interpolation, fluid.f90:975-993 units and
+    # electron model, magnetisation cut) on the synthetic binary dump; golden = compiled reference
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_harm3d_dump
+    g = load("harm3d_40x40x200.npz")
+    dfile, _ = make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
+    assert hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest() == str(g["dump_sha256"])
+    kw = dict(make_golden.HARM3D)
+    for iname, key, extra in (("formal", "ivals_formal", {}), ("delo", "ivals_delo", {}), ("formal", "ivals_formal_sigcut", dict(sigcut=1e-3))):
+        o = O.Oracle(nn=(40, 40, 200), iname=iname, datadir=str(tmp_path), **kw, **extra)
+        pix, npts, _ = o.trace(1, 1600, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g["npts"])
+        ref = g[key].astype(float)
+        assert not np.isnan(ref).any()
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 2e-6, (key, err)
+    assert np.abs(g["ivals_formal_sigcut"] - g["ivals_formal"]).max() / np.abs(g["ivals_formal"]).max() > 1e-3   # the cut acts
+    r = load("harm3d_rays_40x40x200.npz")
+    o = O.Oracle(nn=(40, 40, 200), iname="formal", datadir=str(tmp_path), sigcut=float(r["sigcut"]), **kw)
+    for i in r["rays"]:
+        d = o.ray_dump(int(i), float(r["freq"]))
+        assert d["npts"] == int(r["ray%d_npts" % i])
+        for k in ("rho", "p", "bmag", "u", "b", "ncgs", "ncgsnth", "bcgs", "tcgs"):     # the fp32 sampler is bit-faithful
+            assert relerr(d[k], r["ray%d_%s" % (i, k)]) < 1e-9, (i, k)
+        for k, tol in (("lam", 1e-8), ("x", 1e-8), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6), ("I", 1e-6)):
+            assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
+

@@ -266,6 +266,41 @@ def harm_slowlight():
     np.savez_compressed(os.path.join(G, "harm_slowlight_32x32x100.npz"), freq=FREQ_HARM, **out)
 
 
+HARM3D = dict(fname="HARM3D", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1e20, mu0=0.5,
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=1., dfile="dump3d", hfile="dump3d_header", findf=40, fnt=1)
+HARM3D_ZONES = dict(n1=48, n2=48, n3=24)
+
+
+def harm3d(nx=40, nup=200):
+    # the 3-D HARM sampler on the synthetic dump of tools/make_harm3d_dump.py (no HARM3D data ships with
+    # the reference).  Two runs: sigcut at its default (1e10: no cut) and sigcut=1e-3 (the magnetisation cut zeroes the
+    # funnel), formal and delo; per-stage dumps of a few rays.
+    import hashlib
+    import tempfile
+    import make_harm3d_dump
+    out, rays = {}, {}
+    with tempfile.TemporaryDirectory() as td:
+        dfile, hfile = make_harm3d_dump.write(td, **HARM3D_ZONES)
+        out["dump_sha256"] = np.array(hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest())
+        for iname in ("formal", "delo"):
+            r = R.Ref(nn=(nx, nx, nup), iname=iname, datadir=td, **HARM3D)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["ivals_" + iname] = pix[0]
+            out["npts"] = npts
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, sigcut=1e-3, **HARM3D)
+        pix, _, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+        out["ivals_formal_sigcut"] = pix[0]
+        pick = sorted(set([3, nx // 2 * nx + nx // 2, nx * 10 + 30, nx * 30 + 12, nx * nx - 4, nx * 20 + 5]))
+        for i in pick:
+            d = r.ray_dump(i, FREQ_HARM)
+            for k, v in d.items():
+                rays["ray%d_%s" % (i, k)] = np.asarray(v)
+        rays["rays"] = np.array(pick)
+    zones = np.array([HARM3D_ZONES[k] for k in ("n1", "n2", "n3")])
+    np.savez_compressed(os.path.join(G, "harm3d_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, zones=zones, **out)
+    np.savez_compressed(os.path.join(G, "harm3d_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, zones=zones, sigcut=1e-3, **rays)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -282,4 +317,5 @@ if __name__ == "__main__":
     thindisk()
     harm_movie()
     harm_slowlight()
+    harm3d()
     print("golden fixtures written to", os.path.abspath(G))
