@@ -371,7 +371,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
       else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
       else if (FLUID == GRT_FLUID_HARM3D) harm3d_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       PLPoint plp;
-      if (EMIS == GRT_EMIS_POLSYNCHPL) polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp);
+      if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
+        polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp);
       const double lg = log(g);
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
@@ -390,6 +391,19 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_k
             polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
           }
           else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_HYBRIDTHPL) {
+            // thermal + power-law populations (emis.f90:473-490); one instantiation serves HYBRIDTHPL / HYBRIDTH /
+            // HYBRIDPL (em.type, wave-uniform).  The 25 KB of LDS a 2-D/3-D HARM block already holds leave no room for
+            // the table rows at two blocks per CU, so the power-law tables are read through the scalar/L1 path here.
+            double epl[11];
+            polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
+            polsynchpl_freq(tb, karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), plp, nu, lfreqs[f0 + f] - lg, epl);
+            const int etype = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e11[c] = (etype == GRT_EMIS_HYBRIDTHPL) ? e11[c] + epl[c] : (etype == GRT_EMIS_HYBRIDTH ? e11[c] : epl[c]);
+#pragma unroll
+            for (int c = 4; c < 11; ++c) e11[c] += epl[c];
+          }
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
           if constexpr (IFLAG == GRT_INT_QUAD) {
             // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
@@ -624,6 +638,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
                                           int nfields, int tfield, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
+  if (emis == GRT_EMIS_HYBRIDTH || emis == GRT_EMIS_HYBRIDPL) emis = GRT_EMIS_HYBRIDTHPL;   // one instantiation, em->type selects
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
     launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
@@ -642,6 +657,12 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
 #undef GRT_XFER_CASE
   return hipErrorInvalidValue;
 }

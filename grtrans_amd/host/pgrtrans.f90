@@ -104,6 +104,9 @@ contains
     case ('POLSYNCHPL'); emis_id = GRT_EMIS_POLSYNCHPL
     case ('POLSYNCHTH'); emis_id = GRT_EMIS_POLSYNCHTH
     case ('BB'); emis_id = GRT_EMIS_BB
+    case ('HYBRIDTHPL'); emis_id = GRT_EMIS_HYBRIDTHPL
+    case ('HYBRIDTH'); emis_id = GRT_EMIS_HYBRIDTH
+    case ('HYBRIDPL'); emis_id = GRT_EMIS_HYBRIDPL
     case default; call die('emissivity '//trim(ename)//' is not on the device yet')
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37

@@ -81,6 +81,15 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
     if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    else if (S.emis >= 20 && S.emis <= 22) {
+      // thermal + power-law populations (emis.f90:473-490): HYBRIDTHPL K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep one
+      // population's emission and the total absorption and Faraday coefficients
+      double eth[11], epl[11];
+      polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], eth);
+      polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, epl);
+      for (int c = 0; c < 4; ++c) e[c] = (S.emis == 20) ? eth[c] + epl[c] : (S.emis == 21 ? eth[c] : epl[c]);
+      for (int c = 4; c < 11; ++c) e[c] = eth[c] + epl[c];
+    }
     else if (S.emis == 8) { for (int c = 0; c < 11; ++c) e[c] = 0.0; e[0] = bnu(w.tcgs[i], nu); }   // bbemis, emis.f90:162-168
     else polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);
     for (int c = 0; c < 4; ++c) w.jraw[4 * i + c] = e[c];
@@ -208,7 +217,9 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   else if (fn == "THINDISK") { S.fluid = 2; S.disk = ThinDisk(); S.disk.mbh = (float)mbh; S.disk.mdot = (float)fmdot; }
   else return -1;
   S.mdot = mdot; S.muval = muval;
-  if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8; else return -2;
+  if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8;
+  else if (en == "HYBRIDTHPL") S.emis = 20; else if (en == "HYBRIDTH") S.emis = 21; else if (en == "HYBRIDPL") S.emis = 22;
+  else return -2;
   if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2;
   else if (in == "lsoda" && nn[2] == 1) S.iflag = 0;     // one point per ray: no integrator runs (grtrans_driver.f90:296-300)
   else return -3;

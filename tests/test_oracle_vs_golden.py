@@ -295,3 +295,30 @@ def test_harm3d_polsynchth_image_rays_and_sigcut(tmp_path):
         for k, tol in (("lam", 1e-8), ("x", 1e-8), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6), ("I", 1e-6)):
             assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
 
+
+def test_hybrid_thermal_plus_powerlaw_emissivities(tmp_path):
+    # HYBRIDTHPL / HYBRIDTH / HYBRIDPL (emis.f90:473-490) on the 2-D HARM dump and on a magnetised 3-D HARM dump whose
+    # funnel holds non-thermal electrons (nonthermale_b2, fluid.f90:914-923); golden = compiled reference
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_harm3d_dump
+    import make_harm_dump
+    g = load("hybrid_32x32x150.npz")
+    make_harm3d_dump.write(str(tmp_path), b0=float(g["b0"]), **make_golden.HARM3D_ZONES)
+    make_harm_dump.write(str(tmp_path), n=64)
+    fr = float(g["freq"])
+    cases = [("harm3d_" + en, "formal", dict(make_golden.HARM3D, **make_golden.HYBRID, ename=en)) for en in ("HYBRIDTHPL", "HYBRIDTH", "HYBRIDPL")]
+    cases.append(("harm3d_HYBRIDTHPL_delo", "delo", dict(make_golden.HARM3D, **make_golden.HYBRID, ename="HYBRIDTHPL")))
+    cases += [("harm_" + en, "formal", dict(make_golden.HARM, ename=en, gmin=10., gmax=1e5, p1=3.5)) for en in ("HYBRIDTHPL", "HYBRIDTH")]
+    for key, iname, kw in cases:
+        o = O.Oracle(nn=(32, 32, 150), iname=iname, datadir=str(tmp_path), **kw)
+        pix, npts, _ = o.trace(1, 1024, [fr], nthreads=8)
+        assert np.array_equal(npts, g["harm3d_npts" if key.startswith("harm3d") else "harm_npts"])
+        ref = g[key].astype(float)
+        assert np.array_equal(np.isnan(pix[0]), np.isnan(ref)), key          # (the reference's DELO overflows on 20 pixels here)
+        ok = ~np.isnan(ref).any(axis=1)
+        err = np.abs(pix[0][ok].astype(float) - ref[ok]).max(axis=0) / np.abs(ref[ok]).max(axis=0)
+        assert err.max() < 5e-6, (key, err)
+    assert np.abs(g["harm3d_HYBRIDTHPL"] - g["harm3d_HYBRIDTH"]).max() > 1e-6 * np.abs(g["harm3d_HYBRIDTHPL"]).max()
+

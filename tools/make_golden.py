@@ -301,6 +301,36 @@ def harm3d(nx=40, nup=200):
     np.savez_compressed(os.path.join(G, "harm3d_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, zones=zones, sigcut=1e-3, **rays)
 
 
+HYBRID = dict(gmin=50., gmax=1e5, p1=3.5, p2=3.5, jetalpha=0.02, mdot=1e19)
+
+
+def hybrid(nx=32, nup=150):
+    # thermal + power-law electron populations (HYBRIDTHPL / HYBRIDTH / HYBRIDPL, emis.f90:473-490) on the two GRMHD
+    # samplers: 2-D HARM (non-thermal density = thermal density, fluid.f90:972) and a magnetised 3-D HARM dump
+    # (non-thermal electrons where b^2/rho > 1, fluid.f90:914-923)
+    import tempfile
+    import make_harm_dump
+    import make_harm3d_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        make_harm3d_dump.write(td, b0=2.5, **HARM3D_ZONES)
+        make_harm_dump.write(td, n=64)
+        for en in ("HYBRIDTHPL", "HYBRIDTH", "HYBRIDPL"):
+            kw = dict(HARM3D); kw.update(HYBRID); kw.update(ename=en)
+            r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["harm3d_" + en] = pix[0]; out["harm3d_npts"] = npts
+        kw = dict(HARM3D); kw.update(HYBRID); kw.update(ename="HYBRIDTHPL")
+        r = R.Ref(nn=(nx, nx, nup), iname="delo", datadir=td, **kw)
+        out["harm3d_HYBRIDTHPL_delo"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
+        for en in ("HYBRIDTHPL", "HYBRIDTH"):
+            kw = dict(HARM); kw.update(ename=en, gmin=10., gmax=1e5, p1=3.5, p2=3.5)
+            r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["harm_" + en] = pix[0]; out["harm_npts"] = npts
+    np.savez_compressed(os.path.join(G, "hybrid_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, b0=2.5, **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -318,4 +348,5 @@ if __name__ == "__main__":
     harm_movie()
     harm_slowlight()
     harm3d()
+    hybrid()
     print("golden fixtures written to", os.path.abspath(G))

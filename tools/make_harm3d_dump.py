@@ -19,7 +19,7 @@ SEED = 20261003
 DLEN = 35
 
 
-def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, seed=SEED, time=2000.0, phase=0.0):
+def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, seed=SEED, time=2000.0, phase=0.0, b0=0.12):
     assert n1 <= n2, "the reference's uniqx1 slice (fluid_model_harm3d.f90:139) needs nx1 <= nx2"
     rh = 1.0 + np.sqrt(1.0 - a * a)
     rin = 0.98 * rh
@@ -50,7 +50,7 @@ def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, seed=SEED, time=2000.0, phase=0
     gamma = 1.0 / np.sqrt(1.0 - v2)
     u = gamma[..., None] * (nvec + v)
     B = np.zeros_like(nvec)
-    B0 = 0.12
+    B0 = b0
     B[..., 1] = B0 * np.cos(th) / r ** 2 * (1.0 + 0.3 * np.sin(th) ** 2)
     B[..., 2] = 0.2 * B0 * np.sin(th) / r ** 3 * (1.0 + 0.2 * np.sin(spiral))
     B[..., 3] = -0.8 * B0 / r ** 2.5 * (1.0 + 0.25 * np.cos(spiral + 0.4))
