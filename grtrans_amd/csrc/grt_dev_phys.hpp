@@ -673,9 +673,27 @@ GRT_HD int hunt_index(const float *xx, int n, float x) {
   return jlo;
 }
 
-GRT_HD float sphacc_lookup(const float *xx, const float *yy, int n, float u) {
+// the same bracket from a starting guess: a couple of neighbour comparisons instead of the nine dependent LDS reads of
+// the bisection when the table is (log-)uniform; a bad guess falls back to hunt_index
+GRT_HD int hunt_index_from(const float *xx, int n, float x, int guess) {
+  if (!(x == x)) return hunt_index(xx, n, x);
+  const bool ascnd = xx[n - 1] >= xx[0];
+  int j = guess < 0 ? 0 : (guess > n ? n : guess), steps = 0;
+  // jlo = the largest j in [0,n] with j == 0 or ((x >= xx[j-1]) == ascnd)
+  while (j < n && ((x >= xx[j]) == ascnd)) { ++j; if (++steps > 4) return hunt_index(xx, n, x); }
+  while (j > 0 && ((x >= xx[j - 1]) != ascnd)) { --j; if (++steps > 4) return hunt_index(xx, n, x); }
+  if (x == xx[n - 1]) j = n - 1;
+  if (x == xx[0]) j = 1;
+  return j;
+}
+
+// kind 0: plain bisection; 1: xx uniform; 2: xx = 1/r with r log-uniform (the two SPHACC abscissae)
+GRT_HD float sphacc_lookup(const float *xx, const float *yy, int n, float u, int kind = 0) {
   GRT_NO_CONTRACT
-  int j = hunt_index(xx, n, u);
+  int j;
+  if (kind == 1) j = hunt_index_from(xx, n, u, (int)((u - xx[0]) / (xx[1] - xx[0])) + 1);
+  else if (kind == 2) { const float l0 = logf(xx[0]); j = hunt_index_from(xx, n, u, (int)((l0 - logf(u)) / (l0 - logf(xx[1]))) + 1); }
+  else j = hunt_index(xx, n, u);
   j = j < 1 ? 1 : (j > n - 1 ? n - 1 : j);      // address clamp only
   float w = (u - xx[j - 1]) / (xx[j] - xx[j - 1]);
   return (float)((1.0 - (double)w) * (double)yy[j - 1] + (double)(w * yy[j]));
@@ -690,9 +708,9 @@ GRT_HD void sphacc_sample(const float *tab, double r, FluidPoint &f) {
   const double t2u = 2.0 * (double)u;
   const float n = (float)(393441421008.81982 * (t2u * sqrt(t2u)));
   (void)gamma; (void)alpha; (void)ninf; (void)Tinf; (void)us;
-  const float T = sphacc_lookup(tab + 2 * GRT_SPHACC_NU, tab + 2 * GRT_SPHACC_NU + GRT_SPHACC_NT, GRT_SPHACC_NT, u);
+  const float T = sphacc_lookup(tab + 2 * GRT_SPHACC_NU, tab + 2 * GRT_SPHACC_NU + GRT_SPHACC_NT, GRT_SPHACC_NT, u, 2);
   const float B = (float)sqrt(8.0 * PH_pi * (double)n * 1.67262158e-24 / 2.0 * PH_c2 * (double)u);
-  const float ur = sphacc_lookup(tab, tab + GRT_SPHACC_NU, GRT_SPHACC_NU, u);
+  const float ur = sphacc_lookup(tab, tab + GRT_SPHACC_NU, GRT_SPHACC_NU, u, 1);
   const float g00 = -(1.f - 2.f * u);
   const float grr = (float)(-1.0 / (double)g00);
   f.u[1] = -(double)ur; f.u[2] = 0.0; f.u[3] = 0.0;
@@ -761,16 +779,35 @@ GRT_HD int harm_time_index(const GrtHarm &t, double r, double tcoord, double r1,
   return tindx < 0 ? 0 : tindx;                         // (negative: out of bounds in the reference)
 }
 
+// theta -> zone index of harm_vals (fluid_model_harm.f90:58-71, :141-143), see harm_sample.  brent_only: the
+// reference's literal path for every point (tests).
+GRT_HD int harm_theta_index(float h, const float *uniqx2, const float *uniqth, int nx2, float theta, bool brent_only = false) {
+  GRT_NO_CONTRACT
+  int jlo = 0, jhi = nx2 + 1;
+  while (jhi - jlo > 1) {
+    const int jm = (jhi + jlo) >> 1;
+    if (theta >= uniqth[jm - 1]) jlo = jm; else jhi = jm;
+  }
+  const float below = (jlo >= 1) ? theta - uniqth[jlo - 1] : 1.f, above = (jlo < nx2) ? uniqth[jlo] - theta : 1.f;
+  if (!brent_only && fminf(below, above) > 1.5e-5f) return jlo;
+  HarmX2 fn{(double)theta, (double)h};
+  const float x2 = (float)zbrent_x2(fn, 0.0, 1.0, 1e-6);
+  return (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
+}
+
 GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_d, float a, FluidPoint &f, int tindx = 0) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2;
   const float theta = (float)th_d, zr = (float)r;
   const float x1 = logf_cr(zr);
-  HarmX2 fn{(double)theta, (double)t.h};
-  const float x2 = (float)zbrent_x2(fn, 0.0, 1.0, 1e-6);
+  // theta -> zone index.  The reference inverts theta(x2) with Brent (tol 1e-6) and takes floor() of the REAL(4) root;
+  // theta(x2) is monotonic and uniqth holds it at the zone centres, so the same index is the position of theta in
+  // uniqth (8 LDS reads) -- provably so unless theta lies within 1.5e-5 of a zone-centre angle (Brent's stopping point
+  // is good to 5e-7 in x2, d theta/d x2 <= 5.4, REAL(4) roundings ~3e-7).  Only those points (0.24 % at 256 zones)
+  // run the reference's own Brent iteration, so every point gets the index the reference gets.
   int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
-  int lx2 = (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
+  int lx2 = harm_theta_index(t.h, uniqx2, uniqth, nx2, theta);
   int ux2 = lx2 + 1;
   lx2 = (lx2 >= 1) ? lx2 : 1;
   ux2 = (ux2 <= nx2) ? ux2 : nx2;

@@ -29,9 +29,14 @@ using namespace grtd;
 #ifndef GRT_WPE_GEO
 #define GRT_WPE_GEO 2     // waves per SIMD the register allocator must make room for
 #endif
-#ifndef GRT_WPE_XFER
 #define GRT_AS4 __attribute__((address_space(4)))
-#define GRT_WPE_XFER 2
+// waves per SIMD the transfer kernel is compiled for.  The power-law instantiations fit 256 registers with 84 B/lane of
+// scratch and want two waves for latency hiding (39.5 ms against 51.2 ms at one wave, 1024x1024x400).  The thermal
+// coefficient code (Bessel functions, tanh, cbrt, a dozen exp/log) needs ~350 live registers: at two waves it spills
+// 340-490 B/lane to scratch, at one wave the spills go to the 256 AGPRs (v_accvgpr moves, no memory): SPHACC
+// 57.5 -> 54.4 ms, HARM 93.9 -> 84.2 ms.
+#ifndef GRT_XFER_WPE
+#define GRT_XFER_WPE(EMIS) ((EMIS) == GRT_EMIS_POLSYNCHPL ? 2 : 1)
 #endif
 #define GRT_MAXF 32
 #define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
@@ -207,7 +212,7 @@ template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 
 }
 
 template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
-__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_WPE_XFER) void grt_transfer_kernel(
+__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned long long *__restrict__ flags,

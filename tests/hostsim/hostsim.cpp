@@ -122,6 +122,29 @@ int grt_upload_harm_slices(int nx1, int nx2, int nt, float tstep, float h, const
   g_harm.nt = nt; g_harm.tstep = tstep;
   return 0;
 }
+// guided bracket search against the plain bisection, on both SPHACC abscissae
+void hs_hunt_both(const float *tab, int n, const float *x, int *guided, int *plain) {
+  const float *uu = tab, *ir = tab + 2 * GRT_SPHACC_NU;
+  for (int i = 0; i < n; ++i) {
+    const float l0 = logf(ir[0]);
+    guided[2 * i] = hunt_index_from(uu, GRT_SPHACC_NU, x[i], (int)((x[i] - uu[0]) / (uu[1] - uu[0])) + 1);
+    guided[2 * i + 1] = hunt_index_from(ir, GRT_SPHACC_NT, x[i], (int)((l0 - logf(x[i])) / (l0 - logf(ir[1]))) + 1);
+    plain[2 * i] = hunt_index(uu, GRT_SPHACC_NU, x[i]);
+    plain[2 * i + 1] = hunt_index(ir, GRT_SPHACC_NT, x[i]);
+  }
+}
+
+// zone index of theta: the search in uniqth the kernel runs, and the reference's Brent path for every point
+void hs_harm_theta_index(int n, const float *theta, int *fast, int *brent) {
+  const float *crd = g_crd.data();
+  const int nx1 = g_harm.nx1, nx2 = g_harm.nx2;
+  for (int i = 0; i < n; ++i) {
+    fast[i] = harm_theta_index(g_harm.h, crd + 2 * nx1, crd + 2 * nx1 + nx2, nx2, theta[i], false);
+    brent[i] = harm_theta_index(g_harm.h, crd + 2 * nx1, crd + 2 * nx1 + nx2, nx2, theta[i], true);
+  }
+}
+int hs_harm_uniqth(float *out) { const int nx1 = g_harm.nx1, nx2 = g_harm.nx2; for (int j = 0; j < nx2; ++j) out[j] = g_crd[2 * nx1 + nx2 + j]; return nx2; }
+
 // 3-D HARM: same capture of the loader's arrays
 static GrtHarm3d g_h3;
 static std::vector<float> g_cells3, g_crd3;

@@ -120,6 +120,50 @@ def test_harm_loader_sampler_and_units_match_oracle(L, tmp_path):
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
 
 
+def test_sphacc_guided_bracket_equals_bisection(L):
+    # the kernel brackets u = 1/r in SPHACC's two tables from a computed guess; the bracket must be hunt()'s for every u
+    tab = np.fromfile(os.path.join(ROOT, "grtrans_amd", "data", "sphacc_tables.bin"), dtype=np.float32)
+    rng = np.random.default_rng(11)
+    x = [rng.uniform(-0.1, 0.7, 100000), 1.0 / rng.uniform(1.5, 500.0, 100000), tab[:498], tab[996:996 + 461],
+         np.nextafter(tab[:498], np.float32(9)), np.nextafter(tab[:498], np.float32(-9)),
+         np.nextafter(tab[996:996 + 461], np.float32(9)), np.nextafter(tab[996:996 + 461], np.float32(-9)), [np.nan, 0.0, 1e-30, 1e30]]
+    x = np.concatenate([np.asarray(v, dtype=np.float32) for v in x])
+    x = x[(x > 0) | np.isnan(x)]                    # logf of the guess: u = 1/r is positive on every ray
+    g = np.zeros(2 * len(x), dtype=np.int32); p = np.zeros(2 * len(x), dtype=np.int32)
+    L.hs_hunt_both.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_hunt_both(tab.ctypes.data, len(x), x.ctypes.data, g.ctypes.data, p.ctypes.data)
+    assert np.array_equal(g, p), np.where(g != p)[0][:10]
+
+
+def test_harm_theta_index_equals_brent_index_everywhere(L, tmp_path):
+    # the kernel finds the theta zone by searching uniqth and runs the reference's Brent inversion only near zone-centre
+    # angles; the index must equal the all-Brent index for every theta, including the ones straddling the centres
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_harm_dump
+    for n in (64, 256):
+        make_harm_dump.write(str(tmp_path), n=n)
+        assert L.grt_load_harm_files(str(tmp_path / "dump").encode(), str(tmp_path / "dump040").encode(), 40, 0.9375) == 0
+        uth = np.zeros(n, dtype=np.float32)
+        L.hs_harm_uniqth.argtypes = [C.c_void_p]
+        assert L.hs_harm_uniqth(uth.ctypes.data) == n
+        rng = np.random.default_rng(7)
+        th = [rng.uniform(1e-4, np.pi - 1e-4, 200000).astype(np.float32)]
+        for k in range(-40, 41):                      # fp32 neighbours of every zone-centre angle, and +-1e-5 .. 3e-5 around them
+            t = uth.copy()
+            for _ in range(abs(k)):
+                t = np.nextafter(t, np.float32(10.0 if k > 0 else -10.0), dtype=np.float32)
+            th.append(t)
+        for off in (1e-5, 1.4e-5, 1.6e-5, 2e-5, 3e-5):
+            th += [(uth + np.float32(off)).astype(np.float32), (uth - np.float32(off)).astype(np.float32)]
+        th = np.concatenate(th)
+        th = th[(th > 1e-5) & (th < np.pi - 1e-5)]
+        fast = np.zeros(len(th), dtype=np.int32); brent = np.zeros(len(th), dtype=np.int32)
+        L.hs_harm_theta_index.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hs_harm_theta_index(len(th), th.ctypes.data, fast.ctypes.data, brent.ctypes.data)
+        assert np.array_equal(fast, brent), (n, np.where(fast != brent)[0][:10])
+
+
 def test_harm3d_loader_sampler_and_units_match_oracle(L, tmp_path):
     # product loader (binary 3-D dump -> BL/LNRF arrays) + device harm3d_sample/harm3d_convert, compiled
     # for the host, against the oracle's per-stage dump (itself pinned to the compiled reference, tools/make_golden.py)
