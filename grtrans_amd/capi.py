@@ -11,7 +11,7 @@ LIB = os.environ.get("GRTRANS_AMD_LIB", os.path.join(PKG, "libgrtrans_amd.so"))
 DATA = os.path.join(PKG, "data")
 
 FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13, "HARM3D": 19}       # fluid.f90:40-43
-EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8, "HYBRIDTHPL": 20, "HYBRIDTH": 21, "HYBRIDPL": 22}    # emis.f90:11-18
+EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8, "HYBRIDTHPL": 20, "HYBRIDTH": 21, "HYBRIDPL": 22, "MAXJUTT": 23}    # emis.f90:11-18
 INTEG = {"lsoda": 0, "delo": 1, "formal": 2, "lsodasph": 3}          # rad_trans.f90:29-37
 
 
@@ -29,7 +29,8 @@ class GrtEmis(C.Structure):
                 ("gmin", C.c_double), ("gmax", C.c_double), ("p1", C.c_double), ("muval", C.c_double),
                 ("mdot", C.c_double), ("gminval", C.c_double),
                 ("jetalpha", C.c_double), ("sigcut", C.c_double),
-                ("type", C.c_int32), ("coefindx", C.c_int32 * 7)]
+                ("type", C.c_int32), ("coefindx", C.c_int32 * 7),
+                ("nother", C.c_int32), ("pad1", C.c_int32), ("otherargs", C.c_double * 8)]
 
 
 class GrtStats(C.Structure):
@@ -106,13 +107,19 @@ def make_camera(standard, gridvals, nn, spin, mu0, uout, phi0=-0.5):
     return cam
 
 
-def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7, mdot=0.0, jetalpha=0.02, sigcut=1e10):
+def make_emis(ename, mbh, nfac, bfac, gmin, gmax, p1, muval=0.25, coefindx=(1,) * 7, mdot=0.0, jetalpha=0.02, sigcut=1e10,
+              otherargs=(1.0, 1.0)):
     em = GrtEmis()
     em.mbh, em.nfac, em.bfac = mbh, nfac, bfac
     em.gmin, em.gmax, em.p1 = _f32(gmin), _f32(gmax), _f32(p1)   # REAL(4) in emis_params (emis.f90:32-39)
     em.muval = muval
     em.mdot, em.gminval = mdot, gmin                             # REAL(8) in source_params (fluid.f90:67-74)
     em.jetalpha, em.sigcut = jetalpha, sigcut
+    if len(otherargs) < 2 or len(otherargs) > 8:
+        raise GrtError("otherargs = (delta, 1..7 weights)")
+    em.nother = len(otherargs)
+    for i, v in enumerate(otherargs):
+        em.otherargs[i] = float(v)
     em.type = EMIS[ename]
     for i in range(7):
         em.coefindx[i] = int(coefindx[i])

@@ -392,7 +392,9 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM3D && em->type == GRT_EMIS_POLSYNCHTH) ||
                        ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D) &&
-                        (em->type == GRT_EMIS_HYBRIDTHPL || em->type == GRT_EMIS_HYBRIDTH || em->type == GRT_EMIS_HYBRIDPL));
+                        (em->type == GRT_EMIS_HYBRIDTHPL || em->type == GRT_EMIS_HYBRIDTH || em->type == GRT_EMIS_HYBRIDPL ||
+                         em->type == GRT_EMIS_MAXJUTT));
+  if (em->type == GRT_EMIS_MAXJUTT && (em->nother < 2 || em->nother > 8)) return GRT_E_BADARG;
   if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   // nextra: 0, or the 19 ray diagnostics of extra=1 for nup>1 (pgrtrans.f90:108-114)
@@ -403,7 +405,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (fluid_model == GRT_FLUID_SPHACC && !C.d_sphacc) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM && !C.have_harm) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM3D && !C.have_harm3d) return GRT_E_NOFLUID;
-  if ((em->type == GRT_EMIS_POLSYNCHPL || em->type >= GRT_EMIS_HYBRIDTHPL) && !C.have_tables) return GRT_E_NOTABLES;
+  if ((em->type == GRT_EMIS_POLSYNCHPL || (em->type >= GRT_EMIS_HYBRIDTHPL && em->type <= GRT_EMIS_HYBRIDPL)) && !C.have_tables) return GRT_E_NOTABLES;
   GrtFluidDev fd{};
   fd.fj = C.ffjet;
   fd.sphacc = C.d_sphacc;

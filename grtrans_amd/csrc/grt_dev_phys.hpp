@@ -507,6 +507,28 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   e[8] = w / 2.0 / c * eps11m22; e[9] = 0.0 * ibn; e[10] = w / c * eps12;
 }
 
+// MAXJUTT: calc_maxjutt_subroutine (calc_maxjutt.f90:8-63).  otherargs = (delta, w_1..w_N): N thermal components with
+// densities n w_i / sum(w) at temperatures T delta^(i-1) / sum_i (w_i / sum(w)) delta^(i-1).
+GRT_NI void maxjutt_fast(double nu, double n, double B, double T, double theta, int nother, const double *otherargs, double *e) {
+  const int nw = nother - 1;
+  const double delta = otherargs[0];
+  double wsum = 0.0, dwsum = 0.0, dp = 1.0;
+  for (int q = 0; q < nw; ++q) wsum += otherargs[1 + q];
+  for (int q = 0; q < nw; ++q) { dwsum += otherargs[1 + q] / wsum * dp; dp *= delta; }
+  const double tmin = T / dwsum;
+  for (int c = 0; c < 11; ++c) e[c] = 0.0;
+  dp = 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang loop unroll(disable)
+#endif
+  for (int q = 0; q < nw; ++q) {
+    double et[11];
+    polsynchth_fast(nu, otherargs[1 + q] / wsum * n, B, tmin * dp, theta, et);
+    for (int c = 0; c < 11; ++c) e[c] += et[c];
+    dp *= delta;
+  }
+}
+
 // ------------------------------------------------------------------ integrators
 // calc_O  radtrans_integrate.f90:615   O[i][j] row i col j
 GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]) {

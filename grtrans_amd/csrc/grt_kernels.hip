@@ -202,12 +202,8 @@ __device__ __forceinline__ const char GRT_AS4 *karg_fresh() {     // a kernarg p
   return p;
 }
 template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 *base, size_t off) {
-  static_assert(sizeof(T) % 4 == 0, "dword-sized arguments only");
   T out;
-  unsigned *o = reinterpret_cast<unsigned *>(&out);
-  const unsigned GRT_AS4 *q = reinterpret_cast<const unsigned GRT_AS4 *>(base + off);
-#pragma unroll
-  for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
+  __builtin_memcpy(&out, (const void *)(base + off), sizeof(T));     // (memcpy: no type-punned stores; the source stays in the constant address space)
   return out;
 }
 
@@ -396,6 +392,14 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
             polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
           }
           else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_MAXJUTT) {
+            // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): thermal components w_i n at T delta^i / sum_i w_i delta^i
+            const GrtEmis emj = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
+            double oa[8];                                  // per-lane copy: the component loop indexes it dynamically
+#pragma unroll
+            for (int c = 0; c < 8; ++c) oa[c] = emj.otherargs[c];
+            maxjutt_fast(nu, ncgs, bcgs, tcgs, ang, emj.nother, oa, e11);
+          }
           else if (EMIS == GRT_EMIS_HYBRIDTHPL) {
             // thermal + power-law populations (emis.f90:473-490); one instantiation serves HYBRIDTHPL / HYBRIDTH /
             // HYBRIDPL (em.type, wave-uniform).  The 25 KB of LDS a 2-D/3-D HARM block already holds leave no room for
@@ -662,6 +666,12 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM3D, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_MAXJUTT)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_HYBRIDTHPL)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_HYBRIDTHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_HYBRIDTHPL)

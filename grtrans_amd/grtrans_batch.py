@@ -216,7 +216,7 @@ class grtrans:
                         mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
                         em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
                                             inp.muval, inp.epcoefindx, mdot=float(mdot), jetalpha=float(inp.jetalpha),
-                                            sigcut=float(inp.sigcut))
+                                            sigcut=float(inp.sigcut), otherargs=tuple(inp.epotherargs))
                         pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
                                                                nvals=inp.nvals, nextra=nextra)
                         for k in range(nfreq):

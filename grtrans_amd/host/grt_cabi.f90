@@ -8,7 +8,8 @@ module grt_cabi
   integer(c_int), parameter :: GRT_FLUID_FFJET = 13, GRT_FLUID_HARM = 12, GRT_FLUID_SPHACC = 1, &
        GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM3D = 19
   integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
-       GRT_EMIS_BB = 8, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22
+       GRT_EMIS_BB = 8, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22, &
+       GRT_EMIS_MAXJUTT = 23
 
   type, bind(C) :: grt_camera          ! GrtCam
      real(c_double) :: a1, a2, b1, b2
@@ -25,6 +26,8 @@ module grt_cabi
      real(c_double) :: jetalpha, sigcut
      integer(c_int32_t) :: etype
      integer(c_int32_t) :: coefindx(7)
+     integer(c_int32_t) :: nother, pad1
+     real(c_double) :: otherargs(8)
   end type grt_emis
 
   type, bind(C) :: grt_stats           ! GrtStats

@@ -107,6 +107,7 @@ contains
     case ('HYBRIDTHPL'); emis_id = GRT_EMIS_HYBRIDTHPL
     case ('HYBRIDTH'); emis_id = GRT_EMIS_HYBRIDTH
     case ('HYBRIDPL'); emis_id = GRT_EMIS_HYBRIDPL
+    case ('MAXJUTT'); emis_id = GRT_EMIS_MAXJUTT
     case default; call die('emissivity '//trim(ename)//' is not on the device yet')
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37
@@ -190,6 +191,8 @@ contains
              em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
              em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
              em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
+             if (nepotherargs < 2 .or. nepotherargs > 8) call die('epotherargs = (delta, 1..7 weights)')
+             em%nother = nepotherargs; em%otherargs = 0d0; em%otherargs(1:nepotherargs) = epotherargs   ! pgrtrans.f90:119-120
              em%jetalpha = jetalpha; em%sigcut = sigcut               ! sparams%jetalphaval, %sigcut (pgrtrans.f90:129-136)
              em%mdot = mdots(m); em%gminval = gmin                   ! sparams%mdot, %gminval (pgrtrans.f90:127-131)
              rc = grt_trace_tile(cam, int(i1, c_int64_t), int(i2, c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &

@@ -37,7 +37,9 @@ enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FL
 enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8,
        /* thermal + power-law electron populations (emis.f90:16-17, :473-490): K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep
           one population's emission with the total absorption and Faraday coefficients */
-       GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22 };
+       GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22,
+       /* sum of thermal components n w_i at temperatures T delta^i / sum_i w_i delta^i (calc_maxjutt.f90:8-63) */
+       GRT_EMIS_MAXJUTT = 23 };
 enum { GRT_INT_LSODA = 0, GRT_INT_DELO = 1, GRT_INT_FORMAL = 2 };
 
 /* Camera scalars: what initialize_pixels / INITIALIZE_CAMERA_GEOKERR derive once per camera
@@ -59,6 +61,8 @@ typedef struct GrtEmis {
   double jetalpha, sigcut;    /* sparams%jetalphaval, %sigcut: non-thermal fraction and magnetisation cut of the 3-D
                                  models (fluid.f90:975-993) */
   int32_t type, coefindx[7];
+  int32_t nother, pad1;       /* emis_params%otherargs (pgrtrans.f90:119-120): otherargs[0] = delta, then nother-1 weights */
+  double otherargs[8];        /* (read_inputs.f90:87-98: one weight, or the six of the tabulated distribution) */
 } grt_emis;
 
 typedef struct GrtStats {

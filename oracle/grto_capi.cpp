@@ -25,7 +25,8 @@ struct Setup {
   SphaccTable sphacc;
   HarmTable harm;
   Harm3dTable harm3d;
-  double jetalpha = 0.02, sigcut = 1e10;     // source_params the 3-D models read (fluid.f90:975-993)
+  double jetalpha = 0.02, sigcut = 1e10;
+  std::vector<double> otherargs{1.0, 1.0};     // emis_params%otherargs: (delta, weights...) of MAXJUTT     // source_params the 3-D models read (fluid.f90:975-993)
   ThinDisk disk;
   std::vector<double> t0;     // per-ray time origin (nload > 1), empty = zero
   double mdot = 0, muval = 0;
@@ -81,6 +82,22 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
     if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    else if (S.emis == 23) {
+      // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): a sum of thermal components with densities w_i n and
+      // temperatures T delta^i / sum_i w_i delta^i, weights normalised
+      const int nw = (int)S.otherargs.size() - 1;
+      const double delta = S.otherargs[0];
+      double wsum = 0.0, dwsum = 0.0;
+      for (int q = 0; q < nw; ++q) wsum += S.otherargs[1 + q];
+      for (int q = 0; q < nw; ++q) dwsum += S.otherargs[1 + q] / wsum * std::pow(delta, (double)q);
+      const double tmin = w.tcgs[i] / dwsum;
+      for (int c = 0; c < 11; ++c) e[c] = 0.0;
+      for (int q = 0; q < nw; ++q) {
+        double et[11];
+        polsynchth(nu, S.otherargs[1 + q] / wsum * w.ncgs[i], w.bcgs[i], tmin * std::pow(delta, (double)q), w.ang[i], et);
+        for (int c = 0; c < 11; ++c) e[c] += et[c];
+      }
+    }
     else if (S.emis >= 20 && S.emis <= 22) {
       // thermal + power-law populations (emis.f90:473-490): HYBRIDTHPL K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep one
       // population's emission and the total absorption and Faraday coefficients
@@ -218,6 +235,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   else return -1;
   S.mdot = mdot; S.muval = muval;
   if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8;
+  else if (en == "MAXJUTT") S.emis = 23;
   else if (en == "HYBRIDTHPL") S.emis = 20; else if (en == "HYBRIDTH") S.emis = 21; else if (en == "HYBRIDPL") S.emis = 22;
   else return -2;
   if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2;
@@ -236,6 +254,8 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
 
 // source_params beyond grto_setup's list (jetalphaval, sigcut): call after grto_setup
 void grto_set_source_extras(double jetalpha, double sigcut) { S.jetalpha = jetalpha; S.sigcut = sigcut; }
+
+void grto_set_otherargs(int n, const double *args) { S.otherargs.assign(args, args + n); }
 
 void grto_camera(int npix, double *alpha, double *beta, double *q2, double *l, double *su, double *sm, double *uf,
                  int *tpr, double *scal) {

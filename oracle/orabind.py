@@ -46,7 +46,7 @@ DEFAULTS = dict(standard=1, mu0=0.906, phi0=-0.5, spin=0.998, uout=0.01,
                 pltab=os.path.join(DATA, "polsynchpl_tables.bin"),
                 mbh=3.4e9, gmin=100., gmax=1e5, p1=3.5, ftscl=2.0, frscl=70.0,
                 coefindx=(1,) * 7, nvals=4, hfile="dump040", findf=40, mdot=1.57e15, muval=0.25, datadir=None, fmdot=0.1, fnt=1,
-                jetalpha=0.02, sigcut=1e10)
+                jetalpha=0.02, sigcut=1e10, otherargs=None)
 
 
 class Oracle:
@@ -78,6 +78,8 @@ class Oracle:
             raise RuntimeError("grto_setup failed rc=%d" % rc)
         lib().grto_set_source_extras.argtypes = [C.c_double, C.c_double]
         lib().grto_set_source_extras(p["jetalpha"], p["sigcut"])
+        oa = np.asarray(p["otherargs"] if p["otherargs"] is not None else (1.0, 1.0), dtype=np.float64)
+        lib().grto_set_otherargs(C.c_int(len(oa)), _dp(oa))
         self.npix = int(nn[0]) * int(nn[1])
         self.nup = int(nn[2])
         self.nvals = p["nvals"]

@@ -135,6 +135,14 @@ contains
     call advance_fluid_timestep(fname_s, dt)
   end subroutine ref_advance_timestep
 
+  ! emis_params%otherargs (pgrtrans.f90:119-120): (delta, weights...) of MAXJUTT / MAXCOMP; call after ref_setup
+  subroutine ref_set_otherargs(n, args) bind(C, name='ref_set_otherargs')
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: args(n)
+    if (allocated(eparams0%otherargs)) deallocate(eparams0%otherargs)
+    allocate(eparams0%otherargs(n)); eparams0%otherargs = args
+  end subroutine ref_set_otherargs
+
   subroutine ref_teardown() bind(C, name='ref_teardown')
     if (.not. is_setup) return
     call del_geokerr_args(gargs)

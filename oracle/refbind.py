@@ -87,6 +87,8 @@ class Ref:
         self.npix = int(nn[0]) * int(nn[1])
         self.nup = int(nn[2])
         self.nvals = p["nvals"]
+        if p.get("otherargs") is not None:
+            self.set_otherargs(p["otherargs"])
 
     def camera(self):
         n = self.npix
@@ -139,6 +141,11 @@ class Ref:
         t0 = np.zeros(self.npix)
         lib().ref_nload_t0(C.c_int(i1 or 1), C.c_int(i2 or self.npix), _dp(t0))
         return t0
+
+    def set_otherargs(self, args):
+        """emis_params%otherargs = (delta, weights...) for MAXJUTT (pgrtrans.f90:119-120)."""
+        a = np.asarray(args, dtype=np.float64)
+        lib().ref_set_otherargs(C.c_int(len(a)), _dp(a))
 
     def advance_timestep(self, dt):
         """advance_fluid_timestep between movie frames (HARM: re-loads dumps; relative paths -> run in datadir)."""

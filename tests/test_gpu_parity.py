@@ -697,3 +697,55 @@ def test_hybrid_emissivities_vs_reference_golden(tmp_path):
     finally:
         d.close()
 
+
+def test_maxjutt_vs_reference_golden_device_and_fortran_host(tmp_path, monkeypatch):
+    # MAXJUTT (calc_maxjutt.f90): weighted sum of thermal components; device through the C ABI with explicit otherargs, and
+    # the Fortran host with delta / nweights=6 from the namelist (its tabulated REAL(4) weights, read_inputs.f90:95-96)
+    import subprocess
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    import make_harm3d_dump
+    import make_harm_dump
+    g = np.load(os.path.join(G, "maxjutt_32x32x150.npz"))
+    monkeypatch.chdir(tmp_path)
+    dfile, hfile = make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
+    make_harm_dump.write(str(tmp_path), n=64)
+    H3, H2 = make_golden.HARM3D, make_golden.HARM
+    d = capi.Device(0)
+    try:
+        d.load_tables()
+        d.load_harm3d(dfile, hfile, 40, H3["spin"])
+        cam = capi.make_camera(1, H3["gridvals"], (32, 32, 150), H3["spin"], H3["mu0"], H3["uout"], -0.5)
+        em = capi.make_emis("MAXJUTT", H3["mbh"], 1.0, 6.0, H3["gmin"], 1e5, 3.5, muval=H3["muval"], mdot=H3["mdot"],
+                            otherargs=(2.0,) + make_golden.MAXJUTT_W6)
+        pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM3D", em, [FREQ_HARM], "formal")
+        # 2e-5 of peak: six thermal evaluations per point, each through the folded-constant coefficient routine (measured 1.07e-5)
+        assert np.array_equal(status, g["harm3d_npts"]) and stokes_err(pix[0], g["harm3d_w6_formal"]) < 2 * STOKES_TOL
+        d.load_harm(os.path.join(str(tmp_path), "dump"), os.path.join(str(tmp_path), "dump040"), 40, H2["spin"])
+        cam = capi.make_camera(1, H2["gridvals"], (32, 32, 150), H2["spin"], H2["mu0"], H2["uout"], -0.5)
+        em = capi.make_emis("MAXJUTT", H2["mbh"], 1.0, 6.0, H2["gmin"], 1e5, 3.5, muval=H2["muval"], mdot=H2["mdot"], otherargs=(1.5, 1.0, 0.5))
+        pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], "formal")
+        assert np.array_equal(status, g["harm_npts"]) and stokes_err(pix[0], g["harm_w2_formal"]) < 2 * STOKES_TOL
+        with pytest.raises(capi.GrtError):          # MAXJUTT has no SPHACC instantiation: refused
+            d.load_sphacc()
+            capi.trace_tile(capi.make_camera(1, (-25., 25., -25., 25.), (8, 8, 50), 0.0, 0.5, 0.04, -0.5), 1, 64, "SPHACC", em, [FREQ_SPHACC], "formal")
+    finally:
+        d.close()
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    kw = dict(fname='HARM3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='MAXJUTT', nvals=4, spin=H3["spin"],
+              standard=1, nn=[32, 32, 150], uout=H3["uout"], mbh=H3["mbh"], mdotmin=H3["mdot"], mdotmax=H3["mdot"], nmdot=1,
+              mumin=H3["mu0"], mumax=H3["mu0"], gridvals=list(H3["gridvals"]), muval=H3["muval"], gmin=H3["gmin"], iname='formal',
+              cflag=0, hdfile='dump3d', hhfile='dump3d_header', hindf=40, hnt=1, epotherargs=[2.0] + list(make_golden.MAXJUTT_W6))
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["harm3d_w6_formal"]) < 2 * STOKES_TOL
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
+

@@ -120,6 +120,26 @@ def test_harm_loader_sampler_and_units_match_oracle(L, tmp_path):
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
 
 
+def test_maxjutt_component_sum_matches_oracle(L, tmp_path):
+    # the kernel's MAXJUTT combination (maxjutt_fast), compiled for the host, against the oracle's raw coefficients
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    import make_harm3d_dump
+    make_harm3d_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+    oa = (2.0,) + make_golden.MAXJUTT_W6
+    o = O.Oracle(nn=(24, 24, 200), iname="formal", datadir=str(tmp_path), **dict(make_golden.HARM3D, ename="MAXJUTT", otherargs=oa))
+    L.hs_maxjutt.argtypes = [C.c_double] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+    oa_arr = np.zeros(8); oa_arr[:len(oa)] = oa
+    freq = 2.3e11
+    for i in (293, 92, 300, 1, 24, 553):
+        d = o.ray_dump(i, freq)
+        for k in range(0, d["npts"], 7):
+            e = np.zeros(11)
+            L.hs_maxjutt(freq / d["rshift"][k], d["ncgs"][k], d["bcgs"][k], d["tcgs"][k], d["ang"][k], len(oa), oa_arr.ctypes.data, e.ctypes.data)
+            assert np.allclose(e[:4], d["jraw"][k], rtol=1e-10, atol=0) and np.allclose(e[4:], d["Kraw"][k], rtol=1e-10, atol=0), (i, k)
+
+
 def test_sphacc_guided_bracket_equals_bisection(L):
     # the kernel brackets u = 1/r in SPHACC's two tables from a computed guess; the bracket must be hunt()'s for every u
     tab = np.fromfile(os.path.join(ROOT, "grtrans_amd", "data", "sphacc_tables.bin"), dtype=np.float32)

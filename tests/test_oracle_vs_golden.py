@@ -322,3 +322,24 @@ def test_hybrid_thermal_plus_powerlaw_emissivities(tmp_path):
         assert err.max() < 5e-6, (key, err)
     assert np.abs(g["harm3d_HYBRIDTHPL"] - g["harm3d_HYBRIDTH"]).max() > 1e-6 * np.abs(g["harm3d_HYBRIDTHPL"]).max()
 
+
+def test_maxjutt_weighted_thermal_components(tmp_path):
+    # MAXJUTT (calc_maxjutt.f90:8-63): sum of thermal components w_i n at T delta^i / sum w_i delta^i; six tabulated weights
+    # (read_inputs.f90:95-96) on the 3-D dump, two weights on the 2-D dump; golden = compiled reference
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_harm3d_dump
+    import make_harm_dump
+    g = load("maxjutt_32x32x150.npz")
+    make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
+    make_harm_dump.write(str(tmp_path), n=64)
+    for key, nk, kw in (("harm3d_w6_formal", "harm3d_npts", dict(make_golden.HARM3D, ename="MAXJUTT", otherargs=(2.0,) + make_golden.MAXJUTT_W6)),
+                        ("harm_w2_formal", "harm_npts", dict(make_golden.HARM, ename="MAXJUTT", otherargs=(1.5, 1.0, 0.5)))):
+        o = O.Oracle(nn=(32, 32, 150), iname="formal", datadir=str(tmp_path), **kw)
+        pix, npts, _ = o.trace(1, 1024, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g[nk])
+        ref = g[key].astype(float)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 2e-6, (key, err)
+

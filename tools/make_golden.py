@@ -331,6 +331,31 @@ def hybrid(nx=32, nup=150):
     np.savez_compressed(os.path.join(G, "hybrid_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, b0=2.5, **out)
 
 
+# read_inputs.f90:95-96: the six tabulated weights are REAL(4) literals stored in REAL(8)
+MAXJUTT_W6 = tuple(float(np.float32(v)) for v in (0.10714295, 0.4459917, 1.34219997, 2.17450422, 1.36515333, 0.52892829))
+
+
+def maxjutt(nx=32, nup=150):
+    # MAXJUTT (calc_maxjutt.f90): a weighted sum of thermal components; delta=2 with the six tabulated weights on the 3-D
+    # dump, delta=1.5 with two weights on the 2-D dump
+    import tempfile
+    import make_harm_dump
+    import make_harm3d_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        make_harm3d_dump.write(td, **HARM3D_ZONES)
+        make_harm_dump.write(td, n=64)
+        kw = dict(HARM3D); kw.update(ename="MAXJUTT", otherargs=(2.0,) + MAXJUTT_W6)
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)      # (the reference's DELO overflows on this problem)
+        pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+        out["harm3d_w6_formal"] = pix[0]; out["harm3d_npts"] = npts
+        kw = dict(HARM); kw.update(ename="MAXJUTT", otherargs=(1.5, 1.0, 0.5))
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+        pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+        out["harm_w2_formal"] = pix[0]; out["harm_npts"] = npts
+    np.savez_compressed(os.path.join(G, "maxjutt_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -349,4 +374,5 @@ if __name__ == "__main__":
     harm_slowlight()
     harm3d()
     hybrid()
+    maxjutt()
     print("golden fixtures written to", os.path.abspath(G))
