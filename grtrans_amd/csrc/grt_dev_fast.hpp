@@ -200,6 +200,13 @@ struct RealRay {
   double facm, facmR, m1m, akm, nn, fac2, i1mu, i3mu, rfc, rdc, rjc, tmu1, tmu3, phimu1, phimu3;
   double sgna_pi;
   AgmLadder agm_mu, agm_u;         // Landen ladders of the two Jacobi inversions (moduli m1m, m1u are per-ray constants)
+  // ncase 5 (two real roots u1, u4 and a complex pair, or u2, u3 behind the horizon): the u integrals are Carlson
+  // (1991) "one quadratic factor" forms with f + g u + u^2 the pair's factor (geokerr_wrapper.f ELLQUARTICCOMPLEX);
+  // a1,b1 = (-u1, 1), a4,b4 = (qs u4, -qs); the (a5,b5) pairs are the real case's
+  int cplx;
+  double cf, cg, ca11, cc44, ca142;
+  double cwp[3], cws[3], cpa[3], ci3a[3], ci3b[3];   // per (a5,b5): Wp2 - M2, U2 - W2, P2 - Q2, 2 a11/(3 c55), 4 d14 (a152 + a11 c55)/d15
+  double ci2a, ci2b, ci2c, ct1, ct2, ct3;            // the [-4] integral with (a5,b5) = (0,1)
 };
 
 GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
@@ -215,9 +222,41 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   K.cC = 2.0 * a * (a - l) + a * a / uplus + one / (uplus * uplus * uplus);
   K.cD = 2.0 * a * (a - l) + a * a * umi + umi * umi * umi;
   K.cP = l / uplus + 2.0 * (a - l); K.cQ = l * umi + 2.0 * (a - l);
+  K.cplx = (R.ncase == 5) ? 1 : 0;
   K.a1 = -R.u1; K.b1 = one; K.a4 = R.u4; K.b4 = -one;
   if (R.ncase == 7) { K.a2 = R.u2; K.b2 = -one; K.a3 = R.u3; K.b3 = -one; }
   else { K.a2 = -R.u2; K.b2 = one; K.a3 = -R.u3; K.b3 = one; }
+  if (K.cplx) {
+    const double qs = fsign(1.0, q2), h = one;
+    K.a4 = qs * R.u4; K.b4 = -qs;
+    K.cf = -qs * one / fabs(ee) / R.u1 / R.u4;
+    K.cg = (R.u4 + R.u1) / R.u1 / R.u4 * K.cf;
+    const double f = K.cf, g = K.cg, a1 = K.a1, b1 = K.b1, a4 = K.a4, b4 = K.b4;
+    K.ca11 = sqrt(two * f * b1 * b1 - two * g * a1 * b1 + two * h * a1 * a1);
+    K.cc44 = sqrt(two * f * b4 * b4 - two * g * a4 * b4 + two * h * a4 * a4);
+    K.ca142 = two * f * b1 * b4 - g * (a1 * b4 + a4 * b1) + two * h * a1 * a4;
+    const double d14 = a1 * b4 - a4 * b1;
+    const double A5c[3] = {one, one, 0.0}, B5c[3] = {-one / uplus, -umi, one};
+    for (int k = 0; k < 3; ++k) {
+      const double a5 = A5c[k], b5 = B5c[k];
+      const double d15 = a1 * b5 - a5 * b1, d45 = a4 * b5 - a5 * b4;
+      const double c552 = two * f * b5 * b5 - two * g * a5 * b5 + two * h * a5 * a5, c55 = sqrt(c552);
+      const double a152 = two * f * b1 * b5 - g * (a1 * b5 + a5 * b1) + two * h * a5 * a1;
+      K.cwp[k] = d14 * (a152 + K.ca11 * c55) / d15;
+      K.cws[k] = sq(K.ca11) * d45 / two / d15;
+      K.cpa[k] = sq(c55) * d45 / two / d15;
+      K.ci3a[k] = two * K.ca11 / 3.0 / c55;
+      K.ci3b[k] = (4.0 * d14 / d15) * (a152 + K.ca11 * c55);
+      if (k == 2) {
+        K.ct1 = sq(b5) / (two * d15 * d45) * sq(K.cc44) / c552;
+        K.ct2 = sq(b1) / sq(d15) * (one - 0.5 * sq(b5) * sq(K.ca11) / sq(b1) / c552);
+        K.ct3 = two * sq(b5) / d15 / c552;
+      }
+    }
+    K.ci2a = two * K.ca11 / 3.0 / K.cc44;
+    K.ci2b = 4.0 * (K.ca142 + K.ca11 * K.cc44);
+    K.ci2c = two * K.ca11 / K.cc44;
+  }
   K.d12 = K.a1 * K.b2 - K.a2 * K.b1; K.d13 = K.a1 * K.b3 - K.a3 * K.b1; K.d14 = K.a1 * K.b4 - K.a4 * K.b1;
   K.d24 = K.a2 * K.b4 - K.a4 * K.b2; K.d34 = K.a3 * K.b4 - K.a4 * K.b3;
   const double A5[3] = {one, one, 0.0}, B5[3] = {-one / uplus, -umi, one};
@@ -241,6 +280,7 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   K.iu0 = R.iu0; K.tu01 = R.tu01;
   K.tu0 = K.cA * R.tu01 + K.cB * R.tu02 - K.cC * R.tu03 + K.cD * R.tu04;
   K.phiu0 = -K.cP * R.tu03 + K.cQ * R.tu04;
+  if (K.cplx) { K.iu0 = 0.0; K.tu01 = 0.0; K.tu0 = 0.0; K.phiu0 = 0.0; }   // ncase 5: the u integrals run from u0 itself
   K.jfac = sqrt(fabs(ee) * (R.u3 - R.u1) * (R.u4 - R.u2)) * 0.5;
   K.m1u = (R.u4 - R.u1) * (R.u3 - R.u2) / ((R.u4 - R.u2) * (R.u3 - R.u1));
   // roots of M(mu) with the guards of geokerr_wrapper.f:1116-1160 / 2299-2340
@@ -356,6 +396,62 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   }
 }
 
+// ncase 5: the same four uf-side quantities from ELLQUARTICCOMPLEX (Carlson 1991), integrals between u0 and uf.
+// Signs are arranged so that ray_point_real's assembly (written for "root-side minus uf-side" with the root-side
+// caches zero) reproduces GEOMU / GEOPHITIME (geokerr_wrapper.f:1005-1030, :2236-2262): iu = su sg I1 / sqrt|ee| etc.
+template <int NPH>
+GRT_HD void cplx_upart(const RealRay &K, double uf, UPart &o) {
+  const double two = 2.0;
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
+  const double u0 = K.u0;
+  if (uf == u0) return;
+  const double sg = (u0 < uf) ? 1.0 : -1.0, y = (u0 < uf) ? u0 : uf, x = (u0 < uf) ? uf : u0;
+  const double X1 = fsqrt(K.a1 + K.b1 * x), X4 = fsqrt(K.a4 + K.b4 * x), Y1 = fsqrt(K.a1 + K.b1 * y), Y4 = fsqrt(K.a4 + K.b4 * y);
+  const double xi = fsqrt(K.cf + K.cg * x + x * x), eta = fsqrt(K.cf + K.cg * y + y * y);
+  const double idxy = frcp(x - y);
+  const double M2 = sq((X1 * Y4 + Y1 * X4) * fsqrt(sq(xi + eta) - sq(x - y)) * idxy);
+  const double Lp2 = M2 + K.ca142 + K.ca11 * K.cc44;
+  const double Lm2 = dmax(M2 + K.ca142 - K.ca11 * K.cc44, 0.0);
+  const double Uc = (X1 * X4 * eta + Y1 * Y4 * xi) * idxy, U2 = Uc * Uc;
+  constexpr int NJ = NPH;
+  constexpr int NA = NPH > 0 ? NPH : 1;
+  double Wp2[NA], W2[NA], Q2[NA], P2[NA], rj2[NA], rff, rdd;
+  // everything that needs the six square roots is formed before the duplication loop
+  const double tI2 = K.ci2c * frcp(Uc) + two * X1 * Y1 * frcp(X4 * Y4 * Uc);
+  const double A111m1m2 = X1 * xi * frcp(X4 * x) - Y1 * eta * frcp(Y4 * y);      // (a5,b5) = (0,1): X52 = x, Y52 = y
+  if (NPH > 0) {
+    const double ixy1 = frcp(sq(X1 * Y1));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NPH; ++k) {
+      const double X52 = K.a5[k] + K.b5[k] * x, Y52 = K.a5[k] + K.b5[k] * y;
+      Wp2[k] = M2 + K.cwp[k];
+      W2[k] = U2 - K.cws[k];
+      Q2[k] = X52 * Y52 * ixy1 * W2[k];
+      P2[k] = Q2[k] + K.cpa[k];
+    }
+  }
+  carlson_bundle<NJ>(M2, Lm2, Lp2, Wp2, rff, rdd, rj2);
+  const double I1 = 4.0 * rff;
+  o.iu1 = -sg * I1;
+  const double I2 = K.ci2a * (K.ci2b * rdd - 6.0 * rff) + tI2;
+  const double tu1v = K.ct1 * I2 + K.ct2 * I1 - K.ct3 * A111m1m2;
+  o.tu11 = -sg * tu1v;
+  if (NPH > 0) {
+    double v[NA];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NPH; ++k) {
+      const double I3 = K.ci3a[k] * (K.ci3b[k] * rj2[k] - 6.0 * rff + 3.0 * rc7(U2, W2[k])) + two * rc7(P2[k], Q2[k]);
+      v[k] = (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
+    }
+    o.phiu1 = sg * (K.cP * v[0] - K.cQ * v[1]);
+    if (NPH == 3) o.tu1 = -sg * (K.cA * tu1v + K.cB * v[2] - K.cC * v[0] + K.cD * v[1]);
+  }
+}
+
 // mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)
 struct MuPart { double i2mu, tmuf, phimuf; };
 
@@ -432,7 +528,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
       int Kk = fill ? (idx - (next - 2 * kext)) : idx;
       un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
     }
-    if (c7 ? (un > root) : (un < root)) un = root;        // geokerr_wrapper.f:1079,1089
+    if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;        // geokerr_wrapper.f:1079,1089
   } else {
     indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, K.sm, idx - lo, next, cam.offset, mun, tpm);
   }
@@ -441,7 +537,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 #endif
   for (int pass = 0; pass < 2; ++pass) {
     const bool doU = (pass == 0) != isfill;
-    if (doU) real_upart<NPH>(K, un, U);
+    if (doU) { if (K.cplx) cplx_upart<NPH>(K, un, U); else real_upart<NPH>(K, un, U); }   // (one ray per wave: a uniform branch)
     else real_mupart<PHI>(K, mun, M, isfill);
     if (pass == 0) {
       // argument of the Jacobi inversion
@@ -527,8 +623,8 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       int Kk = fill ? (idx - (next - 2 * kext)) : idx;
       un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
     }
-    if (c7 ? (un > root) : (un < root)) un = root;        // geokerr_wrapper.f:1079,1089
-    real_upart<(PHI ? 2 : 0)>(K, un, U);
+    if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;        // geokerr_wrapper.f:1079,1089
+    if (K.cplx) cplx_upart<(PHI ? 2 : 0)>(K, un, U); else real_upart<(PHI ? 2 : 0)>(K, un, U);   // wave-uniform
     iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
     // mu_f from I_u (Eq. 30-42)
     double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;

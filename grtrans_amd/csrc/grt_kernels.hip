@@ -60,7 +60,13 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   const int lane = threadIdx.x & 63;
   const bool alive = inr && R.npts > 0;
   // fast class: four distinct real roots (a != 0), or the three real roots of a Schwarzschild camera (a == 0)
-  const bool quart = alive && (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12;
+  // ... or two real roots and a complex pair (ncase 5: the plunging rays; no turning point in u, no mu-fill segment)
+  const bool quart = alive && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
+#if !defined(GRT_NO_CPLX_FAST)
+                               (R.ncase == 5 && R.tpr == 0 && cam.a != 0.0 && R.q2 != 0.0));
+#else
+                               false);
+#endif
   const bool cubic = alive && !need_time && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;

@@ -39,7 +39,7 @@ int hs_ray_points_fast(const GrtCam *cam, int ii, int maxn, double *u, double *m
   GrtRay R;
   setup_ray(*cam, ii, R);
   *ncase = R.ncase;
-  bool fast = (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12;
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
   RealRay K;
   if (fast) realray_init(*cam, R, K);
   for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
@@ -55,7 +55,7 @@ int hs_ray_points_fast(const GrtCam *cam, int ii, int maxn, double *u, double *m
 int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *lam, int *tpm, int *tpr) {
   GrtRay R;
   setup_ray(*cam, ii, R);
-  bool fast = (R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12;
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
   if (!fast) return -R.npts;
   RealRay K;
   realray_init(*cam, R, K);

@@ -43,12 +43,15 @@ def test_per_point_paths_match_sequential_oracle(L, spin, mu0, gv, nn, uout, str
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
     nfast = 0
+    ncplx = 0          # rays of the complex-pair class (ncase 5) that went through the fast path
     for i in range(1, nn[0] * nn[1] + 1, stride):
         g = o.geokerr_ray(i)
         for fn in (L.hs_ray_points, L.hs_ray_points_fast):
             d = [np.zeros(maxn) for _ in range(5)]
             tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
-            n = abs(fn(cam, i, maxn, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc)))
+            n = fn(cam, i, maxn, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc))
+            ncplx += int(fn is L.hs_ray_points_fast and n > 0 and nc.value == 5)
+            n = abs(n)
             assert n == g["n"] and nc.value == g["ncase"]
             assert np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"])
             keys = ("u", "mu", "dt", "dphi", "lam")     # the fast path is run with its coordinate-time option too
@@ -64,6 +67,7 @@ def test_per_point_paths_match_sequential_oracle(L, spin, mu0, gv, nn, uout, str
             for a, key in ((u, "u"), (mu, "mu"), (lam, "lam")):
                 assert np.max(np.abs(a[:n] - g[key])) <= 1e-10 * np.max(np.abs(g[key]))
     assert nfast > 0 or spin == 0.0
+    assert ncplx > 0 or spin == 0.0 or abs(mu0) < 0.2
 
 
 def test_sphacc_sampler_and_thermal_coefficients_match_oracle(L):
