@@ -36,6 +36,8 @@ struct Ctx {
   bool init = false;
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;      // the generic-class launches run beside the fast-class ones
+  hipEvent_t evj[2] = {nullptr, nullptr};
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   // fluid + tables
   float *d_cells = nullptr, *d_uniq = nullptr;
@@ -110,6 +112,8 @@ int grt_init(int device) {
   if (C.init) return 0;
   C.device = device;
   HIPCHK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&C.evk[i]));
   HIPCHK(hipMalloc((void **)&C.d_counters, 4 * sizeof(int)));
@@ -131,6 +135,9 @@ int grt_free(void) {
   for (int i = 0; i < 4; ++i)
     if (C.evk[i]) (void)hipEventDestroy(C.evk[i]);
   if (C.stream) (void)hipStreamDestroy(C.stream);
+  if (C.stream2) (void)hipStreamDestroy(C.stream2);
+  for (int i = 0; i < 2; ++i)
+    if (C.evj[i]) (void)hipEventDestroy(C.evj[i]);
   C = Ctx();
   return 0;
 }
@@ -453,17 +460,23 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(hipStreamSynchronize(C.stream));
   const int nlive = ncls[0] + ncls[1];
   HIPCHK(hipEventRecord(C.ev[1], C.stream));
-  // class 0 (four real roots, fast path) sits at the front of live[], class 1 (generic) at the back
+  // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back.  The two classes touch disjoint
+  // rays of the same buffers, so their geo -> transfer chains run on two streams: the few generic-class waves fill the
+  // CUs the big fast-class kernels leave idle in their tails instead of queueing behind them.
+  HIPCHK(hipEventRecord(C.evj[0], C.stream));
+  HIPCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
   HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield, d_t0));
-  HIPCHK(grt_launch_geo(C.stream, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
-                        rstride, fstride, nfields, tfield, d_t0));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
   HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, rstride,
                              fstride, nfields, tfield, C.d_stepcount));
-  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
+  HIPCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
+                        rstride, fstride, nfields, tfield, d_t0));
+  HIPCHK(grt_launch_transfer(C.stream2, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
                              C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount));
+  HIPCHK(hipEventRecord(C.evj[1], C.stream2));
+  HIPCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
   HIPCHK(hipEventRecord(C.ev[2], C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
   if (st) {

@@ -69,7 +69,8 @@ typedef struct GrtStats {
   int64_t ray_steps;          /* sum of stored points over traced rays (the metric's numerator) */
   int64_t rays_live, rays_dead;
   double ms_setup, ms_trace, ms_total;   /* HIP-event times on the library stream; ms_trace = geo + transfer */
-  double ms_geo, ms_transfer;            /* the two kernels of the trace phase */
+  double ms_geo, ms_transfer;            /* ms_geo: the fast-class geodesic kernel; ms_transfer: the rest of the trace phase
+                                            (the generic-class launches overlap both on a second stream) */
 } grt_stats;
 
 /* replaces: nothing in the reference (device bring-up).  device = HIP ordinal. */
