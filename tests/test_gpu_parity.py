@@ -628,6 +628,16 @@ def test_harm3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch)
                 assert np.abs(np.nan_to_num(rec[4:8, ::-1].T[:n]) - I).max() / (np.abs(I).max() + 1e-300) < 1e-5
         finally:
             capi.record_steps(False)
+        # extra=1: the 19 ray diagnostics on the 3-D sampler (column tolerances as in test_extra_ray_diagnostics_vs_reference)
+        cam2 = capi.make_camera(1, H["gridvals"], (24, 24, 120), H["spin"], H["mu0"], H["uout"], -0.5)
+        em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, H["gmin"], 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
+        px, _, status, _ = capi.trace_tile(cam2, 1, 576, "HARM3D", em, [FREQ_HARM], "formal", nvals=4, nextra=19)
+        assert np.array_equal(status, g["extra_npts_24x24x120"])
+        a = np.asarray(px[0], float); b = np.asarray(g["extra_vals_24x24x120"], float)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        tolc = np.array([1e-5] * 4 + [1e-5] * 6 + [5e-5] * 8 + [1e-4] * 5)
+        err = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max(axis=0) / (np.abs(np.nan_to_num(b)).max(axis=0) + 1e-300)
+        assert np.all(err < 2 * tolc), err
         # nvals=1 (quadrature) runs and agrees with the polarized Stokes I where the medium is thin
         em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, H["gmin"], 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
         p1, _, _, _ = capi.trace_tile(cam, 1, 1600, "HARM3D", em, [FREQ_HARM], "formal", nvals=1)

@@ -285,6 +285,9 @@ def test_harm3d_polsynchth_image_rays_and_sigcut(tmp_path):
         err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
         assert err.max() < 2e-6, (key, err)
     assert np.abs(g["ivals_formal_sigcut"] - g["ivals_formal"]).max() / np.abs(g["ivals_formal"]).max() > 1e-3   # the cut acts
+    o = O.Oracle(nn=(24, 24, 120), iname="formal", datadir=str(tmp_path), **kw)                 # extra=1 on the 3-D sampler
+    vals, npts = o.trace_extra(1, 576, float(g["freq"]), nthreads=8)
+    assert np.array_equal(npts, g["extra_npts_24x24x120"]) and extra_err(vals, g["extra_vals_24x24x120"]) < 2e-5
     r = load("harm3d_rays_40x40x200.npz")
     o = O.Oracle(nn=(40, 40, 200), iname="formal", datadir=str(tmp_path), sigcut=float(r["sigcut"]), **kw)
     for i in r["rays"]:

@@ -296,6 +296,9 @@ def harm3d(nx=40, nup=200):
             for k, v in d.items():
                 rays["ray%d_%s" % (i, k)] = np.asarray(v)
         rays["rays"] = np.array(pick)
+        # extra=1 on the 3-D sampler: the phi-weighted diagnostics read the same azimuth the sampler does
+        r = R.Ref(nn=(24, 24, 120), iname="formal", datadir=td, **HARM3D)
+        out["extra_vals_24x24x120"], out["extra_npts_24x24x120"] = r.trace_extra(1, 576, FREQ_HARM, nthreads=1)
     zones = np.array([HARM3D_ZONES[k] for k in ("n1", "n2", "n3")])
     np.savez_compressed(os.path.join(G, "harm3d_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, zones=zones, **out)
     np.savez_compressed(os.path.join(G, "harm3d_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, zones=zones, sigcut=1e-3, **rays)
