@@ -1,4 +1,4 @@
-"""Generate tests/golden/*.npz from the COMPILED, UNMODIFIED reference (oracle/_ref).
+"""Test infrastructure (lives under tests/ because it drives oracle/_ref).  Generate tests/golden/*.npz from the COMPILED, UNMODIFIED reference (oracle/_ref).
 
 Run in the build container only (needs /root/reference built by oracle/build_ref.sh); the
 fixtures it writes are data (inputs + expected outputs) and are committed.  The GPU box only
@@ -6,10 +6,11 @@ ever reads the .npz files.
 """
 import os, sys, pickle
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))     # synthetic dump writers
 from oracle import refbind as R
 
-G = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 os.makedirs(G, exist_ok=True)
 FREQ = 3.45e11
 FFJET = dict(fname="FFJET", ename="POLSYNCHPL", spin=0.998, standard=1, uout=0.01, mbh=3.4e9, mu0=0.906,

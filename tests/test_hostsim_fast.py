@@ -190,7 +190,7 @@ def test_harm_theta_index_equals_brent_index_everywhere(L, tmp_path):
 
 def test_harm3d_loader_sampler_and_units_match_oracle(L, tmp_path):
     # product loader (binary 3-D dump -> BL/LNRF arrays) + device harm3d_sample/harm3d_convert, compiled
-    # for the host, against the oracle's per-stage dump (itself pinned to the compiled reference, tools/make_golden.py)
+    # for the host, against the oracle's per-stage dump (itself pinned to the compiled reference, tests/make_golden.py)
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_harm3d_dump

@@ -1,5 +1,5 @@
 """CPU tests: the C++ oracle (oracle/grto_*.hpp) against golden vectors that were produced by
-the compiled, unmodified reference (tools/make_golden.py).  Tolerances are stated per test."""
+the compiled, unmodified reference (tests/make_golden.py).  Tolerances are stated per test."""
 import os
 import numpy as np
 import pytest
@@ -127,7 +127,7 @@ SPHACC = dict(fname="SPHACC", ename="POLSYNCHTH", spin=0.0, standard=1, uout=0.0
 
 def test_sphacc_polsynchth_image_and_rays():
     # BASELINE config 2 on a 64x64x200 camera.  Golden from the reference run with ONE thread (its SPHACC
-    # path races under OpenMP, see tools/make_golden.py:sphacc); spin 0 exercises the cubic root cases.
+    # path races under OpenMP, see tests/make_golden.py:sphacc); spin 0 exercises the cubic root cases.
     g = load("sphacc_64x64x200.npz")
     for iname in ("formal", "delo"):
         o = O.Oracle(nn=(64, 64, 200), iname=iname, **SPHACC)
