@@ -50,6 +50,9 @@ struct Ctx {
   float *d_h3_cells = nullptr, *d_h3_coords = nullptr;
   GrtHarm3d harm3d{};
   bool have_harm3d = false;
+  float *d_ih_cells = nullptr, *d_ih_coords = nullptr;
+  GrtHarm3d iharm{};
+  bool have_iharm = false;
   double *d_t0 = nullptr;        // per-ray time origin of the current tile (nload > 1), or unset
   size_t cap_t0 = 0;
   long long t0_n = 0;
@@ -127,7 +130,7 @@ int grt_free(void) {
   (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -272,6 +275,32 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
   return 0;
 }
 
+int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const float *x1_arr, const float *x2_arr,
+                     const float *x3_arr, const float *rho, const float *p, const float *b0, const float *br,
+                     const float *bth, const float *bph, const float *u0, const float *vrl, const float *vtl,
+                     const float *vpl, const float *kela) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (nx1 < 2 || nx2 < 2 || nx3 < 2 || nx1 > nx2 || 2 * (nx1 + nx2) + nx3 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr)
+    return GRT_E_BADARG;
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  for (const float *q : src)
+    if (!q) return GRT_E_BADARG;
+  std::vector<float> cells, crd;
+  grt_iharm_pack(nx1, nx2, nx3, hslope, x1_arr, x2_arr, x3_arr, src, kela, cells, crd);
+  if (C.d_ih_cells) { (void)hipFree(C.d_ih_cells); C.d_ih_cells = nullptr; }
+  if (C.d_ih_coords) { (void)hipFree(C.d_ih_coords); C.d_ih_coords = nullptr; }
+  HIPCHK(hipMalloc((void **)&C.d_ih_cells, cells.size() * sizeof(float)));
+  HIPCHK(hipMalloc((void **)&C.d_ih_coords, crd.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(C.d_ih_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(C.d_ih_coords, crd.data(), crd.size() * sizeof(float), hipMemcpyHostToDevice));
+  C.iharm = GrtHarm3d{};
+  C.iharm.cells = C.d_ih_cells; C.iharm.coords = C.d_ih_coords;
+  C.iharm.nx1 = nx1; C.iharm.nx2 = nx2; C.iharm.nx3 = nx3; C.iharm.eheat = kela ? 1 : 0;
+  C.iharm.hslope = hslope; C.iharm.gam = gam;
+  C.have_iharm = true;
+  return 0;
+}
+
 int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_host) {
   if (!C.init) return GRT_E_NOTINIT;
   if (!cam || !t0_host || i2 < i1 || i1 < 1 || i2 > (int64_t)cam->nro * cam->nphi || cam->standard != 1) return GRT_E_BADARG;
@@ -398,6 +427,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM3D && em->type == GRT_EMIS_POLSYNCHTH) ||
+                       (fluid_model == GRT_FLUID_IHARM && em->type == GRT_EMIS_POLSYNCHTH) ||
                        ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D) &&
                         (em->type == GRT_EMIS_HYBRIDTHPL || em->type == GRT_EMIS_HYBRIDTH || em->type == GRT_EMIS_HYBRIDPL ||
                          em->type == GRT_EMIS_MAXJUTT));
@@ -412,12 +442,13 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (fluid_model == GRT_FLUID_SPHACC && !C.d_sphacc) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM && !C.have_harm) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM3D && !C.have_harm3d) return GRT_E_NOFLUID;
+  if (fluid_model == GRT_FLUID_IHARM && !C.have_iharm) return GRT_E_NOFLUID;
   if ((em->type == GRT_EMIS_POLSYNCHPL || (em->type >= GRT_EMIS_HYBRIDTHPL && em->type <= GRT_EMIS_HYBRIDPL)) && !C.have_tables) return GRT_E_NOTABLES;
   GrtFluidDev fd{};
   fd.fj = C.ffjet;
   fd.sphacc = C.d_sphacc;
   fd.hm = C.harm;
-  fd.h3 = C.harm3d;
+  fd.h3 = (fluid_model == GRT_FLUID_IHARM) ? C.iharm : C.harm3d;     // the two 3-D tables share the kernel argument slot
   HIPCHK(hipSetDevice(C.device));
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
@@ -432,7 +463,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const long long maxpts = cam->nup + cam->next;
   const long long rstride = (maxpts + 63) / 64 * 64;      // internal ray stride: 512-byte aligned chunk rows
   // extra=1 weights by phi as well; a 3-D fluid model is sampled at the point's azimuth
-  const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D) ? 4 : 3);
+  const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM) ? 4 : 3);
   // several HARM slices loaded ("slow light"): every point also carries its coordinate time, one more field
   const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1);
   if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;

@@ -749,7 +749,11 @@ GRT_HD void sphacc_sample(const float *tab, double r, FluidPoint &f) {
 // (math.f90:56-135, tol 1e-6): its stopping point, not the exact root, decides the interpolation weights.
 struct HarmX2 {
   double th, h;
-  GRT_HD double operator()(double x) const { return th - PH_pi * x - .5 * (1 - h) * sin(2. * PH_pi * x); }   // :50-56
+  bool grouped = false;     // iharm: theta - (pi x2 + (1-h)/2 sin(2 pi x2))  (fluid_model_iharm.f90:81-86,101-109)
+  GRT_HD double operator()(double x) const {
+    if (grouped) return th - (PH_pi * x + (1. - h) / 2. * sin(2. * PH_pi * x));
+    return th - PH_pi * x - .5 * (1 - h) * sin(2. * PH_pi * x);   // fluid_model_harm.f90:50-56
+  }
 };
 
 GRT_HD double zbrent_x2(const HarmX2 &func, double x1, double x2, double tol) {
@@ -803,7 +807,8 @@ GRT_HD int harm_time_index(const GrtHarm &t, double r, double tcoord, double r1,
 
 // theta -> zone index of harm_vals (fluid_model_harm.f90:58-71, :141-143), see harm_sample.  brent_only: the
 // reference's literal path for every point (tests).
-GRT_HD int harm_theta_index(float h, const float *uniqx2, const float *uniqth, int nx2, float theta, bool brent_only = false) {
+GRT_HD int harm_theta_index(double h, const float *uniqx2, const float *uniqth, int nx2, float theta, bool brent_only = false,
+                            bool grouped = false) {
   GRT_NO_CONTRACT
   int jlo = 0, jhi = nx2 + 1;
   while (jhi - jlo > 1) {
@@ -812,7 +817,7 @@ GRT_HD int harm_theta_index(float h, const float *uniqx2, const float *uniqth, i
   }
   const float below = (jlo >= 1) ? theta - uniqth[jlo - 1] : 1.f, above = (jlo < nx2) ? uniqth[jlo] - theta : 1.f;
   if (!brent_only && fminf(below, above) > 1.5e-5f) return jlo;
-  HarmX2 fn{(double)theta, (double)h};
+  HarmX2 fn{(double)theta, h, grouped};
   const float x2 = (float)zbrent_x2(fn, 0.0, 1.0, 1e-6);
   return (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
 }
@@ -829,7 +834,7 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
   // is good to 5e-7 in x2, d theta/d x2 <= 5.4, REAL(4) roundings ~3e-7).  Only those points (0.24 % at 256 zones)
   // run the reference's own Brent iteration, so every point gets the index the reference gets.
   int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
-  int lx2 = harm_theta_index(t.h, uniqx2, uniqth, nx2, theta);
+  int lx2 = harm_theta_index((double)t.h, uniqx2, uniqth, nx2, theta);
   int ux2 = lx2 + 1;
   lx2 = (lx2 >= 1) ? lx2 : 1;
   ux2 = (ux2 <= nx2) ? ux2 : nx2;
@@ -1010,6 +1015,86 @@ GRT_HD void harm3d_convert(const FluidPoint &f, double mbh, double mdotcgs, doub
   const double b2 = beta * beta;
   const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
   tcgs = tcgs / (1.0 + trat);
+  const double bmagrho = (bmag * bmag) / rho;
+  ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) / 8.0 / PH_pi / gminval * (p1 - 2.0) / (p1 - 1.0) / 8.2e-7 : 0.0;
+  const double sigmacgs = (bcgs * bcgs) / ((ncgs * mp) * 8.988e20 * 4.0 * PH_pi);
+  if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
+}
+
+// ------------------------------------------------------------------ iharm-format 3-D dumps, metric 0 (fluid_model_iharm.f90)
+// iharm_vals (:222-424): the reference forces all three interpolation weights to 1 (:318), so a sample is the zone
+// (x1u, x2u, x3u): one 48-byte record.  theta -> zone index as for 2-D HARM (search in uniqth, the reference's Brent
+// inversion where its tolerance decides); azimuth as for HARM3D; 1e-3 scaling of rho, p, kel inside the innermost zone
+// centre outside the horizon (:296-303).
+GRT_NI void iharm_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &kela) {
+  GRT_NO_CONTRACT
+  const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
+  const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2, *uniqx3 = crd + 2 * (nx1 + nx2);
+  const float theta = (float)th_d, zr = (float)r, zpp = (float)phi_d;
+  const double twopi = 2. * PH_pi;
+  float zphi = (float)bl2ks_phi((double)zr, (double)zpp, (double)a);
+  zphi = (float)fmod((double)zphi, twopi);
+  if (zphi < 0.f) zphi = (float)((double)zphi + twopi);
+  const float x1 = logf_cr(zr), x3 = zphi;
+  const int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
+  const int lx2 = harm_theta_index(t.hslope, uniqx2, uniqth, nx2, theta, false, true);
+  int ux2 = lx2 + 1;
+  const int lx3 = (int)floorf((x3 - uniqx3[0]) / (uniqx3[nx3 - 1] - uniqx3[0]) * (nx3 - 1)) + 1;
+  int ux3 = lx3 + 1;
+  ux2 = (ux2 >= 1) ? ux2 : 1;
+  ux2 = (ux2 <= nx2) ? ux2 : nx2;
+  if (ux3 > nx3) ux3 = 1;
+  // lx1 is not clamped by the reference (it reads outside the table beyond the grid): only addresses are clamped here
+  const int lx1c = lx1 < 1 ? 1 : (lx1 > nx1 - 1 ? nx1 - 1 : lx1), ux1c = lx1c + 1;
+  const float rh = 1.f + sqrtf(1.f - a * a);
+  const double fac = (uniqr[lx1c - 1] <= rh) ? (double)1e-3f : 1.0;
+  const float *c = t.cells + ((size_t)(ux1c - 1) * nx2 * nx3 + (size_t)(ux2 - 1) * nx3 + (size_t)(ux3 - 1)) * 12;
+  const bool inside = x1 > uniqx1[0];
+  f.rho = (float)((double)(inside ? c[0] : 0.f) * fac);
+  f.p = (float)((double)(inside ? c[1] : 1.f) * fac);
+  kela = t.eheat ? (float)((double)(inside ? c[10] : 1.f) * fac) : 0.f;
+  f.b[0] = (double)(inside ? c[2] : 1.f);
+  f.b[1] = (double)(inside ? c[3] : 1.f);
+  f.b[2] = (double)(inside ? c[4] : 1.f);
+  f.b[3] = (double)(inside ? c[5] : 1.f);
+  f.u[0] = inside ? (double)c[6] : 1.0;
+  const float vrl0 = inside ? c[7] : 0.f, vtl0 = inside ? c[8] : 0.f, vpl0 = inside ? c[9] : 0.f;
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  float bm = (float)dot4(f.b, ms, f.b);
+  bm = (bm >= 0.f) ? bm : 0.f;
+  f.bmag = sqrtf(bm);
+  float vr0, vth0, vph0;
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  f.u[1] = f.u[0] * (double)vr0;
+  f.u[2] = f.u[0] * (double)vth0;
+  f.u[3] = f.u[0] * (double)vph0;
+}
+
+// convert_fluidvars_iharm fluid.f90:995-1026: f%p holds the internal energy; gmin >= 1: monika_e on p (gamma-1) and
+// T_e = 2 T / 3 / (2 + trat); gmin = -1: ressler_e (:894-904) on the electron entropy; nonthermale_b2; andrew_sigcut
+GRT_HD void iharm_convert(const FluidPoint &f, float kela, float gam, double mbh, double mdotcgs, double muval, double gminval,
+                          double jetalpha, double p1, double sigcut, double &ncgs, double &ncgsnth, double &bcgs, double &tcgs) {
+  GRT_NO_CONTRACT
+  const double mp = 1.67262158e-24;
+  const double mdot = PH_G * mbh * PH_msun / (PH_c * PH_c * PH_c);
+  const double lcgs = PH_G * mbh * PH_msun / (PH_c * PH_c), tc = lcgs / PH_c;
+  const double rho = (double)f.rho, p = (double)f.p, bmag = (double)f.bmag;
+  const double rhocgs = mdotcgs / mdot / (lcgs * lcgs * lcgs) * tc * rho;
+  ncgs = rhocgs / mp;
+  const double pcgs = p * rhocgs / rho * (PH_c * PH_c);
+  tcgs = pcgs / ncgs / PH_k;
+  bcgs = bmag * sqrt(rhocgs / rho) * PH_c;
+  bcgs = bcgs * sqrt(4.0 * PH_pi);
+  if (gminval >= 1.0) {
+    const float pp = f.p * (gam - 1.f);
+    const double rlow = 1.0 / muval - 1.0, rhigh = gminval * (1.0 / muval - 1.0);
+    const double beta = (double)(pp / (f.bmag * f.bmag)) / 0.5, b2 = beta * beta;
+    const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
+    tcgs = 2.0 * tcgs / 3.0 / (2.0 + trat);
+  } else if (gminval == -1.0) {
+    const double thetae = mp / PH_m * (double)kela * pow((double)f.rho, 4.0 / 3.0 - (double)1.f);
+    tcgs = thetae * PH_m * PH_c2 / PH_k;
+  }
   const double bmagrho = (bmag * bmag) / rho;
   ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) / 8.0 / PH_pi / gminval * (p1 - 2.0) / (p1 - 1.0) / 8.2e-7 : 0.0;
   const double sigmacgs = (bcgs * bcgs) / ((ncgs * mp) * 8.988e20 * 4.0 * PH_pi);

@@ -177,3 +177,60 @@ extern "C" int grt_load_harm3d_files(const char *dfile, const char *hfile, int i
   return grt_upload_harm3d(nx1, nx2, nx3, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(), br.data(), bth.data(),
                            bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data());
 }
+
+// iharm-format dumps, metric 0: read_iharm_data_header / read_iharm_data_file / load_iharm_data
+// (fluid_model_iharm.f90:427-469, 507-671, 712-796).  Header: up to 200 numbers, the first 17 are used; data: a raw stream
+// of REAL(4) data(13+eHEAT, n) with x3 fastest: x1, x2, x3, rho, u, u^mu(4), b^mu(4) [, kel].  MKS -> KS with
+// d theta/d x2 = pi (1 + (1-hslope) cos(2 pi x2)) held in REAL(4) (umksh2uks :186-220), KS -> BL, LNRF velocities.
+extern "C" int grt_load_iharm_files(const char *dfile, const char *hfile, int indf, double spin) {
+  if (!dfile || !hfile) return GRT_E_BADARG;
+  std::vector<double> head;
+  if (!slurp_numbers(hfile, 0, head) || head.size() < 17) return GRT_E_IO;
+  const int nx1 = (int)head[1], nx2 = (int)head[2], nx3 = (int)head[3];
+  const float asim = (float)head[4], gam = (float)head[6];
+  const double hslope = head[5];
+  const int metric = (int)head[11], eheat = (int)head[12];
+  if (nx1 < 2 || nx2 < 2 || nx3 < 2) return GRT_E_IO;
+  if (metric != 0) {
+    std::fprintf(stderr, "grtrans_amd: iharm header metric = %d: only metric 0 (MKS with hslope) is on the device\n", metric);
+    return GRT_E_UNSUPPORTED;
+  }
+  if (std::fabs((double)asim - spin) > 1e-4) {     // fluid_model_iharm.f90:697-700
+    std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
+    return GRT_E_BADARG;
+  }
+  const size_t n = (size_t)nx1 * nx2 * nx3, dlen = 13 + (eheat ? 1 : 0);
+  char suffix[16];
+  std::snprintf(suffix, sizeof suffix, "%03d", indf);          // write(append, fmt='(I5.3)'), adjustl, trim
+  const std::string path = std::string(dfile) + suffix + ".bin";
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) return GRT_E_IO;
+  std::vector<float> data(n * dlen);
+  const size_t got = std::fread(data.data(), sizeof(float), data.size(), f);
+  std::fclose(f);
+  if (got != data.size()) return GRT_E_IO;
+  std::vector<float> x1(n), x2(n), x3(n), rho(n), p(n), u0(n), vrl(n), vtl(n), vpl(n), b0(n), br(n), bth(n), bph(n), kel(eheat ? n : 0);
+  for (size_t i = 0; i < n; ++i) {
+    const float *z = &data[i * dlen];
+    x1[i] = z[0]; x2[i] = z[1]; x3[i] = z[2];
+    const float r = std::exp(x1[i]);
+    const double x2d = (double)x2[i];
+    const float th = (float)(kPi * x2d + (1.0 - hslope) / 2.0 * std::sin(2.0 * kPi * x2d));       // calcthmksh
+    const float dthdx2 = (float)(kPi * (1.0 + (1.0 - hslope) * std::cos(2.0 * kPi * x2d)));
+    const double a = (double)asim, rd = (double)r;
+    auto to_bl = [&](const float *w, double o[4]) {
+      const double wr = rd * (double)w[1], wth = (double)w[2] * (double)dthdx2;
+      const double delta = rd * rd - 2.0 * rd + a * a;
+      o[0] = (double)w[0] - 2.0 * rd / delta * wr; o[1] = wr; o[2] = wth; o[3] = (double)w[3] - a / delta * wr;
+    };
+    double u[4], b[4];
+    to_bl(z + 5, u); to_bl(z + 9, b);
+    lnrf_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r, asim, th, vrl[i], vtl[i], vpl[i]);
+    rho[i] = z[3]; p[i] = z[4];
+    u0[i] = (float)u[0];
+    b0[i] = (float)b[0]; br[i] = (float)b[1]; bth[i] = (float)b[2]; bph[i] = (float)b[3];
+    if (eheat) kel[i] = z[13];
+  }
+  return grt_upload_iharm(nx1, nx2, nx3, hslope, gam, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(), br.data(),
+                          bth.data(), bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data(), eheat ? kel.data() : nullptr);
+}

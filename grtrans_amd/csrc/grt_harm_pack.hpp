@@ -49,3 +49,17 @@ inline void grt_harm3d_pack(int nx1, int nx2, int nx3, const float *x1_arr, cons
   }
   for (int k = 0; k < nx3; ++k) crd[2 * (nx1 + nx2) + k] = x3_arr[k];   // uniqx3 = x3_arr(1:nx3) = uniqph
 }
+
+// IHARM (metric 0): the HARM3D layout with the electron entropy in slot 10 and uniqth = theta(uniqx2) for the zone search
+inline void grt_iharm_pack(int nx1, int nx2, int nx3, double hslope, const float *x1_arr, const float *x2_arr, const float *x3_arr,
+                           const float *const src[10], const float *kela, std::vector<float> &cells, std::vector<float> &crd) {
+  grt_harm3d_pack(nx1, nx2, nx3, x1_arr, x2_arr, x3_arr, src, cells, crd);
+  const size_t n = (size_t)nx1 * nx2 * nx3;
+  if (kela)
+    for (size_t i = 0; i < n; ++i) cells[i * 12 + 10] = kela[i];
+  const double pi = std::acos(-1.0);
+  for (int j = 0; j < nx2; ++j) {
+    const double x2 = (double)crd[2 * nx1 + j];
+    crd[2 * nx1 + nx2 + j] = (float)(pi * x2 + (1.0 - hslope) / 2.0 * std::sin(2.0 * pi * x2));   // calcthmksh (:81-86)
+  }
+}

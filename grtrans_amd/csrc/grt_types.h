@@ -51,7 +51,9 @@ struct GrtHarm {                // device pointers; nt 2-D HARM slices, fluid_mo
 struct GrtHarm3d {              // device pointers; one 3-D HARM slice, fluid_model_harm3d.f90:14-22
   const float *cells;           // [nx1][nx2][nx3][12], x3 (phi) fastest: rho,p,b0,br,bth,bph,u0,vrl,vtl,vpl,pad,pad
   const float *coords;          // [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2][uniqx3 nx3] (staged in LDS)
-  int32_t nx1, nx2, nx3, pad;
+  int32_t nx1, nx2, nx3, eheat;  // eheat (IHARM): slot 10 of a cell holds the electron entropy
+  double hslope;                // IHARM, metric 0: theta = pi x2 + (1-hslope)/2 sin(2 pi x2) (REAL(8) in the reference)
+  float gam, padf;              // IHARM: adiabatic index of the dump (f%gamma)
 };
 #define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 

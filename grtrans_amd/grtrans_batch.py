@@ -58,7 +58,7 @@ class grtrans_inputs:
         # per-model overrides of the generic fluid arguments (grtrans_batch.py:219-322)
         if self.fname == 'FFJET':
             self.fdfile = self.jdfile
-        elif self.fname in ('HARM', 'HARM3D', 'KORAL', 'KORALNTH'):
+        elif self.fname in ('HARM', 'KORAL', 'KORALNTH'):       # (HARM3D, IHARM take the generic t* arguments, as in the reference)
             self.fdfile, self.fhfile, self.fnt, self.findf = self.hdfile, self.hhfile, self.hnt, self.hindf
         else:
             self.fdfile, self.fgfile, self.fhfile = self.tdfile, self.tgfile, self.hhfile
@@ -183,6 +183,10 @@ class grtrans:
                 if int(inp.fnt) > 1 and nextra:
                     raise capi.GrtError("extra=1 with several HARM slices (hnt > 1) is not on the device yet")
                 dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), nt=int(inp.fnt))
+            elif inp.fname == 'IHARM':
+                if int(inp.fnt) != 1 or int(inp.nload) != 1:
+                    raise capi.GrtError("IHARM with several loaded slices (hnt, nload > 1) is not on the device yet")
+                dev.load_iharm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
             elif inp.fname == 'HARM3D':
                 if int(inp.fnt) != 1 or int(inp.nload) != 1:
                     raise capi.GrtError("HARM3D with several loaded slices (hnt, nload > 1) is not on the device yet")
@@ -200,7 +204,7 @@ class grtrans:
                 else:
                     capi.set_t0(None)
                 for l in range(nt):
-                    if l > 0 and inp.fname in ('HARM', 'HARM3D'):
+                    if l > 0 and inp.fname in ('HARM', 'HARM3D', 'IHARM'):
                         # advance_harm_timestep (fluid_model_harm.f90:511-521; the same arithmetic in
                         # advance_harm3d_timestep, fluid_model_harm3d.f90:688-699): REAL(4) tstep, toffset kept across frames
                         nupdate = int(np.floor(float(inp.dt) / float(harm_tstep)))
@@ -210,6 +214,8 @@ class grtrans:
                         harm_indf += nupdate
                         if nupdate > 0 and inp.fname == 'HARM':
                             dev.load_harm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin), nt=int(inp.fnt))
+                        elif nupdate > 0 and inp.fname == 'IHARM':
+                            dev.load_iharm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
                         elif nupdate > 0:
                             dev.load_harm3d(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
                     for m in range(nmdot):

@@ -96,6 +96,7 @@ contains
     case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC
     case ('HARM'); fluid_id = GRT_FLUID_HARM
     case ('HARM3D'); fluid_id = GRT_FLUID_HARM3D
+    case ('IHARM'); fluid_id = GRT_FLUID_IHARM
     case ('THINDISK'); fluid_id = GRT_FLUID_THINDISK
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
@@ -149,6 +150,13 @@ contains
        if (fnt /= 1 .or. nload /= 1) call die('HARM3D with several loaded slices (fnt, nload > 1) is not supported')
        rc = grt_load_harm3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
+       harm_nt = 1
+    else if (fluid_id == GRT_FLUID_IHARM) then
+       ! initialize_iharm_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:199-200; one loaded slice, metric 0
+       if (fnt /= 1 .or. nload /= 1) call die('IHARM with several loaded slices (fnt, nload > 1) is not supported')
+       rc = grt_load_iharm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
+       if (rc /= 0) call die_rc('grt_load_iharm_files '//trim(fdfile)//' '//trim(fhfile), rc)
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
     else if (fluid_id == GRT_FLUID_THINDISK) then
@@ -288,7 +296,7 @@ contains
     use grt_cabi
     real(8), intent(in) :: dtobs
     integer :: nupdate, rc
-    if (cur_fluid /= GRT_FLUID_HARM .and. cur_fluid /= GRT_FLUID_HARM3D) return
+    if (cur_fluid /= GRT_FLUID_HARM .and. cur_fluid /= GRT_FLUID_HARM3D .and. cur_fluid /= GRT_FLUID_IHARM) return
     nupdate = floor(dtobs / harm_tstep)
     harm_toffset = harm_toffset + dtobs - harm_tstep*nupdate
     nupdate = nupdate + floor(harm_toffset/harm_tstep)
@@ -296,7 +304,10 @@ contains
     harm_indf = harm_indf + nupdate
     write(6,*) 'advance harm timestep: ', dtobs, harm_tstep, harm_toffset, harm_indf, nupdate
     ! nupdate = 0 leaves the slice as it is (update_harm_data(0) loads nothing)
-    if (nupdate > 0 .and. cur_fluid == GRT_FLUID_HARM3D) then
+    if (nupdate > 0 .and. cur_fluid == GRT_FLUID_IHARM) then
+       rc = grt_load_iharm_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
+       if (rc /= 0) call die_rc('grt_load_iharm_files (advance) '//trim(harm_dfile), rc)
+    else if (nupdate > 0 .and. cur_fluid == GRT_FLUID_HARM3D) then
        rc = grt_load_harm3d_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
        if (rc /= 0) call die_rc('grt_load_harm3d_files (advance) '//trim(harm_dfile), rc)
     else if (nupdate > 0) then

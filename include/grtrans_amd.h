@@ -33,7 +33,7 @@ extern "C" {
 
 /* ids follow the reference so host Fortran can pass its own constants through:
  * fluid.f90:40-43, emis.f90:11-18, rad_trans.f90:29-37 */
-enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19 };
+enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19, GRT_FLUID_IHARM = 29 };
 enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8,
        /* thermal + power-law electron populations (emis.f90:16-17, :473-490): K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep
           one population's emission with the total absorption and Faraday coefficients */
@@ -121,6 +121,19 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
  * dump `dfile`//I3.3(indf)//'.bin' (one text line, then REAL(4) data(35, n), :516-584); refuses a spin that differs
  * from the dump's by more than 1e-4 (:611-614). */
 int grt_load_harm3d_files(const char *dfile, const char *hfile, int indf, double spin);
+
+/* iharm-format 3-D dumps (fname IHARM, fluid.f90:199-200), metric = 0 (MKS with hslope) only; the MMKS form
+ * (header metric = 1) is refused with GRT_E_UNSUPPORTED.  replaces init_iharm_data + load_iharm_data for one time
+ * slice (fluid_model_iharm.f90:712-796,838-848): module arrays with x3 fastest as for HARM3D, p_arr = internal energy,
+ * kela = electron entropy (NULL when the dump has none, eHEAT = 0); hslope is REAL(8) there, gam = f%gamma.  The
+ * sampler takes the zone (x1u, x2u, x3u) -- the reference forces all interpolation weights to 1 (:318). */
+int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const float *x1_arr, const float *x2_arr,
+                     const float *x3_arr, const float *rho, const float *p, const float *b0, const float *br,
+                     const float *bth, const float *bph, const float *u0, const float *vrl, const float *vtl,
+                     const float *vpl, const float *kela);
+/* replaces initialize_iharm_model (fluid_model_iharm.f90:673-710): text header (>= 17 numbers, :427-469) and the raw
+ * REAL(4) stream `dfile`//I3.3(indf)//'.bin' = data(13+eHEAT, n) (:507-571); spin check as the other loaders. */
+int grt_load_iharm_files(const char *dfile, const char *hfile, int indf, double spin);
 
 /* replaces init_thindisk(a, ifile, mdot, mbh, rin, rout) (fluid_model_thindisk.f90:31-49, called from
  * fluid.f90:226-227 with fargs%mdot, %rin, %rout; the mass comes with grt_emis.mbh).  Only the reference's

@@ -5,6 +5,7 @@
 // bench.py's cpu_baseline leg.  Built by oracle/Makefile into oracle/_build/libgrt_oracle.so.
 #include "grto_harm.hpp"
 #include "grto_harm3d.hpp"
+#include "grto_iharm.hpp"
 #include <omp.h>
 #include <string>
 
@@ -25,6 +26,7 @@ struct Setup {
   SphaccTable sphacc;
   HarmTable harm;
   Harm3dTable harm3d;
+  IharmTable iharm;
   double jetalpha = 0.02, sigcut = 1e10;
   std::vector<double> otherargs{1.0, 1.0};     // emis_params%otherargs: (delta, weights...) of MAXJUTT     // source_params the 3-D models read (fluid.f90:975-993)
   ThinDisk disk;
@@ -60,10 +62,12 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
   const double gmin = (double)(float)S.gmin, gmax = (double)(float)S.gmax, p = (double)(float)S.p1;
   for (int i = 0; i < n; ++i) {
     const double *x = &w.g.x[4 * i], *k = &w.g.k[4 * i];
+    float kela = 0.f;
     if (S.fluid == 13) ffjet_vals(S.ffjet, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 1) sphacc_point(S.sphacc, x[1], w.f[i]);
     else if (S.fluid == 2) thindisk_point(S.disk, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 19) harm3d_vals(S.harm3d, x, (float)S.cam.a, w.f[i]);
+    else if (S.fluid == 29) iharm_vals(S.iharm, x, (float)S.cam.a, w.f[i], kela);
     else harm_vals(S.harm, x, (float)S.cam.a, w.f[i], w.g.x[1]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
@@ -76,6 +80,8 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       w.ncgs[i] = w.f[i].rho; w.bcgs[i] = w.f[i].bmag; w.tcgs[i] = w.f[i].p;
     } else if (S.fluid == 2) {              // fluid.f90:1190-1196
       w.tcgs[i] = w.f[i].rho; w.ncgs[i] = 1.0;
+    } else if (S.fluid == 29) {             // fluid.f90:995-1026
+      iharm_convert(w.f[i], kela, S.iharm.gam, S.mbh, S.mdot, S.muval, S.gmin, S.jetalpha, S.p1, S.sigcut, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     } else if (S.fluid == 19) {             // fluid.f90:975-993
       harm3d_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, S.jetalpha, S.p1, S.sigcut, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     } else {                                // fluid.f90:957-973
@@ -231,6 +237,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   std::string fn(fname), en(ename), in(iname);
   if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else if (fn == "HARM") S.fluid = 12;
   else if (fn == "HARM3D") S.fluid = 19;
+  else if (fn == "IHARM") S.fluid = 29;
   else if (fn == "THINDISK") { S.fluid = 2; S.disk = ThinDisk(); S.disk.mbh = (float)mbh; S.disk.mdot = (float)fmdot; }
   else return -1;
   S.mdot = mdot; S.muval = muval;
@@ -247,6 +254,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   if (S.fluid == 1 && !sphacc_load(dfile, S.sphacc)) return -4;
   if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm, fnt > 0 ? fnt : 1) != 0) return -4;
   if (S.fluid == 19 && harm3d_load(dfile, hfile, indf, spin, S.harm3d, 1) != 0) return -4;
+  if (S.fluid == 29 && iharm_load(dfile, hfile, indf, spin, S.iharm) != 0) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;

@@ -140,8 +140,8 @@ void hs_harm_theta_index(int n, const float *theta, int *fast, int *brent) {
   const float *crd = g_crd.data();
   const int nx1 = g_harm.nx1, nx2 = g_harm.nx2;
   for (int i = 0; i < n; ++i) {
-    fast[i] = harm_theta_index(g_harm.h, crd + 2 * nx1, crd + 2 * nx1 + nx2, nx2, theta[i], false);
-    brent[i] = harm_theta_index(g_harm.h, crd + 2 * nx1, crd + 2 * nx1 + nx2, nx2, theta[i], true);
+    fast[i] = harm_theta_index((double)g_harm.h, crd + 2 * nx1, crd + 2 * nx1 + nx2, nx2, theta[i], false);
+    brent[i] = harm_theta_index((double)g_harm.h, crd + 2 * nx1, crd + 2 * nx1 + nx2, nx2, theta[i], true);
   }
 }
 int hs_harm_uniqth(float *out) { const int nx1 = g_harm.nx1, nx2 = g_harm.nx2; for (int j = 0; j < nx2; ++j) out[j] = g_crd[2 * nx1 + nx2 + j]; return nx2; }
@@ -165,6 +165,30 @@ void hs_harm3d_point(double r, double th, double phi, double a, double mbh, doub
   for (int i = 0; i < 4; ++i) { out15[3 + i] = f.u[i]; out15[7 + i] = f.b[i]; }
   harm3d_convert(f, mbh, mdot, muval, gminval, jetalpha, p1, sigcut, out15[11], out15[14], out15[12], out15[13]);
 }
+// iharm-format dumps: capture of the loader's arrays and the point sampler + unit conversion
+static GrtHarm3d g_ih;
+static std::vector<float> g_cellsi, g_crdi;
+int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const float *x1_arr, const float *x2_arr,
+                     const float *x3_arr, const float *rho, const float *p, const float *b0, const float *br,
+                     const float *bth, const float *bph, const float *u0, const float *vrl, const float *vtl,
+                     const float *vpl, const float *kela) {
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  grt_iharm_pack(nx1, nx2, nx3, hslope, x1_arr, x2_arr, x3_arr, src, kela, g_cellsi, g_crdi);
+  g_ih = GrtHarm3d{};
+  g_ih.cells = g_cellsi.data(); g_ih.coords = g_crdi.data(); g_ih.nx1 = nx1; g_ih.nx2 = nx2; g_ih.nx3 = nx3;
+  g_ih.eheat = kela ? 1 : 0; g_ih.hslope = hslope; g_ih.gam = gam;
+  return 0;
+}
+void hs_iharm_point(double r, double th, double phi, double a, double mbh, double mdot, double muval, double gminval,
+                    double jetalpha, double p1, double sigcut, double *out15) {
+  FluidPoint f;
+  float kela = 0.f;
+  iharm_sample(g_ih, g_crdi.data(), r, th, phi, (float)a, f, kela);
+  out15[0] = f.rho; out15[1] = f.p; out15[2] = f.bmag;
+  for (int i = 0; i < 4; ++i) { out15[3 + i] = f.u[i]; out15[7 + i] = f.b[i]; }
+  iharm_convert(f, kela, g_ih.gam, mbh, mdot, muval, gminval, jetalpha, p1, sigcut, out15[11], out15[14], out15[12], out15[13]);
+}
+
 // t, r1: coordinate time of the point and radius of the ray's first point (slice selection when nt > 1)
 void hs_harm_point_t(double r, double th, double t, double r1, double a, double mbh, double mdot, double muval, double gminval,
                      double *out14) {

@@ -360,6 +360,38 @@ def maxjutt(nx=32, nup=150):
     np.savez_compressed(os.path.join(G, "maxjutt_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, **out)
 
 
+IHARM = dict(fname="IHARM", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1e20, mu0=0.5,
+             gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=1., dfile="dumpih", hfile="dumpih_header", findf=40, fnt=1)
+IHARM_ZONES = dict(n1=48, n2=48, n3=24)
+
+
+def iharm(nx=36, nup=160):
+    # iharm-format dumps, metric 0 (tools/make_iharm_dump.py; no iharm data ships with the reference): the three electron
+    # models of convert_fluidvars_iharm (gmin = 1: constant ratio, gmin = 3: Moscibrodzka beta-dependent, gmin = -1: the
+    # dump's electron entropy), delo, and the magnetisation cut; per-stage dumps of a few rays
+    import hashlib
+    import tempfile
+    import make_iharm_dump
+    out, rays = {}, {}
+    with tempfile.TemporaryDirectory() as td:
+        dfile, hfile = make_iharm_dump.write(td, **IHARM_ZONES)
+        out["dump_sha256"] = np.array(hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest())
+        for key, kw in (("formal_gmin1", dict(iname="formal")), ("delo_gmin1", dict(iname="delo")), ("formal_gmin3", dict(iname="formal", gmin=3.)),
+                        ("formal_kel", dict(iname="formal", gmin=-1.)), ("formal_sigcut", dict(iname="formal", sigcut=1e-3))):
+            r = R.Ref(nn=(nx, nx, nup), datadir=td, **dict(IHARM, **kw))
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["ivals_" + key] = pix[0]; out["npts"] = npts
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(IHARM, gmin=3.))
+        pick = sorted(set([3, nx // 2 * nx + nx // 2, nx * 10 + 30, nx * 30 + 12, nx * nx - 4, nx * 20 + 5]))
+        for i in pick:
+            d = r.ray_dump(i, FREQ_HARM)
+            for k, v in d.items():
+                rays["ray%d_%s" % (i, k)] = np.asarray(v)
+        rays["rays"] = np.array(pick)
+    np.savez_compressed(os.path.join(G, "iharm_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, **out)
+    np.savez_compressed(os.path.join(G, "iharm_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, gmin=3.0, **rays)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -379,4 +411,5 @@ if __name__ == "__main__":
     harm3d()
     hybrid()
     maxjutt()
+    iharm()
     print("golden fixtures written to", os.path.abspath(G))

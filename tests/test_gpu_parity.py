@@ -649,7 +649,7 @@ def test_harm3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch)
     kw = dict(fname='HARM3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=H["spin"],
               standard=1, nn=[40, 40, 200], uout=H["uout"], mbh=H["mbh"], mdotmin=H["mdot"], mdotmax=H["mdot"], nmdot=1,
               mumin=H["mu0"], mumax=H["mu0"], gridvals=list(H["gridvals"]), muval=H["muval"], gmin=H["gmin"], iname='formal',
-              cflag=0, hdfile='dump3d', hhfile='dump3d_header', hindf=40, hnt=1, sigcut=1e-3)
+              cflag=0, tdfile='dump3d', hhfile='dump3d_header', tindf=40, tnt=1, sigcut=1e-3)
     x = gb.grtrans()
     x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
     x.run_grtrans()
@@ -749,7 +749,7 @@ def test_maxjutt_vs_reference_golden_device_and_fortran_host(tmp_path, monkeypat
     kw = dict(fname='HARM3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='MAXJUTT', nvals=4, spin=H3["spin"],
               standard=1, nn=[32, 32, 150], uout=H3["uout"], mbh=H3["mbh"], mdotmin=H3["mdot"], mdotmax=H3["mdot"], nmdot=1,
               mumin=H3["mu0"], mumax=H3["mu0"], gridvals=list(H3["gridvals"]), muval=H3["muval"], gmin=H3["gmin"], iname='formal',
-              cflag=0, hdfile='dump3d', hhfile='dump3d_header', hindf=40, hnt=1, epotherargs=[2.0] + list(make_golden.MAXJUTT_W6))
+              cflag=0, tdfile='dump3d', hhfile='dump3d_header', tindf=40, tnt=1, epotherargs=[2.0] + list(make_golden.MAXJUTT_W6))
     x = gb.grtrans()
     x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
     x.run_grtrans()
@@ -802,4 +802,56 @@ def test_harm3d_camera_sweep_and_frequency_batches(tmp_path):
                 assert stokes_err(multi[k][~nanm], single[0][~nanm]) < 1e-6, (en, k)
     finally:
         d.close()
+
+
+def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
+    # iharm-format 3-D dumps, metric 0: product loader, nearest-upper-zone sampler, the three electron models
+    # (gmin = 1, gmin = 3, gmin = -1: electron entropy), delo, sigcut; then the Fortran host and run_pgrtrans
+    import hashlib
+    import subprocess
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    import make_iharm_dump
+    g = np.load(os.path.join(G, "iharm_36x36x160.npz"))
+    monkeypatch.chdir(tmp_path)
+    dfile, hfile = make_iharm_dump.write(str(tmp_path), **make_golden.IHARM_ZONES)
+    assert hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest() == str(g["dump_sha256"])
+    H = make_golden.IHARM
+    d = capi.Device(0)
+    try:
+        d.load_tables()
+        with pytest.raises(capi.GrtError):
+            d.load_iharm(dfile, hfile, 40, 0.5)
+        d.load_iharm(dfile, hfile, 40, H["spin"])
+        cam = capi.make_camera(1, H["gridvals"], (36, 36, 160), H["spin"], H["mu0"], H["uout"], -0.5)
+        for key, iname, gmin, sig in (("formal_gmin1", "formal", 1., 1e10), ("delo_gmin1", "delo", 1., 1e10), ("formal_gmin3", "formal", 3., 1e10),
+                                      ("formal_kel", "formal", -1., 1e10), ("formal_sigcut", "formal", 1., 1e-3)):
+            em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, gmin, 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], sigcut=sig)
+            pix, _, status, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], iname)
+            assert np.array_equal(status, g["npts"])
+            assert stokes_err(pix[0], g["ivals_" + key]) < 2 * STOKES_TOL, key
+        em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, 1., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
+        p1, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal", nvals=1)
+        assert p1.shape == (1, 1296, 1) and np.isfinite(p1).all() and p1.max() > 0
+        with pytest.raises(capi.GrtError):      # no hybrid instantiation for this sampler yet: refused
+            capi.trace_tile(cam, 1, 1296, "IHARM", capi.make_emis("HYBRIDTHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5, mdot=H["mdot"]), [FREQ_HARM], "formal")
+    finally:
+        d.close()
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    kw = dict(fname='IHARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=H["spin"],
+              standard=1, nn=[36, 36, 160], uout=H["uout"], mbh=H["mbh"], mdotmin=H["mdot"], mdotmax=H["mdot"], nmdot=1,
+              mumin=H["mu0"], mumax=H["mu0"], gridvals=list(H["gridvals"]), muval=H["muval"], gmin=3., iname='formal',
+              cflag=0, tdfile='dumpih', hhfile='dumpih_header', tindf=40, tnt=1)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_gmin3"]) < 2 * STOKES_TOL
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
 

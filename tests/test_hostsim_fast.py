@@ -165,6 +165,7 @@ def test_harm_theta_index_equals_brent_index_everywhere(L, tmp_path):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_harm_dump
+    L.grt_load_harm_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
     for n in (64, 256):
         make_harm_dump.write(str(tmp_path), n=n)
         assert L.grt_load_harm_files(str(tmp_path / "dump").encode(), str(tmp_path / "dump040").encode(), 40, 0.9375) == 0
@@ -219,6 +220,42 @@ def test_harm3d_loader_sampler_and_units_match_oracle(L, tmp_path):
                 err = np.abs(out - want) / np.abs(want)
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
     assert cut > 0          # the magnetisation cut (andrew_sigcut) is exercised
+
+
+@pytest.mark.parametrize("gmin", [1.0, 3.0, -1.0])
+def test_iharm_loader_sampler_and_units_match_oracle(L, tmp_path, gmin):
+    # iharm-format dumps (metric 0): product loader + device iharm_sample/iharm_convert, compiled for the host, against the
+    # oracle's per-stage dump (pinned bit-exact to the compiled reference); gmin selects the electron model
+    # (Moscibrodzka ratios on p (gamma-1), or the dump's electron entropy for gmin = -1)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_iharm_dump
+    dfile, hfile = make_iharm_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+    kw = dict(fname="IHARM", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1e20, mu0=0.5,
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=gmin, dfile="dumpih", hfile="dumpih_header", findf=40,
+              nn=(24, 24, 200), sigcut=1e-3)
+    o = O.Oracle(iname="formal", datadir=str(tmp_path), **kw)
+    L.grt_load_iharm_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+    assert L.grt_load_iharm_files(dfile.encode(), hfile.encode(), 40, 0.9375) == 0
+    assert L.grt_load_iharm_files(dfile.encode(), hfile.encode(), 40, 0.5) != 0          # spin check
+    L.hs_iharm_point.argtypes = [C.c_double] * 11 + [C.c_void_p]
+    for i in (293, 92, 300, 5, 570, 130):
+        d = o.ray_dump(i, 2.3e11)
+        for k in range(0, d["npts"], 3):
+            out = np.zeros(15)
+            L.hs_iharm_point(float(d["x"][k, 1]), float(d["x"][k, 2]), float(d["x"][k, 3]), 0.9375, 4e6, 1e20, 0.25, gmin,
+                             0.02, 3.5, 1e-3, out.ctypes.data)
+            want = np.concatenate([[d["rho"][k], d["p"][k], d["bmag"][k]], d["u"][k], d["b"][k],
+                                   [d["ncgs"][k], d["bcgs"][k], d["tcgs"][k], d["ncgsnth"][k]]])
+            # bmag (REAL(4) metric island: one fp32 ulp) feeds u^mu, B and -- through the plasma beta of the electron model -- T_e
+            tol = np.full(15, 1e-12); tol[2:7] = 3e-7; tol[12] = 3e-7; tol[13] = 3e-7; tol[14] = 6e-7
+            with np.errstate(all="ignore"):
+                err = np.abs(out - want) / np.abs(want)
+            assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
+    # a metric = 1 (MMKS) header is refused, not misread
+    hdr = open(hfile).read().split(); hdr[11] = "1"
+    open(hfile, "w").write(" ".join(hdr) + "\n")
+    assert L.grt_load_iharm_files(dfile.encode(), hfile.encode(), 40, 0.9375) != 0
 
 
 def test_frame_coefficients_and_formal_step_match_oracle(L):

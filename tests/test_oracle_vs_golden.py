@@ -293,8 +293,9 @@ def test_harm3d_polsynchth_image_rays_and_sigcut(tmp_path):
     for i in r["rays"]:
         d = o.ray_dump(int(i), float(r["freq"]))
         assert d["npts"] == int(r["ray%d_npts" % i])
-        for k in ("rho", "p", "bmag", "u", "b", "ncgs", "ncgsnth", "bcgs", "tcgs"):     # the fp32 sampler is bit-faithful
+        for k in ("rho", "p", "bmag", "u", "b", "ncgs", "bcgs", "tcgs"):     # the fp32 sampler is bit-faithful
             assert relerr(d[k], r["ray%d_%s" % (i, k)]) < 1e-9, (i, k)
+        assert np.array_equal(d["ncgsnth"], r["ray%d_ncgsnth" % i])
         for k, tol in (("lam", 1e-8), ("x", 1e-8), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6), ("I", 1e-6)):
             assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
 
@@ -345,4 +346,36 @@ def test_maxjutt_weighted_thermal_components(tmp_path):
         ref = g[key].astype(float)
         err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
         assert err.max() < 2e-6, (key, err)
+
+
+def test_iharm_metric0_electron_models(tmp_path):
+    # iharm-format dumps (metric 0): nearest-upper-zone sampler, the three electron models of convert_fluidvars_iharm,
+    # delo, magnetisation cut; golden = compiled reference on tools/make_iharm_dump.py's synthetic dump
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_iharm_dump
+    g = load("iharm_36x36x160.npz")
+    dfile, _ = make_iharm_dump.write(str(tmp_path), **make_golden.IHARM_ZONES)
+    assert hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest() == str(g["dump_sha256"])
+    for key, kw in (("formal_gmin1", dict(iname="formal")), ("delo_gmin1", dict(iname="delo")), ("formal_gmin3", dict(iname="formal", gmin=3.)),
+                    ("formal_kel", dict(iname="formal", gmin=-1.)), ("formal_sigcut", dict(iname="formal", sigcut=1e-3))):
+        o = O.Oracle(nn=(36, 36, 160), datadir=str(tmp_path), **dict(make_golden.IHARM, **kw))
+        pix, npts, _ = o.trace(1, 1296, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g["npts"])
+        ref = g["ivals_" + key].astype(float)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 2e-6, (key, err)
+    assert np.abs(g["ivals_formal_sigcut"] - g["ivals_formal_gmin1"]).max() > 1e-4 * np.abs(g["ivals_formal_gmin1"]).max()
+    r = load("iharm_rays_36x36x160.npz")
+    o = O.Oracle(nn=(36, 36, 160), iname="formal", datadir=str(tmp_path), **dict(make_golden.IHARM, gmin=float(r["gmin"])))
+    for i in r["rays"]:
+        d = o.ray_dump(int(i), float(r["freq"]))
+        assert d["npts"] == int(r["ray%d_npts" % i])
+        for k in ("rho", "p", "bmag", "u", "b", "ncgs", "bcgs", "tcgs"):     # the fp32 sampler is bit-faithful
+            assert relerr(d[k], r["ray%d_%s" % (i, k)]) < 1e-9, (i, k)
+        # (ncgsnth is not compared: the reference's thermal emissivity object does not carry it, so its dump column is 0)
+        for k, tol in (("lam", 1e-8), ("x", 1e-8), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6), ("I", 1e-6)):
+            assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
 
