@@ -428,7 +428,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM3D && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_IHARM && em->type == GRT_EMIS_POLSYNCHTH) ||
-                       ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D) &&
+                       ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM) &&
                         (em->type == GRT_EMIS_HYBRIDTHPL || em->type == GRT_EMIS_HYBRIDTH || em->type == GRT_EMIS_HYBRIDPL ||
                          em->type == GRT_EMIS_MAXJUTT));
   if (em->type == GRT_EMIS_MAXJUTT && (em->nother < 2 || em->nother > 8)) return GRT_E_BADARG;

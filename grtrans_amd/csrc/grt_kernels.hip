@@ -678,6 +678,12 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_IHARM, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_IHARM, GRT_EMIS_MAXJUTT)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_MAXJUTT)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_MAXJUTT)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_MAXJUTT)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_MAXJUTT)

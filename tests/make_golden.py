@@ -381,6 +381,11 @@ def iharm(nx=36, nup=160):
             r = R.Ref(nn=(nx, nx, nup), datadir=td, **dict(IHARM, **kw))
             pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
             out["ivals_" + key] = pix[0]; out["npts"] = npts
+        # hybrid and MAXJUTT on this sampler (non-thermal electrons where b^2/rho > 1: the scaled zones near the horizon)
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(IHARM, ename="HYBRIDTHPL", gmin=2., gmax=1e5, p1=3.5, p2=3.5, jetalpha=0.02))
+        out["ivals_hybridthpl"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(IHARM, ename="MAXJUTT", otherargs=(2.0, 1.0, 0.5, 0.25)))
+        out["ivals_maxjutt"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
         r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(IHARM, gmin=3.))
         pick = sorted(set([3, nx // 2 * nx + nx // 2, nx * 10 + 30, nx * 30 + 12, nx * nx - 4, nx * 20 + 5]))
         for i in pick:

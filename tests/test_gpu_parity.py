@@ -836,8 +836,14 @@ def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
         em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, 1., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
         p1, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal", nvals=1)
         assert p1.shape == (1, 1296, 1) and np.isfinite(p1).all() and p1.max() > 0
-        with pytest.raises(capi.GrtError):      # no hybrid instantiation for this sampler yet: refused
-            capi.trace_tile(cam, 1, 1296, "IHARM", capi.make_emis("HYBRIDTHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5, mdot=H["mdot"]), [FREQ_HARM], "formal")
+        em = capi.make_emis("HYBRIDTHPL", H["mbh"], 1.0, 6.0, 2., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], jetalpha=0.02)
+        pix, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal")
+        assert stokes_err(pix[0], g["ivals_hybridthpl"]) < 2 * STOKES_TOL
+        em = capi.make_emis("MAXJUTT", H["mbh"], 1.0, 6.0, 1., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], otherargs=(2.0, 1.0, 0.5, 0.25))
+        pix, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal")
+        assert stokes_err(pix[0], g["ivals_maxjutt"]) < 2 * STOKES_TOL
+        with pytest.raises(capi.GrtError):      # power-law-only emissivity has no kernel for this sampler: refused
+            capi.trace_tile(cam, 1, 1296, "IHARM", capi.make_emis("POLSYNCHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5), [FREQ_HARM], "formal")
     finally:
         d.close()
     if not os.path.exists(gb.HOST_EXE):

@@ -360,7 +360,9 @@ def test_iharm_metric0_electron_models(tmp_path):
     dfile, _ = make_iharm_dump.write(str(tmp_path), **make_golden.IHARM_ZONES)
     assert hashlib.sha256(open(dfile + "040.bin", "rb").read()).hexdigest() == str(g["dump_sha256"])
     for key, kw in (("formal_gmin1", dict(iname="formal")), ("delo_gmin1", dict(iname="delo")), ("formal_gmin3", dict(iname="formal", gmin=3.)),
-                    ("formal_kel", dict(iname="formal", gmin=-1.)), ("formal_sigcut", dict(iname="formal", sigcut=1e-3))):
+                    ("formal_kel", dict(iname="formal", gmin=-1.)), ("formal_sigcut", dict(iname="formal", sigcut=1e-3)),
+                    ("hybridthpl", dict(iname="formal", ename="HYBRIDTHPL", gmin=2., gmax=1e5, p1=3.5, jetalpha=0.02)),
+                    ("maxjutt", dict(iname="formal", ename="MAXJUTT", otherargs=(2.0, 1.0, 0.5, 0.25)))):
         o = O.Oracle(nn=(36, 36, 160), datadir=str(tmp_path), **dict(make_golden.IHARM, **kw))
         pix, npts, _ = o.trace(1, 1296, [float(g["freq"])], nthreads=8)
         assert np.array_equal(npts, g["npts"])
