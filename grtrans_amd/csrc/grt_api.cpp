@@ -53,6 +53,8 @@ struct Ctx {
   float *d_ih_cells = nullptr, *d_ih_coords = nullptr;
   GrtHarm3d iharm{};
   bool have_iharm = false;
+  int ih_metric = 0;                   // metric of the next grt_upload_iharm (grt_set_iharm_mmks)
+  double ih_smooth = 0, ih_xt = 0, ih_alpha = 0, ih_startx1 = 0;
   double *d_t0 = nullptr;        // per-ray time origin of the current tile (nload > 1), or unset
   size_t cap_t0 = 0;
   long long t0_n = 0;
@@ -275,18 +277,25 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
   return 0;
 }
 
+int grt_set_iharm_mmks(int metric, double mks_smooth, double poly_xt, double poly_alpha, double startx1) {
+  if (metric != 0 && metric != 1) return GRT_E_UNSUPPORTED;
+  C.ih_metric = metric; C.ih_smooth = mks_smooth; C.ih_xt = poly_xt; C.ih_alpha = poly_alpha; C.ih_startx1 = startx1;
+  return 0;
+}
+
 int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const float *x1_arr, const float *x2_arr,
                      const float *x3_arr, const float *rho, const float *p, const float *b0, const float *br,
                      const float *bth, const float *bph, const float *u0, const float *vrl, const float *vtl,
                      const float *vpl, const float *kela) {
   if (!C.init) return GRT_E_NOTINIT;
-  if (nx1 < 2 || nx2 < 2 || nx3 < 2 || nx1 > nx2 || 2 * (nx1 + nx2) + nx3 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr)
+  if (nx1 < 2 || nx2 < 2 || nx3 < 2 || nx1 > nx2 || 2 * (nx1 + nx2) + nx3 + nx2 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr)
     return GRT_E_BADARG;
   const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
   for (const float *q : src)
     if (!q) return GRT_E_BADARG;
   std::vector<float> cells, crd;
   grt_iharm_pack(nx1, nx2, nx3, hslope, x1_arr, x2_arr, x3_arr, src, kela, cells, crd);
+  if (C.ih_metric == 1) grt_iharm_pack_mmks(nx1, nx2, nx3, hslope, (float)C.ih_xt, (float)C.ih_alpha, crd);
   if (C.d_ih_cells) { (void)hipFree(C.d_ih_cells); C.d_ih_cells = nullptr; }
   if (C.d_ih_coords) { (void)hipFree(C.d_ih_coords); C.d_ih_coords = nullptr; }
   HIPCHK(hipMalloc((void **)&C.d_ih_cells, cells.size() * sizeof(float)));
@@ -297,6 +306,8 @@ int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const 
   C.iharm.cells = C.d_ih_cells; C.iharm.coords = C.d_ih_coords;
   C.iharm.nx1 = nx1; C.iharm.nx2 = nx2; C.iharm.nx3 = nx3; C.iharm.eheat = kela ? 1 : 0;
   C.iharm.hslope = hslope; C.iharm.gam = gam;
+  C.iharm.metric = C.ih_metric; C.iharm.mks_smooth = (float)C.ih_smooth; C.iharm.poly_xt = (float)C.ih_xt;
+  C.iharm.poly_alpha = (float)C.ih_alpha; C.iharm.startx1 = C.ih_startx1;
   C.have_iharm = true;
   return 0;
 }

@@ -10,7 +10,6 @@
 
 namespace grtd {
 
-GRT_HD float powf_cr(float x, float y) { return (float)pow((double)x, (double)y); }
 
 struct GrtDisk { float mbh, mdot, rin, rout; };
 

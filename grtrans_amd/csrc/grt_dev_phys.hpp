@@ -29,6 +29,7 @@ GRT_HD float cosf_cr(float x) { return (float)cos((double)x); }
 GRT_HD float sinf_cr(float x) { return (float)sin((double)x); }
 GRT_HD float acosf_cr(float x) { return (float)acos((double)x); }
 GRT_HD float logf_cr(float x) { return (float)log((double)x); }
+GRT_HD float powf_cr(float x, float y) { return (float)pow((double)x, (double)y); }
 
 struct Metric { double g[10]; };   // slots 1,4,5,8,10 (0-based 0,3,4,7,9) non-zero
 
@@ -1026,6 +1027,70 @@ GRT_HD void harm3d_convert(const FluidPoint &f, double mbh, double mdotcgs, doub
 // (x1u, x2u, x3u): one 48-byte record.  theta -> zone index as for 2-D HARM (search in uniqth, the reference's Brent
 // inversion where its tolerance decides); azimuth as for HARM3D; 1e-3 scaling of rho, p, kel inside the innermost zone
 // centre outside the horizon (:296-303).
+// calcthmmks (fluid_model_iharm.f90:111-122), REAL(4) x2, x1 with the reference's REAL(4)/REAL(8) mixture
+GRT_HD float iharm_thmmks(const GrtHarm3d &t, float x2, float x1) {
+  GRT_NO_CONTRACT
+  const float B = t.poly_xt, C = t.poly_alpha;
+  const float D = (float)(PH_pi / (double)(2.f + 2.f / (powf_cr(B, C) * (1 + C))));
+  const float thetag = (float)(PH_pi * (double)x2 + (1. - t.hslope) / 2. * sin(2. * PH_pi * (double)x2));
+  const float y = 2.f * x2 - 1.f;
+  const float thetaj = (float)((double)(D * y * (1.f + powf_cr(y / B, C) / (1.f + C))) + PH_pi / 2.);
+  return (float)((double)thetag + exp((double)(-t.mks_smooth) * ((double)x1 - t.startx1)) * (double)(thetaj - thetag));
+}
+
+// theta -> zone index for MMKS: transformbl2mmks inverts theta(x2; x1) with Brent on [-1, 1] (tol 1e-6, :132-146).
+// theta(x2; x1) = REAL(thetag(x2) + E(x1) (thetaj(x2) - thetag(x2))) is monotonic in x2, and thetag, thetaj at the zone
+// centres are tabulated (LDS): the index is the position of theta among the centre angles at this x1 (8 probes of one
+// fma each), unless theta lies within 4e-5 of a centre angle (Brent's 5e-7 in x2 times d theta/d x2 <= 26 near the
+// poles, plus the REAL(4) rounding of theta): those points run the reference's Brent iteration.
+struct MmksX2 {
+  const GrtHarm3d *t; double th; float x1;
+  GRT_HD double operator()(double x) const { return th - (double)iharm_thmmks(*t, (float)x, x1); }
+};
+GRT_HD double zbrent_mmks(const MmksX2 &func, double x1, double x2, double tol) {
+  GRT_NO_CONTRACT
+  const double eps = 2.220446049250313e-16;
+  double a = x1, b = x2, c, d = 0, e = 0, fa = func(a), fb = func(b), fc, p, q, r, s, tol1, xm;
+  if ((fa > 0.0 && fb > 0.0) || (fa < 0.0 && fb < 0.0)) return b - b / 0.0 * 0.0;
+  c = b; fc = fb;
+  for (int iter = 1; iter <= 100; ++iter) {
+    if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) { c = a; fc = fa; d = b - a; e = d; }
+    if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+    tol1 = 2.0 * eps * fabs(b) + 0.5 * tol;
+    xm = 0.5 * (c - b);
+    if (fabs(xm) <= tol1 || fb == 0.0) return b;
+    if (fabs(e) >= tol1 && fabs(fa) > fabs(fb)) {
+      s = fb / fa;
+      if (a == c) { p = 2.0 * xm * s; q = 1.0 - s; }
+      else { q = fa / fc; r = fb / fc; p = s * (2.0 * xm * q * (q - r) - (b - a) * (r - 1.0)); q = (q - 1.0) * (r - 1.0) * (s - 1.0); }
+      if (p > 0.0) q = -q;
+      p = fabs(p);
+      if (2.0 * p < dmin(3.0 * xm * q - fabs(tol1 * q), fabs(e * q))) { e = d; d = p / q; }
+      else { d = xm; e = d; }
+    } else { d = xm; e = d; }
+    a = b; fa = fb;
+    b = b + ((fabs(d) > tol1) ? d : copysign(tol1, xm));
+    fb = func(b);
+  }
+  return b;
+}
+GRT_HD int iharm_theta_index_mmks(const GrtHarm3d &t, const float *uniqx2, const float *thg, const float *thj, int nx2, float theta,
+                                  float x1, bool brent_only = false) {
+  GRT_NO_CONTRACT
+  const double E = exp((double)(-t.mks_smooth) * ((double)x1 - t.startx1));
+  int jlo = 0, jhi = nx2 + 1;
+  float below = 1.f, above = 1.f;
+  while (jhi - jlo > 1) {
+    const int jm = (jhi + jlo) >> 1;
+    const float thc = (float)((double)thg[jm - 1] + E * (double)(thj[jm - 1] - thg[jm - 1]));
+    if (theta >= thc) { jlo = jm; below = theta - thc; } else { jhi = jm; above = thc - theta; }
+  }
+  if (!brent_only && fminf(below, above) > 4e-5f) return jlo;
+  MmksX2 fn{&t, (double)theta, x1};
+  const float x2 = (float)zbrent_mmks(fn, -1.0, 1.0, 1e-6);
+  return (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
+}
+
 GRT_NI void iharm_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &kela) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
@@ -1037,7 +1102,8 @@ GRT_NI void iharm_sample(const GrtHarm3d &t, const float *crd, double r, double 
   if (zphi < 0.f) zphi = (float)((double)zphi + twopi);
   const float x1 = logf_cr(zr), x3 = zphi;
   const int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
-  const int lx2 = harm_theta_index(t.hslope, uniqx2, uniqth, nx2, theta, false, true);
+  const int lx2 = t.metric ? iharm_theta_index_mmks(t, uniqx2, uniqth, uniqx3 + nx3, nx2, theta, x1)
+                           : harm_theta_index(t.hslope, uniqx2, uniqth, nx2, theta, false, true);
   int ux2 = lx2 + 1;
   const int lx3 = (int)floorf((x3 - uniqx3[0]) / (uniqx3[nx3 - 1] - uniqx3[0]) * (nx3 - 1)) + 1;
   int ux3 = lx3 + 1;

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include "../../include/grtrans_amd.h"
+#include "grt_harm_pack.hpp"
 
 namespace {
 
@@ -191,10 +192,12 @@ extern "C" int grt_load_iharm_files(const char *dfile, const char *hfile, int in
   const double hslope = head[5];
   const int metric = (int)head[11], eheat = (int)head[12];
   if (nx1 < 2 || nx2 < 2 || nx3 < 2) return GRT_E_IO;
-  if (metric != 0) {
-    std::fprintf(stderr, "grtrans_amd: iharm header metric = %d: only metric 0 (MKS with hslope) is on the device\n", metric);
+  if (metric != 0 && metric != 1) {
+    std::fprintf(stderr, "grtrans_amd: iharm header metric = %d: only 0 (MKS with hslope) and 1 (MMKS) are known\n", metric);
     return GRT_E_UNSUPPORTED;
   }
+  const float mA = (float)head[7], mB = (float)head[8], mC = (float)head[9];     // REAL(4) locals A, B, C of calcthmmks
+  const double startx1 = head[10];
   if (std::fabs((double)asim - spin) > 1e-4) {     // fluid_model_iharm.f90:697-700
     std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
     return GRT_E_BADARG;
@@ -215,11 +218,22 @@ extern "C" int grt_load_iharm_files(const char *dfile, const char *hfile, int in
     x1[i] = z[0]; x2[i] = z[1]; x3[i] = z[2];
     const float r = std::exp(x1[i]);
     const double x2d = (double)x2[i];
-    const float th = (float)(kPi * x2d + (1.0 - hslope) / 2.0 * std::sin(2.0 * kPi * x2d));       // calcthmksh
+    const float th = metric ? grt_mmks_theta(hslope, mA, mB, mC, startx1, x2[i], x1[i])
+                            : (float)(kPi * x2d + (1.0 - hslope) / 2.0 * std::sin(2.0 * kPi * x2d));       // calcthmmks / calcthmksh
     const float dthdx2 = (float)(kPi * (1.0 + (1.0 - hslope) * std::cos(2.0 * kPi * x2d)));
     const double a = (double)asim, rd = (double)r;
+    // MMKS: ummks2uks (:164-184) -- r = exp(x1) in double, d theta/d x1 and d theta/d x2 by central differences of the REAL(4) theta
+    const double x1d = (double)x1[i], rmm = std::exp(x1d), dx2 = 1e-6 * x2d, dx1 = 1e-4 * x1d;
+    double dthdx1m = 0, dthdx2m = 0;
+    if (metric) {
+      dthdx1m = (double)(grt_mmks_theta(hslope, mA, mB, mC, startx1, (float)x2d, (float)(x1d + .5 * dx1)) -
+                         grt_mmks_theta(hslope, mA, mB, mC, startx1, (float)x2d, (float)(x1d - .5 * dx1))) / dx1;
+      dthdx2m = (double)(grt_mmks_theta(hslope, mA, mB, mC, startx1, (float)(x2d + .5 * dx2), (float)x1d) -
+                         grt_mmks_theta(hslope, mA, mB, mC, startx1, (float)(x2d - .5 * dx2), (float)x1d)) / dx2;
+    }
     auto to_bl = [&](const float *w, double o[4]) {
-      const double wr = rd * (double)w[1], wth = (double)w[2] * (double)dthdx2;
+      const double wr = metric ? rmm * (double)w[1] : rd * (double)w[1];
+      const double wth = metric ? dthdx1m * (double)w[1] + dthdx2m * (double)w[2] : (double)w[2] * (double)dthdx2;
       const double delta = rd * rd - 2.0 * rd + a * a;
       o[0] = (double)w[0] - 2.0 * rd / delta * wr; o[1] = wr; o[2] = wth; o[3] = (double)w[3] - a / delta * wr;
     };
@@ -231,6 +245,8 @@ extern "C" int grt_load_iharm_files(const char *dfile, const char *hfile, int in
     b0[i] = (float)b[0]; br[i] = (float)b[1]; bth[i] = (float)b[2]; bph[i] = (float)b[3];
     if (eheat) kel[i] = z[13];
   }
+  const int rcm = grt_set_iharm_mmks(metric, head[7], head[8], head[9], startx1);
+  if (rcm) return rcm;
   return grt_upload_iharm(nx1, nx2, nx3, hslope, gam, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(), br.data(),
                           bth.data(), bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data(), eheat ? kel.data() : nullptr);
 }

@@ -63,3 +63,29 @@ inline void grt_iharm_pack(int nx1, int nx2, int nx3, double hslope, const float
     crd[2 * nx1 + nx2 + j] = (float)(pi * x2 + (1.0 - hslope) / 2.0 * std::sin(2.0 * pi * x2));   // calcthmksh (:81-86)
   }
 }
+
+// calcthmmks (fluid_model_iharm.f90:111-122) split as the kernel uses it: theta = REAL(thetag + exp(-A (x1 - startx1)) (thetaj - thetag))
+// with thetag, thetaj REAL(4) functions of x2 alone.  The REAL(4)/REAL(8) mixture is the reference's.
+inline void grt_mmks_parts(double hslope, float B, float C, float x2, float &thetag, float &thetaj) {
+  const double pi = std::acos(-1.0);
+  const float D = (float)(pi / (double)(2.f + 2.f / (std::pow(B, C) * (1 + C))));
+  thetag = (float)(pi * (double)x2 + (1. - hslope) / 2. * std::sin(2. * pi * (double)x2));
+  const float y = 2.f * x2 - 1.f;
+  thetaj = (float)((double)(D * y * (1.f + std::pow(y / B, C) / (1.f + C))) + pi / 2.);
+}
+inline float grt_mmks_theta(double hslope, float A, float B, float C, double startx1, float x2, float x1) {
+  float tg, tj;
+  grt_mmks_parts(hslope, B, C, x2, tg, tj);
+  return (float)((double)tg + std::exp((double)(-A) * ((double)x1 - startx1)) * (double)(tj - tg));
+}
+
+// MMKS: uniqth slot = thetag at the zone centres; thetaj at the zone centres appended after uniqx3
+inline void grt_iharm_pack_mmks(int nx1, int nx2, int nx3, double hslope, float B, float C, std::vector<float> &crd) {
+  crd.resize((size_t)2 * (nx1 + nx2) + nx3 + nx2);
+  for (int j = 0; j < nx2; ++j) {
+    float tg, tj;
+    grt_mmks_parts(hslope, B, C, crd[2 * nx1 + j], tg, tj);
+    crd[2 * nx1 + nx2 + j] = tg;
+    crd[2 * (nx1 + nx2) + nx3 + j] = tj;
+  }
+}

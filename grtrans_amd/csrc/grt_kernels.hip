@@ -256,7 +256,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
     for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.hm.coords[i];
   }
   if (FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM) {   // uniqx1, uniqr, uniqx2, uniqth, uniqx3
-    const int nc = 2 * (fd.h3.nx1 + fd.h3.nx2) + fd.h3.nx3;
+    const int nc = 2 * (fd.h3.nx1 + fd.h3.nx2) + fd.h3.nx3 + ((FLUID == GRT_FLUID_IHARM && fd.h3.metric) ? fd.h3.nx2 : 0);
     for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.h3.coords[i];
   }
   if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches

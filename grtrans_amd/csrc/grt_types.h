@@ -53,7 +53,10 @@ struct GrtHarm3d {              // device pointers; one 3-D HARM slice, fluid_mo
   const float *coords;          // [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2][uniqx3 nx3] (staged in LDS)
   int32_t nx1, nx2, nx3, eheat;  // eheat (IHARM): slot 10 of a cell holds the electron entropy
   double hslope;                // IHARM, metric 0: theta = pi x2 + (1-hslope)/2 sin(2 pi x2) (REAL(8) in the reference)
-  float gam, padf;              // IHARM: adiabatic index of the dump (f%gamma)
+  float gam;                    // IHARM: adiabatic index of the dump (f%gamma)
+  int32_t metric;               // IHARM: 0 = MKS with hslope, 1 = MMKS (theta also depends on x1, calcthmmks)
+  float mks_smooth, poly_xt, poly_alpha, padf;   // MMKS parameters as the REAL(4) locals A, B, C of calcthmmks
+  double startx1;               // MMKS (REAL(8) there)
 };
 #define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 

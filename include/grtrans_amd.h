@@ -122,8 +122,9 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
  * from the dump's by more than 1e-4 (:611-614). */
 int grt_load_harm3d_files(const char *dfile, const char *hfile, int indf, double spin);
 
-/* iharm-format 3-D dumps (fname IHARM, fluid.f90:199-200), metric = 0 (MKS with hslope) only; the MMKS form
- * (header metric = 1) is refused with GRT_E_UNSUPPORTED.  replaces init_iharm_data + load_iharm_data for one time
+/* iharm-format 3-D dumps (fname IHARM, fluid.f90:199-200), header metric = 0 (MKS with hslope) or 1 (MMKS: theta also
+ * depends on x1, calcthmmks fluid_model_iharm.f90:111-122; select it with grt_set_iharm_mmks BEFORE the upload; the
+ * file loader does that from the header).  replaces init_iharm_data + load_iharm_data for one time
  * slice (fluid_model_iharm.f90:712-796,838-848): module arrays with x3 fastest as for HARM3D, p_arr = internal energy,
  * kela = electron entropy (NULL when the dump has none, eHEAT = 0); hslope is REAL(8) there, gam = f%gamma.  The
  * sampler takes the zone (x1u, x2u, x3u) -- the reference forces all interpolation weights to 1 (:318). */
@@ -131,6 +132,8 @@ int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const 
                      const float *x3_arr, const float *rho, const float *p, const float *b0, const float *br,
                      const float *bth, const float *bph, const float *u0, const float *vrl, const float *vtl,
                      const float *vpl, const float *kela);
+/* metric of the next grt_upload_iharm: 0, or 1 with the header's mks_smooth, poly_xt, poly_alpha, startx1 */
+int grt_set_iharm_mmks(int metric, double mks_smooth, double poly_xt, double poly_alpha, double startx1);
 /* replaces initialize_iharm_model (fluid_model_iharm.f90:673-710): text header (>= 17 numbers, :427-469) and the raw
  * REAL(4) stream `dfile`//I3.3(indf)//'.bin' = data(13+eHEAT, n) (:507-571); spin check as the other loaders. */
 int grt_load_iharm_files(const char *dfile, const char *hfile, int indf, double spin);

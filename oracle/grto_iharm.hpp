@@ -7,7 +7,8 @@
 //                 (x1u, x2u, x3u)
 //   convert       fluid.f90:995-1026 (scale_sim_units, monika_e on p (gamma-1), T_e = 2 T / 3 / (2 + trat); gmin = -1:
 //                 ressler_e on the electron entropy; nonthermale_b2; andrew_sigcut)
-// metric = 0 (MKS with hslope) only; the MMKS (metric = 1) form is not restated.
+// metric = 0 (MKS with hslope) and metric = 1 (MMKS: calcthmmks :111-122, transformbl2mmks :132-146, ummks2uks :164-184,
+// whose derivatives are central differences of the REAL(4) theta).
 #pragma once
 #include "grto_harm3d.hpp"
 
@@ -17,9 +18,20 @@ struct IharmTable {
   int nx1 = 0, nx2 = 0, nx3 = 0, eheat = 0, metric = 0;
   float asim = 0, gam = 0;
   double hslope = 0;                                                   // REAL(8) module variable
+  double mks_smooth = 0, poly_xt = 0, poly_alpha = 0, startx1 = 0;     // MMKS
   std::vector<float> rho, p, u0, vrl, vpl, vtl, b0, br, bth, bph, kela;
   std::vector<float> uniqx1, uniqx2, uniqx3, uniqr;
 };
+
+// calcthmmks (fluid_model_iharm.f90:111-122) with its REAL(4) / REAL(8) mixture; x2, x1 REAL(4)
+inline float calcthmmks(const IharmTable &t, float x2, float x1) {
+  const float A = (float)t.mks_smooth, B = (float)t.poly_xt, C = (float)t.poly_alpha;
+  const float D = (float)(PH_pi / (double)(2.f + 2.f / (std::pow(B, C) * (1 + C))));
+  const float thetag = (float)(PH_pi * (double)x2 + (1. - t.hslope) / 2. * std::sin(2. * PH_pi * (double)x2));
+  const float y = 2.f * x2 - 1.f;
+  const float thetaj = (float)((double)(D * y * (1.f + std::pow(y / B, C) / (1.f + C))) + PH_pi / 2.);
+  return (float)((double)thetag + std::exp((double)(-A) * ((double)x1 - t.startx1)) * (double)(thetaj - thetag));
+}
 
 // returns 0 ok, -1 io, -2 spin mismatch, -3 unsupported metric
 inline int iharm_load(const char *dfile, const char *hfile, int indf, double a, IharmTable &t) {
@@ -32,8 +44,9 @@ inline int iharm_load(const char *dfile, const char *hfile, int indf, double a, 
   if (header.size() < 17) return -1;
   t.nx1 = (int)header[1]; t.nx2 = (int)header[2]; t.nx3 = (int)header[3];
   t.asim = (float)header[4]; t.hslope = header[5]; t.gam = (float)header[6];
+  t.mks_smooth = header[7]; t.poly_xt = header[8]; t.poly_alpha = header[9]; t.startx1 = header[10];
   t.metric = (int)header[11]; t.eheat = (int)header[12];
-  if (t.metric != 0) return -3;
+  if (t.metric != 0 && t.metric != 1) return -3;
   if (std::fabs((double)t.asim - a) > 1e-4) return -2;
   const size_t n = (size_t)t.nx1 * t.nx2 * t.nx3;
   const int dlen = 13 + t.eheat;
@@ -54,15 +67,22 @@ inline int iharm_load(const char *dfile, const char *hfile, int indf, double a, 
     const float r_f = std::exp(x1[i]);
     // th_arr = real(calcthmksh(dble(x2_arr))): pi*x2 + (1.-hslope)/2.*sin(2.*pi*x2) in double (hslope REAL(8))
     const double x2d = (double)x2[i];
-    const float th_f = (float)(PH_pi * x2d + (1.0 - t.hslope) / 2.0 * std::sin(2.0 * PH_pi * x2d));
+    const float th_f = t.metric ? calcthmmks(t, x2[i], x1[i]) : (float)(PH_pi * x2d + (1.0 - t.hslope) / 2.0 * std::sin(2.0 * PH_pi * x2d));
     double u[4] = {(double)row[5], (double)row[6], (double)row[7], (double)row[8]};
     double b[4] = {(double)row[9], (double)row[10], (double)row[11], (double)row[12]};
     // umksh2uks (:186-220): dthdx2 = pi*(1.+(1.-hslope)*cos(2*pi*x2)) assigned to a REAL(4), x2 REAL(4)
     const float dthdx2 = (float)(PH_pi * (1.0 + (1.0 - t.hslope) * std::cos(2.0 * PH_pi * x2d)));
     const double rd = (double)r_f;
+    // ummks2uks (:164-184): r = exp(x1) in double, derivatives = central differences of the REAL(4) theta
+    const double x1d = (double)x1[i], rmm = std::exp(x1d), dx2 = 1e-6 * x2d, dx1 = 1e-4 * x1d;
+    double dthdx1m = 0, dthdx2m = 0;
+    if (t.metric) {
+      dthdx1m = (double)(calcthmmks(t, (float)x2d, (float)(x1d + .5 * dx1)) - calcthmmks(t, (float)x2d, (float)(x1d - .5 * dx1))) / dx1;
+      dthdx2m = (double)(calcthmmks(t, (float)(x2d + .5 * dx2), (float)x1d) - calcthmmks(t, (float)(x2d - .5 * dx2), (float)x1d)) / dx2;
+    }
     auto to_bl = [&](double *w) {
-      w[1] = rd * w[1];
-      w[2] = w[2] * (double)dthdx2;
+      if (t.metric) { const double w1 = w[1]; w[1] = rmm * w1; w[2] = dthdx1m * w1 + dthdx2m * w[2]; }
+      else { w[1] = rd * w[1]; w[2] = w[2] * (double)dthdx2; }
       double delta = rd * rd - 2.0 * rd + as * as;
       double w0 = w[0] - 2.0 * rd / delta * w[1];
       double w3 = w[3] - as / delta * w[1];
@@ -92,7 +112,11 @@ inline void iharm_vals(const IharmTable &t, const double *x, float a, FluidPoint
   if (zphi < 0.f) zphi = (float)((double)zphi + 2. * PH_pi);
   const float x1 = std::log(zr), x3 = zphi;
   const double thd = (double)theta, hs = t.hslope;
-  const float x2 = (float)zbrent([&](double xx) { return thd - (PH_pi * xx + (1. - hs) / 2. * std::sin(2. * PH_pi * xx)); }, 0.0, 1.0, 1e-6);
+  float x2;
+  if (t.metric)     // transformbl2mmks: zbrent(findx2mmks, -1, 1, (dble(x1), dble(th)), 1d-6); theta from REAL(x2), REAL(x1)
+    x2 = (float)zbrent([&](double xx) { return thd - (double)calcthmmks(t, (float)xx, (float)(double)x1); }, -1.0, 1.0, 1e-6);
+  else
+    x2 = (float)zbrent([&](double xx) { return thd - (PH_pi * xx + (1. - hs) / 2. * std::sin(2. * PH_pi * xx)); }, 0.0, 1.0, 1e-6);
   int lx1 = (int)std::floor((x1 - t.uniqx1[0]) / (t.uniqx1[nx1 - 1] - t.uniqx1[0]) * (nx1 - 1)) + 1;
   int lx2 = (int)std::floor((x2 - t.uniqx2[0]) / (t.uniqx2[nx2 - 1] - t.uniqx2[0]) * (nx2 - 1)) + 1;
   int ux2 = lx2 + 1;

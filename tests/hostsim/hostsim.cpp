@@ -168,17 +168,36 @@ void hs_harm3d_point(double r, double th, double phi, double a, double mbh, doub
 // iharm-format dumps: capture of the loader's arrays and the point sampler + unit conversion
 static GrtHarm3d g_ih;
 static std::vector<float> g_cellsi, g_crdi;
+static int g_ihm = 0;
+static double g_ihp[4] = {0, 0, 0, 0};
+int grt_set_iharm_mmks(int metric, double mks_smooth, double poly_xt, double poly_alpha, double startx1) {
+  g_ihm = metric; g_ihp[0] = mks_smooth; g_ihp[1] = poly_xt; g_ihp[2] = poly_alpha; g_ihp[3] = startx1;
+  return 0;
+}
 int grt_upload_iharm(int nx1, int nx2, int nx3, double hslope, float gam, const float *x1_arr, const float *x2_arr,
                      const float *x3_arr, const float *rho, const float *p, const float *b0, const float *br,
                      const float *bth, const float *bph, const float *u0, const float *vrl, const float *vtl,
                      const float *vpl, const float *kela) {
   const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
   grt_iharm_pack(nx1, nx2, nx3, hslope, x1_arr, x2_arr, x3_arr, src, kela, g_cellsi, g_crdi);
+  if (g_ihm == 1) grt_iharm_pack_mmks(nx1, nx2, nx3, hslope, (float)g_ihp[1], (float)g_ihp[2], g_crdi);
   g_ih = GrtHarm3d{};
   g_ih.cells = g_cellsi.data(); g_ih.coords = g_crdi.data(); g_ih.nx1 = nx1; g_ih.nx2 = nx2; g_ih.nx3 = nx3;
   g_ih.eheat = kela ? 1 : 0; g_ih.hslope = hslope; g_ih.gam = gam;
+  g_ih.metric = g_ihm; g_ih.mks_smooth = (float)g_ihp[0]; g_ih.poly_xt = (float)g_ihp[1]; g_ih.poly_alpha = (float)g_ihp[2]; g_ih.startx1 = g_ihp[3];
   return 0;
 }
+// MMKS zone index: the tabulated search against the reference's Brent path, at radius coordinate x1
+void hs_iharm_mmks_index(int n, const float *theta, const float *x1, int *fast, int *brent) {
+  const float *crd = g_crdi.data();
+  const int nx1 = g_ih.nx1, nx2 = g_ih.nx2, nx3 = g_ih.nx3;
+  const float *ux2 = crd + 2 * nx1, *thg = crd + 2 * nx1 + nx2, *thj = crd + 2 * (nx1 + nx2) + nx3;
+  for (int i = 0; i < n; ++i) {
+    fast[i] = iharm_theta_index_mmks(g_ih, ux2, thg, thj, nx2, theta[i], x1[i], false);
+    brent[i] = iharm_theta_index_mmks(g_ih, ux2, thg, thj, nx2, theta[i], x1[i], true);
+  }
+}
+float hs_iharm_thmmks(float x2, float x1) { return iharm_thmmks(g_ih, x2, x1); }
 void hs_iharm_point(double r, double th, double phi, double a, double mbh, double mdot, double muval, double gminval,
                     double jetalpha, double p1, double sigcut, double *out15) {
   FluidPoint f;

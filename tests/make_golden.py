@@ -386,6 +386,14 @@ def iharm(nx=36, nup=160):
         out["ivals_hybridthpl"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
         r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(IHARM, ename="MAXJUTT", otherargs=(2.0, 1.0, 0.5, 0.25)))
         out["ivals_maxjutt"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
+        # MMKS (header metric 1): theta depends on x1 as well; vectors go through central differences of the REAL(4) theta
+        import os as _os
+        tdm = _os.path.join(td, "mmks")
+        dfm, _ = make_iharm_dump.write(tdm, metric=1, **IHARM_ZONES)
+        out["mmks_dump_sha256"] = np.array(hashlib.sha256(open(dfm + "040.bin", "rb").read()).hexdigest())
+        for key, kw in (("mmks_formal_gmin3", dict(iname="formal", gmin=3.)), ("mmks_delo_kel", dict(iname="delo", gmin=-1.))):
+            r = R.Ref(nn=(nx, nx, nup), datadir=tdm, **dict(IHARM, **kw))
+            out["ivals_" + key] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
         r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(IHARM, gmin=3.))
         pick = sorted(set([3, nx // 2 * nx + nx // 2, nx * 10 + 30, nx * 30 + 12, nx * nx - 4, nx * 20 + 5]))
         for i in pick:

@@ -842,6 +842,14 @@ def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
         em = capi.make_emis("MAXJUTT", H["mbh"], 1.0, 6.0, 1., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], otherargs=(2.0, 1.0, 0.5, 0.25))
         pix, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal")
         assert stokes_err(pix[0], g["ivals_maxjutt"]) < 2 * STOKES_TOL
+        # MMKS (header metric 1): theta(x1, x2), zone search on the tabulated thetag / thetaj, Brent near zone-centre angles
+        dfm, hfm = make_iharm_dump.write(str(tmp_path / "mmks"), metric=1, **make_golden.IHARM_ZONES)
+        assert hashlib.sha256(open(dfm + "040.bin", "rb").read()).hexdigest() == str(g["mmks_dump_sha256"])
+        d.load_iharm(dfm, hfm, 40, H["spin"])
+        for key, iname, gmin in (("mmks_formal_gmin3", "formal", 3.), ("mmks_delo_kel", "delo", -1.)):
+            em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, gmin, 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
+            pix, _, status, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], iname)
+            assert np.array_equal(status, g["npts"]) and stokes_err(pix[0], g["ivals_" + key]) < 2 * STOKES_TOL, key
         with pytest.raises(capi.GrtError):      # power-law-only emissivity has no kernel for this sampler: refused
             capi.trace_tile(cam, 1, 1296, "IHARM", capi.make_emis("POLSYNCHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5), [FREQ_HARM], "formal")
     finally:

@@ -222,15 +222,15 @@ def test_harm3d_loader_sampler_and_units_match_oracle(L, tmp_path):
     assert cut > 0          # the magnetisation cut (andrew_sigcut) is exercised
 
 
-@pytest.mark.parametrize("gmin", [1.0, 3.0, -1.0])
-def test_iharm_loader_sampler_and_units_match_oracle(L, tmp_path, gmin):
+@pytest.mark.parametrize("gmin,metric", [(1.0, 0), (3.0, 0), (-1.0, 0), (3.0, 1), (-1.0, 1)])
+def test_iharm_loader_sampler_and_units_match_oracle(L, tmp_path, gmin, metric):
     # iharm-format dumps (metric 0): product loader + device iharm_sample/iharm_convert, compiled for the host, against the
     # oracle's per-stage dump (pinned bit-exact to the compiled reference); gmin selects the electron model
     # (Moscibrodzka ratios on p (gamma-1), or the dump's electron entropy for gmin = -1)
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_iharm_dump
-    dfile, hfile = make_iharm_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+    dfile, hfile = make_iharm_dump.write(str(tmp_path), n1=32, n2=32, n3=16, metric=metric)
     kw = dict(fname="IHARM", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mdot=1e20, mu0=0.5,
               gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=gmin, dfile="dumpih", hfile="dumpih_header", findf=40,
               nn=(24, 24, 200), sigcut=1e-3)
@@ -252,10 +252,43 @@ def test_iharm_loader_sampler_and_units_match_oracle(L, tmp_path, gmin):
             with np.errstate(all="ignore"):
                 err = np.abs(out - want) / np.abs(want)
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
-    # a metric = 1 (MMKS) header is refused, not misread
-    hdr = open(hfile).read().split(); hdr[11] = "1"
+    # an unknown metric code in the header is refused, not misread
+    hdr = open(hfile).read().split(); hdr[11] = "2"
     open(hfile, "w").write(" ".join(hdr) + "\n")
     assert L.grt_load_iharm_files(dfile.encode(), hfile.encode(), 40, 0.9375) != 0
+
+
+def test_iharm_mmks_theta_index_equals_brent_index_everywhere(L, tmp_path):
+    # MMKS: the kernel's tabulated zone search must give the index of the reference's Brent inversion for every (theta, x1),
+    # including angles straddling the zone-centre angles at that radius
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_iharm_dump
+    for n in (32, 96):
+        dfile, hfile = make_iharm_dump.write(str(tmp_path), n1=min(n, 32), n2=n, n3=8, metric=1)
+        L.grt_load_iharm_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+        assert L.grt_load_iharm_files(dfile.encode(), hfile.encode(), 40, 0.9375) == 0
+        L.hs_iharm_thmmks.restype = C.c_float; L.hs_iharm_thmmks.argtypes = [C.c_float, C.c_float]
+        rng = np.random.default_rng(5)
+        x2c = ((np.arange(n) + 0.5) / n).astype(np.float32)
+        th, x1 = [], []
+        for lr in (0.3, 0.9, 1.7, 2.6, 3.5):
+            cen = np.array([L.hs_iharm_thmmks(float(v), float(np.float32(lr))) for v in x2c], dtype=np.float32)
+            t = [rng.uniform(1e-3, np.pi - 1e-3, 40000).astype(np.float32)]
+            for k in range(-30, 31, 3):
+                c = cen.copy()
+                for _ in range(abs(k)):
+                    c = np.nextafter(c, np.float32(10.0 if k > 0 else -10.0), dtype=np.float32)
+                t.append(c)
+            for off in (2e-5, 3.9e-5, 4.1e-5, 6e-5):
+                t += [(cen + np.float32(off)).astype(np.float32), (cen - np.float32(off)).astype(np.float32)]
+            t = np.concatenate(t); t = t[(t > 1e-4) & (t < np.pi - 1e-4)]
+            th.append(t); x1.append(np.full(len(t), lr, dtype=np.float32))
+        th = np.concatenate(th); x1 = np.concatenate(x1)
+        fast = np.zeros(len(th), dtype=np.int32); brent = np.zeros(len(th), dtype=np.int32)
+        L.hs_iharm_mmks_index.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hs_iharm_mmks_index(len(th), th.ctypes.data, x1.ctypes.data, fast.ctypes.data, brent.ctypes.data)
+        assert np.array_equal(fast, brent), (n, np.where(fast != brent)[0][:10], th[np.where(fast != brent)[0][:5]])
 
 
 def test_frame_coefficients_and_formal_step_match_oracle(L):

@@ -370,6 +370,15 @@ def test_iharm_metric0_electron_models(tmp_path):
         err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
         assert err.max() < 2e-6, (key, err)
     assert np.abs(g["ivals_formal_sigcut"] - g["ivals_formal_gmin1"]).max() > 1e-4 * np.abs(g["ivals_formal_gmin1"]).max()
+    # MMKS (header metric 1)
+    dfm, _ = make_iharm_dump.write(str(tmp_path / "mmks"), metric=1, **make_golden.IHARM_ZONES)
+    assert hashlib.sha256(open(dfm + "040.bin", "rb").read()).hexdigest() == str(g["mmks_dump_sha256"])
+    for key, kw in (("mmks_formal_gmin3", dict(iname="formal", gmin=3.)), ("mmks_delo_kel", dict(iname="delo", gmin=-1.))):
+        o = O.Oracle(nn=(36, 36, 160), datadir=str(tmp_path / "mmks"), **dict(make_golden.IHARM, **kw))
+        pix, npts, _ = o.trace(1, 1296, [float(g["freq"])], nthreads=8)
+        ref = g["ivals_" + key].astype(float)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert np.array_equal(npts, g["npts"]) and err.max() < 2e-6, (key, err)
     r = load("iharm_rays_36x36x160.npz")
     o = O.Oracle(nn=(36, 36, 160), iname="formal", datadir=str(tmp_path), **dict(make_golden.IHARM, gmin=float(r["gmin"])))
     for i in r["rays"]:

@@ -18,7 +18,19 @@ from make_harm_dump import ks_metric, SPIN, GAM, HSLOPE
 SEED = 20261004
 
 
-def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED, time=2000.0, eheat=1, b0=0.12):
+MKS_SMOOTH, POLY_XT, POLY_ALPHA = 0.5, 0.82, 14.0
+
+
+def theta_mmks(x1, x2, h, startx1):
+    """calcthmmks (fluid_model_iharm.f90:111-122), double precision"""
+    D = np.pi / (2.0 + 2.0 / (POLY_XT ** POLY_ALPHA * (1.0 + POLY_ALPHA)))
+    y = 2.0 * x2 - 1.0
+    thg = np.pi * x2 + 0.5 * (1.0 - h) * np.sin(2.0 * np.pi * x2)
+    thj = D * y * (1.0 + (y / POLY_XT) ** POLY_ALPHA / (1.0 + POLY_ALPHA)) + np.pi / 2.0
+    return thg + np.exp(-MKS_SMOOTH * (x1 - startx1)) * (thj - thg)
+
+
+def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED, time=2000.0, eheat=1, b0=0.12, metric=0):
     assert n1 <= n2, "the reference's uniqx1 slice (fluid_model_iharm.f90:251) needs nx1 <= nx2"
     rh = 1.0 + np.sqrt(1.0 - a * a)
     rin = 0.98 * rh
@@ -28,8 +40,15 @@ def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED, time=2000.
     x3 = (np.arange(n3) + 0.5) * 2.0 * np.pi / n3
     X1, X2, X3 = np.meshgrid(x1, x2, x3, indexing="ij")
     r, ph = np.exp(X1), X3
-    th = np.pi * X2 + 0.5 * (1.0 - h) * np.sin(2.0 * np.pi * X2)
-    dthdx2 = np.pi * (1.0 + (1.0 - h) * np.cos(2.0 * np.pi * X2))
+    if metric == 0:
+        th = np.pi * X2 + 0.5 * (1.0 - h) * np.sin(2.0 * np.pi * X2)
+        dthdx2 = np.pi * (1.0 + (1.0 - h) * np.cos(2.0 * np.pi * X2))
+        dthdx1 = np.zeros_like(th)
+    else:       # MMKS: theta depends on x1 as well; derivatives by (double precision) central differences
+        th = theta_mmks(X1, X2, h, startx1)
+        e = 1e-6
+        dthdx2 = (theta_mmks(X1, X2 + e, h, startx1) - theta_mmks(X1, X2 - e, h, startx1)) / (2 * e)
+        dthdx1 = (theta_mmks(X1 + e, X2, h, startx1) - theta_mmks(X1 - e, X2, h, startx1)) / (2 * e)
     rng = np.random.default_rng(seed)
     wig = 1.0 + 0.02 * rng.standard_normal(r.shape)
     spiral = ph - 1.3 * np.sqrt(r)
@@ -65,7 +84,7 @@ def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED, time=2000.
     def to_mks(w):
         o = w.copy()
         o[..., 1] = w[..., 1] / r
-        o[..., 2] = w[..., 2] / dthdx2
+        o[..., 2] = (w[..., 2] - dthdx1 * o[..., 1]) / dthdx2
         return o
     um, bm = to_mks(u), to_mks(b)
     dlen = 13 + eheat
@@ -76,7 +95,7 @@ def make(n1=48, n2=48, n3=24, rout=40.0, a=SPIN, h=HSLOPE, seed=SEED, time=2000.
     cols[..., 9:13] = bm
     if eheat:
         cols[..., 13] = kel
-    header = [time, n1, n2, n3, a, h, GAM, 0.5, 0.82, 14.0, startx1, 0, eheat, 0, 8 + eheat, rin, rout]
+    header = [time, n1, n2, n3, a, h, GAM, MKS_SMOOTH, POLY_XT, POLY_ALPHA, startx1, metric, eheat, 0, 8 + eheat, rin, rout]
     return header, cols.reshape(n1 * n2 * n3, dlen)
 
 
