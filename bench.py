@@ -102,7 +102,9 @@ def main():
     if "GRT_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["GRT_BENCH_DEVICE"])
     cdev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # GRT_BENCH_FORCE_DIST=1 (test hook): initialise the process group even for one rank, so that a 1-GPU box runs the
+    # barrier / gather / all_reduce of the N>1 path through RCCL
+    if world > 1 or os.environ.get("GRT_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":

@@ -869,3 +869,21 @@ def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
 
+
+def test_bench_distributed_path_through_rccl_single_rank():
+    # bench.py's N>1 code path (process group over RCCL, barrier, gather of the fp32 tiles, all_reduce of the timings)
+    # launched exactly as the driver does, with one rank on this 1-GPU box (GRT_BENCH_FORCE_DIST=1)
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--nn", "256", "256", "200", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["metric"] == "ray-steps/sec" and j["n_gpus"] == 1 and j["value"] > 1e8 and j["scaling"] == "weak"
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
