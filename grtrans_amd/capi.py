@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB = os.environ.get("GRTRANS_AMD_LIB", os.path.join(PKG, "libgrtrans_amd.so"))
 DATA = os.path.join(PKG, "data")
 
-FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13, "HARM3D": 19, "IHARM": 29}       # fluid.f90:40-43
+FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13, "HARM3D": 19, "KORAL3D": 25, "KORAL3D_DISK": 26, "IHARM": 29}       # fluid.f90:40-43
 EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8, "HYBRIDTHPL": 20, "HYBRIDTH": 21, "HYBRIDPL": 22, "MAXJUTT": 23}    # emis.f90:11-18
 INTEG = {"lsoda": 0, "delo": 1, "formal": 2, "lsodasph": 3}          # rad_trans.f90:29-37
 
@@ -89,6 +89,10 @@ class Device:
 
     def load_iharm(self, dfile, hfile, indf, spin):
         check(lib().grt_load_iharm_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin)), "grt_load_iharm_files")
+
+    def load_koral3d(self, dfile, hfile, indf, spin, scalefac=1.0):
+        check(lib().grt_load_koral3d_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin), C.c_double(scalefac)),
+              "grt_load_koral3d_files")
 
     def set_thindisk(self, mdot, rin, rout):
         check(lib().grt_set_thindisk(C.c_double(mdot), C.c_double(rin), C.c_double(rout)), "grt_set_thindisk")

@@ -53,6 +53,9 @@ struct Ctx {
   float *d_ih_cells = nullptr, *d_ih_coords = nullptr;
   GrtHarm3d iharm{};
   bool have_iharm = false;
+  float *d_ko_cells = nullptr, *d_ko_coords = nullptr;
+  GrtHarm3d koral{};
+  bool have_koral = false;
   int ih_metric = 0;                   // metric of the next grt_upload_iharm (grt_set_iharm_mmks)
   double ih_smooth = 0, ih_xt = 0, ih_alpha = 0, ih_startx1 = 0;
   double *d_t0 = nullptr;        // per-ray time origin of the current tile (nload > 1), or unset
@@ -132,7 +135,7 @@ int grt_free(void) {
   (void)hipStreamSynchronize(C.stream);
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -274,6 +277,32 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
   C.harm3d.cells = C.d_h3_cells; C.harm3d.coords = C.d_h3_coords;
   C.harm3d.nx1 = nx1; C.harm3d.nx2 = nx2; C.harm3d.nx3 = nx3;
   C.have_harm3d = true;
+  return 0;
+}
+
+int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, float bb, float pp, const float *x1_arr,
+                       const float *x2_arr, const float *x3_arr, const float *rho, const float *p, const float *b0,
+                       const float *br, const float *bth, const float *bph, const float *u0, const float *vrl,
+                       const float *vtl, const float *vpl, const float *be) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (nx1 < 2 || nx2 < 4 || nx3 < 2 || nx3 > nx1 || 2 * nx1 + nx2 + nx3 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr || !be)
+    return GRT_E_BADARG;
+  const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
+  for (const float *q : src)
+    if (!q) return GRT_E_BADARG;
+  std::vector<float> cells, crd;
+  grt_koral3d_pack(nx1, nx2, nx3, r0, x1_arr, x2_arr, x3_arr, src, be, cells, crd);
+  if (C.d_ko_cells) { (void)hipFree(C.d_ko_cells); C.d_ko_cells = nullptr; }
+  if (C.d_ko_coords) { (void)hipFree(C.d_ko_coords); C.d_ko_coords = nullptr; }
+  HIPCHK(hipMalloc((void **)&C.d_ko_cells, cells.size() * sizeof(float)));
+  HIPCHK(hipMalloc((void **)&C.d_ko_coords, crd.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(C.d_ko_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(C.d_ko_coords, crd.data(), crd.size() * sizeof(float), hipMemcpyHostToDevice));
+  C.koral = GrtHarm3d{};
+  C.koral.cells = C.d_ko_cells; C.koral.coords = C.d_ko_coords;
+  C.koral.nx1 = nx1; C.koral.nx2 = nx2; C.koral.nx3 = nx3;
+  C.koral.kr0 = r0; C.koral.kh = h; C.koral.kaa = aa; C.koral.kbb = bb; C.koral.kpp = pp;
+  C.have_koral = true;
   return 0;
 }
 
@@ -439,6 +468,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM3D && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_IHARM && em->type == GRT_EMIS_POLSYNCHTH) ||
+                       ((fluid_model == GRT_FLUID_KORAL3D || fluid_model == GRT_FLUID_KORAL3D_DISK) && em->type == GRT_EMIS_POLSYNCHTH) ||
                        ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM) &&
                         (em->type == GRT_EMIS_HYBRIDTHPL || em->type == GRT_EMIS_HYBRIDTH || em->type == GRT_EMIS_HYBRIDPL ||
                          em->type == GRT_EMIS_MAXJUTT));
@@ -454,12 +484,16 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (fluid_model == GRT_FLUID_HARM && !C.have_harm) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_HARM3D && !C.have_harm3d) return GRT_E_NOFLUID;
   if (fluid_model == GRT_FLUID_IHARM && !C.have_iharm) return GRT_E_NOFLUID;
+  const bool is_koral = (fluid_model == GRT_FLUID_KORAL3D || fluid_model == GRT_FLUID_KORAL3D_DISK);
+  if (is_koral && !C.have_koral) return GRT_E_NOFLUID;
   if ((em->type == GRT_EMIS_POLSYNCHPL || (em->type >= GRT_EMIS_HYBRIDTHPL && em->type <= GRT_EMIS_HYBRIDPL)) && !C.have_tables) return GRT_E_NOTABLES;
   GrtFluidDev fd{};
   fd.fj = C.ffjet;
   fd.sphacc = C.d_sphacc;
   fd.hm = C.harm;
-  fd.h3 = (fluid_model == GRT_FLUID_IHARM) ? C.iharm : C.harm3d;     // the two 3-D tables share the kernel argument slot
+  fd.h3 = (fluid_model == GRT_FLUID_IHARM) ? C.iharm : (is_koral ? C.koral : C.harm3d);     // the 3-D tables share the kernel argument slot
+  if (is_koral) fd.h3.ktype = (fluid_model == GRT_FLUID_KORAL3D_DISK) ? 1 : 0;
+  const int kfluid = is_koral ? GRT_FLUID_KORAL3D : fluid_model;      // one instantiation serves both KORAL3D variants
   HIPCHK(hipSetDevice(C.device));
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
@@ -474,7 +508,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const long long maxpts = cam->nup + cam->next;
   const long long rstride = (maxpts + 63) / 64 * 64;      // internal ray stride: 512-byte aligned chunk rows
   // extra=1 weights by phi as well; a 3-D fluid model is sampled at the point's azimuth
-  const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM) ? 4 : 3);
+  const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || is_koral) ? 4 : 3);
   // several HARM slices loaded ("slow light"): every point also carries its coordinate time, one more field
   const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1);
   if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;
@@ -509,12 +543,12 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
   HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield, d_t0));
   HIPCHK(hipEventRecord(C.evk[0], C.stream));
-  HIPCHK(grt_launch_transfer(C.stream, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
+  HIPCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                              C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, rstride,
                              fstride, nfields, tfield, C.d_stepcount));
   HIPCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
                         rstride, fstride, nfields, tfield, d_t0));
-  HIPCHK(grt_launch_transfer(C.stream2, kflag, fluid_model, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
+  HIPCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
                              nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
                              C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount));
   HIPCHK(hipEventRecord(C.evj[1], C.stream2));

@@ -1167,6 +1167,139 @@ GRT_HD void iharm_convert(const FluidPoint &f, float kela, float gam, double mbh
   if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
 }
 
+// ------------------------------------------------------------------ KORAL 3-D dumps (fluid_model_koral3d.f90)
+// transformbl2mksh3 / transformmksh32bl (:64-82): REAL(4) arguments, REAL(8) pi
+GRT_HD float koral_x2_of_theta(float th, float r, float h, float a, float b, float p) {
+  GRT_NO_CONTRACT
+  const float rp = powf_cr(r, p);
+  const float den = (b - a) * powf_cr(2.f, p) + (a - 0.5f) * rp;
+  return (float)(0.5 * (1 + ((double)rp / ((double)h * PH_pi)) * (atan(tan((double)(0.5f * h) * PH_pi) * (1 - (double)(2 * th) / PH_pi)) / (double)den)));
+}
+GRT_HD float koral_theta_of_x2(float x2, float r, float h, float a, float b, float p) {
+  GRT_NO_CONTRACT
+  const float inner = -0.5f + x2 + (1 - 2 * x2) * (a + powf_cr(2.f, p) * (b - a) / powf_cr(r, p));
+  return (float)(0.5 * PH_pi * (1 + tan((double)h * PH_pi * (double)inner) / tan((double)(0.5f * h) * PH_pi)));
+}
+
+// koral3d_vals (:83-341), one loaded slice: closed-form theta -> x2, azimuth folded into (-pi, pi] WITHOUT the Kerr-Schild
+// shift, eight corners (x2 fastest, then x1, then x3), 1e-3 scaling of rho and T_e in the innermost radial zone, the
+// polar trust region (minpolecell = 2 zones; 0.25 rad for the disc variant).  Be (Bernoulli parameter) rides along.
+GRT_NI void koral3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &Be) {
+  GRT_NO_CONTRACT
+  const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
+  const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqx3 = crd + 2 * nx1 + nx2;
+  const float theta = (float)th_d, zr = (float)r;
+  const double twopi = 2. * PH_pi;
+  float zphi = (float)phi_d;
+  zphi = (float)fmod((double)zphi, twopi);
+  if (zphi < 0.f) zphi = (float)((double)zphi + twopi);
+  if ((double)zphi > PH_pi) zphi = (float)((double)zphi - twopi);
+  const float x1 = (float)log((double)zr - (double)t.kr0), x3 = zphi;
+  const float x2 = koral_x2_of_theta(theta, zr, t.kh, t.kaa, t.kbb, t.kpp);
+  int lx1 = (int)floorf((x1 - uniqx1[0]) / (uniqx1[nx1 - 1] - uniqx1[0]) * (nx1 - 1)) + 1;
+  int ux1 = lx1 + 1;
+  lx1 = (lx1 >= 1) ? lx1 : 1;
+  ux1 = (ux1 <= nx1) ? ux1 : nx1;
+  int lx2 = (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
+  int ux2 = lx2 + 1;
+  lx2 = (lx2 >= 1) ? lx2 : 1;
+  ux2 = (ux2 <= nx2) ? ux2 : nx2;
+  int lx3 = (int)floorf((x3 - uniqx3[0]) / (uniqx3[nx3 - 1] - uniqx3[0]) * (nx3 - 1)) + 1;
+  int ux3 = lx3 + 1;
+  ux3 = (ux3 <= nx3) ? ux3 : 1;
+  float minph;
+  if (lx3 < 1) { lx3 = nx3; minph = (float)((double)uniqx3[lx3 - 1] - twopi); }
+  else minph = uniqx3[(lx3 < nx3 ? lx3 : nx3) - 1];
+  // indices beyond the grid read outside the tables in the reference: only addresses are clamped here
+  const int lx1c = lx1 < nx1 ? lx1 : nx1, ux1c = ux1 > 1 ? ux1 : 1, lx2c = lx2 < nx2 ? lx2 : nx2, ux2c = ux2 > 1 ? ux2 : 1, lx3c = lx3 < nx3 ? lx3 : nx3;
+  const float pd = (zphi - minph) / (uniqx3[1] - uniqx3[0]);
+  float rd = (zr - uniqr[lx1c - 1]) / (uniqr[ux1c - 1] - uniqr[lx1c - 1]);
+  const float rh = 1.f + sqrtf(1.f - a * a);
+  double fac = 1.0;
+  if (uniqr[lx1c - 1] <= rh || lx1 == 1) { rd = 1.f; fac = (double)1e-3f; }
+  const float thl = koral_theta_of_x2(uniqx2[lx2c - 1], uniqr[lx1c - 1], t.kh, t.kaa, t.kbb, t.kpp);
+  const float thu = koral_theta_of_x2(uniqx2[ux2c - 1], uniqr[lx1c - 1], t.kh, t.kaa, t.kbb, t.kpp);
+  const float thone = koral_theta_of_x2(uniqx2[0], uniqr[lx1c - 1], t.kh, t.kaa, t.kbb, t.kpp);
+  const float td = (ux2c != lx2c) ? fabsf((theta - thl) / (thu - thl)) : fabsf((theta - thl) / thone);
+  const size_t plane = (size_t)nx1 * nx2 * 12;
+  const float *c_ll = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(lx1c - 1) * nx2 + (lx2c - 1)) * 12;     // (x1l, x2l, x3l)
+  const float *c_lu = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(lx1c - 1) * nx2 + (ux2c - 1)) * 12;     // (x1l, x2u, x3l)
+  const float *c_ul = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(ux1c - 1) * nx2 + (lx2c - 1)) * 12;     // (x1u, x2l, x3l)
+  const float *c_uu = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(ux1c - 1) * nx2 + (ux2c - 1)) * 12;     // (x1u, x2u, x3l)
+  const long long o3 = ((long long)(ux3 - 1) - (long long)(lx3c - 1)) * (long long)plane;                      // to the x3u plane
+  float q[11], m1[11];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang loop unroll(disable)
+#endif
+  for (int side = 0; side < 2; ++side) {
+    const long long o = side ? o3 : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 11; ++k) {
+      float i1 = c_ll[o + k] * (1.f - td) + c_lu[o + k] * td;
+      float i2 = c_ul[o + k] * (1.f - td) + c_uu[o + k] * td;
+      float m = i1 * (1.f - rd) + i2 * rd;
+      if (side == 0) m1[k] = m;
+      else {
+        float w1 = m1[k] * (1.f - pd) + m * pd;
+        q[k] = w1 * (1.f - 0.f) + w1 * 0.f;
+      }
+    }
+  }
+  // first the x1 > uniqx1(1) merges and the 1e-3 factors (:262-272), then the trust cuts replace whole points (:291-314)
+  const bool in1 = x1 > uniqx1[0];
+  bool trust = true;
+  if (t.ktype == 1) trust = (theta > 0.25f && (double)theta < PH_pi - 0.25);
+  const float x2min = uniqx2[1], x2max = uniqx2[nx2 - 2];     // minpolecell = 2
+  trust = trust && (x2 > x2min && x2 < x2max);
+  f.rho = trust ? (float)((double)(in1 ? q[0] : 0.f) * fac) : 0.f;
+  f.p = trust ? (float)((double)(in1 ? q[1] : 1.f) * fac) : 1.f;
+  const bool inside = in1 && trust;
+  Be = inside ? q[10] : 0.f;
+  f.b[0] = (double)(inside ? q[2] : 1.f);
+  f.b[1] = (double)(inside ? q[3] : 1.f);
+  f.b[2] = (double)(inside ? q[4] : 1.f);
+  f.b[3] = (double)(inside ? q[5] : 1.f);
+  f.u[0] = inside ? (double)q[6] : 1.0;
+  const float vrl0 = inside ? q[7] : 0.f, vtl0 = inside ? q[8] : 1.f, vpl0 = inside ? q[9] : 0.f;
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  float bm = (float)dot4(f.b, ms, f.b);
+  bm = (bm >= 0.f) ? bm : 0.f;
+  f.bmag = sqrtf(bm);
+  float vr0, vth0, vph0;
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  f.u[1] = f.u[0] * (double)vr0;
+  f.u[2] = f.u[0] * (double)vth0;
+  f.u[3] = f.u[0] * (double)vph0;
+}
+
+// convert_fluidvars_koral fluid.f90:1075-1162 for types 0 and 1: cgs already; gmin >= 1: charles_e (:814-839) on p + Be,
+// 2p + Be; gmin < 0: T_e = p; andrew_sigcut; the disc variant zeroes rho, B and sets T = 10 K where Be >= 0.05
+GRT_HD void koral3d_convert(const FluidPoint &f, float Be, int type, double nfac, double gminval, double sigcut, double &ncgs,
+                            double &ncgsnth, double &bcgs, double &tcgs) {
+  GRT_NO_CONTRACT
+  const double mp = 1.67262158e-24;
+  double rhocgs = (double)f.rho;
+  ncgs = rhocgs / mp;
+  bcgs = (double)f.bmag * sqrt(4 * PH_pi);
+  bcgs = bcgs * sqrt(nfac);
+  ncgs = ncgs * nfac; rhocgs = rhocgs * nfac;
+  tcgs = 0.0;
+  if (gminval >= 1.0) {
+    const float pe = f.p + Be, ue = 2.f * f.p + Be;
+    const double beta = 2.0 * (double)f.rho * PH_k * (double)pe / mp / (double)(f.bmag * f.bmag), b2 = beta * beta;
+    const double trat = (f.bmag > 0.f) ? gminval * b2 / (1.0 + b2) + 1.0 / (1.0 + b2) : gminval;
+    tcgs = (double)ue / (2.0 + trat);
+  } else if (gminval < 0.0) {
+    tcgs = (double)f.p;
+  }
+  const double sigmacgs = (bcgs * bcgs) / (rhocgs * 8.988e20 * 4.0 * PH_pi);
+  if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
+  if (type == 1 && Be >= 0.05f) { tcgs = 10.0; bcgs = 0.0; }
+  ncgsnth = 0.0;
+}
+
 // ------------------------------------------------------------------ transfer steps as affine maps
 struct Affine {   // I -> A I + b
   double A[4][4], b[4];

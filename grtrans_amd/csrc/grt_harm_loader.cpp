@@ -250,3 +250,42 @@ extern "C" int grt_load_iharm_files(const char *dfile, const char *hfile, int in
   return grt_upload_iharm(nx1, nx2, nx3, hslope, gam, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(), br.data(),
                           bth.data(), bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data(), eheat ? kel.data() : nullptr);
 }
+
+// KORAL 3-D dumps: read_koral3d_data_header / read_koral3d_data_file ("shortfile" layout) / load_koral3d_data
+// (fluid_model_koral3d.f90:357-388, 397-507, 567-633).  11-number header; `dfile`//I4.4(indf) = that header line + one
+// 23-column line per zone, x2 fastest, then x1, then x3: grid columns 4-9, rho 10, u^mu 12-15 and b^mu 16-19 (already
+// Boyer-Lindquist), T_e 21, Be 22.  rho * scalefac, b * sqrt(scalefac), LNRF velocities in REAL(4).
+extern "C" int grt_load_koral3d_files(const char *dfile, const char *hfile, int indf, double spin, double scalefac) {
+  if (!dfile || !hfile) return GRT_E_BADARG;
+  const size_t nhead = 11, dlen = 23;
+  std::vector<double> head;
+  if (!slurp_numbers(hfile, nhead, head)) return GRT_E_IO;
+  const int nx1 = (int)head[1], nx2 = (int)head[2], nx3 = (int)head[3];
+  const float asim = (float)head[4], r0 = (float)head[6], h = (float)head[7], aa = (float)head[8], bb = (float)head[9], pp = (float)head[10];
+  if (nx1 < 2 || nx2 < 4 || nx3 < 2) return GRT_E_IO;
+  if (std::fabs((double)asim - spin) > 1e-4) {     // fluid_model_koral3d.f90:549-552
+    std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
+    return GRT_E_BADARG;
+  }
+  const size_t n = (size_t)nx1 * nx2 * nx3;
+  char suffix[16];
+  std::snprintf(suffix, sizeof suffix, "%04d", indf);          // write(append, fmt='(I4.4)')
+  std::vector<double> all;
+  if (!slurp_numbers(std::string(dfile) + suffix, nhead + n * dlen, all)) return GRT_E_IO;
+  const double *z = all.data() + nhead;
+  const double sq = std::sqrt(scalefac);
+  std::vector<float> x1(n), x2(n), x3(n), rho(n), p(n), be(n), u0(n), vrl(n), vtl(n), vpl(n), b0(n), br(n), bth(n), bph(n);
+  for (size_t i = 0; i < n; ++i, z += dlen) {
+    x1[i] = (float)z[3]; x2[i] = (float)z[4]; x3[i] = (float)z[5];
+    const float r = (float)z[6], th = (float)z[7];
+    const double *u = z + 11, *b = z + 15;
+    lnrf_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r, asim, th, vrl[i], vtl[i], vpl[i]);
+    rho[i] = (float)(z[9] * scalefac);
+    p[i] = (float)z[20];
+    be[i] = (float)z[21];
+    b0[i] = (float)(b[0] * sq); br[i] = (float)(b[1] * sq); bth[i] = (float)(b[2] * sq); bph[i] = (float)(b[3] * sq);
+    u0[i] = (float)u[0];
+  }
+  return grt_upload_koral3d(nx1, nx2, nx3, r0, h, aa, bb, pp, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(),
+                            br.data(), bth.data(), bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data(), be.data());
+}

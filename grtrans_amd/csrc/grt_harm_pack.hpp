@@ -89,3 +89,22 @@ inline void grt_iharm_pack_mmks(int nx1, int nx2, int nx3, double hslope, float 
     crd[2 * (nx1 + nx2) + nx3 + j] = tj;
   }
 }
+
+// KORAL3D: cells [x3][x1][x2][12] (x2 fastest) with Be in slot 10; crd: [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqx3 nx3]
+// (koral3d_vals :111-115: uniqr = r0 + exp(uniqx1) in REAL(4))
+inline void grt_koral3d_pack(int nx1, int nx2, int nx3, float r0, const float *x1_arr, const float *x2_arr, const float *x3_arr,
+                             const float *const src[10], const float *be, std::vector<float> &cells, std::vector<float> &crd) {
+  const size_t n = (size_t)nx1 * nx2 * nx3;
+  cells.assign(n * 12, 0.f);
+  crd.assign((size_t)2 * nx1 + nx2 + nx3, 0.f);
+  for (size_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 10; ++k) cells[i * 12 + k] = src[k][i];
+    cells[i * 12 + 10] = be[i];
+  }
+  for (int i = 0; i < nx1; ++i) {
+    crd[i] = x1_arr[(size_t)i * nx2];                 // uniqx1 = x1_arr(1:nx2*(nx1-1)+1:nx2)
+    crd[nx1 + i] = r0 + std::exp(crd[i]);
+  }
+  for (int j = 0; j < nx2; ++j) crd[2 * nx1 + j] = x2_arr[j];                                   // uniqx2 = x2_arr(1:nx2)
+  for (int k = 0; k < nx3; ++k) crd[2 * nx1 + nx2 + k] = x3_arr[(size_t)k * nx2 * nx1];         // uniqx3
+}

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
   __shared__ int s_ray[NW][64];
   __shared__ int s_n[NW][64];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
-  __shared__ float s_harm[(FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM) ? 2 * GRT_HARM_MAXCOORD : 1];
+  __shared__ float s_harm[(FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? 2 * GRT_HARM_MAXCOORD : 1];
   // polsynchpl: the p-bin's row of every log-G table and slope table (3 x 181 + 11 x 81 doubles = 11.2 KB) lives in
   // LDS: 36 look-ups per step and frequency become ds_reads and the 14 table pointers leave the SGPR file
   constexpr int PLG = 181, PLX = 81, PLN = 3 * PLG + 11 * PLX;
@@ -259,10 +259,14 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
     const int nc = 2 * (fd.h3.nx1 + fd.h3.nx2) + fd.h3.nx3 + ((FLUID == GRT_FLUID_IHARM && fd.h3.metric) ? fd.h3.nx2 : 0);
     for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.h3.coords[i];
   }
+  if (FLUID == GRT_FLUID_KORAL3D) {   // uniqx1, uniqr, uniqx2, uniqx3
+    const int nc = 2 * fd.h3.nx1 + fd.h3.nx2 + fd.h3.nx3;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) s_harm[i] = fd.h3.coords[i];
+  }
   if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches
     for (int i = threadIdx.x; i < GRT_SPHACC_NTAB; i += blockDim.x) s_sphacc[i] = fd.sphacc[i];
   }
-  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_SPHACC || EMIS == GRT_EMIS_POLSYNCHPL) __syncthreads();
+  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D || FLUID == GRT_FLUID_SPHACC || EMIS == GRT_EMIS_POLSYNCHPL) __syncthreads();
   const int slot = blockIdx.x * GRT_XFER_THREADS + threadIdx.x;
   const bool has_ray = slot < nlive;
   const int f0 = blockIdx.y * FB;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
         tl0[rs * GRT_TS + e] = steps[GRT_F_R * field_stride + b];
         tl1[rs * GRT_TS + e] = steps[GRT_F_TH * field_stride + b];
         tl2[rs * GRT_TS + e] = steps[GRT_F_LAM * field_stride + b];
-        if (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM) tl3[rs * GRT_TS + e] = steps[GRT_F_PHI * field_stride + b];
+        if (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) tl3[rs * GRT_TS + e] = steps[GRT_F_PHI * field_stride + b];
         else if (slowlight) tl3[rs * GRT_TS + e] = steps[(long long)tfield * field_stride + b];
       }
     }
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       const double th = valid ? tl1[lane * GRT_TS + e] : 1.0;
       const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
       const int fl8 = (int)((fmm >> (ip & 63)) & 1ull) | ((int)((fmr >> (ip & 63)) & 1ull) << 1);
-      const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM) ? tl3[lane * GRT_TS + e] : 0.0;
+      const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? tl3[lane * GRT_TS + e] : 0.0;
       const double t_i = (slowlight && valid) ? tl3[lane * GRT_TS + e] : 0.0;
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
         harm3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl);
       float kela = 0.f;
       if (FLUID == GRT_FLUID_IHARM) iharm_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela);
+      if (FLUID == GRT_FLUID_KORAL3D) koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela);   // kela carries Be
       double s2xi, c2xi, ang, g;
       comoving_ortho(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
@@ -378,6 +383,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * emk.nfac; bcgs = (double)fl.bmag * emk.bfac; }
       else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
       else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
+      else if (FLUID == GRT_FLUID_KORAL3D) koral3d_convert(fl, kela, fd.h3.ktype, emk.nfac, emk.gminval, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       else if (FLUID == GRT_FLUID_IHARM) iharm_convert(fl, kela, fd.h3.gam, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       else if (FLUID == GRT_FLUID_HARM3D) harm3d_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       PLPoint plp;
@@ -675,6 +681,9 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_KORAL3D, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_KORAL3D, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_KORAL3D, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHTH)

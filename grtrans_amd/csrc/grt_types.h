@@ -57,6 +57,8 @@ struct GrtHarm3d {              // device pointers; one 3-D HARM slice, fluid_mo
   int32_t metric;               // IHARM: 0 = MKS with hslope, 1 = MMKS (theta also depends on x1, calcthmmks)
   float mks_smooth, poly_xt, poly_alpha, padf;   // MMKS parameters as the REAL(4) locals A, B, C of calcthmmks
   double startx1;               // MMKS (REAL(8) there)
+  float kr0, kh, kaa, kbb, kpp;  // KORAL3D: r = r0 + exp(x1), MKSH3 theta(x2, r) parameters (fluid_model_koral3d.f90:64-82)
+  int32_t ktype;                // KORAL3D: 0 whole flow, 1 disc (KORAL3D_DISK)
 };
 #define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 

@@ -58,7 +58,7 @@ class grtrans_inputs:
         # per-model overrides of the generic fluid arguments (grtrans_batch.py:219-322)
         if self.fname == 'FFJET':
             self.fdfile = self.jdfile
-        elif self.fname in ('HARM', 'KORAL', 'KORALNTH'):       # (HARM3D, IHARM take the generic t* arguments, as in the reference)
+        elif self.fname in ('HARM', 'KORAL', 'KORALNTH', 'KORAL3D', 'KORAL3D_DISK', 'KORAL3D_TOPJET', 'KORAL3D_BOTJET'):       # (HARM3D, IHARM take the generic t* arguments, as in the reference)
             self.fdfile, self.fhfile, self.fnt, self.findf = self.hdfile, self.hhfile, self.hnt, self.hindf
         else:
             self.fdfile, self.fgfile, self.fhfile = self.tdfile, self.tgfile, self.hhfile
@@ -183,6 +183,10 @@ class grtrans:
                 if int(inp.fnt) > 1 and nextra:
                     raise capi.GrtError("extra=1 with several HARM slices (hnt > 1) is not on the device yet")
                 dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), nt=int(inp.fnt))
+            elif inp.fname in ('KORAL3D', 'KORAL3D_DISK'):
+                if int(inp.fnt) != 1 or int(inp.nload) != 1:
+                    raise capi.GrtError("KORAL3D with several loaded slices (hnt, nload > 1) is not on the device yet")
+                dev.load_koral3d(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), float(inp.fscalefac))
             elif inp.fname == 'IHARM':
                 if int(inp.fnt) != 1 or int(inp.nload) != 1:
                     raise capi.GrtError("IHARM with several loaded slices (hnt, nload > 1) is not on the device yet")

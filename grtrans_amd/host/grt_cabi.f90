@@ -6,7 +6,8 @@ module grt_cabi
   implicit none
 
   integer(c_int), parameter :: GRT_FLUID_FFJET = 13, GRT_FLUID_HARM = 12, GRT_FLUID_SPHACC = 1, &
-       GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM3D = 19, GRT_FLUID_IHARM = 29
+       GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM3D = 19, GRT_FLUID_IHARM = 29, &
+       GRT_FLUID_KORAL3D = 25, GRT_FLUID_KORAL3D_DISK = 26
   integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
        GRT_EMIS_BB = 8, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22, &
        GRT_EMIS_MAXJUTT = 23
@@ -75,6 +76,13 @@ module grt_cabi
        real(c_double), value :: mdot, rin, rout
        integer(c_int) :: rc
      end function grt_set_thindisk
+     function grt_load_koral3d_files(dfile, hfile, indf, spin, scalefac) bind(C, name='grt_load_koral3d_files') result(rc)
+       import :: c_char, c_int, c_double
+       character(kind=c_char), dimension(*), intent(in) :: dfile, hfile
+       integer(c_int), value :: indf
+       real(c_double), value :: spin, scalefac
+       integer(c_int) :: rc
+     end function grt_load_koral3d_files
      function grt_load_iharm_files(dfile, hfile, indf, spin) bind(C, name='grt_load_iharm_files') result(rc)
        import :: c_char, c_int, c_double
        character(kind=c_char), dimension(*), intent(in) :: dfile, hfile

@@ -97,6 +97,8 @@ contains
     case ('HARM'); fluid_id = GRT_FLUID_HARM
     case ('HARM3D'); fluid_id = GRT_FLUID_HARM3D
     case ('IHARM'); fluid_id = GRT_FLUID_IHARM
+    case ('KORAL3D'); fluid_id = GRT_FLUID_KORAL3D
+    case ('KORAL3D_DISK'); fluid_id = GRT_FLUID_KORAL3D_DISK
     case ('THINDISK'); fluid_id = GRT_FLUID_THINDISK
     case default; call die('fluid model '//trim(fname)//' is not on the device yet')
     end select
@@ -152,6 +154,12 @@ contains
        if (rc /= 0) call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc)
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
+    else if (fluid_id == GRT_FLUID_KORAL3D .or. fluid_id == GRT_FLUID_KORAL3D_DISK) then
+       ! initialize_koral3d_model(a,ifile,.false.,fdfile,fhfile,fnt,findf,fscalefac,...), fluid.f90:205-210; one loaded slice
+       if (fnt /= 1 .or. nload /= 1) call die('KORAL3D with several loaded slices (fnt, nload > 1) is not supported')
+       if (nt > 1) call die('KORAL3D movie frames (nt > 1) are not supported')
+       rc = grt_load_koral3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin, fscalefac)
+       if (rc /= 0) call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc)
     else if (fluid_id == GRT_FLUID_IHARM) then
        ! initialize_iharm_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:199-200; one loaded slice, metric 0
        if (fnt /= 1 .or. nload /= 1) call die('IHARM with several loaded slices (fnt, nload > 1) is not supported')

@@ -33,7 +33,8 @@ extern "C" {
 
 /* ids follow the reference so host Fortran can pass its own constants through:
  * fluid.f90:40-43, emis.f90:11-18, rad_trans.f90:29-37 */
-enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19, GRT_FLUID_IHARM = 29 };
+enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19, GRT_FLUID_KORAL3D = 25, GRT_FLUID_KORAL3D_DISK = 26,
+       GRT_FLUID_IHARM = 29 };
 enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8,
        /* thermal + power-law electron populations (emis.f90:16-17, :473-490): K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep
           one population's emission with the total absorption and Faraday coefficients */
@@ -121,6 +122,20 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
  * dump `dfile`//I3.3(indf)//'.bin' (one text line, then REAL(4) data(35, n), :516-584); refuses a spin that differs
  * from the dump's by more than 1e-4 (:611-614). */
 int grt_load_harm3d_files(const char *dfile, const char *hfile, int indf, double spin);
+
+/* KORAL 3-D dumps (fname KORAL3D and KORAL3D_DISK, fluid.f90:205-210; the TOPJET / BOTJET variants read an
+ * uninitialised array in convert_fluidvars_koral and are refused).  replaces init_koral3d_data + load_koral3d_data for
+ * one time slice (fluid_model_koral3d.f90:567-633): module arrays with x2 fastest, then x1, then x3 (:176-181), REAL(4):
+ * rho [g/cm^3] (times scalefac), p = electron temperature [K], Be = Bernoulli parameter, b (times sqrt(scalefac)), u0 and
+ * LNRF velocities; r = r0 + exp(x1), theta(x2, r) of transformmksh32bl (:74-82) with h, aa, bb, pp.  Needs nx3 <= nx1 as
+ * the reference's own slicing of x3_arr does (:113). */
+int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, float bb, float pp, const float *x1_arr,
+                       const float *x2_arr, const float *x3_arr, const float *rho, const float *p, const float *b0,
+                       const float *br, const float *bth, const float *bph, const float *u0, const float *vrl,
+                       const float *vtl, const float *vpl, const float *be);
+/* replaces initialize_koral3d_model (fluid_model_koral3d.f90:513-565): 11-number header file and the text dump
+ * `dfile`//I4.4(indf) in the reader's 23-column layout (:397-507); scalefac = fargs%scalefac. */
+int grt_load_koral3d_files(const char *dfile, const char *hfile, int indf, double spin, double scalefac);
 
 /* iharm-format 3-D dumps (fname IHARM, fluid.f90:199-200), header metric = 0 (MKS with hslope) or 1 (MMKS: theta also
  * depends on x1, calcthmmks fluid_model_iharm.f90:111-122; select it with grt_set_iharm_mmks BEFORE the upload; the

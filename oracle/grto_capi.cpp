@@ -6,6 +6,7 @@
 #include "grto_harm.hpp"
 #include "grto_harm3d.hpp"
 #include "grto_iharm.hpp"
+#include "grto_koral3d.hpp"
 #include <omp.h>
 #include <string>
 
@@ -27,6 +28,8 @@ struct Setup {
   HarmTable harm;
   Harm3dTable harm3d;
   IharmTable iharm;
+  Koral3dTable koral;
+  int koral_type = 0;
   double jetalpha = 0.02, sigcut = 1e10;
   std::vector<double> otherargs{1.0, 1.0};     // emis_params%otherargs: (delta, weights...) of MAXJUTT     // source_params the 3-D models read (fluid.f90:975-993)
   ThinDisk disk;
@@ -68,6 +71,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
     else if (S.fluid == 2) thindisk_point(S.disk, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 19) harm3d_vals(S.harm3d, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 29) iharm_vals(S.iharm, x, (float)S.cam.a, w.f[i], kela);
+    else if (S.fluid == 25) koral3d_vals(S.koral, x, (float)S.cam.a, S.koral_type, w.f[i], kela);     // kela carries Be here
     else harm_vals(S.harm, x, (float)S.cam.a, w.f[i], w.g.x[1]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
@@ -80,6 +84,8 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       w.ncgs[i] = w.f[i].rho; w.bcgs[i] = w.f[i].bmag; w.tcgs[i] = w.f[i].p;
     } else if (S.fluid == 2) {              // fluid.f90:1190-1196
       w.tcgs[i] = w.f[i].rho; w.ncgs[i] = 1.0;
+    } else if (S.fluid == 25) {             // fluid.f90:1075-1162
+      koral3d_convert(w.f[i], kela, S.koral_type, S.nfac, S.gmin, S.sigcut, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     } else if (S.fluid == 29) {             // fluid.f90:995-1026
       iharm_convert(w.f[i], kela, S.iharm.gam, S.mbh, S.mdot, S.muval, S.gmin, S.jetalpha, S.p1, S.sigcut, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     } else if (S.fluid == 19) {             // fluid.f90:975-993
@@ -238,6 +244,8 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   if (fn == "FFJET") S.fluid = 13; else if (fn == "SPHACC") S.fluid = 1; else if (fn == "HARM") S.fluid = 12;
   else if (fn == "HARM3D") S.fluid = 19;
   else if (fn == "IHARM") S.fluid = 29;
+  else if (fn == "KORAL3D") { S.fluid = 25; S.koral_type = 0; }
+  else if (fn == "KORAL3D_DISK") { S.fluid = 25; S.koral_type = 1; }
   else if (fn == "THINDISK") { S.fluid = 2; S.disk = ThinDisk(); S.disk.mbh = (float)mbh; S.disk.mdot = (float)fmdot; }
   else return -1;
   S.mdot = mdot; S.muval = muval;
@@ -255,6 +263,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm, fnt > 0 ? fnt : 1) != 0) return -4;
   if (S.fluid == 19 && harm3d_load(dfile, hfile, indf, spin, S.harm3d, 1) != 0) return -4;
   if (S.fluid == 29 && iharm_load(dfile, hfile, indf, spin, S.iharm) != 0) return -4;
+  if (S.fluid == 25 && koral3d_load(dfile, hfile, indf, spin, 1.0, S.koral) != 0) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;

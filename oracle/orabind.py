@@ -60,7 +60,7 @@ class Oracle:
         p.update({k: v for k, v in kw.items() if k in DEFAULTS})
         if p["fname"] == "SPHACC" and "dfile" not in kw:
             p["dfile"] = os.path.join(DATA, "sphacc_tables.bin")
-        if p["fname"] in ("HARM", "HARM3D", "IHARM") and p["datadir"]:      # same relative-name convention as the reference
+        if p["fname"] in ("HARM", "HARM3D", "IHARM", "KORAL3D", "KORAL3D_DISK") and p["datadir"]:      # same relative-name convention as the reference
             p["dfile"] = os.path.join(p["datadir"], p["dfile"]); p["hfile"] = os.path.join(p["datadir"], p["hfile"])
         self.p = p
         gv = np.asarray(p["gridvals"], dtype=np.float64)

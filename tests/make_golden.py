@@ -405,6 +405,37 @@ def iharm(nx=36, nup=160):
     np.savez_compressed(os.path.join(G, "iharm_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, gmin=3.0, **rays)
 
 
+KORAL3D = dict(fname="KORAL3D", ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mu0=0.5, gridvals=(-13., 13., -13., 13.),
+               muval=0.25, gmin=-1., dfile="koral", hfile="koral_header", findf=40, fnt=1, ftscl=1.5, sigcut=1e10)
+KORAL3D_ZONES = dict(n1=48, n2=48, n3=24)
+
+
+def koral3d(nx=36, nup=160):
+    # KORAL 3-D dumps (tools/make_koral3d_dump.py; no KORAL data ships with the reference): electron temperature from the
+    # dump (gmin = -1) and from charles_e (gmin = 3), delo, the disc variant (polar and Bernoulli cuts), a sigma cut
+    import hashlib
+    import tempfile
+    import make_koral3d_dump
+    out, rays = {}, {}
+    with tempfile.TemporaryDirectory() as td:
+        dfile, hfile = make_koral3d_dump.write(td, **KORAL3D_ZONES)
+        out["dump_sha256"] = np.array(hashlib.sha256(open(dfile + "0040", "rb").read()).hexdigest())
+        for key, kw in (("formal_te", dict(iname="formal")), ("delo_te", dict(iname="delo")), ("formal_gmin3", dict(iname="formal", gmin=3.)),
+                        ("formal_disk", dict(iname="formal", fname="KORAL3D_DISK")), ("formal_sigcut", dict(iname="formal", sigcut=0.02))):
+            r = R.Ref(nn=(nx, nx, nup), datadir=td, **dict(KORAL3D, **kw))
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["ivals_" + key] = pix[0]; out["npts"] = npts
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **dict(KORAL3D, fname="KORAL3D_DISK"))
+        pick = sorted(set([3, nx // 2 * nx + nx // 2, nx * 10 + 30, nx * 30 + 12, nx * nx - 4, nx * 20 + 5, nx * 17 + 18]))
+        for i in pick:
+            d = r.ray_dump(i, FREQ_HARM)
+            for k, v in d.items():
+                rays["ray%d_%s" % (i, k)] = np.asarray(v)
+        rays["rays"] = np.array(pick)
+    np.savez_compressed(os.path.join(G, "koral3d_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, **out)
+    np.savez_compressed(os.path.join(G, "koral3d_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, **rays)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -425,4 +456,5 @@ if __name__ == "__main__":
     hybrid()
     maxjutt()
     iharm()
+    koral3d()
     print("golden fixtures written to", os.path.abspath(G))

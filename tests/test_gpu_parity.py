@@ -887,3 +887,56 @@ def test_bench_distributed_path_through_rccl_single_rank():
     assert j["metric"] == "ray-steps/sec" and j["n_gpus"] == 1 and j["value"] > 1e8 and j["scaling"] == "weak"
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
+
+def test_koral3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
+    # KORAL 3-D dumps (KORAL3D and KORAL3D_DISK): product loader, eight-corner sampler with the closed-form theta <-> x2 maps,
+    # T_e from the dump or charles_e, delo, disc cuts, sigma cut; then the Fortran host and run_pgrtrans; TOPJET refused
+    import hashlib
+    import subprocess
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    import make_koral3d_dump
+    g = np.load(os.path.join(G, "koral3d_36x36x160.npz"))
+    monkeypatch.chdir(tmp_path)
+    dfile, hfile = make_koral3d_dump.write(str(tmp_path), **make_golden.KORAL3D_ZONES)
+    assert hashlib.sha256(open(dfile + "0040", "rb").read()).hexdigest() == str(g["dump_sha256"])
+    H = make_golden.KORAL3D
+    d = capi.Device(0)
+    try:
+        d.load_tables()
+        with pytest.raises(capi.GrtError):
+            d.load_koral3d(dfile, hfile, 40, 0.5)
+        d.load_koral3d(dfile, hfile, 40, H["spin"])
+        cam = capi.make_camera(1, H["gridvals"], (36, 36, 160), H["spin"], H["mu0"], H["uout"], -0.5)
+        for key, fname, iname, gmin, sig in (("formal_te", "KORAL3D", "formal", -1., 1e10), ("delo_te", "KORAL3D", "delo", -1., 1e10),
+                                             ("formal_gmin3", "KORAL3D", "formal", 3., 1e10), ("formal_disk", "KORAL3D_DISK", "formal", -1., 1e10),
+                                             ("formal_sigcut", "KORAL3D", "formal", -1., 0.02)):
+            em = capi.make_emis("POLSYNCHTH", H["mbh"], H["ftscl"], 6.0, gmin, 1e5, 3.5, muval=H["muval"], sigcut=sig)
+            pix, _, status, _ = capi.trace_tile(cam, 1, 1296, fname, em, [FREQ_HARM], iname)
+            assert np.array_equal(status, g["npts"])
+            assert stokes_err(pix[0], g["ivals_" + key]) < 2 * STOKES_TOL, key
+        with pytest.raises(capi.GrtError):      # no kernel for power-law electrons on this sampler (ncgsnth = 0 there): refused
+            capi.trace_tile(cam, 1, 1296, "KORAL3D", capi.make_emis("POLSYNCHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5), [FREQ_HARM], "formal")
+    finally:
+        d.close()
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    kw = dict(fname='KORAL3D_DISK', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=H["spin"],
+              standard=1, nn=[36, 36, 160], uout=H["uout"], mbh=H["mbh"], nmdot=1, mumin=H["mu0"], mumax=H["mu0"],
+              gridvals=list(H["gridvals"]), muval=H["muval"], gmin=-1., iname='formal', cflag=0, hdfile='koral', hhfile='koral_header',
+              hindf=40, hnt=1, ntscl=H["ftscl"])
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_disk"]) < 2 * STOKES_TOL
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
+    with pytest.raises(Exception):          # the jet variants read an uninitialised array in the reference: refused
+        z = gb.grtrans()
+        z.run_pgrtrans(**dict(kw, fname='KORAL3D_TOPJET'))
+

@@ -291,6 +291,36 @@ def test_iharm_mmks_theta_index_equals_brent_index_everywhere(L, tmp_path):
         assert np.array_equal(fast, brent), (n, np.where(fast != brent)[0][:10], th[np.where(fast != brent)[0][:5]])
 
 
+@pytest.mark.parametrize("fname,gmin", [("KORAL3D", -1.0), ("KORAL3D", 3.0), ("KORAL3D_DISK", -1.0)])
+def test_koral3d_loader_sampler_and_units_match_oracle(L, tmp_path, fname, gmin):
+    # KORAL 3-D dumps: product loader (23-column text dump) + device koral3d_sample/koral3d_convert, compiled for the host,
+    # against the oracle's per-stage dump (pinned bit-exact to the compiled reference)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_koral3d_dump
+    dfile, hfile = make_koral3d_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+    kw = dict(fname=fname, ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mu0=0.5,
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=gmin, dfile="koral", hfile="koral_header", findf=40,
+              nn=(24, 24, 200), ftscl=1.5, sigcut=1e10)
+    o = O.Oracle(iname="formal", datadir=str(tmp_path), **kw)
+    L.grt_load_koral3d_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_double]
+    assert L.grt_load_koral3d_files(dfile.encode(), hfile.encode(), 40, 0.9375, 1.0) == 0
+    assert L.grt_load_koral3d_files(dfile.encode(), hfile.encode(), 40, 0.5, 1.0) != 0          # spin check
+    L.hs_koral3d_point.argtypes = [C.c_double] * 4 + [C.c_int] + [C.c_double] * 3 + [C.c_void_p]
+    for i in (293, 92, 300, 5, 570, 130, 12, 276, 280, 284):
+        d = o.ray_dump(i, 2.3e11)
+        for k in range(0, d["npts"], 3):
+            out = np.zeros(15)
+            L.hs_koral3d_point(float(d["x"][k, 1]), float(d["x"][k, 2]), float(d["x"][k, 3]), 0.9375, int(fname.endswith("DISK")), 1.5, gmin,
+                               1e10, out.ctypes.data)
+            want = np.concatenate([[d["rho"][k], d["p"][k], d["bmag"][k]], d["u"][k], d["b"][k],
+                                   [d["ncgs"][k], d["bcgs"][k], d["tcgs"][k], d["ncgsnth"][k]]])
+            tol = np.full(15, 1e-12); tol[2:7] = 3e-7; tol[12] = 3e-7; tol[13] = 3e-7
+            with np.errstate(all="ignore"):
+                err = np.abs(out - want) / np.abs(want)
+            assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
+
+
 def test_frame_coefficients_and_formal_step_match_oracle(L):
     # photon momentum, comoving tetrad (sparse-metric dots, shared reciprocals), folded polsynchpl and one
     # formal (Landi Degl'Innocenti) step of the product, compiled for the host, against the oracle's FFJET dumps

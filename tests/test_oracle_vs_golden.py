@@ -390,3 +390,39 @@ def test_iharm_metric0_electron_models(tmp_path):
         for k, tol in (("lam", 1e-8), ("x", 1e-8), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6), ("I", 1e-6)):
             assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
 
+
+def test_koral3d_electron_models_disc_variant_and_cuts(tmp_path):
+    # KORAL 3-D dumps: closed-form theta <-> x2, azimuth without the Kerr-Schild shift, eight-corner interpolation, polar trust
+    # region; T_e from the dump (gmin = -1) or charles_e (gmin = 3); KORAL3D_DISK's polar / Bernoulli cuts; sigma cut.
+    # golden = compiled reference on tools/make_koral3d_dump.py's synthetic dump
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_koral3d_dump
+    g = load("koral3d_36x36x160.npz")
+    dfile, _ = make_koral3d_dump.write(str(tmp_path), **make_golden.KORAL3D_ZONES)
+    assert hashlib.sha256(open(dfile + "0040", "rb").read()).hexdigest() == str(g["dump_sha256"])
+    for key, kw in (("formal_te", dict(iname="formal")), ("delo_te", dict(iname="delo")), ("formal_gmin3", dict(iname="formal", gmin=3.)),
+                    ("formal_disk", dict(iname="formal", fname="KORAL3D_DISK")), ("formal_sigcut", dict(iname="formal", sigcut=0.02))):
+        o = O.Oracle(nn=(36, 36, 160), datadir=str(tmp_path), **dict(make_golden.KORAL3D, **kw))
+        pix, npts, _ = o.trace(1, 1296, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g["npts"])
+        ref = g["ivals_" + key].astype(float)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 2e-6, (key, err)
+    assert np.abs(g["ivals_formal_disk"] - g["ivals_formal_te"]).max() > 1e-2 * np.abs(g["ivals_formal_te"]).max()     # the disc cuts act
+    assert np.abs(g["ivals_formal_sigcut"] - g["ivals_formal_te"]).max() > 1e-6 * np.abs(g["ivals_formal_te"]).max()
+    r = load("koral3d_rays_36x36x160.npz")
+    o = O.Oracle(nn=(36, 36, 160), iname="formal", datadir=str(tmp_path), **dict(make_golden.KORAL3D, fname="KORAL3D_DISK"))
+    hit = 0
+    for i in r["rays"]:
+        d = o.ray_dump(int(i), float(r["freq"]))
+        assert d["npts"] == int(r["ray%d_npts" % i])
+        hit += int((r["ray%d_tcgs" % i] == 10.0).any())
+        for k in ("rho", "p", "bmag", "u", "b", "ncgs", "bcgs", "tcgs"):     # the fp32 sampler is bit-faithful
+            assert relerr(d[k], r["ray%d_%s" % (i, k)]) < 1e-9, (i, k)
+        for k, tol in (("lam", 1e-8), ("x", 1e-8), ("ang", 1e-6), ("rshift", 1e-7), ("jraw", 1e-6), ("Kraw", 1e-6), ("I", 1e-6)):
+            assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
+    assert hit > 0          # the Bernoulli cut of the disc variant (T = 10 K) is on the sampled rays
+
