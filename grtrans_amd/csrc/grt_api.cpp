@@ -471,8 +471,9 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                        ((fluid_model == GRT_FLUID_KORAL3D || fluid_model == GRT_FLUID_KORAL3D_DISK) && em->type == GRT_EMIS_POLSYNCHTH) ||
                        ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM) &&
                         (em->type == GRT_EMIS_HYBRIDTHPL || em->type == GRT_EMIS_HYBRIDTH || em->type == GRT_EMIS_HYBRIDPL ||
-                         em->type == GRT_EMIS_MAXJUTT));
+                         em->type == GRT_EMIS_MAXJUTT || em->type == GRT_EMIS_MAXCOMP));
   if (em->type == GRT_EMIS_MAXJUTT && (em->nother < 2 || em->nother > 8)) return GRT_E_BADARG;
+  if (em->type == GRT_EMIS_MAXCOMP && (em->nother < 3 || em->nother > 8)) return GRT_E_BADARG;
   if (!pair_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   // nextra: 0, or the 19 ray diagnostics of extra=1 for nup>1 (pgrtrans.f90:108-114)

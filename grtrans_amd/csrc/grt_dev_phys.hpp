@@ -510,24 +510,34 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
 
 // MAXJUTT: calc_maxjutt_subroutine (calc_maxjutt.f90:8-63).  otherargs = (delta, w_1..w_N): N thermal components with
 // densities n w_i / sum(w) at temperatures T delta^(i-1) / sum_i (w_i / sum(w)) delta^(i-1).
-GRT_NI void maxjutt_fast(double nu, double n, double B, double T, double theta, int nother, const double *otherargs, double *e) {
-  const int nw = nother - 1;
+// maxcomp (calc_maxcomp.f90): otherargs = (delta, selection, w_1..w_N); afterwards the emission of component `selection`
+// (1-based; 0 keeps the sum) replaces the summed emission.
+GRT_NI void maxjutt_fast(double nu, double n, double B, double T, double theta, int nother, const double *otherargs, double *e,
+                         bool maxcomp = false) {
+  const int off = maxcomp ? 2 : 1;
+  const int nw = nother - off;
   const double delta = otherargs[0];
   double wsum = 0.0, dwsum = 0.0, dp = 1.0;
-  for (int q = 0; q < nw; ++q) wsum += otherargs[1 + q];
-  for (int q = 0; q < nw; ++q) { dwsum += otherargs[1 + q] / wsum * dp; dp *= delta; }
+  for (int q = 0; q < nw; ++q) wsum += otherargs[off + q];
+  for (int q = 0; q < nw; ++q) { dwsum += otherargs[off + q] / wsum * dp; dp *= delta; }
   const double tmin = T / dwsum;
   for (int c = 0; c < 11; ++c) e[c] = 0.0;
   dp = 1.0;
+  const int isel = maxcomp ? (int)otherargs[1] : 0;
+  double es[4] = {0.0, 0.0, 0.0, 0.0};
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang loop unroll(disable)
 #endif
   for (int q = 0; q < nw; ++q) {
     double et[11];
-    polsynchth_fast(nu, otherargs[1 + q] / wsum * n, B, tmin * dp, theta, et);
+    polsynchth_fast(nu, otherargs[off + q] / wsum * n, B, tmin * dp, theta, et);
     for (int c = 0; c < 11; ++c) e[c] += et[c];
+    if (q + 1 == isel)
+      for (int c = 0; c < 4; ++c) es[c] = et[c];
     dp *= delta;
   }
+  if (isel > 0 && isel <= nw)
+    for (int c = 0; c < 4; ++c) e[c] = es[c];
 }
 
 // ------------------------------------------------------------------ integrators

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
             double oa[8];                                  // per-lane copy: the component loop indexes it dynamically
 #pragma unroll
             for (int c = 0; c < 8; ++c) oa[c] = emj.otherargs[c];
-            maxjutt_fast(nu, ncgs, bcgs, tcgs, ang, emj.nother, oa, e11);
+            maxjutt_fast(nu, ncgs, bcgs, tcgs, ang, emj.nother, oa, e11, emj.type == GRT_EMIS_MAXCOMP);
           }
           else if (EMIS == GRT_EMIS_HYBRIDTHPL) {
             // thermal + power-law populations (emis.f90:473-490); one instantiation serves HYBRIDTHPL / HYBRIDTH /
@@ -663,6 +663,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           int nfields, int tfield, unsigned long long *step_counter) {
   if (nlive <= 0) return hipSuccess;
   if (emis == GRT_EMIS_HYBRIDTH || emis == GRT_EMIS_HYBRIDPL) emis = GRT_EMIS_HYBRIDTHPL;   // one instantiation, em->type selects
+  if (emis == GRT_EMIS_MAXCOMP) emis = GRT_EMIS_MAXJUTT;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
     launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \

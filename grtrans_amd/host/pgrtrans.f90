@@ -111,6 +111,7 @@ contains
     case ('HYBRIDTH'); emis_id = GRT_EMIS_HYBRIDTH
     case ('HYBRIDPL'); emis_id = GRT_EMIS_HYBRIDPL
     case ('MAXJUTT'); emis_id = GRT_EMIS_MAXJUTT
+    case ('MAXCOMP'); emis_id = GRT_EMIS_MAXCOMP
     case default; call die('emissivity '//trim(ename)//' is not on the device yet')
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37

@@ -40,7 +40,10 @@ enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, G
           one population's emission with the total absorption and Faraday coefficients */
        GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22,
        /* sum of thermal components n w_i at temperatures T delta^i / sum_i w_i delta^i (calc_maxjutt.f90:8-63) */
-       GRT_EMIS_MAXJUTT = 23 };
+       GRT_EMIS_MAXJUTT = 23,
+       /* the same with otherargs = (delta, selection, weights...): emission of component `selection` (1-based, 0 = all),
+          total absorption and Faraday coefficients (calc_maxcomp.f90) */
+       GRT_EMIS_MAXCOMP = 24 };
 enum { GRT_INT_LSODA = 0, GRT_INT_DELO = 1, GRT_INT_FORMAL = 2 };
 
 /* Camera scalars: what initialize_pixels / INITIALIZE_CAMERA_GEOKERR derive once per camera

@@ -94,20 +94,29 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
     if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
-    else if (S.emis == 23) {
+    else if (S.emis == 23 || S.emis == 24) {
       // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): a sum of thermal components with densities w_i n and
       // temperatures T delta^i / sum_i w_i delta^i, weights normalised
-      const int nw = (int)S.otherargs.size() - 1;
+      // MAXCOMP (calc_maxcomp.f90): otherargs = (delta, selection, weights...); the emission of component `selection`
+      // (1-based; 0 = all) with the total absorption and Faraday coefficients
+      const int off = (S.emis == 24) ? 2 : 1;
+      const int nw = (int)S.otherargs.size() - off;
       const double delta = S.otherargs[0];
       double wsum = 0.0, dwsum = 0.0;
-      for (int q = 0; q < nw; ++q) wsum += S.otherargs[1 + q];
-      for (int q = 0; q < nw; ++q) dwsum += S.otherargs[1 + q] / wsum * std::pow(delta, (double)q);
+      for (int q = 0; q < nw; ++q) wsum += S.otherargs[off + q];
+      for (int q = 0; q < nw; ++q) dwsum += S.otherargs[off + q] / wsum * std::pow(delta, (double)q);
       const double tmin = w.tcgs[i] / dwsum;
       for (int c = 0; c < 11; ++c) e[c] = 0.0;
+      const int isel = (S.emis == 24) ? (int)S.otherargs[1] : 0;
       for (int q = 0; q < nw; ++q) {
         double et[11];
-        polsynchth(nu, S.otherargs[1 + q] / wsum * w.ncgs[i], w.bcgs[i], tmin * std::pow(delta, (double)q), w.ang[i], et);
+        polsynchth(nu, S.otherargs[off + q] / wsum * w.ncgs[i], w.bcgs[i], tmin * std::pow(delta, (double)q), w.ang[i], et);
         for (int c = 0; c < 11; ++c) e[c] += et[c];
+      }
+      if (isel > 0 && isel <= nw) {
+        double et[11];
+        polsynchth(nu, S.otherargs[off + isel - 1] / wsum * w.ncgs[i], w.bcgs[i], tmin * std::pow(delta, (double)(isel - 1)), w.ang[i], et);
+        for (int c = 0; c < 4; ++c) e[c] = et[c];
       }
     }
     else if (S.emis >= 20 && S.emis <= 22) {
@@ -251,6 +260,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   S.mdot = mdot; S.muval = muval;
   if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8;
   else if (en == "MAXJUTT") S.emis = 23;
+  else if (en == "MAXCOMP") S.emis = 24;
   else if (en == "HYBRIDTHPL") S.emis = 20; else if (en == "HYBRIDTH") S.emis = 21; else if (en == "HYBRIDPL") S.emis = 22;
   else return -2;
   if (in == "delo") S.iflag = 1; else if (in == "formal") S.iflag = 2;

@@ -109,6 +109,7 @@ void hs_sphacc_point(const float *tab, double r, double *out11) {
 }
 void hs_polsynchth(double nu, double n, double B, double T, double th, double *e11) { polsynchth_fast(nu, n, B, T, th, e11); }   // the form the kernel runs
 void hs_maxjutt(double nu, double n, double B, double T, double th, int nother, const double *oa, double *e11) { maxjutt_fast(nu, n, B, T, th, nother, oa, e11); }
+void hs_maxcomp(double nu, double n, double B, double T, double th, int nother, const double *oa, double *e11) { maxjutt_fast(nu, n, B, T, th, nother, oa, e11, true); }
 
 // HARM: the product's text-dump loader (grt_harm_loader.cpp, compiled into this test library) hands its arrays
 // to grt_upload_harm; here that entry point is a capture stub that packs them exactly as grt_api.cpp does.

@@ -353,6 +353,10 @@ def maxjutt(nx=32, nup=150):
         r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)      # (the reference's DELO overflows on this problem)
         pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
         out["harm3d_w6_formal"] = pix[0]; out["harm3d_npts"] = npts
+        # MAXCOMP (calc_maxcomp.f90): emission of the selected component, absorption / Faraday terms of all of them
+        kw = dict(HARM3D); kw.update(ename="MAXCOMP", otherargs=(2.0, 2.0, 1.0, 0.5, 0.25))
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+        out["harm3d_maxcomp_sel2"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
         kw = dict(HARM); kw.update(ename="MAXJUTT", otherargs=(1.5, 1.0, 0.5))
         r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
         pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)

@@ -734,6 +734,10 @@ def test_maxjutt_vs_reference_golden_device_and_fortran_host(tmp_path, monkeypat
         pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM3D", em, [FREQ_HARM], "formal")
         # 2e-5 of peak: six thermal evaluations per point, each through the folded-constant coefficient routine (measured 1.07e-5)
         assert np.array_equal(status, g["harm3d_npts"]) and stokes_err(pix[0], g["harm3d_w6_formal"]) < 2 * STOKES_TOL
+        em = capi.make_emis("MAXCOMP", H3["mbh"], 1.0, 6.0, H3["gmin"], 1e5, 3.5, muval=H3["muval"], mdot=H3["mdot"],
+                            otherargs=(2.0, 2.0, 1.0, 0.5, 0.25))
+        pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM3D", em, [FREQ_HARM], "formal")
+        assert stokes_err(pix[0], g["harm3d_maxcomp_sel2"]) < 2 * STOKES_TOL
         d.load_harm(os.path.join(str(tmp_path), "dump"), os.path.join(str(tmp_path), "dump040"), 40, H2["spin"])
         cam = capi.make_camera(1, H2["gridvals"], (32, 32, 150), H2["spin"], H2["mu0"], H2["uout"], -0.5)
         em = capi.make_emis("MAXJUTT", H2["mbh"], 1.0, 6.0, H2["gmin"], 1e5, 3.5, muval=H2["muval"], mdot=H2["mdot"], otherargs=(1.5, 1.0, 0.5))

@@ -339,6 +339,7 @@ def test_maxjutt_weighted_thermal_components(tmp_path):
     make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
     make_harm_dump.write(str(tmp_path), n=64)
     for key, nk, kw in (("harm3d_w6_formal", "harm3d_npts", dict(make_golden.HARM3D, ename="MAXJUTT", otherargs=(2.0,) + make_golden.MAXJUTT_W6)),
+                        ("harm3d_maxcomp_sel2", "harm3d_npts", dict(make_golden.HARM3D, ename="MAXCOMP", otherargs=(2.0, 2.0, 1.0, 0.5, 0.25))),
                         ("harm_w2_formal", "harm_npts", dict(make_golden.HARM, ename="MAXJUTT", otherargs=(1.5, 1.0, 0.5)))):
         o = O.Oracle(nn=(32, 32, 150), iname="formal", datadir=str(tmp_path), **kw)
         pix, npts, _ = o.trace(1, 1024, [float(g["freq"])], nthreads=8)
