@@ -1,5 +1,10 @@
 // grtrans_amd/csrc/grt_harm_pack.hpp -- host-side packing of the HARM module arrays into the device layout.
 #pragma once
+// Host-side REAL(4)/REAL(8) arithmetic that must round exactly as the reference does: no contraction in this header,
+// whatever the translation unit is compiled with.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 #include <cmath>
 #include <cstddef>
 #include <vector>
