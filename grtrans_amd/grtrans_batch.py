@@ -186,6 +186,8 @@ class grtrans:
             elif inp.fname in ('KORAL3D', 'KORAL3D_DISK'):
                 if int(inp.fnt) != 1 or int(inp.nload) != 1:
                     raise capi.GrtError("KORAL3D with several loaded slices (hnt, nload > 1) is not on the device yet")
+                if nt > 1:
+                    raise capi.GrtError("KORAL3D movie frames (nt > 1) are not on the device yet")
                 dev.load_koral3d(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), float(inp.fscalefac))
             elif inp.fname == 'IHARM':
                 if int(inp.fnt) != 1 or int(inp.nload) != 1:
