@@ -498,12 +498,6 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   HIPCHK(hipSetDevice(C.device));
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
-  if ((rc = grow(C.d_rays, C.cap_rays, (size_t)nrays))) return rc;
-  if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)nrays * grt_sizeof_realray()))) return rc;
-  if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
-  if ((rc = grow(C.d_live, C.cap_live, (size_t)nrays))) return rc;
-  if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
-  if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   // per-step record in HBM: [field][ray][maxpts] fp64, fields r,theta,lambda always (they carry the
   // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
   const long long maxpts = cam->nup + cam->next;
@@ -517,58 +511,83 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (need_time && C.t0_n != 0 && C.t0_n != (long long)(i2 - i1 + 1)) return GRT_E_BADARG;   // t0 table of another tile
   const double *d_t0 = (need_time && C.t0_n != 0) ? C.d_t0 : nullptr;
   const int nalloc = nfields + (need_time ? 1 : 0);
-  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * nrays * rstride))) return rc;
-  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)nrays * (rstride / 64) * 2))) return rc;
-  C.steps_rays = nrays; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride;
-  const long long fstride = (long long)nrays * rstride;
+  // The geodesic hand-over buffers grow with rays x points (12 KB per ray at nup=400): a tile whose buffers would pass the
+  // cap (GRT_MAX_WORK_BYTES, default 96 GiB of the 288) is traced in passes over sub-ranges of its rays; pixvals and
+  // ray_status always cover the whole tile.  With the per-step record on, the record itself must be resident: one pass.
+  int chunk = nrays;
+  {
+    const size_t per_ray = (size_t)nalloc * rstride * sizeof(double) + (size_t)(rstride / 64) * 16 + sizeof(GrtRay) + grt_sizeof_realray() + 8;
+    size_t cap_bytes = (size_t)96 << 30;
+    if (const char *e = std::getenv("GRT_MAX_WORK_BYTES")) { const double v = std::atof(e); if (v > 0) cap_bytes = (size_t)v; }
+    const size_t fit = cap_bytes / per_ray;
+    if (!C.record_steps && fit < (size_t)nrays) chunk = (int)(fit < 4096 ? (fit < 1 ? 1 : fit) : fit / 4096 * 4096);
+  }
+  if ((rc = grow(C.d_rays, C.cap_rays, (size_t)chunk))) return rc;
+  if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
+  if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
+  if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
+  if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
+  if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
+  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * chunk * rstride))) return rc;
+  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)chunk * (rstride / 64) * 2))) return rc;
+  C.steps_rays = (chunk == nrays) ? nrays : 0; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride;
+  const long long fstride = (long long)chunk * rstride;
   GrtPLConst plc{};
   grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
   double hfreq[64];
   for (int f = 0; f < nfreq; ++f) { hfreq[f] = freqs[f]; hfreq[nfreq + f] = std::log(freqs[f]); }
   HIPCHK(hipMemcpyAsync(C.d_freqs, hfreq, 2 * nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));   // hfreq is on this frame
-  HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
   HIPCHK(hipMemsetAsync(C.d_pixvals, 0, (size_t)nrays * nfreq * (nvals + nextra) * sizeof(float), C.stream));
-  HIPCHK(hipEventRecord(C.ev[0], C.stream));
-  HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1, nrays, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, need_time ? 1 : 0));
-  int ncls[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
-  HIPCHK(hipStreamSynchronize(C.stream));
-  const int nlive = ncls[0] + ncls[1];
-  HIPCHK(hipEventRecord(C.ev[1], C.stream));
-  // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back.  The two classes touch disjoint
-  // rays of the same buffers, so their geo -> transfer chains run on two streams: the few generic-class waves fill the
-  // CUs the big fast-class kernels leave idle in their tails instead of queueing behind them.
-  HIPCHK(hipEventRecord(C.evj[0], C.stream));
-  HIPCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
-  HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield, d_t0));
-  HIPCHK(hipEventRecord(C.evk[0], C.stream));
-  HIPCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
-                             C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps, C.d_flags, rstride,
-                             fstride, nfields, tfield, C.d_stepcount));
-  HIPCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nrays - ncls[1]), ncls[1], C.d_steps, C.d_flags,
-                        rstride, fstride, nfields, tfield, d_t0));
-  HIPCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nrays - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
-                             nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts, (long long)i1, C.d_steps,
-                             C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount));
-  HIPCHK(hipEventRecord(C.evj[1], C.stream2));
-  HIPCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
-  HIPCHK(hipEventRecord(C.ev[2], C.stream));
-  HIPCHK(hipStreamSynchronize(C.stream));
+  double ms_trace_sum = 0.0, ms_geo_sum = 0.0;
+  long long nlive = 0;
+  for (int off = 0; off < nrays; off += chunk) {
+    const int nch = (nrays - off < chunk) ? (nrays - off) : chunk;
+    HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
+    HIPCHK(hipEventRecord(C.ev[0], C.stream));
+    HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1 + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays, need_time ? 1 : 0));
+    int ncls[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    nlive += ncls[0] + ncls[1];
+    const double *t0c = d_t0 ? d_t0 + off : nullptr;
+    HIPCHK(hipEventRecord(C.ev[1], C.stream));
+    // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back.  The two classes touch disjoint
+    // rays of the same buffers, so their geo -> transfer chains run on two streams: the few generic-class waves fill the
+    // CUs the big fast-class kernels leave idle in their tails instead of queueing behind them.
+    HIPCHK(hipEventRecord(C.evj[0], C.stream));
+    HIPCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
+    HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield, t0c));
+    HIPCHK(hipEventRecord(C.evk[0], C.stream));
+    // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
+    HIPCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
+                               C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps, C.d_flags, rstride,
+                               fstride, nfields, tfield, C.d_stepcount));
+    HIPCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nch - ncls[1]), ncls[1], C.d_steps, C.d_flags,
+                          rstride, fstride, nfields, tfield, t0c));
+    HIPCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nch - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
+                               nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,
+                               C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount));
+    HIPCHK(hipEventRecord(C.evj[1], C.stream2));
+    HIPCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
+    HIPCHK(hipEventRecord(C.ev[2], C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, C.ev[1], C.ev[2]));
+    ms_trace_sum += ms;
+    HIPCHK(hipEventElapsedTime(&ms, C.ev[1], C.evk[0]));
+    ms_geo_sum += ms;
+  }
   if (st) {
     unsigned long long steps_done = 0;
     HIPCHK(hipMemcpy(&steps_done, C.d_stepcount, sizeof(steps_done), hipMemcpyDeviceToHost));
-    float ms_trace = 0;
-    HIPCHK(hipEventElapsedTime(&ms_trace, C.ev[1], C.ev[2]));
     st->ray_steps = (int64_t)steps_done;
     st->rays_live = nlive;
     st->rays_dead = nrays - nlive;
-    st->ms_trace = ms_trace;
-    float ms_geo = 0;
-    HIPCHK(hipEventElapsedTime(&ms_geo, C.ev[1], C.evk[0]));
-    st->ms_geo = ms_geo;
-    st->ms_transfer = ms_trace - ms_geo;
+    st->ms_trace = ms_trace_sum;
+    st->ms_geo = ms_geo_sum;
+    st->ms_transfer = ms_trace_sum - ms_geo_sum;
   }
   return 0;
 }

@@ -944,3 +944,24 @@ def test_koral3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch
         z = gb.grtrans()
         z.run_pgrtrans(**dict(kw, fname='KORAL3D_TOPJET'))
 
+
+def test_multi_pass_tracing_under_a_memory_cap_equals_single_pass(monkeypatch):
+    # the geodesic hand-over buffers are capped (GRT_MAX_WORK_BYTES): a tile beyond the cap is traced in passes over
+    # sub-ranges of its rays, with the same pixels, statuses and step counts; the per-step record forces a single pass
+    from grtrans_amd import capi
+    d = capi.Device(0); d.load_ffjet(); d.load_tables()      # (earlier tests closed the module's device)
+    nn = (48, 48, 100)
+    full, _, sfull, stfull = run(nn, "formal")
+    multi1, _, _, _ = run(nn, "formal", freqs=[2.3e11, FREQ])
+    monkeypatch.setenv("GRT_MAX_WORK_BYTES", str(2 * 1024 * 1024))         # ~3.7 KB per ray here -> passes of ~560 rays
+    part, _, spart, stpart = run(nn, "formal")
+    assert np.array_equal(part, full) and np.array_equal(spart, sfull) and stpart.ray_steps == stfull.ray_steps
+    assert stpart.rays_live == stfull.rays_live
+    multi2, _, _, _ = run(nn, "formal", freqs=[2.3e11, FREQ])
+    assert np.array_equal(multi2, multi1)
+    a, _, sa, _ = run(nn, "delo", 101, 1900)                               # a tile that does not start at pixel 1
+    monkeypatch.delenv("GRT_MAX_WORK_BYTES")
+    b, _, sb, _ = run(nn, "delo", 101, 1900)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    d.close()
+
