@@ -393,6 +393,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
       double xJK[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // EXTRA: j_I and K(1:7) of the first frequency after rotate/invariant/cgs
+#ifdef GRT_DEBUG_SEL
+      double dbg[4] = {0, 0, 0, 0};   // experiment builds (tools/build_variant.sh): per-step internals in place of the running I
+#endif
 
       // not unrolled on purpose: FB copies of the coefficient + propagator code cost more (900 ms against 658 ms
       // for 25 frequencies at 1024x1024x400) than indexing the per-frequency intensities dynamically
@@ -428,6 +431,17 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
 #pragma unroll
             for (int c = 4; c < 11; ++c) e11[c] += epl[c];
           }
+#ifdef GRT_DEBUG_SEL
+          if (f == 0) {
+            if (GRT_DEBUG_SEL == 0) { dbg[0] = g; dbg[1] = ang; dbg[2] = s2xi; dbg[3] = c2xi; }
+            if (GRT_DEBUG_SEL == 1) { dbg[0] = ncgsnth; dbg[1] = bcgs; dbg[2] = e11[0]; dbg[3] = e11[4]; }
+            if (GRT_DEBUG_SEL == 2) { dbg[0] = e11[1]; dbg[1] = e11[3]; dbg[2] = e11[5]; dbg[3] = e11[7]; }
+            if (GRT_DEBUG_SEL == 3) { dbg[0] = e11[8]; dbg[1] = e11[10]; dbg[2] = fl.u[0]; dbg[3] = fl.b[0]; }
+            if (GRT_DEBUG_SEL == 4) { dbg[0] = kv[0]; dbg[1] = kv[1]; dbg[2] = kv[2]; dbg[3] = kv[3]; }
+            if (GRT_DEBUG_SEL == 5) { dbg[0] = fl.b[1]; dbg[1] = fl.b[2]; dbg[2] = fl.b[3]; dbg[3] = fl.bmag; }
+            if (GRT_DEBUG_SEL == 6) { dbg[0] = fl.u[1]; dbg[1] = fl.u[2]; dbg[2] = fl.u[3]; dbg[3] = fl.rho; }
+          }
+#endif
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
           if constexpr (IFLAG == GRT_INT_QUAD) {
             // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
@@ -519,6 +533,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
         tl1[lane * GRT_TS + e] = I[0][1] * LBH;
         tl2[lane * GRT_TS + e] = I[0][2] * LBH;
         tl3[lane * GRT_TS + e] = I[0][3] * LBH;
+#ifdef GRT_DEBUG_SEL
+        tl0[lane * GRT_TS + e] = dbg[0]; tl1[lane * GRT_TS + e] = dbg[1]; tl2[lane * GRT_TS + e] = dbg[2]; tl3[lane * GRT_TS + e] = dbg[3];
+#endif
       }
       if (valid) lam_prev = lam_i;
     }

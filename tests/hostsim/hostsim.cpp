@@ -111,6 +111,26 @@ void hs_polsynchth(double nu, double n, double B, double T, double th, double *e
 void hs_maxjutt(double nu, double n, double B, double T, double th, int nother, const double *oa, double *e11) { maxjutt_fast(nu, n, B, T, th, nother, oa, e11); }
 void hs_maxcomp(double nu, double n, double B, double T, double th, int nother, const double *oa, double *e11) { maxjutt_fast(nu, n, B, T, th, nother, oa, e11, true); }
 
+// FFJET: the table packed exactly as grt_upload_ffjet does (grt_api.cpp), sampled by the kernel's ffjet_sample
+static GrtFFJet g_fj;
+static std::vector<float> g_fjcells, g_fjuniq;
+void hs_ffjet_load(int nx, const float *rc, const float *thc, const float *rho, const float *b0, const float *br,
+                   const float *bth, const float *bph, const float *u0, const float *vr, const float *vth, const float *vph) {
+  const int nx1 = (int)std::sqrt((float)nx);
+  const float *src[10] = {rho, nullptr, b0, br, bth, bph, u0, vr, vth, vph};
+  g_fjcells.assign((size_t)nx * 12, 0.f); g_fjuniq.assign((size_t)3 * nx1, 0.f);
+  for (int i = 0; i < nx; ++i)
+    for (int k = 0; k < 10; ++k) g_fjcells[(size_t)i * 12 + k] = src[k] ? src[k][i] : 0.f;
+  for (int i = 0; i < nx1; ++i) { g_fjuniq[i] = rc[i]; g_fjuniq[nx1 + i] = thc[(size_t)i * nx1]; g_fjuniq[2 * nx1 + i] = std::log(rc[i]); }
+  g_fj.cells = g_fjcells.data(); g_fj.uniqr = g_fjuniq.data(); g_fj.uniqth = g_fjuniq.data() + nx1; g_fj.uniqx1 = g_fjuniq.data() + 2 * nx1; g_fj.nx1 = nx1;
+}
+void hs_ffjet_point(double r, double th, double a, double *out11) {
+  FluidPoint f;
+  ffjet_sample(g_fj, r, th, (float)a, f);
+  out11[0] = f.rho; out11[1] = f.p; out11[2] = f.bmag;
+  for (int i = 0; i < 4; ++i) { out11[3 + i] = f.u[i]; out11[7 + i] = f.b[i]; }
+}
+
 // HARM: the product's text-dump loader (grt_harm_loader.cpp, compiled into this test library) hands its arrays
 // to grt_upload_harm; here that entry point is a capture stub that packs them exactly as grt_api.cpp does.
 static GrtHarm g_harm;

@@ -1,9 +1,10 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
  (a) golden vectors produced by the compiled unmodified reference (tests/golden), and
  (b) the C++ oracle on the same inputs.
-Bars: stored-point counts (npts) bit-exact; fp32 Stokes images within 1e-5 of each Stokes peak
-(the reference computes the FFJET fluid variables in REAL(4); device libm differs from glibc in the
-last ulp of cosf/acosf/logf, which moves a pixel by a few fp32 ulps)."""
+Bars: stored-point counts (npts) bit-exact; fp32 Stokes images within 1e-5 of each Stokes peak.
+The reference computes the fluid variables in REAL(4) and its power-law emissivity jumps by ~0.5% where the
+frequency crosses a bin of the G(x) tables, so the REAL(4) islands must be bit-identical on the device (built with
+-ffp-contract=fast-honor-pragmas; test_fp32_islands_* and test_table_bin_flip_cameras hold that)."""
 import os
 import numpy as np
 import pytest
@@ -965,3 +966,43 @@ def test_multi_pass_tracing_under_a_memory_cap_equals_single_pass(monkeypatch):
     assert np.array_equal(a, b) and np.array_equal(sa, sb)
     d.close()
 
+
+
+def test_fp32_islands_bit_identical_on_device_and_host():
+    # tests/fp32_island_check.hip runs the REAL(4) building blocks of the fluid samplers (correctly rounded
+    # transcendentals, divide, sqrt, the bilinear blend, the REAL(4) metric and LNRF transform) on a million inputs on the
+    # device and on the host and compares bit patterns.  With -ffp-contract=fast the SLP-packed v_pk_fma_f32 ignored the
+    # contract(off) pragma and a quarter of the blends were one ulp off.
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "fp32_island_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "csrc"), "../../tests/fp32_island_check"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+# cameras a random sweep (tools/fuzz_cameras.py 300 31) found: one ray each crosses a bin edge of the power-law G(x)
+# tables within 1e-7, where the reference's emissivity is discontinuous (0.5% in j_I); with the REAL(4) fluid variables
+# one ulp off, that pixel moved by 4e-5 .. 2e-4 of the Stokes peak
+BIN_FLIP_CAMS = [
+    (-0.9685100068278336, 0.999, (-24.80464485595749, 32.04212916452268, -31.650583856482534, 25.196190163997635), 0.04, 60),
+    (0.5, 0.999, (-38.13646298455784, 27.794847340807493, -39.85794389728005, 26.07336642808528), 0.04, 60),
+    (0.5674915055438341, 0.999, (-40.73979773709904, 42.01881718390271, -41.68701977325127, 41.07159514775048), 0.02, 100),
+    (0.48720383370589426, 0.999, (-13.171512055540557, 8.30424745186863, -16.81854110666402, 4.657218400745164), 0.02, 40),
+    (-0.7092107459104384, 0.0, (-16.83951670346117, 9.247214594667486, -19.710436728366844, 6.376294569761814), 0.01, 100),
+]
+
+
+@pytest.mark.parametrize("spin,mu0,gv,uout,nup", BIN_FLIP_CAMS)
+def test_table_bin_flip_cameras(dev, spin, mu0, gv, uout, nup):
+    from grtrans_amd import capi
+    from oracle import orabind
+    nn = (12, 12, nup)
+    o = orabind.Oracle(nn=nn, iname="formal", spin=spin, mu0=mu0, gridvals=gv, uout=uout)
+    ref, rn, _ = o.trace(1, nn[0] * nn[1], [FREQ], nthreads=0)
+    cam = capi.make_camera(1, gv, nn, spin, mu0, uout, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [FREQ], "formal")
+    assert np.array_equal(status, rn)
+    assert stokes_err(pix[0], ref[0]) < 2e-6

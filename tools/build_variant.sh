@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../grtrans_amd/csrc"
 mkdir -p ../../build/variants/obj_$1
 O=../../build/variants/obj_$1
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -I. -Wno-unused-result $2"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast-honor-pragmas -I. -Wno-unused-result $2"
 /opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage -c grt_kernels.hip -o $O/k.o 2> $O/usage.txt
 /opt/rocm/bin/hipcc $F -x hip -c grt_api.cpp -o $O/a.o
 /opt/rocm/bin/hipcc $F -x hip -c grt_gather.cpp -o $O/g.o

@@ -1,6 +1,6 @@
 """Random small cameras: device (C ABI) against the CPU oracle -- stored-point counts must be equal, Stokes within 1e-5
 of each Stokes peak.  A robustness sweep over spins (both signs), inclinations, fields of view and uout; run on a GPU box:
-    python tools/fuzz_cameras.py [ncams] [seed]"""
+    python tools/fuzz_cameras.py [ncams] [seed] [all]      ("all": also the GRMHD samplers on small synthetic dumps)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -8,33 +8,82 @@ from grtrans_amd import capi
 from oracle import orabind
 ncams = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-dev = capi.Device(0); dev.load_ffjet(); dev.load_tables()
-em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+import tempfile
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_harm_dump, make_harm3d_dump, make_iharm_dump, make_koral3d_dump
+td = tempfile.mkdtemp(prefix="grt_fuzz_")
+make_harm_dump.write(td, n=64)
+d3, h3 = make_harm3d_dump.write(td, n1=32, n2=32, n3=16)
+di, hi = make_iharm_dump.write(td, n1=32, n2=32, n3=16, metric=1)
+dk, hk = make_koral3d_dump.write(td, n1=32, n2=32, n3=16)
+dev = capi.Device(0); dev.load_ffjet(); dev.load_tables(); dev.load_sphacc()
+dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
+dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375); dev.load_koral3d(dk, hk, 40, 0.9375)
+# (fluid model, emissivity, oracle keywords, make_emis arguments, frequency, tolerance); GRMHD dumps fix the spin
+MODELS = [
+    ("FFJET", "POLSYNCHPL", {}, dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 3.45e11, 1e-5),
+    ("HARM", "POLSYNCHTH", dict(dfile="dump", hfile="dump040", findf=40, mbh=4e6, mdot=1.57e15, muval=0.25, gmin=1.), dict(mbh=4e6, gmin=1., mdot=1.57e15), 2.3e11, 2e-5),
+    ("HARM3D", "HYBRIDTHPL", dict(dfile="dump3d", hfile="dump3d_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=2.), dict(mbh=4e6, gmin=2., mdot=1e20), 2.3e11, 3e-5),
+    ("IHARM", "POLSYNCHTH", dict(dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=3.), dict(mbh=4e6, gmin=3., mdot=1e20), 2.3e11, 3e-5),
+    ("KORAL3D", "POLSYNCHTH", dict(dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5), dict(mbh=4e6, gmin=-1., nfac=1.5), 2.3e11, 3e-5),
+]
+only = set(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else None      # examine these camera indices in detail
 bad = 0
 for c in range(ncams):
-    a = float(rng.choice([rng.uniform(0.01, 0.998), -rng.uniform(0.05, 0.99), 0.998, 0.5]))
+    fname, ename, okw, ekw, freq, tol = MODELS[int(rng.integers(0, len(MODELS)))] if (len(sys.argv) > 3 and sys.argv[3] == "all") else MODELS[0]
+    a = float(rng.choice([rng.uniform(0.01, 0.998), -rng.uniform(0.05, 0.99), 0.998, 0.5])) if fname == "FFJET" else 0.9375
     mu0 = float(rng.choice([rng.uniform(-0.99, 0.99), 0.0, 0.999]))
-    half = float(rng.uniform(4., 45.))
+    half = float(rng.uniform(4., 45.)) if fname == "FFJET" else float(rng.uniform(4., 16.))
     cx, cy = float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8))
     gv = (cx - half, cx + half, cy - half, cy + half)
-    uout = float(rng.choice([0.01, 0.02, 0.04]))
+    uout = float(rng.choice([0.01, 0.02, 0.04])) if fname == "FFJET" else 0.04          # the synthetic dumps end at r = 40
     nn = (12, 12, int(rng.choice([40, 60, 100])))
     iname = str(rng.choice(["formal", "delo"]))
     rec = bool(rng.integers(0, 2))
-    o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout)
-    ref, rn, _ = o.trace(1, nn[0] * nn[1], [3.45e11], nthreads=0)
+    if only is not None and c not in only:
+        continue
+    o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)
+    ref, rn, _ = o.trace(1, nn[0] * nn[1], [freq], nthreads=0)
     capi.record_steps(rec)
     cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
-    pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [3.45e11], iname)
+    em = capi.make_emis(ename, ekw["mbh"], ekw.get("nfac", 1.0), ekw.get("bfac", 6.0), ekw["gmin"], 1e5, 3.5, muval=0.25, mdot=ekw.get("mdot", 0.0))
+    pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], fname, em, [freq], iname)
     ok_n = np.array_equal(status, rn)
-    nanm = np.isnan(ref[0]).any(axis=1) | np.isnan(pix[0]).any(axis=1)
+    # pixels where the integrator overflowed (NaN or inf, as in the reference) must be the same pixels; the rest is compared
+    nanm = (~np.isfinite(ref[0])).any(axis=1) | (~np.isfinite(pix[0])).any(axis=1)
     pk = np.abs(ref[0][~nanm]).max(axis=0) if (~nanm).any() else np.ones(4)
-    err = (np.abs(pix[0][~nanm] - ref[0][~nanm]).max(axis=0) / (pk + 1e-300)).max() if (~nanm).any() else 0.0
-    same_nan = np.array_equal(np.isnan(ref[0]), np.isnan(pix[0]))
-    flag = "" if (ok_n and err < 1e-5 and same_nan) else "  <-- MISMATCH"
+    errs = np.abs(pix[0][~nanm] - ref[0][~nanm]).max(axis=0) / (pk + 1e-300) if (~nanm).any() else np.zeros(4)
+    err = errs.max()
+    same_nan = np.array_equal(~np.isfinite(ref[0]), ~np.isfinite(pix[0]))
+    flag = "" if (ok_n and err < tol and same_nan) else "  <-- MISMATCH"
     bad += bool(flag)
-    print("cam %2d a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d: npts %s nan-mask %s err %.2e%s" %
-          (c, a, mu0, half, uout, nn, iname, rec, ok_n, same_nan, err, flag))
+    print("cam %2d %-8s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d: npts %s nan-mask %s err %.2e%s%s" %
+          (c, fname, a, mu0, half, uout, nn, iname, rec, ok_n, same_nan, err, flag, (" IQUV " + str(errs)) if flag else ""))
+    if only is not None:
+        d = np.abs(pix[0] - ref[0]) / (pk + 1e-300)
+        worst = np.argsort(-d.max(axis=1))[:1]
+        capi.record_steps(True)
+        capi.trace_tile(cam, 1, nn[0] * nn[1], fname, em, [freq], iname)
+        for w in worst:
+            od = o.ray_dump(int(w) + 1, freq)
+            n = od["npts"]
+            recd = capi.download_steps(int(w), 1, cam.nup + cam.next)[:, 0, :n]
+            x = od["x"]
+            gr = o.geokerr_ray(int(w) + 1)
+            print("   pixel %d npts %d ncase %d err %s  dev %s ref %s" % (w + 1, n, gr["ncase"], d[w], pix[0][w], ref[0][w]))
+            print("      max|dr|/r %.2e  max|dth| %.2e  max|dphi| %.2e  max|dlam|/lam %.2e  tpm changes %d tpr changes %d" % (
+                np.abs(recd[0] - x[:, 1]).max() / np.abs(x[:, 1]).max(), np.abs(recd[1] - x[:, 2]).max(), np.abs(recd[2] - x[:, 3]).max(),
+                np.abs(recd[3] - od["lam"]).max() / (np.abs(od["lam"]).max() + 1e-300), int(np.abs(np.diff(od["tpm"])).sum()), int(np.abs(np.diff(od["tpr"])).sum())))
+            Idev = recd[4:8, ::-1].T[:n]; Iref = np.nan_to_num(np.asarray(od["I"]))     # device record is stored far end first?
+            if np.abs(np.nan_to_num(Idev) - Iref).max() > np.abs(np.nan_to_num(recd[4:8].T[:n]) - Iref).max():
+                Idev = recd[4:8].T[:n]
+            dI = np.abs(np.nan_to_num(Idev) - Iref) / (np.abs(Iref).max(axis=0) + 1e-300)
+            jump = np.argmax(np.abs(np.diff(dI.max(axis=1), prepend=0.0)))
+            print("      per-step record: max rel diff %s, largest change of the difference at step %d of %d" % (dI.max(axis=0), jump, n))
+            for kk in range(max(0, jump - 2), min(n, jump + 3)):
+                print("        step %d r %.6f th %.9f rho %.6g bmag %.6g ang %.6g g %.6g tpm %d tpr %d  dI %s" % (kk, x[kk, 1], x[kk, 2], od["rho"][kk], od["bmag"][kk], od["ang"][kk], od["rshift"][kk], od["tpm"][kk], od["tpr"][kk], dI[kk]))
+            k = int(np.argmax(np.abs(recd[1] - x[:, 2])))
+            print("      worst theta point %d of %d: dev th %.12g ref th %.12g | r dev %.12g ref %.12g" % (k, n, recd[1][k], x[k, 2], recd[0][k], x[k, 1]))
 capi.record_steps(False)
 dev.close()
 print("MISMATCHES:", bad)
