@@ -1,7 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
  (a) golden vectors produced by the compiled unmodified reference (tests/golden), and
  (b) the C++ oracle on the same inputs.
-Bars: stored-point counts (npts) bit-exact; fp32 Stokes images within 1e-5 of each Stokes peak.
+Bars: stored-point counts (npts) bit-exact; fp32 Stokes images within 2e-6 of each Stokes peak.
 The reference computes the fluid variables in REAL(4) and its power-law emissivity jumps by ~0.5% where the
 frequency crosses a bin of the G(x) tables, so the REAL(4) islands must be bit-identical on the device (built with
 -ffp-contract=fast-honor-pragmas; test_fp32_islands_* and test_table_bin_flip_cameras hold that)."""
@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 FREQ = 3.45e11
-STOKES_TOL = 1e-5
+STOKES_TOL = 2e-6      # measured on MI355X with bit-identical REAL(4) islands: <= 6.6e-7 of peak over every case below
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +37,12 @@ def run(nn, iname, i1=None, i2=None, freqs=(FREQ,)):
 def stokes_err(pix, ref):
     ref = ref.astype(float)
     peak = np.abs(ref).reshape(-1, ref.shape[-1]).max(axis=0)
-    return (np.abs(pix.astype(float) - ref).reshape(-1, ref.shape[-1]).max(axis=0) / peak).max()
+    e = (np.abs(pix.astype(float) - ref).reshape(-1, ref.shape[-1]).max(axis=0) / peak).max()
+    if os.environ.get("GRT_TEST_ERRLOG"):      # measured margins, for setting the bars (tools/)
+        import inspect
+        with open(os.environ["GRT_TEST_ERRLOG"], "a") as f:
+            f.write("%d %s %.3e\n" % (inspect.stack()[1].lineno, inspect.stack()[1].function, e))
+    return e
 
 
 @pytest.mark.parametrize("nx,nup", [(32, 100), (100, 400)])
@@ -688,10 +693,10 @@ def test_hybrid_emissivities_vs_reference_golden(tmp_path):
             assert np.array_equal(status, g["harm3d_npts"])
             ref = g[key]
             ok = ~np.isnan(ref).any(axis=1)          # the reference's DELO overflows on 20 pixels of this problem
-            # Q, U tolerance 5e-5 of peak here: the magnetised dump has rays with ~1e3 rad of Faraday rotation, which
-            # multiplies the one-fp32-ulp differences of the REAL(4) |b| island (2.4e-8 relative in rho_V) by that depth
-            # (measured: I 8e-7, Q/U 2.4e-5, V 1.7e-5 of peak; the same against the oracle with plain POLSYNCHTH)
-            assert stokes_err(pix[0][ok], ref[ok]) < 5e-5, key
+            # Q, U tolerance 1e-5 of peak here: the magnetised dump has rays with ~1e3 rad of Faraday rotation, which
+            # multiplies the fp64 rounding differences in rho_V by that depth (measured: I 4e-8, Q/U 3.4e-6 of peak;
+            # it was 2.4e-5 while the REAL(4) |b| island was one ulp off)
+            assert stokes_err(pix[0][ok], ref[ok]) < 1e-5, key
             assert stokes_err(pix[0][ok][:, :1], ref[ok][:, :1]) < STOKES_TOL, key
         d.load_harm(os.path.join(str(tmp_path), "dump"), os.path.join(str(tmp_path), "dump040"), 40, H2["spin"])
         cam = capi.make_camera(1, H2["gridvals"], (32, 32, 150), H2["spin"], H2["mu0"], H2["uout"], -0.5)
@@ -699,7 +704,7 @@ def test_hybrid_emissivities_vs_reference_golden(tmp_path):
             em = capi.make_emis(en, H2["mbh"], 1.0, 6.0, 10., 1e5, 3.5, muval=H2["muval"], mdot=H2["mdot"])
             pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], "formal")
             assert np.array_equal(status, g["harm_npts"])
-            assert stokes_err(pix[0], g["harm_" + en]) < 2 * STOKES_TOL, en
+            assert stokes_err(pix[0], g["harm_" + en]) < STOKES_TOL, en
         # a pair without a kernel is refused, never emulated
         em = capi.make_emis("HYBRIDTHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
         d.load_ffjet()
@@ -733,17 +738,17 @@ def test_maxjutt_vs_reference_golden_device_and_fortran_host(tmp_path, monkeypat
         em = capi.make_emis("MAXJUTT", H3["mbh"], 1.0, 6.0, H3["gmin"], 1e5, 3.5, muval=H3["muval"], mdot=H3["mdot"],
                             otherargs=(2.0,) + make_golden.MAXJUTT_W6)
         pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM3D", em, [FREQ_HARM], "formal")
-        # 2e-5 of peak: six thermal evaluations per point, each through the folded-constant coefficient routine (measured 1.07e-5)
-        assert np.array_equal(status, g["harm3d_npts"]) and stokes_err(pix[0], g["harm3d_w6_formal"]) < 2 * STOKES_TOL
+        # six thermal evaluations per point, each through the folded-constant coefficient routine (measured 6.5e-7 of peak)
+        assert np.array_equal(status, g["harm3d_npts"]) and stokes_err(pix[0], g["harm3d_w6_formal"]) < STOKES_TOL
         em = capi.make_emis("MAXCOMP", H3["mbh"], 1.0, 6.0, H3["gmin"], 1e5, 3.5, muval=H3["muval"], mdot=H3["mdot"],
                             otherargs=(2.0, 2.0, 1.0, 0.5, 0.25))
         pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM3D", em, [FREQ_HARM], "formal")
-        assert stokes_err(pix[0], g["harm3d_maxcomp_sel2"]) < 2 * STOKES_TOL
+        assert stokes_err(pix[0], g["harm3d_maxcomp_sel2"]) < STOKES_TOL
         d.load_harm(os.path.join(str(tmp_path), "dump"), os.path.join(str(tmp_path), "dump040"), 40, H2["spin"])
         cam = capi.make_camera(1, H2["gridvals"], (32, 32, 150), H2["spin"], H2["mu0"], H2["uout"], -0.5)
         em = capi.make_emis("MAXJUTT", H2["mbh"], 1.0, 6.0, H2["gmin"], 1e5, 3.5, muval=H2["muval"], mdot=H2["mdot"], otherargs=(1.5, 1.0, 0.5))
         pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], "formal")
-        assert np.array_equal(status, g["harm_npts"]) and stokes_err(pix[0], g["harm_w2_formal"]) < 2 * STOKES_TOL
+        assert np.array_equal(status, g["harm_npts"]) and stokes_err(pix[0], g["harm_w2_formal"]) < STOKES_TOL
         with pytest.raises(capi.GrtError):          # MAXJUTT has no SPHACC instantiation: refused
             d.load_sphacc()
             capi.trace_tile(capi.make_camera(1, (-25., 25., -25., 25.), (8, 8, 50), 0.0, 0.5, 0.04, -0.5), 1, 64, "SPHACC", em, [FREQ_SPHACC], "formal")
@@ -759,7 +764,7 @@ def test_maxjutt_vs_reference_golden_device_and_fortran_host(tmp_path, monkeypat
     x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
     x.run_grtrans()
     x.read_grtrans_output(bin=1)
-    assert stokes_err(x.ivals[:, :, 0], g["harm3d_w6_formal"]) < 2 * STOKES_TOL
+    assert stokes_err(x.ivals[:, :, 0], g["harm3d_w6_formal"]) < STOKES_TOL
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
@@ -791,7 +796,7 @@ def test_harm3d_camera_sweep_and_frequency_batches(tmp_path):
             em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, H["gmin"], 1e5, 3.5, muval=H["muval"], mdot=3e19)
             pix, _, status, _ = capi.trace_tile(cam, 1, 400, "HARM3D", em, [FREQ_HARM], "formal")
             assert np.array_equal(status, rn)
-            assert stokes_err(pix[0], ref[0]) < 2 * STOKES_TOL, mu0
+            assert stokes_err(pix[0], ref[0]) < STOKES_TOL, mu0
         cam = capi.make_camera(1, H["gridvals"], nn, H["spin"], H["mu0"], H["uout"], -0.5)
         freqs = list(2.3e10 * np.exp(np.arange(15) * np.log(2.3e13 / 2.3e10) / 14))
         for en, iname, oa in (("POLSYNCHTH", "formal", (1.0, 1.0)), ("HYBRIDTHPL", "delo", (1.0, 1.0)), ("MAXJUTT", "formal", (2.0, 1.0, 0.5, 0.25))):
@@ -837,16 +842,16 @@ def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
             em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, gmin, 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], sigcut=sig)
             pix, _, status, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], iname)
             assert np.array_equal(status, g["npts"])
-            assert stokes_err(pix[0], g["ivals_" + key]) < 2 * STOKES_TOL, key
+            assert stokes_err(pix[0], g["ivals_" + key]) < STOKES_TOL, key
         em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, 1., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
         p1, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal", nvals=1)
         assert p1.shape == (1, 1296, 1) and np.isfinite(p1).all() and p1.max() > 0
         em = capi.make_emis("HYBRIDTHPL", H["mbh"], 1.0, 6.0, 2., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], jetalpha=0.02)
         pix, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal")
-        assert stokes_err(pix[0], g["ivals_hybridthpl"]) < 2 * STOKES_TOL
+        assert stokes_err(pix[0], g["ivals_hybridthpl"]) < STOKES_TOL
         em = capi.make_emis("MAXJUTT", H["mbh"], 1.0, 6.0, 1., 1e5, 3.5, muval=H["muval"], mdot=H["mdot"], otherargs=(2.0, 1.0, 0.5, 0.25))
         pix, _, _, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], "formal")
-        assert stokes_err(pix[0], g["ivals_maxjutt"]) < 2 * STOKES_TOL
+        assert stokes_err(pix[0], g["ivals_maxjutt"]) < STOKES_TOL
         # MMKS (header metric 1): theta(x1, x2), zone search on the tabulated thetag / thetaj, Brent near zone-centre angles
         dfm, hfm = make_iharm_dump.write(str(tmp_path / "mmks"), metric=1, **make_golden.IHARM_ZONES)
         assert hashlib.sha256(open(dfm + "040.bin", "rb").read()).hexdigest() == str(g["mmks_dump_sha256"])
@@ -854,7 +859,7 @@ def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
         for key, iname, gmin in (("mmks_formal_gmin3", "formal", 3.), ("mmks_delo_kel", "delo", -1.)):
             em = capi.make_emis("POLSYNCHTH", H["mbh"], 1.0, 6.0, gmin, 1e5, 3.5, muval=H["muval"], mdot=H["mdot"])
             pix, _, status, _ = capi.trace_tile(cam, 1, 1296, "IHARM", em, [FREQ_HARM], iname)
-            assert np.array_equal(status, g["npts"]) and stokes_err(pix[0], g["ivals_" + key]) < 2 * STOKES_TOL, key
+            assert np.array_equal(status, g["npts"]) and stokes_err(pix[0], g["ivals_" + key]) < STOKES_TOL, key
         with pytest.raises(capi.GrtError):      # power-law-only emissivity has no kernel for this sampler: refused
             capi.trace_tile(cam, 1, 1296, "IHARM", capi.make_emis("POLSYNCHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5), [FREQ_HARM], "formal")
     finally:
@@ -869,7 +874,7 @@ def test_iharm_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
     x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
     x.run_grtrans()
     x.read_grtrans_output(bin=1)
-    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_gmin3"]) < 2 * STOKES_TOL
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_gmin3"]) < STOKES_TOL
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
@@ -922,7 +927,7 @@ def test_koral3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch
             em = capi.make_emis("POLSYNCHTH", H["mbh"], H["ftscl"], 6.0, gmin, 1e5, 3.5, muval=H["muval"], sigcut=sig)
             pix, _, status, _ = capi.trace_tile(cam, 1, 1296, fname, em, [FREQ_HARM], iname)
             assert np.array_equal(status, g["npts"])
-            assert stokes_err(pix[0], g["ivals_" + key]) < 2 * STOKES_TOL, key
+            assert stokes_err(pix[0], g["ivals_" + key]) < STOKES_TOL, key
         with pytest.raises(capi.GrtError):      # no kernel for power-law electrons on this sampler (ncgsnth = 0 there): refused
             capi.trace_tile(cam, 1, 1296, "KORAL3D", capi.make_emis("POLSYNCHPL", H["mbh"], 1.0, 6.0, 50., 1e5, 3.5), [FREQ_HARM], "formal")
     finally:
@@ -937,7 +942,7 @@ def test_koral3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch
     x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
     x.run_grtrans()
     x.read_grtrans_output(bin=1)
-    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_disk"]) < 2 * STOKES_TOL
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal_disk"]) < STOKES_TOL
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
@@ -995,14 +1000,16 @@ BIN_FLIP_CAMS = [
 
 
 @pytest.mark.parametrize("spin,mu0,gv,uout,nup", BIN_FLIP_CAMS)
-def test_table_bin_flip_cameras(dev, spin, mu0, gv, uout, nup):
+def test_table_bin_flip_cameras(spin, mu0, gv, uout, nup):
     from grtrans_amd import capi
     from oracle import orabind
+    d = capi.Device(0); d.load_ffjet(); d.load_tables()      # tests above open and close their own devices
     nn = (12, 12, nup)
     o = orabind.Oracle(nn=nn, iname="formal", spin=spin, mu0=mu0, gridvals=gv, uout=uout)
     ref, rn, _ = o.trace(1, nn[0] * nn[1], [FREQ], nthreads=0)
     cam = capi.make_camera(1, gv, nn, spin, mu0, uout, -0.5)
     em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
     pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [FREQ], "formal")
+    d.close()
     assert np.array_equal(status, rn)
-    assert stokes_err(pix[0], ref[0]) < 2e-6
+    assert stokes_err(pix[0], ref[0]) < STOKES_TOL

@@ -1,5 +1,5 @@
-"""Random small cameras: device (C ABI) against the CPU oracle -- stored-point counts must be equal, Stokes within 1e-5
-of each Stokes peak.  A robustness sweep over spins (both signs), inclinations, fields of view and uout; run on a GPU box:
+"""Random small cameras: device (C ABI) against the CPU oracle -- stored-point counts must be equal, Stokes within 2e-6
+of each Stokes peak (1e-5 for Q/U/V of the Faraday-thick HARM3D hybrid case).  A robustness sweep over spins (both signs), inclinations, fields of view and uout; run on a GPU box:
     python tools/fuzz_cameras.py [ncams] [seed] [all]      ("all": also the GRMHD samplers on small synthetic dumps)"""
 import os, sys
 import numpy as np
@@ -21,11 +21,11 @@ dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
 dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375); dev.load_koral3d(dk, hk, 40, 0.9375)
 # (fluid model, emissivity, oracle keywords, make_emis arguments, frequency, tolerance); GRMHD dumps fix the spin
 MODELS = [
-    ("FFJET", "POLSYNCHPL", {}, dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 3.45e11, 1e-5),
-    ("HARM", "POLSYNCHTH", dict(dfile="dump", hfile="dump040", findf=40, mbh=4e6, mdot=1.57e15, muval=0.25, gmin=1.), dict(mbh=4e6, gmin=1., mdot=1.57e15), 2.3e11, 2e-5),
-    ("HARM3D", "HYBRIDTHPL", dict(dfile="dump3d", hfile="dump3d_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=2.), dict(mbh=4e6, gmin=2., mdot=1e20), 2.3e11, 3e-5),
-    ("IHARM", "POLSYNCHTH", dict(dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=3.), dict(mbh=4e6, gmin=3., mdot=1e20), 2.3e11, 3e-5),
-    ("KORAL3D", "POLSYNCHTH", dict(dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5), dict(mbh=4e6, gmin=-1., nfac=1.5), 2.3e11, 3e-5),
+    ("FFJET", "POLSYNCHPL", {}, dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 3.45e11, 2e-6),
+    ("HARM", "POLSYNCHTH", dict(dfile="dump", hfile="dump040", findf=40, mbh=4e6, mdot=1.57e15, muval=0.25, gmin=1.), dict(mbh=4e6, gmin=1., mdot=1.57e15), 2.3e11, 2e-6),
+    ("HARM3D", "HYBRIDTHPL", dict(dfile="dump3d", hfile="dump3d_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=2.), dict(mbh=4e6, gmin=2., mdot=1e20), 2.3e11, 1e-5),
+    ("IHARM", "POLSYNCHTH", dict(dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=3.), dict(mbh=4e6, gmin=3., mdot=1e20), 2.3e11, 2e-6),
+    ("KORAL3D", "POLSYNCHTH", dict(dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5), dict(mbh=4e6, gmin=-1., nfac=1.5), 2.3e11, 2e-6),
 ]
 only = set(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else None      # examine these camera indices in detail
 bad = 0
