@@ -574,6 +574,12 @@ GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]
   double ep = exp(lam1 * dx), em = frcp(ep);
   double ch = 0.5 * (ep + em), zz = lam1 * dx;
   double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz / 6.0 * (1.0 + zz * zz / 20.0)) : 0.5 * (ep - em);
+  if (zz > 709.0) {
+    // e^zz overflows at 709.78 but cosh/sinh stay finite up to 710.4758, and the reference's COSH/SINH intrinsics return
+    // them there (the step then gives O = exp(-a_I dx) * finite, usually 0, instead of NaN): (e^{zz/2}/2) e^{zz/2}
+    const double w = exp(0.5 * zz);
+    ch = (0.5 * w) * w; sh = ch;
+  }
   double co, si;
 #if defined(__HIP_DEVICE_COMPILE__)
   sincos(lam2 * dx, &si, &co);

@@ -441,3 +441,29 @@ def test_harm_slow_light_slice_selection_matches_oracle(L, tmp_path):
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
             seen.add(int(np.floor((-d["x"][k, 0]) / 20.0)))
     assert len(seen) >= 2          # the rays really cross slice boundaries
+
+
+def test_formal_step_in_the_cosh_overflow_window(L):
+    # lambda_1 dx in (709.78, 710.4758): e^x overflows but cosh/sinh do not, and the reference's COSH/SINH intrinsics return
+    # finite values there, so the step gives O = exp(-a_I dx) * finite (here 0) and not NaN.  Found by
+    # tools/fuzz_cameras.py on a Faraday- and optically-thick HARM3D ray at 23 GHz (one pixel NaN on the device only).
+    L.hs_formal_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    K = np.array([[0.3, 0.05, -0.02, 0.01, 0.4, -0.1, 1.5],
+                  [4427.39777847, -2774.70273186, -1927.02499991, 136.97246561, -2508.43460807, -1742.10236825, 4706.39599268],
+                  [0.2, 0.03, 0.01, -0.02, 0.1, 0.2, -0.7]])
+    j = np.array([[1.0, 0.3, -0.2, 0.05], [2e-3, -1.4e-3, -6.7e-4, 7e-5], [0.5, 0.1, 0.1, 0.0]])
+    x = np.array([0.323044391348958 + 0.25, 0.25, 0.0])
+    a2, p2 = (K[1, 1:4] ** 2).sum(), (K[1, 4:] ** 2).sum()
+    ap = (K[1, 1:4] * K[1, 4:]).sum()
+    lam1 = np.sqrt(np.sqrt((a2 - p2) ** 2 / 4 + ap * ap) + (a2 - p2) / 2)
+    assert 709.79 < lam1 * (x[0] - x[1]) < 710.47          # the case is inside the window
+    want = O.integrate(2, x, j, K, np.zeros(3))
+    assert np.isfinite(want).all()
+    I = np.zeros(4)
+    for k in (1, 0):
+        nxt = np.zeros(4)
+        jj = np.ascontiguousarray(j[k]); KK = np.ascontiguousarray(K[k])
+        L.hs_formal_step(jj.ctypes.data, KK.ctypes.data, float(x[k] - x[k + 1]), I.ctypes.data, nxt.ctypes.data)
+        I = nxt
+        assert np.isfinite(I).all()
+        assert np.abs(I - want[2 - k]).max() <= 1e-12 * np.abs(want).max()
