@@ -405,6 +405,54 @@ GRT_HD double bnu(double T, double nu) {   // polsynchemis.f90:1014
   return b;
 }
 
+// The scalar emissivities of emis.f90:532-548 (nvals = 1): SYNCHTHAV / SYNCHTHAVNOABS (synchemis, polsynchemis.f90:865-913),
+// BREMS (brememisHEROIC, emis.f90:188-238; its REAL(4) literals kept as such), SYNCHTHBREMS (their sum) and RHO (n g).
+// Only e[0] = j_I and e[4] = alpha_I are produced; `type` is wave-uniform.
+GRT_HD void scalar_emis_fast(int type, double nu, double n, double B, double T, double g, double *e) {
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k, h = PH_h;
+  double j = 0.0, a = 0.0;
+  if (type == GRT_EMIS_RHO) j = n * g;
+  else {
+    const double ibn = frcp(bnu(T, nu));
+    if (type != GRT_EMIS_BREMS) {
+      const double thetae = k * T / m / PH_c2 + 1e-10;
+      const double nucrit = 3.0 * ec * B / (4 * pi * m * c) * (thetae * thetae) + 1.0;
+      const double lx = log(nu / nucrit), x16 = exp(lx / 6.0), x13 = x16 * x16;     // x^(1/6), x^(1/3)
+      const double isx = frcp(x13 * x16);                                           // 1/sqrt(x)
+      const double ipx = 4.0505 * frcp(x16) * (1 + 0.40 * fsqrt(isx) + 0.5316 * isx) * exp(-1.8899 * x13);
+      const double js = 4.43e-30 / 2.0 * nu * n * ipx / (thetae * thetae);
+      j = js;
+      a = (type == GRT_EMIS_SYNCHTHAVNOABS || !(fabs(js) > 0.0)) ? 0.0 : js * ibn;
+    }
+    if (type == GRT_EMIS_BREMS || type == GRT_EMIS_SYNCHTHBREMS) {
+      const double rho = n * (double)1.67219e-24f;
+      const double sqrtt = fsqrt(T), thetae = k * T / m / PH_c2, sqrtthetae = fsqrt(thetae);
+      const double q = 1e5 / T, q2 = q * q, q5 = q2 * q2 * q;
+      const double tempfactor = 1.0 / (sqrtt + q5 * q5) + 1e-32;
+      const double arg = h * nu / (k * T);
+      double fei, fee;
+      if (thetae < 1.0) {
+        fei = (double)1.016f * sqrtthetae * (1 + (double)1.781f * pow(thetae, (double)1.34f));
+        fee = thetae * sqrtthetae * (1 + (double)1.1f * thetae + thetae * thetae * (1 - (double)1.25f * sqrtthetae));
+      } else {
+        fei = (double)1.432f * thetae * (log((double)1.123f * thetae + (double)0.48f) + 1.5);
+        fee = (double)1.328f * thetae * (log((double)1.123f * thetae) + (double)1.28f);
+      }
+      double ab = 0.0;
+      if (!(arg > 100.0)) {
+        const double w = (arg < (double)1e-8f) ? arg : (1 - exp(-arg));
+        const double inu2 = frcp(nu * nu);
+        ab = (1.10e61 / sqrtt) * rho * rho * fei * w * tempfactor * inu2 / nu + (1.14e51 / sqrtt / T) * rho * rho * fee * w * tempfactor * inu2;
+      }
+      j += ab * bnu(T, nu);
+      a += ab;
+    }
+  }
+  for (int q = 0; q < 11; ++q) e[q] = 0.0;
+  e[0] = j; e[4] = a;
+}
+
+
 // polsynchemis.f90:700
 GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, double *e) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;

@@ -418,6 +418,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
             for (int c = 0; c < 8; ++c) oa[c] = emj.otherargs[c];
             maxjutt_fast(nu, ncgs, bcgs, tcgs, ang, emj.nother, oa, e11, emj.type == GRT_EMIS_MAXCOMP);
           }
+          else if (EMIS == GRT_EMIS_SYNCHTHAV)   // the scalar family (nvals = 1): one instantiation, em.type selects
+            scalar_emis_fast(karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type, nu, ncgs, bcgs, tcgs, g, e11);
           else if (EMIS == GRT_EMIS_HYBRIDTHPL) {
             // thermal + power-law populations (emis.f90:473-490); one instantiation serves HYBRIDTHPL / HYBRIDTH /
             // HYBRIDPL (em.type, wave-uniform).  The 25 KB of LDS a 2-D/3-D HARM block already holds leave no room for
@@ -681,6 +683,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   if (nlive <= 0) return hipSuccess;
   if (emis == GRT_EMIS_HYBRIDTH || emis == GRT_EMIS_HYBRIDPL) emis = GRT_EMIS_HYBRIDTHPL;   // one instantiation, em->type selects
   if (emis == GRT_EMIS_MAXCOMP) emis = GRT_EMIS_MAXJUTT;
+  if (emis == GRT_EMIS_SYNCHTHAVNOABS || emis == GRT_EMIS_BREMS || emis == GRT_EMIS_SYNCHTHBREMS || emis == GRT_EMIS_RHO) emis = GRT_EMIS_SYNCHTHAV;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
     launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
@@ -723,6 +726,11 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_SYNCHTHAV)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_SYNCHTHAV)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_SYNCHTHAV)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_SYNCHTHAV)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_KORAL3D, GRT_EMIS_SYNCHTHAV)
 #undef GRT_XFER_CASE
   return hipErrorInvalidValue;
 }

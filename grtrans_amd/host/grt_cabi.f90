@@ -10,7 +10,8 @@ module grt_cabi
        GRT_FLUID_KORAL3D = 25, GRT_FLUID_KORAL3D_DISK = 26
   integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
        GRT_EMIS_BB = 8, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22, &
-       GRT_EMIS_MAXJUTT = 23, GRT_EMIS_MAXCOMP = 24
+       GRT_EMIS_MAXJUTT = 23, GRT_EMIS_MAXCOMP = 24, GRT_EMIS_SYNCHTHAV = 13, GRT_EMIS_SYNCHTHAVNOABS = 14, &
+       GRT_EMIS_BREMS = 5, GRT_EMIS_SYNCHTHBREMS = 27, GRT_EMIS_RHO = 12
 
   type, bind(C) :: grt_camera          ! GrtCam
      real(c_double) :: a1, a2, b1, b2

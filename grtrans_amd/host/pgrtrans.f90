@@ -112,6 +112,11 @@ contains
     case ('HYBRIDPL'); emis_id = GRT_EMIS_HYBRIDPL
     case ('MAXJUTT'); emis_id = GRT_EMIS_MAXJUTT
     case ('MAXCOMP'); emis_id = GRT_EMIS_MAXCOMP
+    case ('SYNCHTHAV'); emis_id = GRT_EMIS_SYNCHTHAV
+    case ('SYNCHTHAVNOABS'); emis_id = GRT_EMIS_SYNCHTHAVNOABS
+    case ('BREMS'); emis_id = GRT_EMIS_BREMS
+    case ('SYNCHTHBREMS'); emis_id = GRT_EMIS_SYNCHTHBREMS
+    case ('RHO'); emis_id = GRT_EMIS_RHO
     case default; call die('emissivity '//trim(ename)//' is not on the device yet')
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37

@@ -43,7 +43,11 @@ enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, G
        GRT_EMIS_MAXJUTT = 23,
        /* the same with otherargs = (delta, selection, weights...): emission of component `selection` (1-based, 0 = all),
           total absorption and Faraday coefficients (calc_maxcomp.f90) */
-       GRT_EMIS_MAXCOMP = 24 };
+       GRT_EMIS_MAXCOMP = 24,
+       /* scalar (Stokes I) emissivities, nvals = 1 only -- with nvals = 4 the reference itself returns NaN or garbage for
+          them: angle-averaged thermal synchrotron with LTE absorption (polsynchemis.f90:865-904) and without it (:906-913),
+          free-free (brememisHEROIC, emis.f90:188-238), their sum (emis.f90:534-537), and n * g (rhoemis, emis.f90:144-151) */
+       GRT_EMIS_SYNCHTHAV = 13, GRT_EMIS_SYNCHTHAVNOABS = 14, GRT_EMIS_BREMS = 5, GRT_EMIS_SYNCHTHBREMS = 27, GRT_EMIS_RHO = 12 };
 enum { GRT_INT_LSODA = 0, GRT_INT_DELO = 1, GRT_INT_FORMAL = 2 };
 
 /* Camera scalars: what initialize_pixels / INITIALIZE_CAMERA_GEOKERR derive once per camera

@@ -129,6 +129,15 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       for (int c = 4; c < 11; ++c) e[c] = eth[c] + epl[c];
     }
     else if (S.emis == 8) { for (int c = 0; c < 11; ++c) e[c] = 0.0; e[0] = bnu(w.tcgs[i], nu); }   // bbemis, emis.f90:162-168
+    else if (S.emis == 13) synchemis(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], e);                       // emis.f90:532-533
+    else if (S.emis == 14) { synchemis(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], e); e[4] = 0.0; }      // synchemisnoabs
+    else if (S.emis == 5) brememis_heroic(nu, w.ncgs[i], w.tcgs[i], e);                             // emis.f90:538-539
+    else if (S.emis == 27) {                                                                        // emis.f90:534-537
+      double eb[11];
+      synchemis(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], e); brememis_heroic(nu, w.ncgs[i], w.tcgs[i], eb);
+      e[0] += eb[0]; e[4] += eb[4];
+    }
+    else if (S.emis == 12) { for (int c = 0; c < 11; ++c) e[c] = 0.0; e[0] = w.ncgs[i] * w.rshift[i]; }   // rhoemis, emis.f90:144-151
     else polsynchth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);
     for (int c = 0; c < 4; ++c) w.jraw[4 * i + c] = e[c];
     for (int c = 0; c < 7; ++c) w.Kraw[7 * i + c] = S.coefindx[c] ? e[4 + c] : 0.0;
@@ -259,6 +268,8 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   else return -1;
   S.mdot = mdot; S.muval = muval;
   if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8;
+  else if (en == "SYNCHTHAV") S.emis = 13; else if (en == "SYNCHTHAVNOABS") S.emis = 14; else if (en == "BREMS") S.emis = 5;
+  else if (en == "SYNCHTHBREMS") S.emis = 27; else if (en == "RHO") S.emis = 12;
   else if (en == "MAXJUTT") S.emis = 23;
   else if (en == "MAXCOMP") S.emis = 24;
   else if (en == "HYBRIDTHPL") S.emis = 20; else if (en == "HYBRIDTH") S.emis = 21; else if (en == "HYBRIDPL") S.emis = 22;
@@ -409,6 +420,20 @@ int grto_load_pltables(const char *path) { return pltables_load(path, S.pl) ? 0 
 void grto_polsynchth(int n, const double *nu, const double *dens, const double *b, const double *t, const double *th,
                      double *eout) {
   for (int i = 0; i < n; ++i) polsynchth(nu[i], dens[i], b[i], t[i], th[i], &eout[11 * i]);
+}
+
+// the scalar emissivities by their emis.f90 type number (13 SYNCHTHAV, 14 SYNCHTHAVNOABS, 5 BREMS, 27 SYNCHTHBREMS, 12 RHO)
+void grto_scalar_emis(int type, int n, const double *nu, const double *dens, const double *b, const double *t, const double *g,
+                      double *eout) {
+  for (int i = 0; i < n; ++i) {
+    double *e = &eout[11 * i], eb[11];
+    for (int c = 0; c < 11; ++c) e[c] = 0.0;
+    if (type == 13 || type == 14 || type == 27) synchemis(nu[i], dens[i], b[i], t[i], e);
+    if (type == 14) e[4] = 0.0;
+    if (type == 5) brememis_heroic(nu[i], dens[i], t[i], e);
+    if (type == 27) { brememis_heroic(nu[i], dens[i], t[i], eb); e[0] += eb[0]; e[4] += eb[4]; }
+    if (type == 12) e[0] = dens[i] * g[i];
+  }
 }
 
 void grto_integrate(int iflag, int n, const double *x, const double *j /*[n][4]*/, const double *K /*[n][7]*/,

@@ -377,6 +377,54 @@ inline double bnu(double T, double nu) {   // polsynchemis.f90:1014
   return b;
 }
 
+// synchemis  polsynchemis.f90:865-904: angle-averaged thermal synchrotron (Mahadevan et al. 1996), absorption from LTE
+inline void synchemis(double nu, double n, double B, double T, double *e) {
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
+  const double nucminval = 1.0, thetaemin = 1e-10;
+  double thetae = k * T / m / PH_c2 + thetaemin;
+  double nucrit = 3.0 * ec * B / (4 * pi * m * c) * (thetae * thetae) + nucminval;
+  double x = nu / nucrit;
+  double ipx = 4.0505 / std::exp(std::log(x) / 6.0) * (1 + 0.40 / std::sqrt(std::sqrt(x)) + 0.5316 / std::sqrt(x)) *
+               std::exp(-1.8899 * std::exp(std::log(x) / 3.0));
+  double jnu = 4.43e-30 / 2.0 * nu * n * ipx / (thetae * thetae);
+  double anu = (std::fabs(jnu) > 0.0) ? jnu / bnu(T, nu) : 0.0;
+  for (int c = 0; c < 11; ++c) e[c] = 0.0;
+  e[0] = jnu; e[4] = anu;
+}
+
+// brememisHEROIC  emis.f90:188-238: free-free emission; only columns 1 and 5 are defined by the reference (the other nine
+// are never assigned), so the oracle offers it for nvals = 1 only.  REAL(4) literals of the source are kept as such.
+inline void brememis_heroic(double nu, double ne, double T, double *e) {
+  auto F = [](float v) { return (double)v; };
+  const double h = PH_h, k = PH_k, m = PH_m, c2 = PH_c2;
+  const double epsilon = 1e-32;
+  double temp = T;
+  double rho = ne * F(1.67219e-24f);
+  double sqrtt = std::sqrt(temp);
+  double thetae = k * temp / m / c2;
+  double sqrtthetae = std::sqrt(thetae);
+  double q = 1e5 / temp, q2 = q * q, q3 = q2 * q, q5 = q3 * q2, q10 = q5 * q5;      // **10 by the compiler's addition chain
+  double tempfactor = 1.0 / (sqrtt + q10) + epsilon;
+  double arg = h * nu / (k * temp);
+  double fei, fee;
+  if (thetae < 1.0) {
+    fei = F(1.016f) * sqrtthetae * (1 + F(1.781f) * std::pow(thetae, F(1.34f)));
+    fee = thetae * sqrtthetae * (1 + F(1.1f) * thetae + thetae * thetae * (1 - F(1.25f) * sqrtthetae));
+  } else {
+    fei = F(1.432f) * thetae * (std::log(F(1.123f) * thetae + F(0.48f)) + 1.5);
+    fee = F(1.328f) * thetae * (std::log(F(1.123f) * thetae) + F(1.28f));
+  }
+  double anu;
+  if (arg > 100.0) anu = 0.0;
+  else {
+    const double w = (arg < F(1e-8f)) ? arg : (1 - std::exp(-arg));
+    anu = (1.10e61 / sqrtt) * rho * rho * fei * w * tempfactor / (nu * nu * nu);
+    anu = anu + (1.14e51 / sqrtt / temp) * rho * rho * fee * w * tempfactor / (nu * nu);
+  }
+  for (int c = 0; c < 11; ++c) e[c] = 0.0;
+  e[0] = anu * bnu(temp, nu); e[4] = anu;
+}
+
 // polsynchemis.f90:700
 inline void polsynchth(double nu, double n, double B, double T, double theta, double *e) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;

@@ -172,6 +172,14 @@ def polsynchth(nu, dens, b, t, th):
     return e
 
 
+def scalar_emis(etype, nu, dens, b, t, g):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (nu, dens, b, t, g)]
+    n = len(arrs[0])
+    e = np.zeros((n, 11))
+    lib().grto_scalar_emis(C.c_int(etype), C.c_int(n), *[_dp(a) for a in arrs], _dp(e))
+    return e
+
+
 def integrate(iflag, x, j, K, tau):
     x = np.ascontiguousarray(x, dtype=np.float64)
     n = len(x)

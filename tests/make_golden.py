@@ -440,6 +440,33 @@ def koral3d(nx=36, nup=160):
     np.savez_compressed(os.path.join(G, "koral3d_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, **rays)
 
 
+def unpolarized(nx=32, nup=120):
+    # the scalar emissivities of emis.f90:532-548: angle-averaged thermal synchrotron (SYNCHTHAV, with and without its LTE
+    # absorption), free-free (BREMS, SYNCHTHBREMS: nvals = 1 only -- the reference leaves nine of their eleven columns
+    # unassigned) and RHO, on the 2-D HARM dump, the 3-D one and the Bondi flow.  nvals = 1 throughout: with nvals = 4 the
+    # reference returns NaN (formal) or 1e9-sized garbage (delo) for these, its polarized branch never being set up.
+    import tempfile
+    import make_harm_dump
+    import make_harm3d_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        make_harm_dump.write(td, n=64)
+        make_harm3d_dump.write(td, **HARM3D_ZONES)
+        for en, nv, iname in (("SYNCHTHAV", 1, "formal"), ("SYNCHTHAVNOABS", 1, "formal"),
+                              ("BREMS", 1, "formal"), ("SYNCHTHBREMS", 1, "formal"), ("RHO", 1, "formal")):
+            kw = dict(HARM); kw.update(ename=en, nvals=nv)
+            r = R.Ref(nn=(nx, nx, nup), iname=iname, datadir=td, **kw)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["harm_%s_%d_%s" % (en, nv, iname)] = pix[0]; out["harm_npts"] = npts
+        kw = dict(HARM3D); kw.update(ename="SYNCHTHBREMS", nvals=1)
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+        out["harm3d_SYNCHTHBREMS_1_formal"], out["harm3d_npts"], _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+        kw = dict(SPHACC); kw.update(ename="SYNCHTHAV", nvals=1)
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", **kw)
+        out["sphacc_SYNCHTHAV_1_formal"], out["sphacc_npts"], _ = r.trace(1, nx * nx, [FREQ_SPHACC], nthreads=1)
+    np.savez_compressed(os.path.join(G, "unpolarized_%dx%dx%d.npz" % (nx, nx, nup)), **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -461,4 +488,5 @@ if __name__ == "__main__":
     maxjutt()
     iharm()
     koral3d()
+    unpolarized()
     print("golden fixtures written to", os.path.abspath(G))

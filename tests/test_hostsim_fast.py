@@ -467,3 +467,23 @@ def test_formal_step_in_the_cosh_overflow_window(L):
         I = nxt
         assert np.isfinite(I).all()
         assert np.abs(I - want[2 - k]).max() <= 1e-12 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("etype", [13, 14, 5, 27, 12])
+def test_scalar_emissivities_match_oracle(L, etype):
+    # SYNCHTHAV / SYNCHTHAVNOABS / BREMS / SYNCHTHBREMS / RHO: the kernel's scalar_emis_fast against the oracle's restatement
+    # of synchemis and brememisHEROIC over the ranges GRMHD dumps and the Bondi flow produce (incl. theta_e on both sides of 1
+    # and h nu / k T from 1e-12 to > 100)
+    rng = np.random.default_rng(etype)
+    n = 4000
+    nu = 10 ** rng.uniform(8.5, 15.5, n); dens = 10 ** rng.uniform(0, 12, n); b = 10 ** rng.uniform(-3, 4, n)
+    t = 10 ** rng.uniform(3.5, 12.5, n); g = rng.uniform(0.1, 3.0, n)
+    want = O.scalar_emis(etype, nu, dens, b, t, g)
+    L.hs_scalar_emis.argtypes = [C.c_int] + [C.c_double] * 5 + [C.c_void_p]
+    got = np.zeros((n, 11))
+    for i in range(n):
+        L.hs_scalar_emis(etype, nu[i], dens[i], b[i], t[i], g[i], got[i].ctypes.data)
+    assert np.array_equal(got[:, [1, 2, 3, 5, 6, 7, 8, 9, 10]], np.zeros((n, 9)))
+    for c in (0, 4):
+        ok = np.abs(got[:, c] - want[:, c]) <= 1e-11 * np.abs(want[:, c]) + 1e-300
+        assert ok.all(), (c, np.where(~ok)[0][:5], got[~ok][:3, c], want[~ok][:3, c])

@@ -427,3 +427,26 @@ def test_koral3d_electron_models_disc_variant_and_cuts(tmp_path):
             assert relerr(d[k], r["ray%d_%s" % (i, k)]) < tol, (i, k)
     assert hit > 0          # the Bernoulli cut of the disc variant (T = 10 K) is on the sampled rays
 
+
+
+def test_scalar_emissivities_nvals1(tmp_path):
+    # SYNCHTHAV / SYNCHTHAVNOABS / BREMS / SYNCHTHBREMS / RHO (emis.f90:532-548) with the quadrature integrator (nvals = 1) on
+    # the 2-D and 3-D HARM dumps and the Bondi flow; golden = compiled reference.  The oracle is bit-equal on all of them.
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_harm3d_dump
+    import make_harm_dump
+    g = load("unpolarized_32x32x120.npz")
+    make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
+    make_harm_dump.write(str(tmp_path), n=64)
+    cases = [("harm_%s_1_formal" % en, "harm_npts", make_golden.FREQ_HARM, dict(make_golden.HARM, ename=en)) for en in ("SYNCHTHAV", "SYNCHTHAVNOABS", "BREMS", "SYNCHTHBREMS", "RHO")]
+    cases.append(("harm3d_SYNCHTHBREMS_1_formal", "harm3d_npts", make_golden.FREQ_HARM, dict(make_golden.HARM3D, ename="SYNCHTHBREMS")))
+    cases.append(("sphacc_SYNCHTHAV_1_formal", "sphacc_npts", make_golden.FREQ_SPHACC, dict(make_golden.SPHACC, ename="SYNCHTHAV")))
+    for key, nk, fr, kw in cases:
+        o = O.Oracle(nn=(32, 32, 120), iname="formal", datadir=str(tmp_path), nvals=1, **kw)
+        pix, npts, _ = o.trace(1, 1024, [fr], nthreads=8)
+        assert np.array_equal(npts, g[nk])
+        ref = g[key].reshape(1024, 1)
+        assert np.array_equal(pix[0], ref), key
+    assert np.abs(g["harm_SYNCHTHAV_1_formal"] - g["harm_SYNCHTHAVNOABS_1_formal"]).max() > 0.1 * np.abs(g["harm_SYNCHTHAV_1_formal"]).max()
