@@ -12,7 +12,7 @@ DATA = os.path.join(PKG, "data")
 
 FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13, "HARM3D": 19, "KORAL3D": 25, "KORAL3D_DISK": 26, "IHARM": 29}       # fluid.f90:40-43
 EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8, "HYBRIDTHPL": 20, "HYBRIDTH": 21, "HYBRIDPL": 22, "MAXJUTT": 23, "MAXCOMP": 24,
-        "SYNCHTHAV": 13, "SYNCHTHAVNOABS": 14, "BREMS": 5, "SYNCHTHBREMS": 27, "RHO": 12}    # emis.f90:11-18
+        "POLSYNCHSYMTH": 15, "SYNCHTHAV": 13, "SYNCHTHAVNOABS": 14, "BREMS": 5, "SYNCHTHBREMS": 27, "RHO": 12}    # emis.f90:11-18
 INTEG = {"lsoda": 0, "delo": 1, "formal": 2, "lsodasph": 3}          # rad_trans.f90:29-37
 
 

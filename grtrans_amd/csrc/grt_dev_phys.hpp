@@ -508,6 +508,9 @@ GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, do
 // one sincos, a cube root instead of two pow(), every x^c as exp(c log x) over two logs, the constant
 // 2^(-1/3) 3^(-23/6) pi 1e4 folded, K_0 and K_1 evaluated once (K_2 = K_0 + 2 theta_e K_1) -- and the per-point
 // seed+Newton division.  Values agree with the literal routine to rounding (tests/test_hostsim_fast.py).
+// SYM: POLSYNCHSYMTH (sympolemisth, polsynchemis.f90:915-969) -- the Pandya et al. (2016) fitting functions replace the
+// emissivities (absorption by Kirchhoff's law as before), the Faraday coefficients are the same.
+template <bool SYM = false>
 GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double theta, double *e) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
   const double nucminval = 1.0, thetaemin = 1e-10, s3 = 1.7320508075688772;
@@ -527,8 +530,22 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   const double iqx = 2.5651 * (1.0 + .93193 * i13 + .499873 * i23) * ex;
   const double ivx = (1.81384 * ixm + 3.42319 * i23 + 0.0292545 * frcp(fsqrt(xm)) + 2.03773 * i13) * ex;
   const double jfac = (ec * ec / c / s3 / 2.0) * n * frcp(th2) * nu;
-  const double ji = jfac * iix, jq = jfac * iqx;
-  const double jv = (4.0 * (ec * ec) / c / 3.0 / s3) * fdiv(cth, sth) * n / 2.0 * frcp(th2 * thetae) * nu * ivx;
+  double ji = jfac * iix, jq = jfac * iqx;
+  double jv = (4.0 * (ec * ec) / c / 3.0 / s3) * fdiv(cth, sth) * n / 2.0 * frcp(th2 * thetae) * nu * ivx;
+  if (SYM) {
+    const double nucs = ec * B / m / c / 2.0 / pi + nucminval;
+    const double lxs = log(nu / (2.0 / 9.0 * nucs * th2 * sth));          // log x
+    const double x16 = exp(lxs / 6.0), x13s = x16 * x16, sqx = x13s * x16;  // x^(1/6), x^(1/3), sqrt(x)
+    const double lte = log(thetae), t2425 = exp(0.96 * lte);
+    const double c1112 = 1.8877486253633870;                                // 2^(11/12)
+    const double pf = 1.4142135623730951 * pi / 27.0 * sth;
+    const double jis = pf * sq(sqx + c1112 * x16);
+    const double jqs = -pf * sq(sqx + (7.0 * t2425 + 35.0) / (10.0 * t2425 + 75.0) * c1112 * x16);
+    const double jvs = -(37.0 - 87.0 * sin(theta - 28.0 / 25.0)) / 100.0 / (thetae + 1.0) *
+                       exp(5.0 / 3.0 * log(1.0 + (exp(0.6 * lte) / 25.0 + 7.0 / 10.0) * exp(0.36 * lxs)));
+    const double fac = n * (ec * ec) / c * nucs * exp(-x13s);
+    ji = fac * jis; jq = -fac * jqs; jv = -fac * jvs;
+  }
   const double ibn = frcp(bnu(T, nu));
   const double ai = ji * ibn, aq = jq * ibn, av = jv * ibn;
   const double wp2 = 4.0 * pi * n * (ec * ec) / m;

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
             polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
           }
           else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_POLSYNCHSYMTH) polsynchth_fast<true>(nu, ncgs, bcgs, tcgs, ang, e11);
           else if (EMIS == GRT_EMIS_MAXJUTT) {
             // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): thermal components w_i n at T delta^i / sum_i w_i delta^i
             const GrtEmis emj = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
@@ -726,6 +727,18 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_HYBRIDTHPL)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHSYMTH)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHSYMTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_SYNCHTHAV)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_SYNCHTHAV)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_SYNCHTHAV)

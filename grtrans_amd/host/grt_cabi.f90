@@ -11,7 +11,7 @@ module grt_cabi
   integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
        GRT_EMIS_BB = 8, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22, &
        GRT_EMIS_MAXJUTT = 23, GRT_EMIS_MAXCOMP = 24, GRT_EMIS_SYNCHTHAV = 13, GRT_EMIS_SYNCHTHAVNOABS = 14, &
-       GRT_EMIS_BREMS = 5, GRT_EMIS_SYNCHTHBREMS = 27, GRT_EMIS_RHO = 12
+       GRT_EMIS_BREMS = 5, GRT_EMIS_SYNCHTHBREMS = 27, GRT_EMIS_RHO = 12, GRT_EMIS_POLSYNCHSYMTH = 15
 
   type, bind(C) :: grt_camera          ! GrtCam
      real(c_double) :: a1, a2, b1, b2

@@ -112,6 +112,7 @@ contains
     case ('HYBRIDPL'); emis_id = GRT_EMIS_HYBRIDPL
     case ('MAXJUTT'); emis_id = GRT_EMIS_MAXJUTT
     case ('MAXCOMP'); emis_id = GRT_EMIS_MAXCOMP
+    case ('POLSYNCHSYMTH'); emis_id = GRT_EMIS_POLSYNCHSYMTH
     case ('SYNCHTHAV'); emis_id = GRT_EMIS_SYNCHTHAV
     case ('SYNCHTHAVNOABS'); emis_id = GRT_EMIS_SYNCHTHAVNOABS
     case ('BREMS'); emis_id = GRT_EMIS_BREMS

@@ -35,7 +35,7 @@ extern "C" {
  * fluid.f90:40-43, emis.f90:11-18, rad_trans.f90:29-37 */
 enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19, GRT_FLUID_KORAL3D = 25, GRT_FLUID_KORAL3D_DISK = 26,
        GRT_FLUID_IHARM = 29 };
-enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8,
+enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_POLSYNCHSYMTH = 15 /* sympolemisth, polsynchemis.f90:915-1010: Pandya et al. fits */, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8,
        /* thermal + power-law electron populations (emis.f90:16-17, :473-490): K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep
           one population's emission with the total absorption and Faraday coefficients */
        GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22,

@@ -129,6 +129,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       for (int c = 4; c < 11; ++c) e[c] = eth[c] + epl[c];
     }
     else if (S.emis == 8) { for (int c = 0; c < 11; ++c) e[c] = 0.0; e[0] = bnu(w.tcgs[i], nu); }   // bbemis, emis.f90:162-168
+    else if (S.emis == 15) sympolemisth(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], w.ang[i], e);          // emis.f90:496-497
     else if (S.emis == 13) synchemis(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], e);                       // emis.f90:532-533
     else if (S.emis == 14) { synchemis(nu, w.ncgs[i], w.bcgs[i], w.tcgs[i], e); e[4] = 0.0; }      // synchemisnoabs
     else if (S.emis == 5) brememis_heroic(nu, w.ncgs[i], w.tcgs[i], e);                             // emis.f90:538-539
@@ -268,6 +269,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   else return -1;
   S.mdot = mdot; S.muval = muval;
   if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8;
+  else if (en == "POLSYNCHSYMTH") S.emis = 15;
   else if (en == "SYNCHTHAV") S.emis = 13; else if (en == "SYNCHTHAVNOABS") S.emis = 14; else if (en == "BREMS") S.emis = 5;
   else if (en == "SYNCHTHBREMS") S.emis = 27; else if (en == "RHO") S.emis = 12;
   else if (en == "MAXJUTT") S.emis = 23;
@@ -434,6 +436,11 @@ void grto_scalar_emis(int type, int n, const double *nu, const double *dens, con
     if (type == 27) { brememis_heroic(nu[i], dens[i], t[i], eb); e[0] += eb[0]; e[4] += eb[4]; }
     if (type == 12) e[0] = dens[i] * g[i];
   }
+}
+
+void grto_sympolemisth(int n, const double *nu, const double *dens, const double *b, const double *t, const double *th,
+                       double *eout) {
+  for (int i = 0; i < n; ++i) sympolemisth(nu[i], dens[i], b[i], t[i], th[i], &eout[11 * i]);
 }
 
 void grto_integrate(int iflag, int n, const double *x, const double *j /*[n][4]*/, const double *K /*[n][7]*/,

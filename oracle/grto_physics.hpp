@@ -377,6 +377,54 @@ inline double bnu(double T, double nu) {   // polsynchemis.f90:1014
   return b;
 }
 
+// sympolemisth  polsynchemis.f90:915-1010: Pandya et al. (2016) fitting functions for the thermal emissivities, absorption
+// from Kirchhoff's law, Faraday coefficients as in polsynchth (Shcherbakov 2008 with the reference's modifications)
+inline void sympolemisth(double nu, double n, double B, double T, double theta, double *e) {
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
+  const double nucminval = 1.0, thetaemin = 1e-10;
+  for (int q = 0; q < 11; ++q) e[q] = 0.0;
+  double thetae = k * T / m / (c * c) + thetaemin;
+  double nuc = ec * B / m / c / 2.0 / pi + nucminval;
+  double x = nu / (2.0 / 9.0 * nuc * (thetae * thetae) * std::sin(theta));
+  double t2425 = std::pow(thetae, 24.0 / 25.0);
+  double jis = std::sqrt(2.0) * pi / 27.0 * std::sin(theta) * sq(std::sqrt(x) + std::pow(2.0, 11.0 / 12.0) * std::pow(x, 1.0 / 6.0));
+  double jqs = -std::sqrt(2.0) * pi / 27.0 * std::sin(theta) *
+               sq(std::sqrt(x) + (7.0 * t2425 + 35.0) / (10.0 * t2425 + 75.0) * std::pow(2.0, 11.0 / 12.0) * std::pow(x, 1.0 / 6.0));
+  double jvs = -(37.0 - 87.0 * std::sin(theta - 28.0 / 25.0)) / 100.0 / (thetae + 1.0) *
+               std::pow(1.0 + (std::pow(thetae, 3.0 / 5.0) / 25.0 + 7.0 / 10.0) * std::pow(x, 9.0 / 25.0), 5.0 / 3.0);
+  double fac = n * (ec * ec) / c * nuc * std::exp(-std::pow(x, 1.0 / 3.0));
+  double ji = fac * jis, jq = -fac * jqs, jv = -fac * jvs;
+  double bnutnu = bnu(T, nu);
+  e[0] = ji; e[1] = jq; e[3] = jv;
+  e[4] = ji / bnutnu; e[5] = jq / bnutnu; e[7] = jv / bnutnu;
+  double wp2 = 4.0 * pi * n * (ec * ec) / m;
+  double omega0 = ec * B / m / c;
+  double xarg = thetae * std::sqrt(std::sqrt(2.0) * std::sin(theta) * (1e3 * omega0 / 2.0 / pi / nu));
+  auto jffunc = [&](double xx) {
+    double extraterm = (.011 * std::exp(-xx / 47.2) - std::pow(2.0, -1.0 / 3.0) / std::pow(3.0, 23.0 / 6.0) * pi * 1e4 *
+                                                            std::pow(xx + 1e-16, -8.0 / 3.0)) *
+                       (0.5 + 0.5 * std::tanh((std::log(xx) - std::log(120.0)) / 0.1));
+    return 2.011 * std::exp(-std::pow(xx, 1.035) / 4.7) - std::cos(xx / 2.0) * std::exp(-std::pow(xx, 1.2) / 2.73) -
+           .011 * std::exp(-xx / 47.2) + extraterm;
+  };
+  auto shgmfunc = [&](double xx) {
+    return (double)0.43793091f * std::log(1.0 + (double)0.00185777f * std::pow(xx, (double)1.50316886f));
+  };
+  double eps11m22, eps12;
+  double w4 = std::pow(2.0 * pi * nu, 4), w3 = std::pow(2.0 * pi * nu, 3);
+  if (thetae > 1e-2) {
+    eps11m22 = jffunc(xarg) * wp2 * (omega0 * omega0) / w4 *
+               (besselk1(1.0 / thetae) / besselk(2, 1.0 / thetae) + 6.0 * thetae) * sq(std::sin(theta));
+    double step = 0.5 + 0.5 * std::tanh((thetae - 1.0) / 0.05);
+    eps12 = wp2 * omega0 / w3 * (besselk0(1.0 / thetae) - step * shgmfunc(xarg)) / besselk(2, 1.0 / thetae) * std::cos(theta);
+  } else {
+    eps11m22 = jffunc(xarg) * wp2 * (omega0 * omega0) / w4 * (1.0 + 6.0 * thetae) * sq(std::sin(theta));
+    eps12 = wp2 * omega0 / w3 * std::cos(theta);
+  }
+  e[10] = 2.0 * pi * nu / c * eps12;
+  e[8] = 2.0 * pi * nu / 2.0 / c * eps11m22;
+}
+
 // synchemis  polsynchemis.f90:865-904: angle-averaged thermal synchrotron (Mahadevan et al. 1996), absorption from LTE
 inline void synchemis(double nu, double n, double B, double T, double *e) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;

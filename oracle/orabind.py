@@ -172,6 +172,14 @@ def polsynchth(nu, dens, b, t, th):
     return e
 
 
+def sympolemisth(nu, dens, b, t, th):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (nu, dens, b, t, th)]
+    n = len(arrs[0])
+    e = np.zeros((n, 11))
+    lib().grto_sympolemisth(C.c_int(n), *[_dp(a) for a in arrs], _dp(e))
+    return e
+
+
 def scalar_emis(etype, nu, dens, b, t, g):
     arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (nu, dens, b, t, g)]
     n = len(arrs[0])

@@ -108,6 +108,7 @@ void hs_sphacc_point(const float *tab, double r, double *out11) {
   for (int i = 0; i < 4; ++i) { out11[3 + i] = f.u[i]; out11[7 + i] = f.b[i]; }
 }
 void hs_polsynchth(double nu, double n, double B, double T, double th, double *e11) { polsynchth_fast(nu, n, B, T, th, e11); }   // the form the kernel runs
+void hs_sympol(double nu, double n, double B, double T, double th, double *e11) { polsynchth_fast<true>(nu, n, B, T, th, e11); }
 void hs_scalar_emis(int type, double nu, double n, double B, double T, double g, double *e11) { scalar_emis_fast(type, nu, n, B, T, g, e11); }
 void hs_maxjutt(double nu, double n, double B, double T, double th, int nother, const double *oa, double *e11) { maxjutt_fast(nu, n, B, T, th, nother, oa, e11); }
 void hs_maxcomp(double nu, double n, double B, double T, double th, int nother, const double *oa, double *e11) { maxjutt_fast(nu, n, B, T, th, nother, oa, e11, true); }

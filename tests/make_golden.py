@@ -467,6 +467,34 @@ def unpolarized(nx=32, nup=120):
     np.savez_compressed(os.path.join(G, "unpolarized_%dx%dx%d.npz" % (nx, nx, nup)), **out)
 
 
+def sympol(nx=32, nup=120):
+    # POLSYNCHSYMTH (sympolemisth, polsynchemis.f90:915-1010): Pandya et al. fitting functions, polarized
+    import tempfile
+    import make_harm_dump
+    import make_harm3d_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        make_harm_dump.write(td, n=64)
+        make_harm3d_dump.write(td, **HARM3D_ZONES)
+        for iname in ("formal", "delo"):
+            kw = dict(HARM); kw.update(ename="POLSYNCHSYMTH")
+            r = R.Ref(nn=(nx, nx, nup), iname=iname, datadir=td, **kw)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+            out["harm_" + iname] = pix[0]; out["harm_npts"] = npts
+        kw = dict(HARM); kw.update(ename="POLSYNCHSYMTH", nvals=1)
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+        out["harm_nvals1"] = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)[0][0]
+        kw = dict(HARM3D); kw.update(ename="POLSYNCHSYMTH")
+        r = R.Ref(nn=(nx, nx, nup), iname="formal", datadir=td, **kw)
+        pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=1)
+        out["harm3d_formal"] = pix[0]; out["harm3d_npts"] = npts
+    kw = dict(SPHACC); kw.update(ename="POLSYNCHSYMTH")
+    r = R.Ref(nn=(nx, nx, nup), iname="formal", **kw)
+    pix, npts, _ = r.trace(1, nx * nx, [FREQ_SPHACC], nthreads=1)
+    out["sphacc_formal"] = pix[0]; out["sphacc_npts"] = npts
+    np.savez_compressed(os.path.join(G, "sympol_%dx%dx%d.npz" % (nx, nx, nup)), **out)
+
+
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
@@ -489,4 +517,5 @@ if __name__ == "__main__":
     iharm()
     koral3d()
     unpolarized()
+    sympol()
     print("golden fixtures written to", os.path.abspath(G))

@@ -487,3 +487,20 @@ def test_scalar_emissivities_match_oracle(L, etype):
     for c in (0, 4):
         ok = np.abs(got[:, c] - want[:, c]) <= 1e-11 * np.abs(want[:, c]) + 1e-300
         assert ok.all(), (c, np.where(~ok)[0][:5], got[~ok][:3, c], want[~ok][:3, c])
+
+
+def test_polsynchsymth_matches_oracle(L):
+    # POLSYNCHSYMTH: polsynchth_fast<true> (Pandya et al. fits for j, Kirchhoff absorption, the Faraday part of POLSYNCHTH)
+    # against the oracle's literal sympolemisth
+    rng = np.random.default_rng(15)
+    n = 4000
+    nu = 10 ** rng.uniform(9.5, 13.5, n); dens = 10 ** rng.uniform(2, 10, n); b = 10 ** rng.uniform(-2, 3.5, n)
+    t = 10 ** rng.uniform(8.5, 12.0, n); th = rng.uniform(0.02, np.pi - 0.02, n)
+    want = O.sympolemisth(nu, dens, b, t, th)
+    L.hs_sympol.argtypes = [C.c_double] * 5 + [C.c_void_p]
+    got = np.zeros((n, 11))
+    for i in range(n):
+        L.hs_sympol(nu[i], dens[i], b[i], t[i], th[i], got[i].ctypes.data)
+    scale = np.abs(want[:, [0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 10]]) + np.abs(want[:, [0] * 4 + [4] * 4 + [10, 10, 8]]) * np.array([0] * 8 + [1, 1, 1]) + 1e-300
+    err = np.abs(got - want) / scale
+    assert err.max() < 1e-9, (err.max(), np.unravel_index(err.argmax(), err.shape))

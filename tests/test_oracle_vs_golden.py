@@ -450,3 +450,28 @@ def test_scalar_emissivities_nvals1(tmp_path):
         ref = g[key].reshape(1024, 1)
         assert np.array_equal(pix[0], ref), key
     assert np.abs(g["harm_SYNCHTHAV_1_formal"] - g["harm_SYNCHTHAVNOABS_1_formal"]).max() > 0.1 * np.abs(g["harm_SYNCHTHAV_1_formal"]).max()
+
+
+def test_polsynchsymth_pandya_fits(tmp_path):
+    # POLSYNCHSYMTH (sympolemisth, polsynchemis.f90:915-1010) on the 2-D and 3-D HARM dumps and the Bondi flow, formal / delo /
+    # nvals = 1; golden = compiled reference (99.9 % of the fp32 values bit-equal; the Faraday-thick 3-D dump 3e-7)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    import make_harm3d_dump
+    import make_harm_dump
+    g = load("sympol_32x32x120.npz")
+    make_harm3d_dump.write(str(tmp_path), **make_golden.HARM3D_ZONES)
+    make_harm_dump.write(str(tmp_path), n=64)
+    for key, nk, iname, fr, kw in (("harm_formal", "harm_npts", "formal", make_golden.FREQ_HARM, dict(make_golden.HARM)),
+                                   ("harm_delo", "harm_npts", "delo", make_golden.FREQ_HARM, dict(make_golden.HARM)),
+                                   ("harm_nvals1", "harm_npts", "formal", make_golden.FREQ_HARM, dict(make_golden.HARM, nvals=1)),
+                                   ("harm3d_formal", "harm3d_npts", "formal", make_golden.FREQ_HARM, dict(make_golden.HARM3D)),
+                                   ("sphacc_formal", "sphacc_npts", "formal", make_golden.FREQ_SPHACC, dict(make_golden.SPHACC))):
+        kw.update(ename="POLSYNCHSYMTH")
+        o = O.Oracle(nn=(32, 32, 120), iname=iname, datadir=str(tmp_path), **kw)
+        pix, npts, _ = o.trace(1, 1024, [fr], nthreads=8)
+        assert np.array_equal(npts, g[nk])
+        ref = g[key].reshape(pix[0].shape).astype(float)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 1e-6, (key, err)
