@@ -482,7 +482,8 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (em->type == GRT_EMIS_MAXCOMP && (em->nother < 3 || em->nother > 8)) return GRT_E_BADARG;
   const bool sym_ok = em->type == GRT_EMIS_POLSYNCHSYMTH && nextra == 0 &&
                       (fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || fluid_model == GRT_FLUID_SPHACC);
-  if (!pair_ok && !scalar_ok && !sym_ok) return GRT_E_UNSUPPORTED;
+  const bool synchpl_ok = em->type == GRT_EMIS_SYNCHPL && fluid_model == GRT_FLUID_FFJET && nvals == 1 && nextra == 0;   // nvals = 1 only, as the scalar set
+  if (!pair_ok && !scalar_ok && !sym_ok && !synchpl_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   // nextra: 0, or the 19 ray diagnostics of extra=1 for nup>1 (pgrtrans.f90:108-114)
   if (cam->standard != 1 || cam->nup < 2 || (nvals != 4 && nvals != 1) || (nextra != 0 && nextra != 19)) return GRT_E_UNSUPPORTED;
@@ -495,7 +496,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (fluid_model == GRT_FLUID_IHARM && !C.have_iharm) return GRT_E_NOFLUID;
   const bool is_koral = (fluid_model == GRT_FLUID_KORAL3D || fluid_model == GRT_FLUID_KORAL3D_DISK);
   if (is_koral && !C.have_koral) return GRT_E_NOFLUID;
-  if ((em->type == GRT_EMIS_POLSYNCHPL || (em->type >= GRT_EMIS_HYBRIDTHPL && em->type <= GRT_EMIS_HYBRIDPL)) && !C.have_tables) return GRT_E_NOTABLES;
+  if ((em->type == GRT_EMIS_POLSYNCHPL || em->type == GRT_EMIS_SYNCHPL || (em->type >= GRT_EMIS_HYBRIDTHPL && em->type <= GRT_EMIS_HYBRIDPL)) && !C.have_tables) return GRT_E_NOTABLES;
   GrtFluidDev fd{};
   fd.fj = C.ffjet;
   fd.sphacc = C.d_sphacc;

@@ -290,7 +290,8 @@ GRT_HD double interp_fast(double lx, int ix, int iy, const double *xv, int nx, c
 // The frequency-independent half of polsynchpl_fast, computed once per point and shared by all frequencies
 struct PLPoint { double itanth, nubperp, lnub, A, kperp, omega0; };
 
-GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P) {
+// plain: SYNCHPL (synchpl, polsynchemis.f90:657) forms nu_B,perp with sin(th) itself, POLSYNCHPL with sin(th) + 1e-10
+GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P, bool plain = false) {
   const double nufloor = 1e-10, thsafe = 1e-10;
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
   double s0, c0;
@@ -301,7 +302,7 @@ GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double 
 #endif
   double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe;
   P.itanth = frcp(tanth);
-  double sinth = s0 + thsafe;
+  double sinth = s0 + (plain ? 0.0 : thsafe);
   P.nubperp = ec * B / m / c / 2.0 / pi * sinth + nufloor;
   P.lnub = log(P.nubperp);
   P.A = C.A0 * nnth;

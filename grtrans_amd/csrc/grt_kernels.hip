@@ -388,7 +388,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       else if (FLUID == GRT_FLUID_HARM3D) harm3d_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       PLPoint plp;
       if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
-        polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp);
+        polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp,
+                         IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
       const double lg = log(g);
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
             GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
             plck.iy = 0;                                   // the LDS copy holds the p-bin's row only
             polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
+            // SYNCHPL (nvals = 1; same instantiation): j_I with the REAL(4) sqrt(3.) of polsynchemis.f90:665
+            if (IFLAG == GRT_INT_QUAD && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL)
+              e11[0] *= (double)1.7320508075688772f / 1.7320508075688772;
           }
           else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
           else if (EMIS == GRT_EMIS_POLSYNCHSYMTH) polsynchth_fast<true>(nu, ncgs, bcgs, tcgs, ang, e11);
@@ -684,6 +688,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   if (nlive <= 0) return hipSuccess;
   if (emis == GRT_EMIS_HYBRIDTH || emis == GRT_EMIS_HYBRIDPL) emis = GRT_EMIS_HYBRIDTHPL;   // one instantiation, em->type selects
   if (emis == GRT_EMIS_MAXCOMP) emis = GRT_EMIS_MAXJUTT;
+  if (emis == GRT_EMIS_SYNCHPL) emis = GRT_EMIS_POLSYNCHPL;
   if (emis == GRT_EMIS_SYNCHTHAVNOABS || emis == GRT_EMIS_BREMS || emis == GRT_EMIS_SYNCHTHBREMS || emis == GRT_EMIS_RHO) emis = GRT_EMIS_SYNCHTHAV;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \

@@ -105,6 +105,7 @@ contains
     cur_fluid = fluid_id
     select case (trim(ename))
     case ('POLSYNCHPL'); emis_id = GRT_EMIS_POLSYNCHPL
+    case ('SYNCHPL'); emis_id = GRT_EMIS_SYNCHPL
     case ('POLSYNCHTH'); emis_id = GRT_EMIS_POLSYNCHTH
     case ('BB'); emis_id = GRT_EMIS_BB
     case ('HYBRIDTHPL'); emis_id = GRT_EMIS_HYBRIDTHPL

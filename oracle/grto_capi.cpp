@@ -94,6 +94,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
       harm_convert(w.f[i], S.mbh, S.mdot, S.muval, S.gmin, w.ncgs[i], w.ncgsnth[i], w.bcgs[i], w.tcgs[i]);
     }
     if (S.emis == 4) polsynchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);
+    else if (S.emis == 3) synchpl(S.pl, nu, w.ncgsnth[i], w.bcgs[i], w.ang[i], p, gmin, gmax, e);       // emis.f90:527-531
     else if (S.emis == 23 || S.emis == 24) {
       // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): a sum of thermal components with densities w_i n and
       // temperatures T delta^i / sum_i w_i delta^i, weights normalised
@@ -269,7 +270,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   else return -1;
   S.mdot = mdot; S.muval = muval;
   if (en == "POLSYNCHPL") S.emis = 4; else if (en == "POLSYNCHTH") S.emis = 2; else if (en == "BB") S.emis = 8;
-  else if (en == "POLSYNCHSYMTH") S.emis = 15;
+  else if (en == "POLSYNCHSYMTH") S.emis = 15; else if (en == "SYNCHPL") S.emis = 3;
   else if (en == "SYNCHTHAV") S.emis = 13; else if (en == "SYNCHTHAVNOABS") S.emis = 14; else if (en == "BREMS") S.emis = 5;
   else if (en == "SYNCHTHBREMS") S.emis = 27; else if (en == "RHO") S.emis = 12;
   else if (en == "MAXJUTT") S.emis = 23;

@@ -324,6 +324,30 @@ inline void polsynchpl(const PLTables &T, double nu, double nnth, double B, doub
   e[8] = kstarq; e[9] = 0.0; e[10] = kstarv;
 }
 
+// synchpl  polsynchemis.f90:633-698: Stokes-I half of polsynchpl (no thsafe in sin(th), a REAL(4) sqrt(3.) in jfac); the
+// other nine columns are never assigned by the reference, so it is an nvals = 1 emissivity
+inline void synchpl(const PLTables &T, double nu, double nnth, double B, double th, double p, double gmin, double gmax, double *e) {
+  const double nufloor = 1e-10;
+  const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
+  double nubperp = ec * B / m / c / 2.0 / pi * std::sin(th) + nufloor;
+  double nucmin = 3.0 / 2.0 * nubperp * (gmin * gmin), nucmax = 3.0 / 2.0 * nubperp * (gmax * gmax);
+  double omega0 = nubperp * 2.0 * pi, omega = nu * 2.0 * pi;
+  double xmin = nu / nucmin, xmax = nu / nucmax;
+  double A = (p - 1.0) * nnth / (std::pow(gmin, 1.0 - p) - std::pow(gmax, 1.0 - p));
+  int ix1, ix2, iy1, iy2;
+  find_inds_gxp(xmax, p, T.gx, ix2, iy2);
+  find_inds_gxp(xmin, p, T.gx, ix1, iy1);
+  double gxfac = interp_gxp(xmax, ix2, iy2, T.gx, T.gy) - interp_gxp(xmin, ix1, iy1, T.gx, T.gy);
+  find_inds_gxp(xmin, p, T.xv, ix1, iy1);
+  find_inds_gxp(xmax, p, T.xv, ix2, iy2);
+  double gafac = interp_gxp(xmax, ix2, iy2, T.xv, T.ya) - interp_gxp(xmin, ix1, iy1, T.xv, T.ya);
+  double jfac = A * ec * ec / c * (double)std::sqrt(3.0f) / 4.0 * std::pow(3.0 * nubperp / 2.0 / nu, (p - 1) / 2.0) * nubperp;
+  double afac = std::pow(2.0 * pi, 3) * A * ec * ec * std::sqrt(3.0) * omega0 * (p + 2.0) / 32.0 / (pi * pi) / m / c /
+                (omega * omega) * std::pow(2.0 * omega / 3.0 / omega0, -p / 2.0);
+  for (int q = 0; q < 11; ++q) e[q] = 0.0;
+  e[0] = jfac * gxfac; e[4] = afac * gafac;
+}
+
 // bessel.f90
 inline double poly(double x, const double *c, int m) {
   double r = c[m - 1];

@@ -180,6 +180,9 @@ def nvals1():
     out["ffjet_ivals"], out["ffjet_npts"], _ = r.trace(1, 1024, [FREQ], nthreads=8)
     r = R.Ref(nn=(32, 32, 100), iname="delo", nvals=1, **SPHACC)
     out["sphacc_ivals"], out["sphacc_npts"], _ = r.trace(1, 1024, [FREQ_SPHACC], nthreads=1)
+    # SYNCHPL (synchpl, polsynchemis.f90:633-698): the Stokes-I half of POLSYNCHPL, an nvals = 1 emissivity
+    r = R.Ref(nn=(32, 32, 100), iname="formal", nvals=1, **dict(FFJET, ename="SYNCHPL"))
+    out["ffjet_synchpl_ivals"], _, _ = r.trace(1, 1024, [FREQ], nthreads=8)
     np.savez_compressed(os.path.join(G, "nvals1_32x32x100.npz"), **out)
 
 

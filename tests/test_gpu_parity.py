@@ -262,6 +262,17 @@ def test_nvals1_quadrature_vs_reference_golden(dev):
         em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
         pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "SPHACC", em, [FREQ_SPHACC], iname, nvals=1)
         assert np.array_equal(status, g["sphacc_npts"]) and stokes_err(pix, g["sphacc_ivals"]) < STOKES_TOL
+    # SYNCHPL: the Stokes-I half of POLSYNCHPL with its own constants (same kernel instantiation, em.type selects); nvals = 1 only
+    from grtrans_amd import capi
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (32, 32, 100), 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("SYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "FFJET", em, [FREQ], "formal", nvals=1)
+    assert np.array_equal(status, g["ffjet_npts"])
+    e = np.abs(pix - g["ffjet_synchpl_ivals"]).max() / np.abs(g["ffjet_synchpl_ivals"]).max()
+    e_pol = np.abs(pix - g["ffjet_ivals"]).max() / np.abs(g["ffjet_synchpl_ivals"]).max()      # the two goldens differ by 1.2e-7
+    assert e < STOKES_TOL and e < 0.6 * e_pol, (e, e_pol)
+    with pytest.raises(capi.GrtError):
+        capi.trace_tile(cam, 1, 1024, "FFJET", em, [FREQ], "formal")
 
 
 def test_extra_ray_diagnostics_vs_reference(dev):

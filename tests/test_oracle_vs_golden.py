@@ -475,3 +475,18 @@ def test_polsynchsymth_pandya_fits(tmp_path):
         ref = g[key].reshape(pix[0].shape).astype(float)
         err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
         assert err.max() < 1e-6, (key, err)
+
+
+def test_synchpl_nvals1():
+    # SYNCHPL (synchpl, polsynchemis.f90:633-698): the Stokes-I half of POLSYNCHPL with its own constants; golden = compiled
+    # reference (differs from POLSYNCHPL at nvals = 1 by 1.2e-7: sin(th) without the 1e-10 guard, a REAL(4) sqrt(3.))
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import make_golden
+    g = load("nvals1_32x32x100.npz")
+    o = O.Oracle(nn=(32, 32, 100), iname="formal", nvals=1, **dict(make_golden.FFJET, ename="SYNCHPL"))
+    pix, npts, _ = o.trace(1, 1024, [make_golden.FREQ], nthreads=8)
+    assert np.array_equal(npts, g["ffjet_npts"])
+    ref = g["ffjet_synchpl_ivals"]
+    assert np.abs(pix - ref).max() <= 1e-7 * np.abs(ref).max()
+    assert np.abs(ref - g["ffjet_ivals"]).max() > 5e-8 * np.abs(ref).max()
