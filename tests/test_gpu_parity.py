@@ -273,6 +273,14 @@ def test_nvals1_quadrature_vs_reference_golden(dev):
     assert e < STOKES_TOL and e < 0.6 * e_pol, (e, e_pol)
     with pytest.raises(capi.GrtError):
         capi.trace_tile(cam, 1, 1024, "FFJET", em, [FREQ], "formal")
+    # the reference's "polunpol" regression problem (run_grtrans_test_problems_public.py:127-143): SYNCHPL nvals = 1 at
+    # 100x100x400 against Stokes I of the shipped test_grtrans_ffjet.p.  Its pass mark 1e-2 is for LSODA on both sides; the
+    # fixed-step quadrature at nup = 400 is 1.2 % from the LSODA vector (formal / DELO: 2 %)
+    gp = np.load(os.path.join(G, "test_grtrans_ffjet_lsoda.npz"))["ivals"].astype(float)
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (100, 100, 400), 0.998, 0.906, 0.01, -0.5)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 10000, "FFJET", em, [FREQ], "formal", nvals=1)
+    terr = np.abs(pix[0, :, 0] - gp[:, 0]).sum() / np.abs(gp[:, 0]).sum()
+    assert terr < 0.015, terr
 
 
 def test_extra_ray_diagnostics_vs_reference(dev):
