@@ -1125,6 +1125,35 @@ def test_polsynchsymth_vs_reference_golden(tmp_path):
         d.close()
 
 
+def test_reference_regression_problem_sphacc_synchthav_through_the_fortran_host(tmp_path, monkeypatch):
+    # the same problem through the file-based branch of the reference's script (write_grtrans_inputs -> ./grtrans ->
+    # read_grtrans_output -> calc_spec with its 2*3.14), i.e. the Fortran 90 host: 25 cameras of a 10000 x 1 strip, nvals = 1
+    import subprocess
+    from grtrans_amd import grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "test_grtrans_sphacc_lsoda.npz"))
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', fname='SPHACC', nfreq=25, nmu=1, fmin=1e8, fmax=1e15, ename='SYNCHTHAV', nvals=1, spin=0., mbh=1.,
+                           standard=1, nn=[10000, 1, 100], gridvals=[0., 400., 0., 0.], uout=.0025, oname='sphacc_abs.out', iname='formal',
+                           cflag=0)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    gi = g["intensity"].astype(float)
+    terr = np.sum(np.abs(x.ivals[:, 0, 14] - gi)) / np.sum(np.abs(gi))
+    assert terr < 0.1 and terr < 0.03, terr
+    x.calc_spec(25)
+    gs = g["spectrum"].astype(float)
+    terr = np.sum(np.abs(x.spec - gs)) / np.sum(np.abs(gs))
+    assert terr < 0.1, terr
+    y = gb.grtrans()
+    y.run_pgrtrans(fname='SPHACC', nfreq=25, nmu=1, fmin=1e8, fmax=1e15, ename='SYNCHTHAV', nvals=1, spin=0., mbh=1., standard=1,
+                   nn=[10000, 1, 100], gridvals=[0., 400., 0., 0.], uout=.0025, iname='formal')
+    assert np.array_equal(y.ivals[0].astype(np.float32), x.ivals[:, 0, :].astype(np.float32))      # both hosts, bit for bit
+
+
 def test_reference_regression_problem_sphacc_synchthav_through_the_harness():
     # the reference's own first regression problem, called the way run_grtrans_test_problems_public.py:27-36 calls it
     # (pgrtrans branch), against the golden vectors the reference ships (LSODA; its criterion sum|x-g|/sum|g| < 0.1) and
