@@ -20,6 +20,7 @@
 // Splitting the two keeps each kernel's live state small (the fused version needed 512 registers per
 // lane plus scratch); the 24 B/step that cross HBM between them are part of the record anyway.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "grt_dev_cubic.hpp"
 #include "grt_dev_disk.hpp"
 
@@ -44,7 +45,7 @@ using namespace grtd;
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
-                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time) {
+                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time, double polar_l2) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
   GrtRay R;
@@ -61,7 +62,10 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   const bool alive = inr && R.npts > 0;
   // fast class: four distinct real roots (a != 0), or the three real roots of a Schwarzschild camera (a == 0)
   // ... or two real roots and a complex pair (ncase 5: the plunging rays; no turning point in u, no mu-fill segment)
-  const bool quart = alive && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
+  // near-polar rays (l^2 below polar_l2 (q2 + a^2): the characteristic of the azimuthal Pi integrals within ~polar_l2 of 1) stay on the generic, reference-literal path: tools/fuzz_cameras.py found
+  // one such ray (l = -4e-5) whose azimuth came out of the fast path 1.49 rad off after crossing the equator on the device
+  const bool polar = R.l * R.l < polar_l2 * (R.q2 + cam.a * cam.a);
+  const bool quart = alive && !polar && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
 #if !defined(GRT_NO_CPLX_FAST)
                                (R.ncase == 5 && R.tpr == 0 && cam.a != 0.0 && R.q2 != 0.0));
 #else
@@ -625,13 +629,18 @@ extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mb
 }
 
 // ---- host-side launch helpers (called from grt_api.cpp) ----
+#ifndef GRT_POLAR_L2_DEFAULT
+#define GRT_POLAR_L2_DEFAULT 1.e-6
+#endif
 extern "C" size_t grt_sizeof_realray(void) { return GRT_RR_STRIDE; }
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
                                        int *ray_npts, int *live, int *counters, void *rrays, int need_time) {
   int blocks = (nrays + 255) / 256;
+  // GRT_POLAR_L2: experiment knob for the near-polar routing threshold (tools/polar_phi.py); the default is the product's
+  static const double polar_l2 = std::getenv("GRT_POLAR_L2") ? std::atof(std::getenv("GRT_POLAR_L2")) : GRT_POLAR_L2_DEFAULT;
   hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
-                     (char *)rrays, need_time);
+                     (char *)rrays, need_time, polar_l2);
   return hipGetLastError();
 }
 

@@ -1182,3 +1182,39 @@ def test_reference_regression_problem_sphacc_synchthav_through_the_harness():
     assert np.array_equal(x.status if hasattr(x, "status") else npts, npts)
     for k in range(25):
         assert stokes_err(x.ivals[:, :, k].T, ref[k]) < 2e-5, k
+
+
+def test_near_polar_ray_azimuth_on_a_3d_dump(tmp_path):
+    # a face-on camera whose pixel 90 has l = -4e-5: the ray passes within 1e-5 rad of the axis.  On the fast path its
+    # azimuth came out 1.49 rad off after the equator crossing on the device (found by tools/fuzz_cameras.py 400 21 all;
+    # only a 3-D fluid model sees phi): 27 % of the Stokes peak.  Such rays (l^2 < 1e-6 (q2 + a^2)) now take the generic path.
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_iharm_dump
+    from grtrans_amd import capi
+    from oracle import orabind
+    di, hi = make_iharm_dump.write(str(tmp_path), n1=32, n2=32, n3=16, metric=1)
+    gv = (-7.183576656227343, 4.3115989742937995, -11.852649562661194, -0.3574739321400511)
+    nn = (12, 12, 60)
+    o = orabind.Oracle(nn=nn, iname="formal", spin=0.9375, mu0=0.999, gridvals=gv, uout=0.04, fname="IHARM", ename="POLSYNCHTH", datadir=str(tmp_path),
+                       dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=3.)
+    ref, rn, _ = o.trace(1, 144, [FREQ_HARM], nthreads=0)
+    assert abs(o.camera()["l"][89]) < 1e-4
+    d = capi.Device(0)
+    try:
+        d.load_tables(); d.load_iharm(di, hi, 40, 0.9375)
+        cam = capi.make_camera(1, gv, nn, 0.9375, 0.999, 0.04, -0.5)
+        em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 3., 1e5, 3.5, muval=0.25, mdot=1e20)
+        capi.record_steps(True)
+        pix, _, status, _ = capi.trace_tile(cam, 1, 144, "IHARM", em, [FREQ_HARM], "formal")
+        n = int(status[89])
+        rec = capi.download_steps(89, 1, cam.nup + cam.next)[:, 0, :n]
+    finally:
+        capi.record_steps(False)
+        d.close()
+    assert np.array_equal(status, rn)
+    od = o.ray_dump(90, FREQ_HARM)
+    # azimuth along the near-polar ray: the reference's own formulas are ill-conditioned this close to the axis (device and
+    # oracle, both literal, differ by up to 2e-5 rad at l^2/(q2+a^2) ~ 1e-11: tools/polar_phi.py); the fast path was off by radians
+    assert np.abs(rec[2] - od["x"][:n, 3]).max() < 1e-4
+    assert stokes_err(pix[0], ref[0]) < STOKES_TOL

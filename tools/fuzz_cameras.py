@@ -28,6 +28,10 @@ MODELS = [
     ("HARM3D", "HYBRIDTHPL", dict(dfile="dump3d", hfile="dump3d_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=2.), dict(mbh=4e6, gmin=2., mdot=1e20), 2.3e11, 1e-5),
     ("IHARM", "POLSYNCHTH", dict(dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=3.), dict(mbh=4e6, gmin=3., mdot=1e20), 2.3e11, 2e-6),
     ("SPHACC", "POLSYNCHTH", dict(mbh=10., gmin=100.), dict(mbh=10., gmin=100., nfac=1.0, bfac=6.0), 2.41e11, 2e-6),
+    ("HARM", "SYNCHTHBREMS", dict(dfile="dump", hfile="dump040", findf=40, mbh=4e6, mdot=1.57e15, muval=0.25, gmin=1., nvals=1), dict(mbh=4e6, gmin=1., mdot=1.57e15), 2.3e11, 2e-6),
+    ("SPHACC", "SYNCHTHAV", dict(mbh=10., gmin=100., nvals=1), dict(mbh=10., gmin=100., nfac=1.0, bfac=6.0), 2.41e11, 2e-6),
+    ("IHARM", "POLSYNCHSYMTH", dict(dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=3.), dict(mbh=4e6, gmin=3., mdot=1e20), 2.3e11, 2e-6),
+    ("FFJET", "SYNCHPL", dict(nvals=1), dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 3.45e11, 2e-6),
     ("KORAL3D", "POLSYNCHTH", dict(dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5), dict(mbh=4e6, gmin=-1., nfac=1.5), 2.3e11, 2e-6),
 ]
 EXT = len(sys.argv) > 3 and sys.argv[3] in ("ext", "allext")      # also vary the power-law index, frequency count and tile
@@ -36,6 +40,7 @@ bad = 0; cond = 0
 for c in range(ncams):
     fname, ename, okw, ekw, freq, tol = MODELS[int(rng.integers(0, len(MODELS)))] if (len(sys.argv) > 3 and sys.argv[3] in ("all", "allext")) else MODELS[0]
     a = float(rng.choice([rng.uniform(0.01, 0.998), -rng.uniform(0.05, 0.99), 0.998, 0.5])) if fname == "FFJET" else 0.9375
+    nst = okw.get("nvals", 4)
     if fname == "SPHACC":
         a = float(rng.choice([0.0, 0.0, rng.uniform(0.01, 0.99)]))
     mu0 = float(rng.choice([rng.uniform(-0.99, 0.99), 0.0, 0.999]))
@@ -59,15 +64,15 @@ for c in range(ncams):
     capi.record_steps(rec)
     cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
     em = capi.make_emis(ename, ekw["mbh"], ekw.get("nfac", 1.0), ekw.get("bfac", 6.0), ekw["gmin"], 1e5, p1, muval=0.25, mdot=ekw.get("mdot", 0.0))
-    pix, _, status, _ = capi.trace_tile(cam, i1, i2, fname, em, freqs, iname)
+    pix, _, status, _ = capi.trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=okw.get("nvals", 4))
     ok_n = np.array_equal(status, rn)
     # pixels where the integrator overflowed (NaN or inf, as in the reference) must be the same pixels; the rest is compared
     err, same_nan, perf = 0.0, True, {}
     for k in range(len(freqs)):
         nanm = (~np.isfinite(ref[k])).any(axis=1) | (~np.isfinite(pix[k])).any(axis=1)
-        pk = np.abs(ref[k][~nanm]).max(axis=0) if (~nanm).any() else np.ones(4)
+        pk = np.abs(ref[k][~nanm]).max(axis=0) if (~nanm).any() else np.ones(nst)
         pk = np.maximum(pk, 1e-2 * pk[0])     # a Stokes that vanishes by symmetry is a sum of cancelling contributions
-        errs = np.abs(pix[k][~nanm] - ref[k][~nanm]).max(axis=0) / (pk + 1e-300) if (~nanm).any() else np.zeros(4)
+        errs = np.abs(pix[k][~nanm] - ref[k][~nanm]).max(axis=0) / (pk + 1e-300) if (~nanm).any() else np.zeros(nst)
         err = max(err, errs.max()); perf[k] = errs
         same_k = np.array_equal(~np.isfinite(ref[k]), ~np.isfinite(pix[k]))
         if not same_k:
@@ -113,8 +118,8 @@ for c in range(ncams):
         if err < 10 * floor and same_nan:
             flag = "  (ill-conditioned in the reference: it moves by %.1e itself when the frequency changes by 1e-13 or the camera by one ulp)" % floor; cond += 1
     bad += ("MISMATCH" in flag)
-    print("cam %2d %-8s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
-          (c, fname, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag, (" IQUV per frequency " + str(perf)) if flag else ""))
+    print("cam %2d %-8s %s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
+          (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag, (" IQUV per frequency " + str(perf)) if flag else ""))
     if only is not None:
         kb = max(perf, key=lambda k: perf[k].max()); freq = freqs[kb]      # detail: the worst frequency, traced alone
         pix, ref = [pix[kb]], [ref[kb]]
@@ -142,6 +147,12 @@ for c in range(ncams):
             print("      per-step record: max rel diff %s, largest change of the difference at step %d of %d" % (dI.max(axis=0), jump, n))
             for kk in range(max(0, jump - 2), min(n, jump + 3)):
                 print("        step %d r %.6f th %.9f rho %.6g bmag %.6g ang %.6g g %.6g tpm %d tpr %d  dI %s" % (kk, x[kk, 1], x[kk, 2], od["rho"][kk], od["bmag"][kk], od["ang"][kk], od["rshift"][kk], od["tpm"][kk], od["tpr"][kk], dI[kk]))
+            kp = int(np.argmax(np.abs(recd[2] - x[:, 3])))
+            print("        phi dev - ref along the ray:", np.array2string(recd[2] - x[:, 3], precision=6, max_line_width=220))
+            print("        geokerr_ray dphi (oracle):", np.array2string(np.asarray(gr["dphi"])[:8], precision=6), " l %.6e q2 %.6e alpha %.4f beta %.4f" % (o.camera()["l"][w], o.camera()["q2"][w], o.camera()["alpha"][w], o.camera()["beta"][w]))
+            jumps = [int(v) for v in np.where(np.abs(np.diff(recd[2] - x[:, 3])) > 1e-3)[0]]
+            for kk in sorted(set([q for jv in jumps for q in (jv - 1, jv, jv + 1, jv + 2) if 0 <= q < n] + list(range(max(0, kp - 1), min(n, kp + 2))))):
+                print("        point %d r %.6f th dev %.12f ref %.12f  phi dev %.9f ref %.9f  tpm %d tpr %d  mu %.3e" % (kk, x[kk, 1], recd[1][kk], x[kk, 2], recd[2][kk], x[kk, 3], od["tpm"][kk], od["tpr"][kk], np.cos(x[kk, 2])))
             k = int(np.argmax(np.abs(recd[1] - x[:, 2])))
             print("      worst theta point %d of %d: dev th %.12g ref th %.12g | r dev %.12g ref %.12g" % (k, n, recd[1][k], x[k, 2], recd[0][k], x[k, 1]))
 capi.record_steps(False)
