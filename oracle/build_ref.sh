@@ -5,9 +5,13 @@
 # (our bind(C) glue).  Nothing is copied into the repo; objects and .mod files live in
 # oracle/_ref/ (git-ignored, but shipped to the GPU box with the snapshot).
 #
-# Left out on purpose: fits.f90, camera.f90, grtrans_driver.f90, pgrtrans.f90, grtrans.f90,
-# grtrans_program.f90 -- the chain that needs cfitsio, which this image lacks (no stubs are
-# written).  ref_driver.f90 re-states only the sequencing of grtrans_driver.
+# The whole call chain is compiled: fits.f90, camera.f90, grtrans_driver.f90, pgrtrans.f90 and
+# grtrans.f90 (grtrans_run) included.  fits.f90 references 19 cfitsio entry points (ft*_) that
+# this image lacks; NO stubs are written: the shared library is linked with those symbols left
+# undefined and is loaded with RTLD_LAZY (oracle/refbind.py, oracle/refmain.py).  cflag=0 (the
+# binary writer of camera.f90:321-340) never calls them.  Only grtrans_program.f90 (the PROGRAM
+# unit) is left out.  oracle/refmain.py drives the reference's own grtrans_run; ref_driver.f90
+# stays as the per-stage probe and is asserted bit-equal to it (tests/test_ref_main.py).
 set -e
 REF=${GRT_REFERENCE:-/root/reference}
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -32,6 +36,7 @@ compile() {  # recompile only when the source is newer than the object
 for f in $CORE; do compile "$REF/$f"; done
 for m in $MODELS; do compile "$REF/fluid_model_$m.f90"; done
 compile "$REF/fluid.f90"
+for f in fits camera grtrans_driver pgrtrans grtrans; do compile "$REF/$f.f90"; done
 compile "$HERE/ref_driver.f90"
 $FC -fopenmp -shared -o "$OUT/libgrtrans_ref.so" *.o
 echo "build_ref: wrote $OUT/libgrtrans_ref.so"

@@ -4,9 +4,11 @@
 ! from /root/reference by oracle/build_ref.sh into oracle/_ref/libgrtrans_ref.so.
 ! Nothing here restates reference numerics: every number comes out of the reference's
 ! own geokerr / fluid / kerr / emissivity / radtrans_integrate modules.  The only thing
-! re-stated is the *sequencing* of grtrans_driver (grtrans_driver.f90:57-466) for the
-! extra=0, debug=0 case, because grtrans_driver.f90 itself USEs module ray_trace ->
-! fits, which needs cfitsio (absent in this image; we do not stub it).
+! re-stated is the *sequencing* of grtrans_driver (grtrans_driver.f90:57-466) so that every
+! per-stage array of a ray can be probed.  The reference's own driver chain (grtrans_run ->
+! grtrans_main -> grtrans_driver) is compiled into the same library and driven by
+! oracle/refmain.py; tests/test_ref_main.py and tests/make_golden.py:crosscheck_main assert
+! that the restated loop below gives the same bits (image goldens and extra=1 diagnostics).
 !
 ! Entry points (all bind(C)):
 !   ref_setup        camera + fluid model + parameter structs (pgrtrans.f90:87-171)

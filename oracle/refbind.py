@@ -22,7 +22,8 @@ def available():
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(LIB)
+        # RTLD_LAZY: the library leaves the 19 cfitsio entry points of fits.f90 undefined (never called with cflag=0)
+        _lib = C.CDLL(LIB, mode=os.RTLD_LAZY)
         for n in ("ref_rf", "ref_rc", "ref_rd", "ref_rj"):
             getattr(_lib, n).restype = C.c_double
         _lib.ref_rf.argtypes = [C.c_double] * 3

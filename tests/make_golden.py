@@ -508,14 +508,96 @@ def reference_pickle():
     np.savez_compressed(os.path.join(G, "test_grtrans_sphacc_lsoda.npz"), intensity=np.asarray(gi), spectrum=np.asarray(gs))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Fixtures made by the reference's OWN driver chain: grtrans_run -> read_inputs -> grtrans_main -> grtrans_driver ->
+# kwrite_raytrace_camera (oracle/refmain.py; nothing restated).  FFJET_KW / SPHACC_KW are grtrans_batch.py kwargs.
+FFJET_KW = dict(fname='FFJET', nfreq=1, nmu=1, fmin=FREQ, fmax=FREQ, ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1, uout=0.01,
+                mbh=3.4e9, mdotmin=1.57e15, mdotmax=1.57e15, nn=[100, 100, 400], gridvals=[-40., 20., -20., 40.], mumin=.906,
+                mumax=.906, ntscl=2., nrscl=70., gmin=100., gmax=1e5, p1=3.5, p2=3.5, iname='formal')
+SPHACC_KW = dict(fname='SPHACC', nfreq=1, nmu=1, fmin=FREQ_SPHACC, fmax=FREQ_SPHACC, ename='POLSYNCHTH', nvals=4, spin=0., standard=1,
+                 uout=0.04, mbh=10., nn=[64, 64, 200], gridvals=[-25., 25., -25., 25.], mumin=.5, mumax=.5, iname='formal')
+
+
+def extra_main():
+    # extra=1 through grtrans_driver.f90:230-292 itself: Stokes + 19 diagnostics (nup > 1)
+    from oracle import refmain
+    out = {}
+    r = refmain.run(dict(FFJET_KW, nn=[32, 32, 100], extra=1), nthreads=8)
+    out["ffjet_vals"] = r["ivals"][0]
+    r = refmain.run(dict(SPHACC_KW, nn=[32, 32, 100], extra=1), nthreads=1)
+    out["sphacc_vals"] = r["ivals"][0]
+    old = np.load(os.path.join(G, "extra_32x32x100.npz"))
+    out["ffjet_npts"], out["sphacc_npts"] = old["ffjet_npts"], old["sphacc_npts"]
+    np.savez_compressed(os.path.join(G, "extra_32x32x100.npz"), **out)
+
+
+def config5(nx=64, nup=400):
+    # BASELINE config 5's frequency grid (README:45: nfreq=25, fmin=2.41e10, fmax=6.31e14) on the FFJET problem, formal and
+    # DELO, through the reference's own main.  `cond_*`: the reference's own response, per frequency and Stokes parameter
+    # (max |delta| over the image / Stokes peak), to one-ulp changes of spin, mu0 and uout and of fmin/fmax -- the floor
+    # below which no other implementation of the same algorithm can be expected to agree.
+    from oracle import refmain
+    out = {}
+    base = dict(FFJET_KW, nn=[nx, nx, nup], nfreq=25, fmin=2.41e10, fmax=6.31e14)
+    up = lambda x: float(np.nextafter(x, np.inf))  # noqa: E731
+    perts = [dict(spin=up(0.998)), dict(mumin=up(0.906), mumax=up(0.906)), dict(uout=up(0.01)), dict(fmin=up(2.41e10), fmax=up(6.31e14))]
+    for iname in ("formal", "delo"):
+        r = refmain.run(dict(base, iname=iname), nthreads=8)
+        iv = r["ivals"]                                   # [25][npix][4]
+        out["ivals_" + iname] = iv
+        out["nu"] = r["nu"]
+        peak = np.abs(iv.astype(float)).max(axis=1)       # [25][4]
+        cond = np.zeros_like(peak)
+        for p in perts:
+            rp = refmain.run(dict(base, iname=iname, **p), nthreads=8)
+            cond = np.maximum(cond, np.abs(rp["ivals"].astype(float) - iv.astype(float)).max(axis=1) / peak)
+        out["cond_" + iname] = cond
+        print(iname, "cond per frequency (max over Stokes):", cond.max(axis=1))
+    np.savez_compressed(os.path.join(G, "ffjet_nfreq25_%dx%dx%d.npz" % (nx, nx, nup)), fmin=2.41e10, fmax=6.31e14, **out)
+
+
+def crosscheck_main():
+    # the image goldens above were produced through oracle/ref_driver.f90 (per-stage probes + a restated pixel loop);
+    # assert that the reference's own main gives the same bits, and record it
+    from oracle import refmain
+    import json
+    rec = {}
+    g = np.load(os.path.join(G, "ffjet_100x100x400.npz"))
+    for iname in ("formal", "delo"):
+        r = refmain.run(dict(FFJET_KW, iname=iname), nthreads=8)
+        rec["ffjet_100x100x400_" + iname] = bool(np.array_equal(r["ivals"][0], g["ivals_" + iname]))
+    g = np.load(os.path.join(G, "sphacc_64x64x200.npz"))
+    for iname in ("formal", "delo"):
+        r = refmain.run(dict(SPHACC_KW, iname=iname), nthreads=1)
+        rec["sphacc_64x64x200_" + iname] = bool(np.array_equal(r["ivals"][0], g["ivals_" + iname]))
+    g = np.load(os.path.join(G, "nvals1_32x32x100.npz"))
+    r = refmain.run(dict(FFJET_KW, nn=[32, 32, 100], nvals=1), nthreads=8)
+    rec["nvals1_ffjet"] = bool(np.array_equal(r["ivals"][0], g["ffjet_ivals"][0]))
+    r = refmain.run(dict(FFJET_KW, nn=[32, 32, 100], nvals=1, ename='SYNCHPL'), nthreads=8)
+    rec["nvals1_ffjet_synchpl"] = bool(np.array_equal(r["ivals"][0], g["ffjet_synchpl_ivals"][0]))
+    g = np.load(os.path.join(G, "thindisk_100x100x1.npz"))
+    r = refmain.run(dict(standard=2, spin=0.998, uout=1e-4, gridvals=[-25., 25., -25., 25.], nn=[100, 100, 1], fname='THINDISK', ename='BB',
+                         nvals=1, iname='lsoda', mbh=10., tmdot=0.1, nmu=2, mumin=0.1, mumax=0.7, nfreq=1, fmin=1e17, fmax=1e17), nthreads=8)
+    rec["thindisk_mu01"] = bool(np.array_equal(r["ivals"][0], g["ivals_mu01"]))
+    rec["thindisk_mu07"] = bool(np.array_equal(r["ivals"][1], g["ivals_mu07"]))
+    print(rec)
+    json.dump(rec, open(os.path.join(G, "refmain_crosscheck.json"), "w"), indent=1)
+    assert all(rec.values()), rec
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # e.g. `python tests/make_golden.py config5 extra_main crosscheck_main`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     leafs(); coeffs(); integrators(); reference_pickle()
     ffjet(100, 400)
     ffjet(32, 100)
     sphacc(64, 200)
     harm(48, 200)
     nvals1()
-    extra()
+    extra()          # ref_driver.f90's restated diagnostics (kept as the npts source) ...
+    extra_main()     # ... overwritten by the reference's own grtrans_driver
     thindisk()
     harm_movie()
     harm_slowlight()
@@ -526,4 +608,6 @@ if __name__ == "__main__":
     koral3d()
     unpolarized()
     sympol()
+    config5()
+    crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

@@ -1218,3 +1218,51 @@ def test_near_polar_ray_azimuth_on_a_3d_dump(tmp_path):
     # oracle, both literal, differ by up to 2e-5 rad at l^2/(q2+a^2) ~ 1e-11: tools/polar_phi.py); the fast path was off by radians
     assert np.abs(rec[2] - od["x"][:n, 3]).max() < 1e-4
     assert stokes_err(pix[0], ref[0]) < STOKES_TOL
+
+
+CONFIG5_FREQS = list(2.41e10 * np.exp(np.arange(25) * np.log(6.31e14 / 2.41e10) / 24))     # pgrtrans.f90:87-91, README:45
+
+
+@pytest.mark.parametrize("iname", ["formal", "delo"])
+def test_config5_frequency_grid_vs_compiled_reference(dev, iname):
+    # BASELINE config 5's 25 frequencies 2.41e10 .. 6.31e14 Hz through the frequency-batch kernels (FB = 13 formal / 8 DELO)
+    # against the reference's own grtrans_main (tests/make_golden.py:config5).  Bar per frequency: 2e-6 of each Stokes
+    # peak, or 10x the reference's own response to one-ulp input changes at that frequency where that is larger.
+    g = np.load(os.path.join(G, "ffjet_nfreq25_64x64x400.npz"))
+    assert np.allclose(g["nu"], np.float32(CONFIG5_FREQS), rtol=1e-7)
+    pix, _, status, st = run((64, 64, 400), iname, freqs=CONFIG5_FREQS)
+    ref = g["ivals_" + iname].astype(float)                  # [25][npix][4]
+    peak = np.abs(ref).max(axis=1)
+    err = np.abs(pix.astype(float) - ref).max(axis=1) / peak  # [25][4]
+    bar = np.maximum(STOKES_TOL, 10.0 * g["cond_" + iname])
+    for k in range(25):
+        print("%s %.3e Hz: err I,Q,U,V = %s  bar = %s" % (iname, CONFIG5_FREQS[k], " ".join("%.1e" % v for v in err[k]),
+                                                         " ".join("%.1e" % v for v in bar[k])))
+    assert np.array_equal(np.isfinite(pix), np.isfinite(g["ivals_" + iname]))
+    assert (err < bar).all(), np.argwhere(err >= bar)
+
+
+def test_config5_full_size_properties(dev):
+    # 1024 x 1024 x 400, 25 frequencies, image only: size-independent properties at BASELINE's full size
+    from grtrans_amd import capi
+    nn = (1024, 1024, 400)
+    capi.record_steps(False)
+    _, _, s1, st1 = run(nn, "formal")
+    full, _, s25, st25 = run(nn, "formal", freqs=CONFIG5_FREQS)
+    assert np.array_equal(s1, s25) and st1.ray_steps == st25.ray_steps == int(s25.sum())
+    assert np.isfinite(full).all()                           # the reference's mask on this camera is empty (64 x 64 golden)
+    assert (full[:, :, 0] >= 0).all() and (full[:, s25 == 0] == 0).all()
+    h = nn[0] * nn[1] // 2
+    a, _, sa, _ = run(nn, "formal", 1, h, freqs=CONFIG5_FREQS)
+    b, _, sb, _ = run(nn, "formal", h + 1, 2 * h, freqs=CONFIG5_FREQS)
+    assert np.array_equal(np.concatenate([a, b], axis=1), full)
+    assert np.array_equal(np.concatenate([sa, sb]), s25)
+    # the frequency nearest the nominal one equals a single-frequency run of the same frequency (batch vs FB=1 kernel)
+    k = 7
+    one, _, _, _ = run(nn, "formal", freqs=[CONFIG5_FREQS[k]])
+    assert np.array_equal(one[0], full[k])
+    # and the 64 x 64 golden camera is the 16-fold subsample of no pixel grid of this one: compare integrated fluxes instead
+    g = np.load(os.path.join(G, "ffjet_nfreq25_64x64x400.npz"))
+    flux_full = full[:, :, 0].astype(float).sum(axis=1) / (1024.0 * 1024.0)
+    flux_gold = g["ivals_formal"][:, :, 0].astype(float).sum(axis=1) / (64.0 * 64.0)
+    assert np.allclose(flux_full, flux_gold, rtol=0.02), np.abs(flux_full / flux_gold - 1).max()

@@ -510,3 +510,19 @@ def test_reference_regression_problem_sphacc_synchthav():
     gs = g["spectrum"].astype(float).ravel()
     terr = np.abs(spec - gs).sum() / np.abs(gs).sum()
     assert terr < 0.1, terr
+
+
+def test_config5_frequency_grid():
+    # BASELINE config 5: 25 frequencies 2.41e10 .. 6.31e14 Hz; golden = the reference's own grtrans_main (make_golden.py:config5).
+    # A band of 12 image columns through the jet base (768 rays x 25 cameras) keeps this in seconds.
+    g = load("ffjet_nfreq25_64x64x400.npz")
+    freqs = 2.41e10 * np.exp(np.arange(25) * np.log(6.31e14 / 2.41e10) / 24)
+    i1, i2 = 26 * 64 + 1, 38 * 64
+    for iname in ("formal", "delo"):
+        o = O.Oracle(nn=(64, 64, 400), iname=iname)
+        pix, npts, _ = o.trace(i1, i2, freqs, nthreads=8)
+        ref = g["ivals_" + iname].astype(float)
+        peak = np.abs(ref).max(axis=1)                                    # [25][4] over the whole image
+        err = np.abs(pix.astype(float) - ref[:, i1 - 1:i2]).max(axis=1) / peak
+        bar = np.maximum(1e-6, 10.0 * g["cond_" + iname])
+        assert (err < bar).all(), (iname, err.max(axis=1))
