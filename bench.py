@@ -7,10 +7,15 @@ POLSYNCHPL nvals=4 spin=0.998 nn=[1024,1024,400] nfreq=1, formal integrator -- t
 the metric "ray-steps/sec + HBM GB/s" is quoted on.  Inputs (fluid table, coefficient tables) are
 resident in HBM before the timed region; outputs stay in HBM (16 B/ray D2H is outside).
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  Weak scaling: the camera is
-nn=[1024*N,1024,400] over the same field of view and rank r traces the contiguous pixel strip
-i1..i2 of 1024*1024 rays (the reference's own i1,i2 partition key); the only exchange is one
-gather of the fp32 tiles to rank 0 over xGMI after the timed kernels of each step.
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).
+  --scaling weak (default): the camera is nn=[1024*N,1024,400] over the same field of view and rank r traces the
+      contiguous pixel strip i1..i2 of 1024*1024 rays (the reference's own i1,i2 partition key).
+  --scaling strong: BASELINE config 5's shape -- the SAME nn=[1024,1024,400] camera shared out over the N ranks in
+      tiles of --tile-cols image columns dealt round-robin (grtrans_amd/tiling.py:ranges, the share-out
+      module pgrtrans uses); `value` = ray-steps of the whole image / max-over-ranks time.
+Either way the only exchange is one gather of the ranks' fp32 cameras to rank 0 over xGMI after the timed steps,
+through the library's own RCCL communicator (grt_stage_* / grt_gather_stage, include/grtrans_amd.h; the ncclUniqueId
+travels over torch.distributed) with torch.distributed.gather as the fall-back; `gather_ms` is reported.
 """
 import argparse
 import json
@@ -36,6 +41,7 @@ WORKLOADS = {
 }
 BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lambda,I,Q,U,V) per ray-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
 
 
 def cpu_baseline(nx, ny, nup, budget_s=15.0):
@@ -88,6 +94,8 @@ def main():
     ap.add_argument("--nfreq", type=int, default=1, help="BASELINE config 5 uses 25 log-spaced frequencies 2.41e10..6.31e14")
     ap.add_argument("--no-steps-record", action="store_true", help="do not write the per-step SoA record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--tile-cols", type=int, default=32, help="strong scaling: image columns per tile (round-robin over the ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +122,8 @@ def main():
     from grtrans_amd import capi
 
     nx, ny, nup = args.nn
-    nx_total = nx * world                      # weak scaling: camera widens with the rank count
+    strong = (args.scaling == "strong")
+    nx_total = nx if strong else nx * world    # weak scaling: camera widens with the rank count
     dev = capi.Device(local_rank)
     W = WORKLOADS[args.workload]
     dev.load_ffjet()
@@ -129,9 +138,16 @@ def main():
         dev.load_harm(os.path.join(hd, "dump"), os.path.join(hd, "dump040"), 40, W["spin"])
     cam = capi.make_camera(1, W["gridvals"], (nx_total, ny, nup), W["spin"], W["mu0"], W["uout"], -0.5)
     em = capi.make_emis(W["ename"], W["mbh"], W["nfac"], W["bfac"], W.get("gmin", 100.), 1e5, 3.5, mdot=W.get("mdot", 0.0))
-    i1 = rank * nx * ny + 1
-    i2 = (rank + 1) * nx * ny
+    from grtrans_amd.tiling import ranges as pixel_ranges
+    if strong:
+        my_ranges = pixel_ranges(rank, world, 1, nx * ny, ny, args.tile_cols if world > 1 else 0)
+        all_ranges = [pixel_ranges(r, world, 1, nx * ny, ny, args.tile_cols if world > 1 else 0) for r in range(world)]
+    else:
+        my_ranges = [(rank * nx * ny + 1, (rank + 1) * nx * ny)]
+        all_ranges = [[(r * nx * ny + 1, (r + 1) * nx * ny)] for r in range(world)]
+    npix_of_rank = [sum(b - a + 1 for a, b in rr) for rr in all_ranges]
     capi.record_steps(not args.no_steps_record)
+    capi.geo_reuse(False)      # every timed step is the whole hot path: set-up + geodesics + transfer (no resident-record re-use)
 
     def barrier():
         if dist is not None:
@@ -140,9 +156,24 @@ def main():
 
     freqs = [W["freq"]] if args.nfreq == 1 else list(2.41e10 * np.exp(np.arange(args.nfreq) * np.log(6.31e14 / 2.41e10) / (args.nfreq - 1)))
 
-    def one_step():
-        _, _, _, st = capi.trace_tile(cam, i1, i2, W["fname"], em, freqs, args.iname, resident=True)
-        return st
+    import ctypes as C
+
+    class Acc:           # one step = every range of this rank traced once (one range unless --scaling strong with N > 1)
+        ray_steps = 0
+        ms_trace = ms_setup = ms_geo = ms_xfer = ms_total = 0.0
+
+    def one_step(stage=False):
+        a = Acc()
+        off = 0
+        for (i1, i2) in my_ranges:
+            _, _, _, st = capi.trace_tile(cam, i1, i2, W["fname"], em, freqs, args.iname, resident=True)
+            a.ray_steps += st.ray_steps; a.ms_trace += st.ms_trace; a.ms_setup += st.ms_setup
+            a.ms_geo += st.ms_geo; a.ms_xfer += st.ms_transfer; a.ms_total += st.ms_total
+            if stage:    # device-to-device into the rank-level image the gather sends
+                capi.check(capi.lib().grt_stage_resident(C.c_int(0), C.c_int(args.nfreq), C.c_int64(i2 - i1 + 1), C.c_int64(off)),
+                           "grt_stage_resident")
+            off += i2 - i1 + 1
+        return a
 
     # secondary figure: image-only mode (no per-step record, azimuth integrals skipped), untimed region
     image_only = None
@@ -151,7 +182,7 @@ def main():
         one_step()
         st0 = one_step()
         image_only = {"ray_steps_per_s": st0.ray_steps / (st0.ms_total / 1e3), "ms_geo": st0.ms_geo,
-                      "ms_transfer": st0.ms_transfer}
+                      "ms_transfer": st0.ms_xfer}
         capi.record_steps(True)
     for _ in range(args.warmup):
         one_step()
@@ -168,26 +199,70 @@ def main():
         ms_trace += st.ms_trace
         ms_setup += st.ms_setup
         ms_geo += st.ms_geo
-        ms_xfer += st.ms_transfer
+        ms_xfer += st.ms_xfer
     barrier()
     dt = time.perf_counter() - t0
-    gather_ms = None
+    gather_ms, gather_via = None, None
     if dist is not None:
-        # assemble ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the fp32 tiles over xGMI
-        import ctypes as C
-        from grtrans_amd.tiling import gather_tiles
-        tile = torch.empty((args.nfreq, nx * ny, 4), dtype=torch.float32, device="cuda")
-        capi.check(capi.lib().grt_copy_resident_pixvals(C.c_void_p(tile.data_ptr()), C.c_int64(tile.numel())),
-                   "grt_copy_resident_pixvals")
+        # assemble ivals on rank 0 (pgrtrans.f90:221-242): ONE gather of the ranks' fp32 cameras over xGMI, after the timed steps
+        L = capi.lib()
+        nv = 4
+        capi.check(L.grt_stage_reset(C.c_int(args.nfreq), C.c_int(nv), C.c_int64(npix_of_rank[rank])), "grt_stage_reset")
+        one_step(stage=True)                                    # untimed: fills the rank-level image (same bits as the timed steps)
         torch.cuda.synchronize()
-        if cdev == "cpu":
-            tile = tile.cpu()
-        tg = time.perf_counter()
-        full = gather_tiles(tile, dist, 0)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - tg) * 1e3
+        full = None
+        try:
+            if cdev != "cuda" or os.environ.get("GRT_BENCH_GATHER") == "torch":
+                raise RuntimeError("torch gather requested")
+            # the library's own RCCL communicator; its ncclUniqueId travels over the process group that exists already
+            idbuf = C.create_string_buffer(128)
+            if rank == 0:
+                capi.check(L.grt_comm_unique_id(idbuf), "grt_comm_unique_id")
+            box = [idbuf.raw]
+            dist.broadcast_object_list(box, src=0)
+            capi.check(L.grt_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(box[0])), "grt_comm_init")
+            cnt = (C.c_int64 * world)(*npix_of_rank)
+            host = np.zeros((args.nfreq, sum(npix_of_rank), nv), dtype=np.float32) if rank == 0 else None
+            dist.barrier(); torch.cuda.synchronize()
+            tg = time.perf_counter()
+            capi.check(L.grt_gather_stage(cnt, C.c_int(0), host.ctypes.data_as(C.c_void_p) if rank == 0 else None), "grt_gather_stage")
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            gather_via = "grt_gather_stage (library RCCL communicator, grouped send/recv per camera, incl. D2H on rank 0)"
+            full = host
+            L.grt_comm_free()
+        except Exception as exc:      # fall back to the process group's own gather (rank-ordered tiles, same layout)
+            from grtrans_amd.tiling import gather_tiles
+            tile = torch.empty((args.nfreq, npix_of_rank[rank], nv), dtype=torch.float32, device="cuda")
+            off = 0
+            L.grt_comm_free()
+            for (i1, i2) in my_ranges:
+                capi.trace_tile(cam, i1, i2, W["fname"], em, freqs, args.iname, resident=True)
+                t1 = torch.empty((args.nfreq, i2 - i1 + 1, nv), dtype=torch.float32, device="cuda")
+                capi.check(L.grt_copy_resident_pixvals(C.c_void_p(t1.data_ptr()), C.c_int64(t1.numel())), "grt_copy_resident_pixvals")
+                tile[:, off:off + i2 - i1 + 1] = t1
+                off += i2 - i1 + 1
+            torch.cuda.synchronize()
+            if cdev == "cpu":
+                tile = tile.cpu()
+            dist.barrier()
+            tg = time.perf_counter()
+            fullt = gather_tiles(tile, dist, 0)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            gather_via = "torch.distributed.gather (%s)" % (str(exc)[:80])
+            full = fullt.cpu().numpy() if rank == 0 else None
         if rank == 0:
-            assert full.shape[1] == nx * ny * world
+            assert full.shape[1] == sum(npix_of_rank)
+            if os.environ.get("GRT_BENCH_CHECK_IMAGE") == "1":
+                # test hook: the gathered, un-permuted image equals one whole-image trace on this rank, bit for bit
+                img = np.zeros((args.nfreq, nx_total * ny, nv), dtype=np.float32)
+                pre = 0
+                for rr in all_ranges:
+                    for (a, b) in rr:
+                        img[:, a - 1:b] = full[:, pre:pre + b - a + 1]
+                        pre += b - a + 1
+                ref, _, _, _ = capi.trace_tile(cam, 1, nx_total * ny, W["fname"], em, freqs, args.iname)
+                assert np.array_equal(img, ref), "gathered image differs from the single-GPU image"
         tmax = torch.tensor([dt, float(ray_steps), ms_trace], dtype=torch.float64, device=cdev)
         tsum = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -205,34 +280,53 @@ def main():
         t_kernel = ms_trace / args.steps / 1e3
         achieved = BYTES_PER_STEP * (ray_steps / args.steps) / t_kernel / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        # the PMC passes were collected on the default workload only (tools/profile_round.sh)
+        valu = None
+        # the PMC passes were collected on the default workload only (tools/profile_round.sh -> profiles/traffic.json, valu.json)
         same_as_profiled = (args.workload == "ffjet" and [nx, ny, nup] == [1024, 1024, 400] and args.nfreq == 1
-                            and args.iname == "formal" and not args.no_steps_record)
-        if os.path.exists(tfile) and same_as_profiled:
+                            and args.iname == "formal" and not args.no_steps_record and len(my_ranges) == 1)
+        if same_as_profiled:
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+            try:
+                # fp64 VALU roofline (the bound that matters): instruction counts per launch from the committed
+                # SQ-counter summary (same workload, same library), priced over THIS run's HIP-event kernel time
+                v = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+                flop = 2.0 * v["fma_f64_wave_insts"] * 64 + (v["mul_f64_wave_insts"] + v["add_f64_wave_insts"]) * 64.0
+                valu = {"bound": "fp64 vector ALU", "fma_f64": v["fma_f64_wave_insts"], "mul_f64": v["mul_f64_wave_insts"],
+                        "add_f64": v["add_f64_wave_insts"], "trans_f64": v["trans_f64_wave_insts"], "valu_wave_insts": v["valu_wave_insts"],
+                        "counts": "wave64 instructions per trace phase (geo + transfer launches of both classes), %s" % v["source"],
+                        "flop_per_launch": flop, "achieved": flop / t_kernel / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flop / t_kernel / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                        # issue slots: 4 cycles per wave64 fp64 instruction (16 for the quarter-rate seeds) on each of 4 SIMDs x 256 CUs
+                        "valu_issue_utilisation": (4.0 * (v["valu_wave_insts"] - v["trans_f64_wave_insts"]) + 16.0 * v["trans_f64_wave_insts"]) /
+                                                  (t_kernel * v["sclk_hz"] * 4 * 256)}
+            except Exception:
+                valu = None
         out = {
             "metric": "ray-steps/sec", "value": value, "unit": "ray-steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "deterministic: BL09 FFJET table shipped with the reference (no RNG in the path)",
-            "config": {"workload": "%s %s nvals=4 spin=%g mu0=%g nn=[%d,%d,%d] per GPU, nfreq=%d (%g Hz), iname=%s, "
-                                   "gridvals=%s, uout=%g" % (W["fname"], W["ename"], W["spin"], W["mu0"], nx, ny, nup, args.nfreq,
+            "config": {"workload": "%s %s nvals=4 spin=%g mu0=%g nn=[%d,%d,%d] %s, nfreq=%d (%g Hz), iname=%s, "
+                                   "gridvals=%s, uout=%g" % (W["fname"], W["ename"], W["spin"], W["mu0"], nx, ny, nup,
+                                                             "whole image over all GPUs" if strong else "per GPU", args.nfreq,
                                                              freqs[0], args.iname, list(W["gridvals"]), W["uout"]),
-                       "pixels_per_gpu": nx * ny, "ray_steps_per_step_per_gpu": ray_steps // args.steps,
-                       "parallelism": "pixel strips i1..i2 per GPU, 1 process/GPU, RCCL gather of fp32 tiles",
+                       "pixels_per_gpu": npix_of_rank[0], "ray_steps_per_step_per_gpu": ray_steps // args.steps,
+                       "parallelism": ("tiles of %d image columns round-robin over the GPUs" % args.tile_cols if strong and world > 1 else
+                                       "pixel strips i1..i2 per GPU") + ", 1 process/GPU, one RCCL gather of the fp32 cameras",
                        "per_step_record_written": not args.no_steps_record, "nfreq": args.nfreq,
                        "ray_step_frequencies_per_s": value * args.nfreq,
-                       "gather_ms": gather_ms, "setup_kernel_ms": ms_setup / args.steps,
+                       "gather_ms": gather_ms, "gather_via": gather_via, "setup_kernel_ms": ms_setup / args.steps,
                        "geo_kernel_ms": ms_geo / args.steps, "transfer_kernel_ms": ms_xfer / args.steps,
                        "image_only_mode": image_only},
             "roofline": {"bound": "hbm", "kernel": "grt_geo_kernel+grt_transfer_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "algorithmic 64 B per ray-step (SURVEY 8d) over the trace kernel's HIP-event time; "
-                                 "the kernel is fp64-VALU bound (~1e4 flop-equivalents per step), see DESIGN.md"},
+                         "traffic_ratio": (traffic / (BYTES_PER_STEP * (ray_steps / args.steps))) if traffic else None,
+                         "valu": valu,
+                         "note": "algorithmic 64 B per ray-step (SURVEY 8d) over the trace kernels' HIP-event time; the path is "
+                                 "fp64-VALU issue bound, not HBM bound: see roofline.valu and DESIGN.md 5"},
         }
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "ffjet":
             out["cpu_baseline"] = cpu_baseline(nx, ny, nup)

@@ -176,6 +176,11 @@ def set_t0(t0):
         check(lib().grt_set_t0(t0.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(t0.size)), "grt_set_t0")
 
 
+def geo_reuse(enable):
+    """0: every trace recomputes its geodesics (benchmarks); 1 (default): same camera + pixel range re-uses the resident record."""
+    check(lib().grt_set_geo_reuse(C.c_int(1 if enable else 0)), "grt_set_geo_reuse")
+
+
 def record_steps(enable):
     check(lib().grt_set_record_steps(C.c_int(1 if enable else 0)), "grt_set_record_steps")
 
@@ -184,4 +189,51 @@ def download_steps(ray0, nrays, maxpts):
     out = np.zeros((8, nrays, maxpts))
     check(lib().grt_download_steps(C.c_int64(ray0), C.c_int64(nrays), C.c_int(maxpts),
                                    out.ctypes.data_as(C.POINTER(C.c_double))), "grt_download_steps")
+    return out
+
+
+def harm_tstep():
+    """tstep of the loaded HARM slices (fluid_model_harm.f90:493-500)."""
+    t = C.c_float(0)
+    check(lib().grt_get_harm_tstep(C.byref(t)), "grt_get_harm_tstep")
+    return np.float32(t.value)
+
+
+def camera_pixels(cam, i1, i2):
+    """class_geokerr.pixel (class_geokerr.f90:122-141): the per-pixel constants of pixels i1..i2 of a standard=1 camera."""
+    n = i2 - i1 + 1
+    d = {k: np.zeros(n) for k in ("alpha", "beta", "q2", "l", "su", "sm", "uf", "muf")}
+    tpm = np.zeros(n, dtype=np.int32)
+    tpr = np.zeros(n, dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    check(lib().grt_camera_pixels(C.byref(cam), C.c_int64(i1), C.c_int64(i2), dp(d["alpha"]), dp(d["beta"]), dp(d["q2"]), dp(d["l"]),
+                                  dp(d["su"]), dp(d["sm"]), dp(d["uf"]), dp(d["muf"]), ip(tpm), ip(tpr)), "grt_camera_pixels")
+    d["tpm"], d["tpr"] = tpm, tpr
+    d["u0"], d["offset"] = cam.u0, cam.offset
+    return d
+
+
+def geokerr_rays(u0, uout, mu0, a, offset, nup, uf, l, q2, alpha, beta, tpr, su, sm, phit=1, usegeor=0, mufill=1, kext=0, next=0):
+    """class_geokerr.call_geokerr (class_geokerr.f90:69-107) for a batch of rays: GEOKERR's raw output arrays
+    u, mu, dt, dphi, lam, tpmi, tpri [nrays][nup+next-2kext], ncase[nrays], npts[nrays]."""
+    arrs = [np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (uf, l, q2, alpha, beta, su, sm)]
+    n = arrs[1].size
+    arrs = [np.full(n, v[0]) if v.size == 1 and n > 1 else v for v in arrs]
+    tpr = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(tpr), (n,)), dtype=np.int32)
+    m = nup + next - 2 * kext
+    out = {k: np.zeros((n, m)) for k in ("u", "mu", "dt", "dphi", "lam")}
+    tpmi = np.zeros((n, m), dtype=np.int32)
+    tpri = np.zeros((n, m), dtype=np.int32)
+    ncase = np.zeros(n, dtype=np.int32)
+    npts = np.zeros(n, dtype=np.int32)
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    ufa, la, q2a, ala, bea, sua, sma = arrs
+    check(lib().grt_geokerr_rays(C.c_int64(n), C.c_double(u0), C.c_double(uout), C.c_double(mu0), C.c_double(a), C.c_double(offset),
+                                 C.c_int(nup), C.c_int(phit), C.c_int(usegeor), C.c_int(mufill), C.c_int(kext), C.c_int(next),
+                                 dp(ufa), dp(la), dp(q2a), dp(ala), dp(bea), ip(tpr), dp(sua), dp(sma),
+                                 dp(out["u"]), dp(out["mu"]), dp(out["dt"]), dp(out["dphi"]), dp(out["lam"]), ip(tpmi), ip(tpri),
+                                 ip(ncase), ip(npts)), "grt_geokerr_rays")
+    out.update(tpmi=tpmi, tpri=tpri, ncase=ncase, npts=npts)
     return out

@@ -13,18 +13,18 @@
 #include "grt_pl_pack.hpp"
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time);
+                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin);
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
-                                     const int *live, int nlive, double *steps, unsigned long long *flags,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0);
+                                     const int *live, const int *nlive_dev, int nrays, double *steps, unsigned long long *flags,
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw);
 extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long i1, int nrays, double *t0);
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
-                                          int nfields, int tfield, unsigned long long *step_counter);
+                                          int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back);
 
 extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mbh, float mdot, float rin, float rout, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
@@ -83,6 +83,21 @@ struct Ctx {
   unsigned long long *d_stepcount = nullptr;
   int record_steps = 0;
   long long steps_rays = 0, steps_maxpts = 0;
+  std::vector<double> h_freqs;          // host staging of (freqs, log freqs): must outlive the async copy
+  // The geodesic record resident in d_rays / d_live / d_steps / d_flags / d_counters, and what it was computed for.  A trace
+  // call with the same key (e.g. the next mdot of grtrans_main's loop, grtrans_driver.f90:134: one geodesic serves every
+  // m = 1..nparams; or the next movie frame of a fast-light run) re-launches only the transfer kernels.
+  struct GeoKey {
+    bool valid = false;
+    grt_camera cam{};
+    long long i1 = 0, i2 = 0, t0_version = 0;
+    int nfields = 0, tfield = 0;
+  } geo;
+  long long t0_version = 0;
+  int geo_reuse = 1;                    // grt_set_geo_reuse
+  int class_order = 3;
+  long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
+  int n_class[2] = {0, 0};              // class sizes of the resident record
 };
 Ctx C;
 
@@ -99,12 +114,27 @@ Ctx C;
 template <class T>
 int grow(T *&p, size_t &cap, size_t need) {
   if (need <= cap && p) return 0;
-  if (p) HIPCHK(hipFree(p));
+  if (p) (void)hipFree(p);
   p = nullptr;
+  cap = 0;
   HIPCHK(hipMalloc((void **)&p, need * sizeof(T)));
   cap = need;
   return 0;
 }
+
+// both streams drained: called before an error leaves a function that has launches in flight, and before buffers are freed
+void drain() {
+  if (C.stream) (void)hipStreamSynchronize(C.stream);
+  if (C.stream2) (void)hipStreamSynchronize(C.stream2);
+}
+
+struct EventPair {       // destroyed on every exit path
+  hipEvent_t a = nullptr, b = nullptr;
+  ~EventPair() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
 
 }  // namespace
 
@@ -120,7 +150,15 @@ int grt_init(int device) {
   if (C.init) return 0;
   C.device = device;
   HIPCHK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+  {
+    // the generic-class chain is the critical tail of a trace (few waves, long per-point code): it goes first, on a
+    // stream of the highest priority, so that its waves are placed ahead of the fast-class kernels' backlog
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char *po = std::getenv("GRT_CLASS_ORDER");     // experiment knob: bit 0 = generic chain first, bit 1 = high priority
+    C.class_order = po ? std::atoi(po) : 3;
+    HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
+  }
   for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&C.evk[i]));
@@ -132,7 +170,7 @@ int grt_init(int device) {
 
 int grt_free(void) {
   if (!C.init) return 0;
-  (void)hipStreamSynchronize(C.stream);
+  drain();
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
                   C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
@@ -348,7 +386,7 @@ int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_hos
   const int nrays = (int)(i2 - i1 + 1);
   int rc;
   if ((rc = grow(C.d_t0, C.cap_t0, (size_t)nrays))) return rc;
-  C.t0_n = 0;
+  C.t0_n = 0; C.t0_version++;
   HIPCHK(grt_launch_t0(C.stream, cam, (long long)i1, nrays, C.d_t0));
   HIPCHK(hipStreamSynchronize(C.stream));
   HIPCHK(hipMemcpy(t0_host, C.d_t0, (size_t)nrays * sizeof(double), hipMemcpyDeviceToHost));
@@ -357,11 +395,11 @@ int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_hos
 
 int grt_set_t0(const double *t0_host, int64_t n) {
   if (!C.init) return GRT_E_NOTINIT;
-  if (!t0_host || n <= 0) { C.t0_n = 0; return 0; }
+  if (!t0_host || n <= 0) { if (C.t0_n != 0) C.t0_version++; C.t0_n = 0; return 0; }
   int rc;
   if ((rc = grow(C.d_t0, C.cap_t0, (size_t)n))) return rc;
   HIPCHK(hipMemcpy(C.d_t0, t0_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-  C.t0_n = n;
+  C.t0_n = n; C.t0_version++;
   return 0;
 }
 
@@ -424,6 +462,14 @@ int grt_make_camera(grt_camera *cam, int standard, const double gridvals[4], con
   return 0;
 }
 
+long long grt_geo_passes(void) { return C.geo_passes; }
+
+int grt_set_geo_reuse(int enable) {
+  C.geo_reuse = enable ? 1 : 0;
+  C.geo.valid = false;
+  return 0;
+}
+
 int grt_set_record_steps(int enable) {
   C.record_steps = enable ? 1 : 0;
   return 0;
@@ -432,7 +478,7 @@ int grt_set_record_steps(int enable) {
 static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
                         const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
   if (!C.init) return GRT_E_NOTINIT;
-  if (!cam || !em || !freqs || nfreq < 1 || nfreq > 32 || i2 < i1 || i1 < 1) return GRT_E_BADARG;
+  if (!cam || !em || !freqs || nfreq < 1 || i2 < i1 || i1 < 1) return GRT_E_BADARG;     // any nfreq (pgrtrans.f90:87-91 has no limit)
   if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
   if (cam->standard == 2) {
     // the one standard=2 problem on the device: one point per ray on a thin disk (BASELINE config 1)
@@ -440,6 +486,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
       return GRT_E_UNSUPPORTED;
     if (!C.have_disk) return GRT_E_NOFLUID;
     HIPCHK(hipSetDevice(C.device));
+    C.geo.valid = false;
     const int nrays = (int)(i2 - i1 + 1);
     int rc;
     if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
@@ -531,6 +578,11 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
     const size_t fit = cap_bytes / per_ray;
     if (!C.record_steps && fit < (size_t)nrays) chunk = (int)(fit < 4096 ? (fit < 1 ? 1 : fit) : fit / 4096 * 4096);
   }
+  // does the resident geodesic record serve this call?  (same camera, pixel range, field layout and time-origin table)
+  const bool reuse = C.geo.valid && chunk == nrays && std::memcmp(&C.geo.cam, cam, sizeof(*cam)) == 0 && C.geo.i1 == (long long)i1 &&
+                     C.geo.i2 == (long long)i2 && C.geo.nfields == nfields && C.geo.tfield == tfield && C.geo.t0_version == C.t0_version &&
+                     C.geo_reuse && !std::getenv("GRT_NO_GEO_REUSE");
+  C.geo.valid = false;
   if ((rc = grow(C.d_rays, C.cap_rays, (size_t)chunk))) return rc;
   if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
@@ -543,50 +595,79 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const long long fstride = (long long)chunk * rstride;
   GrtPLConst plc{};
   grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
-  double hfreq[64];
-  for (int f = 0; f < nfreq; ++f) { hfreq[f] = freqs[f]; hfreq[nfreq + f] = std::log(freqs[f]); }
-  HIPCHK(hipMemcpyAsync(C.d_freqs, hfreq, 2 * nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
-  HIPCHK(hipStreamSynchronize(C.stream));   // hfreq is on this frame
+  C.h_freqs.resize((size_t)2 * nfreq);     // context-owned staging: the asynchronous copy may outlive this frame
+  for (int f = 0; f < nfreq; ++f) { C.h_freqs[f] = freqs[f]; C.h_freqs[nfreq + f] = std::log(freqs[f]); }
+  HIPCHK(hipMemcpyAsync(C.d_freqs, C.h_freqs.data(), 2 * nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
   HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
   HIPCHK(hipMemsetAsync(C.d_pixvals, 0, (size_t)nrays * nfreq * (nvals + nextra) * sizeof(float), C.stream));
   double ms_trace_sum = 0.0, ms_geo_sum = 0.0;
   long long nlive = 0;
+  // an error between the first launch and the final synchronisation must not leave kernels of either stream running on
+  // buffers the caller may free or re-use next
+#define LAUNCHCHK(x)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      fprintf(stderr, "grtrans_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      drain();                                                                             \
+      return (int)e_;                                                                      \
+    }                                                                                      \
+  } while (0)
   for (int off = 0; off < nrays; off += chunk) {
     const int nch = (nrays - off < chunk) ? (nrays - off) : chunk;
-    HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
-    HIPCHK(hipEventRecord(C.ev[0], C.stream));
-    HIPCHK(grt_launch_setup(C.stream, cam, (long long)i1 + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays, need_time ? 1 : 0));
-    int ncls[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
-    nlive += ncls[0] + ncls[1];
     const double *t0c = d_t0 ? d_t0 + off : nullptr;
-    HIPCHK(hipEventRecord(C.ev[1], C.stream));
-    // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back.  The two classes touch disjoint
-    // rays of the same buffers, so their geo -> transfer chains run on two streams: the few generic-class waves fill the
-    // CUs the big fast-class kernels leave idle in their tails instead of queueing behind them.
-    HIPCHK(hipEventRecord(C.evj[0], C.stream));
-    HIPCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
-    HIPCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, ncls[0], C.d_steps, C.d_flags, rstride, fstride, nfields, tfield, t0c));
-    HIPCHK(hipEventRecord(C.evk[0], C.stream));
-    // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
-    HIPCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, ncls[0], &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
-                               C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps, C.d_flags, rstride,
-                               fstride, nfields, tfield, C.d_stepcount));
-    HIPCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live + (nch - ncls[1]), ncls[1], C.d_steps, C.d_flags,
-                          rstride, fstride, nfields, tfield, t0c));
-    HIPCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live + (nch - ncls[1]), ncls[1], &fd, &C.tables, em, &plc,
-                               nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,
-                               C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount));
-    HIPCHK(hipEventRecord(C.evj[1], C.stream2));
-    HIPCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
-    HIPCHK(hipEventRecord(C.ev[2], C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    if (!reuse) {
+      C.geo_passes++;
+      LAUNCHCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
+      LAUNCHCHK(hipEventRecord(C.ev[0], C.stream));
+      LAUNCHCHK(grt_launch_setup(C.stream, cam, (long long)i1 + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays, need_time ? 1 : 0, nullptr));
+    }
+    LAUNCHCHK(hipEventRecord(C.ev[1], C.stream));
+    // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back; their sizes stay on the device
+    // (counters[0], counters[1]: every launch below is sized for the worst case and reads its count there, so the host
+    // never waits between set-up and trace).  The two classes touch disjoint rays of the same buffers: two geo -> transfer
+    // chains on two streams.  The generic chain -- few rays, but the longest per-point code at one wave per SIMD -- is
+    // launched FIRST on the high-priority stream: launched second it trailed the fast-class kernels by up to 40 ms.
+    LAUNCHCHK(hipEventRecord(C.evj[0], C.stream));
+    LAUNCHCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
+    for (int turn = 0; turn < 2; ++turn) {
+      const bool generic = ((C.class_order & 1) != 0) == (turn == 0);
+      if (generic) {
+        if (!reuse)
+          LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps, C.d_flags,
+                                   rstride, fstride, nfields, tfield, t0c, 0));
+        // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
+        LAUNCHCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc,
+                                      nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,
+                                      C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount, C.d_counters + 1, nch));
+        LAUNCHCHK(hipEventRecord(C.evj[1], C.stream2));
+      } else {
+        if (!reuse)
+          LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, C.d_flags, rstride, fstride,
+                                   nfields, tfield, t0c, 0));
+        LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
+        LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
+                                      C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps, C.d_flags, rstride,
+                                      fstride, nfields, tfield, C.d_stepcount, C.d_counters, 0));
+      }
+    }
+    LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
+    LAUNCHCHK(hipEventRecord(C.ev[2], C.stream));
+    int ncls[2] = {0, 0};
+    LAUNCHCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    LAUNCHCHK(hipStreamSynchronize(C.stream));          // end of the pass: its buffers are re-used by the next one
+    nlive += ncls[0] + ncls[1];
+    C.n_class[0] = ncls[0]; C.n_class[1] = ncls[1];
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, C.ev[1], C.ev[2]));
     ms_trace_sum += ms;
     HIPCHK(hipEventElapsedTime(&ms, C.ev[1], C.evk[0]));
     ms_geo_sum += ms;
+  }
+#undef LAUNCHCHK
+  if (chunk == nrays) {      // a complete record is resident: the next call with the same key skips set-up and geodesics
+    C.geo.valid = true; C.geo.cam = *cam; C.geo.i1 = (long long)i1; C.geo.i2 = (long long)i2; C.geo.nfields = nfields;
+    C.geo.tfield = tfield; C.geo.t0_version = C.t0_version;
   }
   if (st) {
     unsigned long long steps_done = 0;
@@ -603,22 +684,19 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
 
 int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
                             int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
-  hipEvent_t t0, t1;
   if (!C.init) return GRT_E_NOTINIT;
-  HIPCHK(hipEventCreate(&t0));
-  HIPCHK(hipEventCreate(&t1));
-  HIPCHK(hipEventRecord(t0, C.stream));
+  EventPair ev;                          // destroyed on every exit path
+  HIPCHK(hipEventCreate(&ev.a));
+  HIPCHK(hipEventCreate(&ev.b));
+  HIPCHK(hipEventRecord(ev.a, C.stream));
   int rc = trace_common(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
-  if (rc == 0) {
-    HIPCHK(hipEventRecord(t1, C.stream));
-    HIPCHK(hipEventSynchronize(t1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, t0, t1));
-    if (st) { st->ms_total = ms; st->ms_setup = ms - st->ms_trace; }
-  }
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
-  return rc;
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ev.b, C.stream));
+  HIPCHK(hipEventSynchronize(ev.b));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+  if (st) { st->ms_total = ms; st->ms_setup = ms - st->ms_trace; }
+  return 0;
 }
 
 int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status) {
@@ -652,6 +730,125 @@ int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_mode
       pixloc[2 * t + 1] = (float)(cam->b1 + (cam->b2 - cam->b1) * ((double)(j - 1) + 0.5) / (double)cam->nphi);
     }
   }
+  return 0;
+}
+
+// ---- G-10: class_geokerr's f2py surface (class_geokerr.f90:69-144) --------------------------------------------------
+extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *out6);
+
+int grt_camera_pixels(const grt_camera *cam, int64_t i1, int64_t i2, double *alpha, double *beta, double *q2, double *l,
+                      double *su, double *sm, double *uf, double *muf, int32_t *tpm, int32_t *tpr) {
+  if (!cam || i2 < i1 || i1 < 1 || i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
+  if (cam->standard != 1 && cam->standard != 2) return GRT_E_UNSUPPORTED;
+  const double uplus = 1.0 / (1.0 + std::sqrt(1.0 - cam->a * cam->a));
+  for (int64_t ii = i1; ii <= i2; ++ii) {
+    double v[6];
+    grt_host_camera_pixel(cam, (long long)ii, v);      // alpha, beta, l, q2, su and standard=1's sm
+    const int64_t t = ii - i1;
+    if (alpha) alpha[t] = v[0];
+    if (beta) beta[t] = v[1];
+    if (l) l[t] = v[2];
+    if (q2) q2[t] = v[3];
+    if (su) su[t] = v[4];
+    if (cam->standard == 1) {
+      if (sm) sm[t] = v[5];
+      if (uf) uf[t] = uplus;               // geokerr_wrapper.f:255
+      if (muf) muf[t] = 0.0;               // (an output of GEOKERR for standard=1)
+      if (tpm) tpm[t] = 0;                 // :320
+      if (tpr) tpr[t] = 1;                 // :257
+    } else {                               // standard=2 (:167-234): sm without the beta=0 case, tpm from it, muf = 0
+      const double smv = (v[1] > 0.0 && cam->mu0 < 1.0) ? 1.0 : -1.0;
+      if (sm) sm[t] = smv;
+      if (uf) uf[t] = 0.0;                 // (UFARR is not assigned on this branch)
+      if (muf) muf[t] = 0.0;
+      if (tpm) tpm[t] = (int32_t)((std::copysign(1.0, cam->mu0) * smv + 1.0) / 2.0);
+      if (tpr) tpr[t] = 0;                 // (TPRARR is not assigned on this branch)
+    }
+  }
+  return 0;
+}
+
+int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a, double offset, int nup, int phit, int usegeor,
+                     int mufill, int kext, int next, const double *uf, const double *l, const double *q2, const double *alpha,
+                     const double *beta, const int32_t *tpr, const double *su, const double *sm, double *ufi, double *mufi,
+                     double *dti, double *dphi, double *lambdai, int32_t *tpmi, int32_t *tpri, int32_t *ncase, int32_t *npts) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (nrays < 1 || nrays > 0x7fffffff || nup < 1 || kext < 0 || next < 0 || !uf || !l || !q2 || !alpha || !beta || !tpr || !su || !sm)
+    return GRT_E_BADARG;
+  if (usegeor != 0 || phit == 0) return GRT_E_UNSUPPORTED;      // the mu-stepping branch (geokerr_wrapper.f:421-461) is not on the device
+  if (!mufill && (kext || next)) return GRT_E_BADARG;
+  HIPCHK(hipSetDevice(C.device));
+  C.geo.valid = false;                     // the work buffers are about to hold these rays
+  grt_camera cam;
+  std::memset(&cam, 0, sizeof(cam));
+  cam.a = a; cam.mu0 = mu0; cam.uout = uout; cam.u0 = u0; cam.offset = offset;
+  cam.standard = 1; cam.nro = (int)nrays; cam.nphi = 1; cam.nup = nup; cam.phit = 1; cam.mufill = mufill ? 1 : 0;
+  cam.kext = kext; cam.next = next;
+  const int n = (int)nrays;
+  const long long maxpts = (long long)nup + next - 2 * kext;     // the reference's array length (class_geokerr.f90:75)
+  const long long alloc_pts = (long long)nup + next;
+  const long long rstride = (alloc_pts + 63) / 64 * 64;
+  const int nf = 7;                         // u, mu, lambda, dphi, dt, tpm, tpr
+  {
+    size_t cap_bytes = (size_t)96 << 30;
+    if (const char *e = std::getenv("GRT_MAX_WORK_BYTES")) { const double v = std::atof(e); if (v > 0) cap_bytes = (size_t)v; }
+    if ((size_t)nf * n * rstride * sizeof(double) > cap_bytes) return GRT_E_BADARG;      // split the batch
+  }
+  int rc;
+  if ((rc = grow(C.d_rays, C.cap_rays, (size_t)n))) return rc;
+  if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)n * grt_sizeof_realray()))) return rc;
+  if ((rc = grow(C.d_npts, C.cap_npts, (size_t)n))) return rc;
+  if ((rc = grow(C.d_live, C.cap_live, (size_t)n))) return rc;
+  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nf * n * rstride))) return rc;
+  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)n * (rstride / 64) * 2))) return rc;
+  C.steps_rays = 0;
+  struct Tmp { void *p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } din, dtpr;
+  HIPCHK(hipMalloc(&din.p, (size_t)7 * n * sizeof(double)));
+  HIPCHK(hipMalloc(&dtpr.p, (size_t)n * sizeof(int32_t)));
+  const double *src[7] = {alpha, beta, l, q2, su, sm, uf};
+  double *d7 = (double *)din.p;
+  for (int k = 0; k < 7; ++k) HIPCHK(hipMemcpy(d7 + (size_t)k * n, src[k], (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dtpr.p, tpr, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  GrtRayIn rin{d7, d7 + (size_t)n, d7 + (size_t)2 * n, d7 + (size_t)3 * n, d7 + (size_t)4 * n, d7 + (size_t)5 * n, d7 + (size_t)6 * n,
+               (const int32_t *)dtpr.p};
+  const long long fstride = (long long)n * rstride;
+  HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
+  HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
+  hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 1, &rin);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, C.d_flags, rstride, fstride, nf, 4, nullptr, 1);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, C.d_flags, rstride, fstride, nf, 4, nullptr, 1);
+  if (e != hipSuccess) { drain(); return (int)e; }
+  HIPCHK(hipStreamSynchronize(C.stream));
+  // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them
+  double *outs[5] = {ufi, mufi, lambdai, dphi, dti};
+  for (int f = 0; f < 5; ++f)
+    if (outs[f])
+      HIPCHK(hipMemcpy2D(outs[f], (size_t)maxpts * sizeof(double), C.d_steps + (size_t)f * fstride, (size_t)rstride * sizeof(double),
+                         (size_t)maxpts * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+  if (tpmi || tpri) {
+    std::vector<double> tmp((size_t)n * maxpts);
+    int32_t *io[2] = {tpmi, tpri};
+    for (int f = 0; f < 2; ++f) {
+      if (!io[f]) continue;
+      HIPCHK(hipMemcpy2D(tmp.data(), (size_t)maxpts * sizeof(double), C.d_steps + (size_t)(5 + f) * fstride, (size_t)rstride * sizeof(double),
+                         (size_t)maxpts * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < tmp.size(); ++k) io[f][k] = (int32_t)tmp[k];
+    }
+  }
+  if (npts) HIPCHK(hipMemcpy(npts, C.d_npts, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (ncase) {
+    std::vector<GrtRay> hr((size_t)n);
+    HIPCHK(hipMemcpy(hr.data(), C.d_rays, (size_t)n * sizeof(GrtRay), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k) ncase[k] = hr[k].ncase;
+  }
+  return 0;
+}
+
+int grt_get_harm_tstep(float *tstep) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!tstep) return GRT_E_BADARG;
+  if (!C.have_harm) return GRT_E_NOFLUID;
+  *tstep = C.harm.tstep;
   return 0;
 }
 

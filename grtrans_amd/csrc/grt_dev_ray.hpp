@@ -45,15 +45,17 @@ GRT_HD void camera_pixel(const GrtCam &cam, int ii, GrtRay &R) {
   R.pix = ii;
 }
 
-GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
+// Everything after the pixel constants: R.alpha, beta, l, q2, su, sm are set by the caller (camera_pixel for a camera
+// pixel; the caller's own arrays for grt_geokerr_rays = class_geokerr's call_geokerr).  uf_in, tpr_in: GEOKERR's UF and
+// TPR arguments (the camera passes the horizon and 1, geokerr_wrapper.f:255-257).
+GRT_HD void setup_ray_core(const GrtCam &cam, GrtRay &R, double uf_in, int tpr_in) {
   const double one = 1.0, two = 2.0;
-  camera_pixel(cam, ii, R);
   const double a = cam.a, mu0 = cam.mu0, uout = cam.uout, offset = cam.offset, l = R.l, q2 = R.q2, su = R.su, sm = R.sm;
   const int nup = cam.nup, kext = cam.kext, next = cam.next;
   const double uplus = one / (one + sqrt(one - a * a));
   GKCache c;
-  double u0 = cam.u0, uf = uplus, muf = 0.0, l2 = l * l, iu = 0.0, mun = 0.0;
-  int tpm = 0, tpr = 1;
+  double u0 = cam.u0, uf = uf_in, muf = 0.0, l2 = l * l, iu = 0.0, mun = 0.0;
+  int tpm = 0, tpr = tpr_in;
   R.npts = 0; R.kmax = 0; R.tpr = 0; R.tpr_out = 0; R.fill_tpm0 = 0; R.fill_tpm1 = 0;
   R.fill_muminus = R.fill_muplus = R.fill_mu0 = R.fill_muf = 0.0; R.dt1 = 0.0; R.lam1 = 0.0;
   geomu(u0, uf, mu0, muf, a, l, l2, q2, iu, tpm, tpr, su, sm, c, true, true);
@@ -118,6 +120,12 @@ GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
     R.tpr_out = tpr;
   }
   R.npts = npts;
+}
+
+GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
+  camera_pixel(cam, ii, R);
+  const double a = cam.a;
+  setup_ray_core(cam, R, 1.0 / (1.0 + sqrt(1.0 - a * a)), 1);
 }
 
 struct GeoPoint {

@@ -45,13 +45,20 @@ using namespace grtd;
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
-                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time, double polar_l2) {
+                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time, double polar_l2,
+                                                         GrtRayIn rin) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
   GrtRay R;
   R.npts = 0;
   if (inr) {
-    setup_ray(cam, (int)(i1 + tid), R);
+    if (rin.l) {     // caller-given rays (call_geokerr, class_geokerr.f90:69-107): ray tid of the arrays
+      R.alpha = rin.alpha[tid]; R.beta = rin.beta[tid]; R.l = rin.l[tid]; R.q2 = rin.q2[tid]; R.su = rin.su[tid]; R.sm = rin.sm[tid];
+      R.pix = tid + 1;
+      setup_ray_core(cam, R, rin.uf[tid], rin.tpr[tid]);
+    } else {
+      setup_ray(cam, (int)(i1 + tid), R);
+    }
     rays[tid] = R;
     ray_npts[tid] = R.npts;
   }
@@ -128,14 +135,18 @@ extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long 
 template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
-    int nlive, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
-    long long field_stride, int nfields, int tfield, const double *__restrict__ t0) {
+    const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
+    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
   constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int slot = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
-  if (slot >= nlive) return;   // whole wave leaves together
-  slot = __builtin_amdgcn_readfirstlane(slot);
-  const int rayidx = live[slot];
+  // the class size is read on the device (the set-up kernel's counter): the host never waits for it between the launches.
+  // The fast-class grid covers the worst case (surplus waves leave at once); the generic-class grid is capped and strides.
+  int slot0 = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
+  if (slot0 >= *nlive_dev) return;   // whole wave leaves together
+  do {
+  const int slot = __builtin_amdgcn_readfirstlane(slot0);
+  // fast classes fill live[] from the front, the generic class from the back (grt_setup_kernel)
+  const int rayidx = FAST ? live[slot] : live[nrays - 1 - slot];
   const GrtRay *Rp = rays + rayidx;
   const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)(FAST ? rayidx : 0) * GRT_RR_STRIDE);
   const CubRay *Cp = reinterpret_cast<const CubRay *>(Kp);
@@ -169,7 +180,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
     }
     if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
-    if (valid) {   // geodesics.f90:333-347
+    if (NPH == 3 && valid && raw) {   // grt_geokerr_rays: GEOKERR's own output arrays UFI, MUFI, LAMBDAI, DPHI, DTI, TPMI, TPRI
+      double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
+      sp[0] = P.u; sp[field_stride] = P.mu; sp[2 * field_stride] = P.lam; sp[3 * field_stride] = P.dphi;
+      sp[4 * field_stride] = P.dt; sp[5 * field_stride] = (double)P.tpm; sp[6 * field_stride] = (double)P.tpr;
+    } else if (valid) {   // geodesics.f90:333-347
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
       sp[GRT_F_R * field_stride] = 1.0 / P.u;
       sp[GRT_F_TH * field_stride] = acos(P.mu);
@@ -184,6 +199,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       fp[0] = mm; fp[1] = mr;
     }
   }
+  slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
+  } while (FAST == 0 && slot0 < *nlive_dev);     // only the generic class strides (capped grid); a fast-class wave serves one ray
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -219,11 +236,16 @@ template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 
 
 template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
 __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_transfer_kernel(
-    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive, GrtFluidDev fd, GrtTables tb,
+    GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive_arg, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned long long *__restrict__ flags,
-    long long ray_stride, long long field_stride, int nfields, int tfield, unsigned long long *__restrict__ step_counter) {
+    long long ray_stride, long long field_stride, int nfields, int tfield, unsigned long long *__restrict__ step_counter,
+    const int *__restrict__ nlive_dev, int from_back) {
   constexpr int NW = GRT_XFER_THREADS / 64;
+  // class size from the set-up kernel's device counter (no host round trip between the launches); the grid covers the
+  // worst case nlive_arg and surplus blocks leave before they stage anything
+  const int nlive = nlive_dev ? *nlive_dev : nlive_arg;
+  if ((int)(blockIdx.x * GRT_XFER_THREADS) >= nlive) return;
   const double *lfreqs = freqs + nfreq;      // log(freqs), appended by the host
   __shared__ double s_tile[NW][4][64 * GRT_TS];
   __shared__ int s_ray[NW][64];
@@ -277,7 +299,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
   const int nf = (nfreq - f0 < FB) ? (nfreq - f0) : FB;
   const bool first_batch = (blockIdx.y == 0);
   const bool record = (nfields > GRT_F_I) && first_batch;
-  const int rayidx = has_ray ? live[slot] : 0;
+  const int rayidx = has_ray ? (from_back ? live[from_back - 1 - slot] : live[slot]) : 0;   // generic class: filled from the back of live[]
   const int n = has_ray ? rays[rayidx].npts : 0;
   int nmax = n;
   for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
@@ -629,33 +651,45 @@ extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mb
 }
 
 // ---- host-side launch helpers (called from grt_api.cpp) ----
+// pixel constants of camera pixel ii on the host (the same camera_pixel the set-up kernel runs): alpha, beta, l, q2, su, sm
+extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *out6) {
+  GrtRay R;
+  camera_pixel(*cam, (int)ii, R);
+  out6[0] = R.alpha; out6[1] = R.beta; out6[2] = R.l; out6[3] = R.q2; out6[4] = R.su; out6[5] = R.sm;
+}
+
 #ifndef GRT_POLAR_L2_DEFAULT
 #define GRT_POLAR_L2_DEFAULT 1.e-6
 #endif
 extern "C" size_t grt_sizeof_realray(void) { return GRT_RR_STRIDE; }
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time) {
+                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin) {
   int blocks = (nrays + 255) / 256;
   // GRT_POLAR_L2: experiment knob for the near-polar routing threshold (tools/polar_phi.py); the default is the product's
   static const double polar_l2 = std::getenv("GRT_POLAR_L2") ? std::atof(std::getenv("GRT_POLAR_L2")) : GRT_POLAR_L2_DEFAULT;
+  GrtRayIn none{};
   hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
-                     (char *)rrays, need_time, polar_l2);
+                     (char *)rrays, need_time, polar_l2, rin ? *rin : none);
   return hipGetLastError();
 }
 
+// nlive_dev: device counter of the class (counters[0] fast, counters[1] generic); nrays: rays of the pass = worst case
+// the grid is sized for, and the length of live[] (the generic class is read from its back)
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
-                                     const int *live, int nlive, double *steps, unsigned long long *flags,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0) {
-  if (nlive <= 0) return hipSuccess;
-  dim3 g((nlive + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK), b(64 * GRT_WAVES_PER_BLOCK);
+                                     const int *live, const int *nlive_dev, int nrays, double *steps, unsigned long long *flags,
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw) {
+  if (nrays <= 0) return hipSuccess;
+  unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
+  if (!fast && nblk > 8192u) nblk = 8192u;     // the generic class is small as a rule: a capped grid that strides over its rays
+  dim3 g(nblk), b(64 * GRT_WAVES_PER_BLOCK);
   const char *rr = (const char *)rrays;
   // the time field needs the azimuth integrals anyway (Eq. 47 shares them), so NPH = 3 also when phi is not stored
   const int nph = (tfield >= 0) ? 3 : ((nfields > GRT_F_PHI) ? 2 : 0);
   const int kind = !fast ? 0 : (cam->a == 0.0 ? 2 : 1);
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P)                                                                                            \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive, steps, flags, ray_stride, field_stride, nfields, tfield, t0);
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, flags, ray_stride, field_stride, nfields, tfield, t0, raw);
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE
   return hipGetLastError();
@@ -666,16 +700,16 @@ static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
                               double *steps, const unsigned long long *flags, long long ray_stride, long long field_stride,
-                              int nfields, int tfield, unsigned long long *step_counter) {
+                              int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
                        rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags,
-                       ray_stride, field_stride, nfields, tfield, step_counter);
+                       ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   } else if (nfreq == 1) {
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
                        *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride,
-                       field_stride, nfields, tfield, step_counter);
+                       field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   } else {
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
@@ -683,7 +717,7 @@ static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
                        dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
-                       nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter);
+                       nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   }
 }
 
@@ -693,7 +727,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
-                                          int nfields, int tfield, unsigned long long *step_counter) {
+                                          int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   if (nlive <= 0) return hipSuccess;
   if (emis == GRT_EMIS_HYBRIDTH || emis == GRT_EMIS_HYBRIDPL) emis = GRT_EMIS_HYBRIDTHPL;   // one instantiation, em->type selects
   if (emis == GRT_EMIS_MAXCOMP) emis = GRT_EMIS_MAXJUTT;
@@ -702,7 +736,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
     launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
-                               ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter);   \
+                               ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);   \
     return hipGetLastError();                                                                                           \
   }
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)

@@ -35,6 +35,12 @@ struct GrtRay {
   int32_t fill_tpm0, fill_tpm1, tpr_out, pix;   // tpr_out: TPR seen by the outbound leg; pix: 1-based pixel
 };
 
+// grt_geokerr_rays: the caller's own per-ray constants instead of a camera's pixel grid (all NULL for a camera)
+struct GrtRayIn {
+  const double *alpha, *beta, *l, *q2, *su, *sm, *uf;
+  const int32_t *tpr;
+};
+
 struct GrtFFJet {               // device pointers; cell-interleaved copy of the BL09 table
   const float *cells;           // [nx1*nx1][12]: rho,p,b0,br,bth,bph,u0,vr,vth,vph,pad,pad
   const float *uniqr, *uniqth, *uniqx1;

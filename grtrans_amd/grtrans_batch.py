@@ -3,9 +3,10 @@
 Mirrors (reference grtrans_batch.py): the defaults table and kwargs (:23-170), i1/i2 clamping
 (:155-164), nweights/delta (:165-170), the inputs.in / files.in writer (:172-330, :378-388),
 run_grtrans (:334-357, executes ./grtrans = grtrans_amd/host/grtrans), run_pgrtrans (:397-414,
-same kwargs -> ivals(nvals, npix, ncams), ab(2, npix), nu), the binary reader (:450-477, cflag=0)
-and calc_spec / calc_spec_pgrtrans (:499-542).  The f2py module `pgrtrans` of the reference is
-replaced by calls into the C ABI; there is no CPU path behind it.
+same kwargs -> pgrtrans.grtrans_main(85 positional arguments) -> ivals(nvals, npix, ncams), ab(2, npix), nu),
+the binary reader (:450-477, cflag=0) and calc_spec / calc_spec_pgrtrans (:499-542).  The f2py module
+`pgrtrans` of the reference is grtrans_amd/pgrtrans.py here: a ctypes view of the Fortran module pgrtrans in
+host/libpgrtrans.so, the same module the executable runs (one host); there is no CPU path behind it.
 """
 import os
 import subprocess
@@ -139,6 +140,21 @@ def read_fits(path):
     return out
 
 
+def _rank_envs(ngpus, tile_cols, base):
+    """Environment of rank r = 0..ngpus-1 of a one-process-per-GPU run (read by module pgrtrans, pgrtrans.f90)."""
+    import tempfile
+    fd, comm = tempfile.mkstemp(prefix="grtrans_amd_comm_")
+    os.close(fd)
+    os.remove(comm)             # rank 0 creates it (grt_comm_init_file)
+    envs = []
+    for r in range(ngpus):
+        e = dict(base)
+        e.update(GRT_RANK=str(r), GRT_WORLD_SIZE=str(ngpus), GRT_LOCAL_RANK=str(r), GRT_COMM_FILE=comm, GRT_TILE_COLS=str(int(tile_cols)))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(e)
+    return envs
+
+
 class grtrans:
     """run & analyze grtrans on the MI355X path (same methods as the reference's class grtrans)"""
 
@@ -152,93 +168,87 @@ class grtrans:
         self.ifile = fname
         self.ofile = oname
 
-    def run_grtrans(self, exe=None, **kwargs):
+    def run_grtrans(self, exe=None, ngpus=1, tile_cols=0, **kwargs):
+        """os.system('./grtrans') of the reference (grtrans_batch.py:334-357).  ngpus > 1: one ./grtrans process per GPU
+        (started before any of them touches a GPU), each reads the same files.in / inputs.in, traces its share of the pixels
+        and rank 0 gathers the image over RCCL and writes the output file (pgrtrans.f90 of this package)."""
         if os.path.exists(self.ofile):
             os.remove(self.ofile)
         env = dict(os.environ)
         env.setdefault("GRTRANS_AMD_DATA", capi.DATA)
-        subprocess.check_call([exe or HOST_EXE], env=env)
+        if ngpus <= 1:
+            subprocess.check_call([exe or HOST_EXE], env=env)
+            return
+        procs = []
+        for r, e in enumerate(_rank_envs(ngpus, tile_cols, env)):
+            procs.append(subprocess.Popen([exe or HOST_EXE], env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise capi.GrtError("grtrans ranks exited with %s" % rcs)
 
-    def run_pgrtrans(self, device=0, **kwargs):
-        """Same kwargs as write_grtrans_inputs; fills ivals(nvals,npix,ncams), ab(2,npix), nu."""
-        inp = self.inputs = grtrans_inputs(**kwargs)
-        nt = int(inp.nt)
-        nextra = 19 if int(inp.extra) == 1 else 0           # pgrtrans.f90:108-114 (nup > 1)
-        nfreq, nmu, nmdot = int(inp.nfreq), int(inp.nmu), int(inp.nmdot)
-        freqs = np.array([inp.fmin]) if nfreq == 1 else inp.fmin * np.exp(np.arange(nfreq) * np.log(inp.fmax / inp.fmin) / (nfreq - 1))
-        mu0 = np.array([inp.mumin]) if nmu == 1 else inp.mumin + (inp.mumax - inp.mumin) / (nmu - 1) * np.arange(nmu)
-        npix = inp.nn[0] * inp.nn[1]
-        ncams = nmdot * nfreq * nmu * nt
-        dev = capi.Device(device)
+    def run_pgrtrans(self, ngpus=1, tile_cols=0, **kwargs):
+        """grtrans_batch.py:397-414: same kwargs as write_grtrans_inputs; pgrtrans.grtrans_main with the 85 positional
+        arguments, then copies of the module arrays ivals(nvals,npix,ncams), ab(2,npix), freqs.  `pgrtrans` is the Fortran
+        module of host/libpgrtrans.so (grtrans_amd/pgrtrans.py), the same one ./grtrans runs.
+        ngpus > 1: this process is rank 0; ranks 1..N-1 are child processes running the same call (grtrans_amd.rank_worker),
+        started before this process touches a GPU."""
+        from .pgrtrans import pgrtrans
+        if len(np.shape(pgrtrans.ivals)) > 0:
+            print('ERROR in run_pgrtrans: data already exist!')
+            return
+        self.inputs = grtrans_inputs(**kwargs)
+        procs, saved = [], {}
+        if ngpus > 1:
+            import pickle
+            import sys
+            import tempfile
+            envs = _rank_envs(ngpus, tile_cols, dict(os.environ))
+            job = tempfile.NamedTemporaryFile(prefix="grt_job_", suffix=".pkl", delete=False)
+            pickle.dump(kwargs, job)
+            job.close()
+            for r in range(1, ngpus):
+                procs.append(subprocess.Popen([sys.executable, "-m", "grtrans_amd.rank_worker", job.name], env=envs[r],
+                                              cwd=os.getcwd(), stdout=subprocess.DEVNULL))
+            for k in ("GRT_RANK", "GRT_WORLD_SIZE", "GRT_LOCAL_RANK", "GRT_COMM_FILE", "GRT_TILE_COLS"):
+                saved[k] = os.environ.get(k)
+                os.environ[k] = envs[0][k]
         try:
-            dev.load_tables()
-            if inp.fname == 'FFJET':
-                path = inp.fdfile if os.path.exists(inp.fdfile) else os.path.join(capi.DATA, inp.fdfile)
-                dev.load_ffjet(path)
-            elif inp.fname == 'SPHACC':
-                dev.load_sphacc()
-            elif inp.fname == 'THINDISK':
-                dev.set_thindisk(float(inp.tmdot), float(inp.srin), float(inp.srout))   # fmdot, frin, frout of the namelist
-            elif inp.fname == 'HARM':
-                if int(inp.fnt) > 1 and nextra:
-                    raise capi.GrtError("extra=1 with several HARM slices (hnt > 1) is not on the device yet")
-                dev.load_harm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), nt=int(inp.fnt))
-            elif inp.fname in ('KORAL3D', 'KORAL3D_DISK'):
-                if int(inp.fnt) != 1 or int(inp.nload) != 1:
-                    raise capi.GrtError("KORAL3D with several loaded slices (hnt, nload > 1) is not on the device yet")
-                if nt > 1:
-                    raise capi.GrtError("KORAL3D movie frames (nt > 1) are not on the device yet")
-                dev.load_koral3d(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin), float(inp.fscalefac))
-            elif inp.fname == 'IHARM':
-                if int(inp.fnt) != 1 or int(inp.nload) != 1:
-                    raise capi.GrtError("IHARM with several loaded slices (hnt, nload > 1) is not on the device yet")
-                dev.load_iharm(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
-            elif inp.fname == 'HARM3D':
-                if int(inp.fnt) != 1 or int(inp.nload) != 1:
-                    raise capi.GrtError("HARM3D with several loaded slices (hnt, nload > 1) is not on the device yet")
-                dev.load_harm3d(inp.fdfile, inp.fhfile, int(inp.findf), float(inp.spin))
-            ivals = np.zeros((inp.nvals + nextra, npix, ncams))
-            ab = np.zeros((2, npix))
-            harm_indf, harm_toffset, harm_tstep = int(inp.findf), np.float32(0.), np.float32(20.)
-            for j in range(nmu):
-                cam = capi.make_camera(inp.standard, inp.gridvals, inp.nn, inp.spin, float(mu0[j]), inp.uout, inp.phi0)
-                if int(inp.nload) > 1:
-                    # pgrtrans.f90:172-189: per-ray time origins from one-point geodesics, normalised over the image;
-                    # initialize_geo_tabs leaves the mu-fill segment switched off for the traces that follow
-                    cam.mufill, cam.kext, cam.next = 0, 0, 0
-                    capi.set_t0(capi.normalise_t0(capi.compute_t0(cam, inp.i1, inp.i2)))
-                else:
-                    capi.set_t0(None)
-                for l in range(nt):
-                    if l > 0 and inp.fname in ('HARM', 'HARM3D', 'IHARM'):
-                        # advance_harm_timestep (fluid_model_harm.f90:511-521; the same arithmetic in
-                        # advance_harm3d_timestep, fluid_model_harm3d.f90:688-699): REAL(4) tstep, toffset kept across frames
-                        nupdate = int(np.floor(float(inp.dt) / float(harm_tstep)))
-                        harm_toffset = np.float32(float(harm_toffset) + float(inp.dt) - float(harm_tstep) * nupdate)
-                        nupdate += int(np.floor(harm_toffset / harm_tstep))
-                        harm_toffset = np.float32(harm_toffset - np.float32(np.floor(harm_toffset / harm_tstep)) * harm_tstep)
-                        harm_indf += nupdate
-                        if nupdate > 0 and inp.fname == 'HARM':
-                            dev.load_harm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin), nt=int(inp.fnt))
-                        elif nupdate > 0 and inp.fname == 'IHARM':
-                            dev.load_iharm(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
-                        elif nupdate > 0:
-                            dev.load_harm3d(inp.fdfile, inp.fhfile, harm_indf, float(inp.spin))
-                    for m in range(nmdot):
-                        mdot = inp.mdotmin if nmdot == 1 else inp.mdotmin * np.exp(m * np.log(inp.mdotmax / inp.mdotmin) / (nmdot - 1))
-                        em = capi.make_emis(inp.ename, inp.mbh, inp.ntscl, inp.nrscl, inp.gmin, inp.gmax, inp.p1,
-                                            inp.muval, inp.epcoefindx, mdot=float(mdot), jetalpha=float(inp.jetalpha),
-                                            sigcut=float(inp.sigcut), otherargs=tuple(inp.epotherargs))
-                        pix, loc, status, st = capi.trace_tile(cam, inp.i1, inp.i2, inp.fname, em, freqs, inp.iname,
-                                                               nvals=inp.nvals, nextra=nextra)
-                        for k in range(nfreq):
-                            c = ((j * nt + l) * nfreq * nmdot) + m * nfreq + k      # grtrans_driver.f90:324 with l -> (j-1)*nt+l
-                            ivals[:, inp.i1 - 1:inp.i2, c] = pix[k].T
-                        ab[:, inp.i1 - 1:inp.i2] = loc.T
+            self._call_grtrans_main(pgrtrans)
         finally:
-            dev.close()
-        self.ivals, self.ab, self.nu = ivals, ab, freqs
-        self.nx, self.ny, self.nvals = int(inp.nn[0]), int(inp.nn[1]), int(inp.nvals) + nextra
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise capi.GrtError("pgrtrans ranks exited with %s" % rcs)
+        self.ivals = pgrtrans.ivals.copy()
+        self.ab = pgrtrans.ab.copy()
+        self.nu = pgrtrans.freqs.copy()
+        self.nx = int(self.inputs.nn[0])
+        self.ny = int(self.inputs.nn[1])
+        self.nvals = int(np.shape(self.ivals)[0])          # nvals + nextra (the reference leaves int(inputs.nvals) here)
+        self.ray_steps, self.kernel_ms = pgrtrans.last_ray_steps, pgrtrans.last_kernel_ms
+        self.del_pgrtrans_data()
+
+    def _call_grtrans_main(self, pgrtrans):
+        i = self.inputs
+        pgrtrans.grtrans_main(i.standard, i.mumin, i.mumax, i.nmu, i.phi0, i.spin, i.uout, i.uin, i.rcut, i.nrotype, i.gridvals, i.nn,
+                              i.i1, i.i2, i.fname, i.dt, i.nt, i.nload, i.nmdot, i.mdotmin, i.mdotmax, i.ename, i.mbh, i.nfreq, i.fmin,
+                              i.fmax, i.muval, i.gmin, i.gmax, i.p1, i.p2, i.jetalpha, i.stype, i.use_geokerr, i.nvals, i.iname,
+                              i.cflag, i.extra, i.debug, i.outfile, i.fdfile, i.fhfile, i.fgfile, i.fsim, i.fnt, i.findf, i.fnfiles,
+                              i.fjonfix, i.pnw, i.pnfreq_tab, i.pnr, i.foffset, i.fdindf, i.fmagcrit, i.hrspot, i.hr0spot, i.hn0spot,
+                              i.ntscl, i.nrscl, i.pwmin, i.pwmax, i.pfmin, i.pfmax, i.prmax, i.psigt, i.pfcol, i.tmdot, i.snscl,
+                              i.snnthscl, i.snnthp, i.sbeta, i.sbl06, i.snp, i.snt, i.srin, i.srout, i.sthin, i.sthout, i.sphiin,
+                              i.sphiout, i.fscalefac, i.sigcut, i.epcoefindx, i.epotherargs, i.nep)
+
+    def del_pgrtrans_data(self):
+        from .pgrtrans import pgrtrans
+        if len(np.shape(pgrtrans.ivals)) == 0:
+            print('ERROR in del_pgrtrans_data: no data to delete!')
+            return
+        pgrtrans.del_pgrtrans_data()
 
     def read_grtrans_output(self, bin=1):
         """cflag=0 binary file (camera.f90:321-340): Fortran sequential records per camera."""

@@ -105,6 +105,55 @@ module grt_cabi
        real(c_double), value :: spin
        integer(c_int) :: rc
      end function grt_load_harm_files_nt
+     function grt_comm_init_file(rank, nranks, path, timeout_s) bind(C, name='grt_comm_init_file') result(rc)
+       import :: c_int, c_char, c_double
+       integer(c_int), value :: rank, nranks
+       character(kind=c_char), dimension(*), intent(in) :: path
+       real(c_double), value :: timeout_s
+       integer(c_int) :: rc
+     end function grt_comm_init_file
+     function grt_comm_free() bind(C, name='grt_comm_free') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function grt_comm_free
+     function grt_comm_allreduce(vals, n, op) bind(C, name='grt_comm_allreduce') result(rc)
+       import :: c_int, c_double
+       real(c_double), intent(inout) :: vals(*)
+       integer(c_int), value :: n, op
+       integer(c_int) :: rc
+     end function grt_comm_allreduce
+     function grt_stage_reset(ncams, nvals, npix_rank) bind(C, name='grt_stage_reset') result(rc)
+       import :: c_int, c_int64_t
+       integer(c_int), value :: ncams, nvals
+       integer(c_int64_t), value :: npix_rank
+       integer(c_int) :: rc
+     end function grt_stage_reset
+     function grt_stage_resident(cam0, nfreq, npix_tile, pix_offset) bind(C, name='grt_stage_resident') result(rc)
+       import :: c_int, c_int64_t
+       integer(c_int), value :: cam0, nfreq
+       integer(c_int64_t), value :: npix_tile, pix_offset
+       integer(c_int) :: rc
+     end function grt_stage_resident
+     function grt_gather_stage(npix_of_rank, root, host_full) bind(C, name='grt_gather_stage') result(rc)
+       import :: c_int, c_int64_t, c_float
+       integer(c_int64_t), intent(in) :: npix_of_rank(*)
+       integer(c_int), value :: root
+       real(c_float), intent(out) :: host_full(*)
+       integer(c_int) :: rc
+     end function grt_gather_stage
+     function grt_camera_pixels(cam, i1, i2, alpha, beta, q2, l, su, sm, uf, muf, tpm, tpr) bind(C, name='grt_camera_pixels') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr, grt_camera
+       type(grt_camera), intent(in) :: cam
+       integer(c_int64_t), value :: i1, i2
+       real(c_double), intent(out) :: alpha(*), beta(*)
+       type(c_ptr), value :: q2, l, su, sm, uf, muf, tpm, tpr      ! optional outputs: c_null_ptr to skip
+       integer(c_int) :: rc
+     end function grt_camera_pixels
+     function grt_get_harm_tstep(tstep) bind(C, name='grt_get_harm_tstep') result(rc)
+       import :: c_int, c_float
+       real(c_float), intent(out) :: tstep
+       integer(c_int) :: rc
+     end function grt_get_harm_tstep
      function grt_load_sphacc_tables_file(path) bind(C, name='grt_load_sphacc_tables_file') result(rc)
        import :: c_int, c_char
        character(kind=c_char), dimension(*), intent(in) :: path

@@ -13,6 +13,12 @@ module pgrtrans
   real(8), allocatable, dimension(:,:) :: ab
   real(8), allocatable, dimension(:) :: freqs
   real(8) :: last_ray_steps = 0d0, last_kernel_ms = 0d0    ! extra: what the tracer reported
+  ! Error convention.  The reference has none: unsupported input runs into a Fortran STOP (e.g. math.f90:75-79).  So does
+  ! this module by default (error stop, exit code 2 or 3).  With soft errors on, grtrans_main instead releases what it
+  ! holds, sets last_error (2: refused request, 3: a C-ABI call failed) and last_error_msg, and returns.
+  integer, save :: last_error = 0
+  character(len=512), save :: last_error_msg = ' '
+  logical, save :: soft_errors = .false.
   ! HARM time-stepping state (module variables of fluid_model_harm.f90:12-16)
   integer, save :: cur_fluid = 0, harm_indf = 0, harm_nt = 1
   real, save :: harm_tstep = 20., harm_toffset = 0.
@@ -50,8 +56,16 @@ contains
 
     integer :: nro, nphi, nup, ncams, nextra, j, l, m, k, cam_index, rc, fluid_id, emis_id, iflag, npix, ntile, dev
     real(8), allocatable :: mdots(:), mu0(:), t0tab(:)
-    real(c_float), allocatable :: pixvals(:), pixloc(:)
+    real(c_float), allocatable :: pixvals(:), pixloc(:), full(:)
     integer(c_int32_t), allocatable :: status(:)
+    ! one process per GPU: rank, world size, the pixel ranges of this rank (and, on the root, of every rank)
+    integer :: rank, world, local_rank, tilecols, nrng, g, p, nv, force_comm
+    integer, allocatable :: rlo(:), rhi(:), plo(:), phi_(:)
+    integer(c_int64_t), allocatable :: npix_of_rank(:)
+    integer(c_int64_t) :: npix_rank, off, pre
+    real(8) :: red(2)
+    real(8), allocatable :: alpha_all(:), beta_all(:)
+    logical :: multi
     type(grt_camera) :: cam
     type(grt_emis) :: em
     type(grt_stats) :: st
@@ -59,7 +73,9 @@ contains
     character(len=512) :: datadir, path
     integer :: tempi
 
+    last_error = 0; last_error_msg = ' '
     nro = nn(1); nphi = nn(2); nup = nn(3); npix = nro*nphi
+    if (allocated(ivals) .or. allocated(ab) .or. allocated(freqs)) call del_pgrtrans_data()
     allocate(freqs(nfreq), mu0(nmu), mdots(nmdot))
     ncams = nmdot*nfreq*nmu*nt
     ! log-spaced frequencies / mdots, linear mu0 (pgrtrans.f90:87-104)
@@ -88,9 +104,20 @@ contains
     end if
 
     ! ---- what this build can put on the device; everything else stops loudly (no CPU path) ----
-    if (.not. use_geokerr) call die('use_geokerr=F is not supported')
-    if (debug /= 0) call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps')
-    if (extra == 1 .and. nup <= 1) call die('extra=1 with nup=1 is not supported yet')
+    if (.not. use_geokerr) then
+       call die('use_geokerr=F is not supported'); goto 999
+    end if
+    ! nrotype=1 is the polar alpha/beta grid of geokerr_wrapper.f:138-149,181-195 (rcut = its outer radius); the device
+    ! builds the rectangular grid (nrotype > 1) only.  uin never reaches GEOKERR in the reference either (geodesics.f90:71-75).
+    if (nrotype <= 1) then
+       call die('nrotype=1 (polar camera grid, rcut) is not supported: use nrotype=2 with gridvals'); goto 999
+    end if
+    if (debug /= 0) then
+       call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps'); goto 999
+    end if
+    if (extra == 1 .and. nup <= 1) then
+       call die('extra=1 with nup=1 is not supported yet'); goto 999
+    end if
     select case (trim(fname))
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
     case ('SPHACC'); fluid_id = GRT_FLUID_SPHACC
@@ -100,7 +127,7 @@ contains
     case ('KORAL3D'); fluid_id = GRT_FLUID_KORAL3D
     case ('KORAL3D_DISK'); fluid_id = GRT_FLUID_KORAL3D_DISK
     case ('THINDISK'); fluid_id = GRT_FLUID_THINDISK
-    case default; call die('fluid model '//trim(fname)//' is not on the device yet')
+    case default; call die('fluid model '//trim(fname)//' is not on the device yet'); goto 999
     end select
     cur_fluid = fluid_id
     select case (trim(ename))
@@ -119,7 +146,7 @@ contains
     case ('BREMS'); emis_id = GRT_EMIS_BREMS
     case ('SYNCHTHBREMS'); emis_id = GRT_EMIS_SYNCHTHBREMS
     case ('RHO'); emis_id = GRT_EMIS_RHO
-    case default; call die('emissivity '//trim(ename)//' is not on the device yet')
+    case default; call die('emissivity '//trim(ename)//' is not on the device yet'); goto 999
     end select
     select case (trim(iname))          ! rad_trans.f90:29-37
     case ('delo'); iflag = 1
@@ -127,18 +154,36 @@ contains
     case ('lsoda', 'lsodasph')
        iflag = 0
        ! one stored point per ray: no integrator runs (grtrans_driver.f90:296-300), so the name is immaterial
-       if (nup /= 1) call die('iname='//trim(iname)//': LSODA has no device implementation, use formal or delo')
-    case default; call die('unknown iname '//trim(iname))
+       if (nup /= 1) then
+          call die('iname='//trim(iname)//': LSODA has no device implementation, use formal or delo'); goto 999
+       end if
+    case default; call die('unknown iname '//trim(iname)); goto 999
     end select
 
-    call get_environment_variable('GRT_DEVICE', path)
-    dev = 0
-    if (len_trim(path) > 0) read(path, *) dev
-    rc = grt_init(int(dev, c_int)); if (rc /= 0) call die_rc('grt_init', rc)
+    ! One process per GPU.  The launcher (torchrun, grtrans_batch.run_grtrans(ngpus=N), or any shell loop) starts N copies
+    ! with RANK / WORLD_SIZE / LOCAL_RANK set (GRT_RANK / GRT_WORLD_SIZE / GRT_LOCAL_RANK take precedence); every copy reads
+    ! the same inputs, traces its share of the pixels i1..i2 and rank 0 assembles ivals / ab and writes the output file.
+    rank = env_int('GRT_RANK', env_int('RANK', 0))
+    world = env_int('GRT_WORLD_SIZE', env_int('WORLD_SIZE', 1))
+    local_rank = env_int('GRT_LOCAL_RANK', env_int('LOCAL_RANK', rank))
+    force_comm = env_int('GRT_FORCE_COMM', 0)           ! test hook: the gather path with a one-rank communicator
+    multi = (world > 1 .or. force_comm == 1)
+    ! share-out of the pixels: contiguous strips of i1..i2 (default) or -- SURVEY 8e, for cameras whose captured or dead
+    ! rays cluster -- tiles of GRT_TILE_COLS image columns dealt round-robin to the ranks
+    tilecols = env_int('GRT_TILE_COLS', 0)
+    if (world < 1 .or. rank < 0 .or. rank >= world) then
+       call die('bad RANK / WORLD_SIZE'); goto 999
+    end if
+    dev = env_int('GRT_DEVICE', merge(local_rank, 0, world > 1))
+    rc = grt_init(int(dev, c_int)); if (rc /= 0) then
+       call die_rc('grt_init', rc); goto 999
+    end if
     call get_environment_variable('GRTRANS_AMD_DATA', datadir)
     if (len_trim(datadir) == 0) datadir = '.'
     path = trim(datadir)//'/polsynchpl_tables.bin'
-    rc = grt_load_polsynchpl_tables_file(cstr(path)); if (rc /= 0) call die_rc('grt_load_polsynchpl_tables_file '//trim(path), rc)
+    rc = grt_load_polsynchpl_tables_file(cstr(path)); if (rc /= 0) then
+       call die_rc('grt_load_polsynchpl_tables_file '//trim(path), rc); goto 999
+    end if
     if (fluid_id == GRT_FLUID_FFJET) then
        path = trim(fdfile)              ! as load_fluid_model does (fluid.f90:226-228)
        rc = grt_load_ffjet_file(cstr(path))
@@ -146,95 +191,259 @@ contains
           path = trim(datadir)//'/'//trim(fdfile)
           rc = grt_load_ffjet_file(cstr(path))
        end if
-       if (rc /= 0) call die_rc('grt_load_ffjet_file '//trim(fdfile), rc)
+       if (rc /= 0) then
+          call die_rc('grt_load_ffjet_file '//trim(fdfile), rc); goto 999
+       end if
     else if (fluid_id == GRT_FLUID_HARM) then
        ! initialize_harm_model(a,ifile,fdfile,fhfile,fnt,findf), fluid.f90:193-194
        ! fnt > 1: that many time slices are loaded and each point reads the one its look-back time selects (slow light)
-       if (fnt > 1 .and. extra /= 0) call die('extra=1 with several HARM slices (fnt > 1) is not supported')
+       if (fnt > 1 .and. extra /= 0) then
+          call die('extra=1 with several HARM slices (fnt > 1) is not supported'); goto 999
+       end if
        rc = grt_load_harm_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(fnt, c_int), spin)
-       if (rc /= 0) call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       if (rc /= 0) then
+          call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+       end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = fnt
+       ! tstep = t(1)-t(2) of the loaded dumps when fnt > 1, the module default 20. otherwise (fluid_model_harm.f90:493-500)
+       rc = grt_get_harm_tstep(harm_tstep); if (rc /= 0) then
+          call die_rc('grt_get_harm_tstep', rc); goto 999
+       end if
     else if (fluid_id == GRT_FLUID_HARM3D) then
+       harm_tstep = 20.
        ! initialize_harm3d_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:195-196; one loaded slice
-       if (fnt /= 1 .or. nload /= 1) call die('HARM3D with several loaded slices (fnt, nload > 1) is not supported')
+       if (fnt /= 1 .or. nload /= 1) then
+          call die('HARM3D with several loaded slices (fnt, nload > 1) is not supported'); goto 999
+       end if
        rc = grt_load_harm3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
-       if (rc /= 0) call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       if (rc /= 0) then
+          call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+       end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
     else if (fluid_id == GRT_FLUID_KORAL3D .or. fluid_id == GRT_FLUID_KORAL3D_DISK) then
        ! initialize_koral3d_model(a,ifile,.false.,fdfile,fhfile,fnt,findf,fscalefac,...), fluid.f90:205-210; one loaded slice
-       if (fnt /= 1 .or. nload /= 1) call die('KORAL3D with several loaded slices (fnt, nload > 1) is not supported')
-       if (nt > 1) call die('KORAL3D movie frames (nt > 1) are not supported')
+       if (fnt /= 1 .or. nload /= 1) then
+          call die('KORAL3D with several loaded slices (fnt, nload > 1) is not supported'); goto 999
+       end if
+       if (nt > 1) then
+          call die('KORAL3D movie frames (nt > 1) are not supported'); goto 999
+       end if
        rc = grt_load_koral3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin, fscalefac)
-       if (rc /= 0) call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       if (rc /= 0) then
+          call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+       end if
     else if (fluid_id == GRT_FLUID_IHARM) then
+       harm_tstep = 20.
        ! initialize_iharm_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:199-200; one loaded slice, metric 0
-       if (fnt /= 1 .or. nload /= 1) call die('IHARM with several loaded slices (fnt, nload > 1) is not supported')
+       if (fnt /= 1 .or. nload /= 1) then
+          call die('IHARM with several loaded slices (fnt, nload > 1) is not supported'); goto 999
+       end if
        rc = grt_load_iharm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
-       if (rc /= 0) call die_rc('grt_load_iharm_files '//trim(fdfile)//' '//trim(fhfile), rc)
+       if (rc /= 0) then
+          call die_rc('grt_load_iharm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+       end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
     else if (fluid_id == GRT_FLUID_THINDISK) then
        ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
-       rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) call die_rc('grt_set_thindisk', rc)
+       rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) then
+          call die_rc('grt_set_thindisk', rc); goto 999
+       end if
     else if (fluid_id == GRT_FLUID_SPHACC) then
        ! the reference holds these tables as DATA statements (fluid_model_sphacc.f90:40-448)
        path = trim(datadir)//'/sphacc_tables.bin'
-       rc = grt_load_sphacc_tables_file(cstr(path)); if (rc /= 0) call die_rc('grt_load_sphacc_tables_file '//trim(path), rc)
+       rc = grt_load_sphacc_tables_file(cstr(path)); if (rc /= 0) then
+          call die_rc('grt_load_sphacc_tables_file '//trim(path), rc); goto 999
+       end if
     end if
 
-    write(6,*) 'welcome to grtrans! (MI355X per-pixel path)'
-    allocate(ivals(nvals+nextra, npix, ncams)); ivals = 0d0
+    if (rank == 0) write(6,*) 'welcome to grtrans! (MI355X per-pixel path)'
+    nv = nvals + nextra
+    allocate(ivals(nv, npix, ncams)); ivals = 0d0
     allocate(ab(2, npix)); ab = 0d0
-    ntile = i2 - i1 + 1
-    allocate(pixvals(int(nvals+nextra,8)*ntile*nfreq), pixloc(2*ntile), status(ntile))
+    ! this rank's pixel ranges (one range = one grt_trace_tile call); with one process it is i1..i2 itself
+    call pixel_ranges(rank, world, i1, i2, nphi, tilecols, nrng, rlo, rhi)
+    npix_rank = 0
+    ntile = 1
+    do g = 1, nrng
+       npix_rank = npix_rank + (rhi(g) - rlo(g) + 1)
+       ntile = max(ntile, rhi(g) - rlo(g) + 1)
+    end do
+    if (multi) then
+       call get_environment_variable('GRT_COMM_FILE', path)
+       if (len_trim(path) == 0) then
+          call get_environment_variable('MASTER_PORT', path)
+          path = '/tmp/grtrans_amd_comm_'//trim(path)
+       end if
+       rc = grt_comm_init_file(int(rank, c_int), int(world, c_int), cstr(trim(path)), 600d0)
+       if (rc /= 0) then
+          call die_rc('grt_comm_init_file '//trim(path), rc); goto 999
+       end if
+       rc = grt_stage_reset(int(ncams, c_int), int(nv, c_int), npix_rank); if (rc /= 0) then
+          call die_rc('grt_stage_reset', rc); goto 999
+       end if
+    end if
+    allocate(pixvals(int(nv,8)*ntile*nfreq), pixloc(2*ntile), status(ntile))
     last_ray_steps = 0d0; last_kernel_ms = 0d0
     do j = 1, nmu
        rc = grt_make_camera(cam, int(standard, c_int), gridvals, int(nn, c_int), spin, mu0(j), uout, phi0)
-       if (rc /= 0) call die_rc('grt_make_camera', rc)
+       if (rc /= 0) then
+          call die_rc('grt_make_camera', rc); goto 999
+       end if
        if (nload > 1) then
-          ! pgrtrans.f90:172-189: time origin of every ray from a one-point geodesic, normalised over the image;
+          ! pgrtrans.f90:172-189: time origin of every ray from a one-point geodesic, normalised over the image
+          ! (over all ranks: two max-reductions of statistics, not a data-path collective);
           ! initialize_geo_tabs (geodesics.f90:120) leaves the mu-fill segment switched off for what follows
           cam%mufill = 0; cam%kext = 0; cam%next = 0
-          allocate(t0tab(ntile))
-          rc = grt_compute_t0(cam, int(i1, c_int64_t), int(i2, c_int64_t), t0tab); if (rc /= 0) call die_rc('grt_compute_t0', rc)
+          allocate(t0tab(max(npix_rank, 1_c_int64_t)))
+          off = 0
+          do g = 1, nrng
+             rc = grt_compute_t0(cam, int(rlo(g), c_int64_t), int(rhi(g), c_int64_t), t0tab(off+1:))
+             if (rc /= 0) then
+                call die_rc('grt_compute_t0', rc); goto 999
+             end if
+             off = off + (rhi(g) - rlo(g) + 1)
+          end do
+          red(1) = -huge(1d0)
+          if (npix_rank > 0) red(1) = maxval(t0tab(1:npix_rank))
+          if (multi) then
+             rc = grt_comm_allreduce(red, 1_c_int, 1_c_int); if (rc /= 0) then
+                call die_rc('grt_comm_allreduce', rc); goto 999
+             end if
+          end if
           where (t0tab > 0.)
-             t0tab = t0tab - maxval(t0tab)
+             t0tab = t0tab - red(1)
           elsewhere
              t0tab = 0.
           end where
-          t0tab = t0tab - minval(t0tab)
-          rc = grt_set_t0(t0tab, int(ntile, c_int64_t)); if (rc /= 0) call die_rc('grt_set_t0', rc)
-          deallocate(t0tab)
+          red(1) = -huge(1d0)
+          if (npix_rank > 0) red(1) = -minval(t0tab(1:npix_rank))
+          if (multi) then
+             rc = grt_comm_allreduce(red, 1_c_int, 1_c_int); if (rc /= 0) then
+                call die_rc('grt_comm_allreduce', rc); goto 999
+             end if
+          end if
+          t0tab = t0tab + red(1)
        end if
        wtime = omp_get_wtime()
        do l = 1, nt
-          if (l > 1) call advance_fluid_timestep(dt)             ! pgrtrans.f90:211 (after frame l-1)
-          do m = 1, nmdot
-             em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
-             em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
-             em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
-             if (nepotherargs < 2 .or. nepotherargs > 8) call die('epotherargs = (delta, 1..7 weights)')
-             em%nother = nepotherargs; em%otherargs = 0d0; em%otherargs(1:nepotherargs) = epotherargs   ! pgrtrans.f90:119-120
-             em%jetalpha = jetalpha; em%sigcut = sigcut               ! sparams%jetalphaval, %sigcut (pgrtrans.f90:129-136)
-             em%mdot = mdots(m); em%gminval = gmin                   ! sparams%mdot, %gminval (pgrtrans.f90:127-131)
-             rc = grt_trace_tile(cam, int(i1, c_int64_t), int(i2, c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &
-                  int(iflag, c_int), int(nvals, c_int), int(nextra, c_int), pixvals, pixloc, status, st)
-             if (rc /= 0) call die_rc('grt_trace_tile', rc)
-             last_ray_steps = last_ray_steps + dble(st%ray_steps); last_kernel_ms = last_kernel_ms + st%ms_total
-             do k = 1, nfreq
+          if (l > 1) then
+             call advance_fluid_timestep(dt)             ! pgrtrans.f90:211 (after frame l-1)
+             if (last_error /= 0) goto 999
+          end if
+          off = 0
+          do g = 1, nrng
+             ntile = rhi(g) - rlo(g) + 1
+             if (nload > 1) then
+                rc = grt_set_t0(t0tab(off+1:), int(ntile, c_int64_t)); if (rc /= 0) then
+                   call die_rc('grt_set_t0', rc); goto 999
+                end if
+             end if
+             ! one geodesic serves every m = 1..nmdot (grtrans_driver.f90:134): after the first mdot the library re-uses the
+             ! resident geodesic record of this camera and range and launches only the transfer kernels
+             do m = 1, nmdot
+                em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
+                em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
+                em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
+                if (nepotherargs < 2 .or. nepotherargs > 8) then
+                   call die('epotherargs = (delta, 1..7 weights)'); goto 999
+                end if
+                em%nother = nepotherargs; em%otherargs = 0d0; em%otherargs(1:nepotherargs) = epotherargs   ! pgrtrans.f90:119-120
+                em%jetalpha = jetalpha; em%sigcut = sigcut               ! sparams%jetalphaval, %sigcut (pgrtrans.f90:129-136)
+                em%mdot = mdots(m); em%gminval = gmin                   ! sparams%mdot, %gminval (pgrtrans.f90:127-131)
+                rc = grt_trace_tile(cam, int(rlo(g), c_int64_t), int(rhi(g), c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &
+                     int(iflag, c_int), int(nvals, c_int), int(nextra, c_int), pixvals, pixloc, status, st)
+                if (rc /= 0) then
+                   call die_rc('grt_trace_tile', rc); goto 999
+                end if
+                last_ray_steps = last_ray_steps + dble(st%ray_steps); last_kernel_ms = last_kernel_ms + st%ms_total
                 ! camera index (l-1)*nfreq*nparams+(m-1)*nfreq+k with l -> (j-1)*nt+l (grtrans_driver.f90:324)
-                cam_index = ((j-1)*nt + l - 1)*nfreq*nmdot + (m-1)*nfreq + k
-                ivals(:, i1:i2, cam_index) = reshape(dble(pixvals((k-1)*int(nvals+nextra,8)*ntile+1 : &
-                     k*int(nvals+nextra,8)*ntile)), (/nvals+nextra, ntile/))
+                cam_index = ((j-1)*nt + l - 1)*nfreq*nmdot + (m-1)*nfreq
+                if (multi) then
+                   ! the tile stays in HBM: device-to-device into this rank's image, gathered once at the end
+                   rc = grt_stage_resident(int(cam_index, c_int), int(nfreq, c_int), int(ntile, c_int64_t), off)
+                   if (rc /= 0) then
+                      call die_rc('grt_stage_resident', rc); goto 999
+                   end if
+                else
+                   do k = 1, nfreq
+                      ivals(:, rlo(g):rhi(g), cam_index + k) = reshape(dble(pixvals((k-1)*int(nv,8)*ntile+1 : &
+                           k*int(nv,8)*ntile)), (/nv, ntile/))
+                   end do
+                end if
              end do
+             off = off + ntile
           end do
        end do
-       write(6,*) 'grtrans wall time elapsed: ', omp_get_wtime() - wtime
-       write(6,*) 'ray-steps: ', last_ray_steps, ' device ms: ', last_kernel_ms
+       if (allocated(t0tab)) deallocate(t0tab)
+       if (rank == 0) write(6,*) 'grtrans wall time elapsed: ', omp_get_wtime() - wtime
     end do
-    ab(:, i1:i2) = reshape(dble(pixloc), (/2, ntile/))      ! c(1)%pixloc (pgrtrans.f90:227)
+    ! ---- assembly of ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the ranks' fp32 images over xGMI ----
+    if (multi) then
+       allocate(npix_of_rank(world))
+       do p = 0, world - 1
+          call pixel_ranges(p, world, i1, i2, nphi, tilecols, k, plo, phi_)
+          npix_of_rank(p+1) = 0
+          do g = 1, k
+             npix_of_rank(p+1) = npix_of_rank(p+1) + (phi_(g) - plo(g) + 1)
+          end do
+       end do
+       if (rank == 0) then
+          allocate(full(max(int(nv,8)*sum(npix_of_rank)*ncams, 1_8)))
+       else
+          allocate(full(1))
+       end if
+       rc = grt_gather_stage(npix_of_rank, 0_c_int, full); if (rc /= 0) then
+          call die_rc('grt_gather_stage', rc); goto 999
+       end if
+       red(1) = last_ray_steps; red(2) = 0d0
+       rc = grt_comm_allreduce(red, 1_c_int, 0_c_int); if (rc /= 0) then
+          call die_rc('grt_comm_allreduce', rc); goto 999
+       end if
+       last_ray_steps = red(1)
+       red(1) = last_kernel_ms
+       rc = grt_comm_allreduce(red, 1_c_int, 1_c_int); if (rc /= 0) then
+          call die_rc('grt_comm_allreduce', rc); goto 999
+       end if
+       last_kernel_ms = red(1)
+       if (rank == 0) then
+          ! full = [ncams][all ranks' pixels, rank after rank, each rank's ranges in order][nv]
+          pre = 0
+          do p = 0, world - 1
+             call pixel_ranges(p, world, i1, i2, nphi, tilecols, k, plo, phi_)
+             off = 0
+             do g = 1, k
+                ntile = phi_(g) - plo(g) + 1
+                do m = 1, ncams
+                   ivals(:, plo(g):phi_(g), m) = reshape(dble(full((int(m-1,8)*sum(npix_of_rank) + pre + off)*nv + 1 : &
+                        (int(m-1,8)*sum(npix_of_rank) + pre + off + ntile)*nv)), (/nv, ntile/))
+                end do
+                off = off + ntile
+             end do
+             pre = pre + npix_of_rank(p+1)
+          end do
+       end if
+       deallocate(full, npix_of_rank)
+       rc = grt_comm_free()
+    end if
+    if (rank == 0) write(6,*) 'ray-steps: ', last_ray_steps, ' device ms: ', last_kernel_ms, ' ranks: ', world
+    ! c(1)%pixloc (pgrtrans.f90:227): alpha, beta of the traced pixels i1..i2 as REAL(4) (camera.f90:36); pure arithmetic
+    ntile = i2 - i1 + 1
+    allocate(alpha_all(ntile), beta_all(ntile))
+    rc = grt_make_camera(cam, int(standard, c_int), gridvals, int(nn, c_int), spin, mu0(nmu), uout, phi0)
+    rc = grt_camera_pixels_ab(cam, int(i1, c_int64_t), int(i2, c_int64_t), alpha_all, beta_all)
+    if (rc /= 0) then
+       call die_rc('grt_camera_pixels', rc); goto 999
+    end if
+    ab(1, i1:i2) = dble(real(alpha_all)); ab(2, i1:i2) = dble(real(beta_all))
+    deallocate(alpha_all, beta_all)
+    if (rank /= 0) then          ! only the root holds the assembled image and writes the file
+       deallocate(pixvals, pixloc, status, mu0, mdots)
+       rc = grt_free()
+       return
+    end if
     if (len_trim(outfile) > 0 .and. cflag /= 1) then
        do m = 1, ncams
           call write_camera(trim(outfile), m, nro, nphi, nvals+nextra, freqs(1+mod(m-1,nfreq)), ab, ivals(:,:,m), cflag)
@@ -274,6 +483,21 @@ contains
     end if
     deallocate(pixvals, pixloc, status, mu0, mdots)
     rc = grt_free()
+    return
+    ! soft-error exit (pgrtrans_set_soft_errors: callers that must survive a refusal, e.g. the Python harness): everything
+    ! this call allocated is released, last_error / last_error_msg say why
+999 continue
+    if (allocated(pixvals)) deallocate(pixvals)
+    if (allocated(pixloc)) deallocate(pixloc)
+    if (allocated(status)) deallocate(status)
+    if (allocated(mu0)) deallocate(mu0)
+    if (allocated(mdots)) deallocate(mdots)
+    if (allocated(t0tab)) deallocate(t0tab)
+    if (allocated(full)) deallocate(full)
+    if (allocated(npix_of_rank)) deallocate(npix_of_rank)
+    call del_pgrtrans_data()
+    rc = grt_comm_free()
+    rc = grt_free()
   end subroutine grtrans_main
 
   ! Binary camera file, one block per camera: the record structure of camera.f90:321-340
@@ -306,8 +530,9 @@ contains
     if (allocated(freqs)) deallocate(freqs)
   end subroutine del_pgrtrans_data
 
-  ! advance_fluid_timestep (fluid.f90:246-262) for one loaded slice: only HARM steps (advance_harm_timestep,
-  ! fluid_model_harm.f90:511-521, REAL(4) tstep=20. and toffset kept across calls); the other device models are static
+  ! advance_fluid_timestep (fluid.f90:246-262): only HARM-family models step (advance_harm_timestep,
+  ! fluid_model_harm.f90:511-521: REAL(4) tstep -- the dumps' own spacing when several slices are loaded, 20. otherwise --
+  ! and toffset kept across calls); the other device models are static
   subroutine advance_fluid_timestep(dtobs)
     use grt_cabi
     real(8), intent(in) :: dtobs
@@ -332,9 +557,83 @@ contains
     end if
   end subroutine advance_fluid_timestep
 
+  integer function env_int(name, default)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: default
+    character(len=64) :: v
+    integer :: ios
+    env_int = default
+    call get_environment_variable(name, v)
+    if (len_trim(v) > 0) then
+       read(v, *, iostat=ios) env_int
+       if (ios /= 0) env_int = default
+    end if
+  end function env_int
+
+  ! Pixel ranges (1-based inclusive, the reference's own i1..i2 key, read_inputs.f90:8-9) of rank r out of `world`.
+  ! tilecols <= 0: one contiguous near-equal strip of i1..i2 per rank.  tilecols > 0: the image columns (alpha index; a
+  ! column = nphi consecutive pixels, geokerr_wrapper.f:258-259) in tiles of tilecols, dealt round-robin (one range per
+  ! tile, also with a single rank).  Every pixel of i1..i2 belongs to exactly one range of exactly one rank.
+  subroutine pixel_ranges(r, world, i1, i2, nphi, tilecols, n, lo, hi)
+    integer, intent(in) :: r, world, i1, i2, nphi, tilecols
+    integer, intent(out) :: n
+    integer, allocatable, intent(out) :: lo(:), hi(:)
+    integer :: ntot, base, rem, t, t1, t2, a, b, cnt
+    ntot = i2 - i1 + 1
+    if (tilecols <= 0) then
+       base = ntot / world; rem = mod(ntot, world)
+       a = i1 + r*base + min(r, rem)
+       b = a + base - 1
+       if (r < rem) b = b + 1
+       if (b >= a) then
+          n = 1; allocate(lo(1), hi(1)); lo(1) = a; hi(1) = b
+       else
+          n = 0; allocate(lo(0), hi(0))
+       end if
+       return
+    end if
+    t1 = (i1 - 1) / (tilecols*nphi); t2 = (i2 - 1) / (tilecols*nphi)
+    cnt = 0
+    do t = t1, t2
+       if (mod(t, world) == r) cnt = cnt + 1
+    end do
+    allocate(lo(cnt), hi(cnt))
+    n = 0
+    do t = t1, t2
+       if (mod(t, world) /= r) cycle
+       a = max(i1, t*tilecols*nphi + 1); b = min(i2, (t+1)*tilecols*nphi)
+       if (b < a) cycle
+       n = n + 1; lo(n) = a; hi(n) = b
+    end do
+  end subroutine pixel_ranges
+
+  ! test access to the share-out (tests/test_host_and_abi.py compares it with grtrans_amd/tiling.py)
+  subroutine pgrtrans_pixel_ranges(r, world, i1, i2, nphi, tilecols, nmax, n, lo, hi) bind(C, name='pgrtrans_pixel_ranges')
+    integer(c_int), value :: r, world, i1, i2, nphi, tilecols, nmax
+    integer(c_int), intent(out) :: n, lo(*), hi(*)
+    integer, allocatable :: a(:), b(:)
+    integer :: nn_
+    call pixel_ranges(r, world, i1, i2, nphi, tilecols, nn_, a, b)
+    n = nn_
+    lo(1:min(nn_, nmax)) = a(1:min(nn_, nmax)); hi(1:min(nn_, nmax)) = b(1:min(nn_, nmax))
+  end subroutine pgrtrans_pixel_ranges
+
+  integer function grt_camera_pixels_ab(cam, i1, i2, alpha, beta) result(rc)
+    use grt_cabi
+    type(grt_camera), intent(in) :: cam
+    integer(c_int64_t), intent(in) :: i1, i2
+    real(8), intent(out) :: alpha(*), beta(*)
+    rc = grt_camera_pixels(cam, i1, i2, alpha, beta, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, &
+         c_null_ptr, c_null_ptr)
+  end function grt_camera_pixels_ab
+
   subroutine die(msg)
     character(len=*), intent(in) :: msg
     write(0,*) 'grtrans_amd: ', trim(msg)
+    if (soft_errors) then
+       last_error = 2; last_error_msg = msg
+       return
+    end if
     error stop 2
   end subroutine die
 
@@ -342,7 +641,53 @@ contains
     character(len=*), intent(in) :: what
     integer, intent(in) :: rc
     write(0,*) 'grtrans_amd: ', trim(what), ' failed, code ', rc
+    if (soft_errors) then
+       last_error = 3
+       write(last_error_msg, '(a,a,i0)') trim(what), ' failed, code ', rc
+       return
+    end if
     error stop 3
   end subroutine die_rc
+
+  ! ---- what an f2py wrapper of this module gives a Python caller: the module arrays, by copy (ctypes cannot read a
+  ! Fortran array descriptor) ----
+  subroutine pgrtrans_shape(nv, npix, ncams, nfreq) bind(C, name='pgrtrans_shape')
+    integer(c_int), intent(out) :: nv, npix, ncams, nfreq
+    nv = 0; npix = 0; ncams = 0; nfreq = 0
+    if (allocated(ivals)) then
+       nv = size(ivals, 1); npix = size(ivals, 2); ncams = size(ivals, 3)
+    end if
+    if (allocated(freqs)) nfreq = size(freqs)
+  end subroutine pgrtrans_shape
+
+  subroutine pgrtrans_copy(ivals_out, ab_out, freqs_out) bind(C, name='pgrtrans_copy')
+    real(c_double), intent(out) :: ivals_out(*), ab_out(*), freqs_out(*)
+    if (allocated(ivals)) ivals_out(1:size(ivals)) = reshape(ivals, (/size(ivals)/))
+    if (allocated(ab)) ab_out(1:size(ab)) = reshape(ab, (/size(ab)/))
+    if (allocated(freqs)) freqs_out(1:size(freqs)) = freqs
+  end subroutine pgrtrans_copy
+
+  subroutine pgrtrans_set_soft_errors(flag) bind(C, name='pgrtrans_set_soft_errors')
+    integer(c_int), value :: flag
+    soft_errors = (flag /= 0)
+    last_error = 0; last_error_msg = ' '
+  end subroutine pgrtrans_set_soft_errors
+
+  subroutine pgrtrans_last_error(code, msg, nmsg) bind(C, name='pgrtrans_last_error')
+    integer(c_int), intent(out) :: code
+    integer(c_int), value :: nmsg
+    character(kind=c_char), intent(out) :: msg(*)
+    integer :: i
+    code = last_error
+    do i = 1, min(nmsg - 1, len_trim(last_error_msg))
+       msg(i) = last_error_msg(i:i)
+    end do
+    msg(min(nmsg, len_trim(last_error_msg) + 1)) = c_null_char
+  end subroutine pgrtrans_last_error
+
+  subroutine pgrtrans_stats(ray_steps, kernel_ms) bind(C, name='pgrtrans_stats')
+    real(c_double), intent(out) :: ray_steps, kernel_ms
+    ray_steps = last_ray_steps; kernel_ms = last_kernel_ms
+  end subroutine pgrtrans_stats
 
 end module pgrtrans

@@ -14,6 +14,25 @@ def strip(rank, world, npix):
     return lo + 1, lo + n
 
 
+def ranges(rank, world, i1, i2, nphi, tile_cols=0):
+    """Pixel ranges [(lo, hi)] (1-based inclusive) of `rank`: the share-out module pgrtrans uses (pgrtrans.f90:pixel_ranges).
+    tile_cols <= 0: one contiguous near-equal strip of i1..i2.  tile_cols > 0: tiles of tile_cols image columns (a column =
+    nphi consecutive pixels, alpha-major order) dealt round-robin over the ranks -- SURVEY 8e: captured and dead rays
+    cluster in image regions, interleaving spreads them over the GPUs."""
+    if tile_cols <= 0:
+        lo, hi = strip(rank, world, i2 - i1 + 1)
+        return [(i1 - 1 + lo, i1 - 1 + hi)] if hi >= lo else []
+    w = tile_cols * nphi
+    out = []
+    for t in range((i1 - 1) // w, (i2 - 1) // w + 1):
+        if t % world != rank:
+            continue
+        a, b = max(i1, t * w + 1), min(i2, (t + 1) * w)
+        if b >= a:
+            out.append((a, b))
+    return out
+
+
 def counts(world, npix, per_pixel):
     return [(strip(r, world, npix)[1] - strip(r, world, npix)[0] + 1) * per_pixel for r in range(world)]
 

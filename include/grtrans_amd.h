@@ -183,11 +183,18 @@ int grt_compute_t0(const grt_camera *cam, int64_t i1, int64_t i2, double *t0_hos
 int grt_set_t0(const double *t0_host, int64_t n);
 
 /* replaces the i=i1..i2 loop over grtrans_driver (pgrtrans.f90:200-207).
+ *   nfreq     any number of frequencies (the cameras of one geodesic, grtrans_driver.f90:157)
+ *   A call with the same camera and pixel range as the previous one (the next mdot of grtrans_main's loop,
+ *   grtrans_driver.f90:134, or the next movie frame) re-uses the resident geodesic record: only the transfer kernels run.
  *   i1,i2     1-based inclusive pixel range, reference semantics (read_inputs.f90:8-9)
  *   pixvals   HOST out, [nfreq][i2-i1+1][nvals+nextra] REAL(4): c(cam)%pixvals(:,i) (camera.f90:35)
  *   pixloc    HOST out or NULL, [i2-i1+1][2] REAL(4): alpha,beta (camera.f90:36)
  *   ray_status HOST out or NULL, [i2-i1+1]: stored points of the ray; 0 = never enters uout,
  *             negative = geodesic rejected (status=-1, geodesics.f90:255) */
+/* 0: every trace call recomputes its geodesics (benchmarks, timing tools); 1 (default): the resident record is re-used as
+ * described below */
+int grt_set_geo_reuse(int enable);
+long long grt_geo_passes(void);     /* passes since grt_init that ran the set-up + geodesic kernels (a re-used record adds none) */
 int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
                    const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
                    int32_t *ray_status, grt_stats *st);
@@ -205,10 +212,58 @@ int grt_copy_resident_pixvals(void *d_dst, int64_t count);
 int grt_set_record_steps(int enable);
 int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out);
 
-/* Multi-GPU assembly of ivals (pgrtrans.f90:221-242): every rank passes its tile (device resident);
- * comm is an ncclComm_t owned by the caller (RCCL), root receives [sum counts] floats. */
-int grt_gather(const float *d_tile, int64_t count, float *d_full, const int64_t *counts, int nranks, int rank,
-               int root, void *comm, void *stream);
+/* replaces class_geokerr's f2py surface (class_geokerr.f90:69-144; consumer geokerr_interface.py:36-86).
+ * grt_camera_pixels = `pixel` -> get_pixel_locations (INITIALIZE_CAMERA_GEOKERR, geokerr_wrapper.f:1-354) for a standard=1
+ * camera: the module arrays aarr, barr, q2arr, larr, suarr, smarr, ufarr, mufarr, tpmarr, tprarr of pixels i1..i2 (u0 and
+ * offset are cam->u0, cam->offset).  Any output pointer may be NULL.  Pure host arithmetic.
+ * grt_geokerr_rays = `call_geokerr` for a batch of rays: GEOKERR(U0,UF,UOUT,MU0,MUF,A,L,Q2,ALPHA,BETA,TPM,TPR,SU,SM,NUP,
+ * OFFSET,PHIT,USEGEOR,MUFILL,NCASE,KEXT,NEXT, UFI,MUFI,DTI,DPHI,TPMI,TPRI,LAMBDAI) (geokerr_wrapper.f:357-604, call shape
+ * geodesics.f90:286-292) with the scalars shared by the batch and uf,l,q2,alpha,beta,tpr,su,sm per ray; MUF and TPM are
+ * outputs of GEOKERR when USEGEOR is false and are not taken.  Outputs are HOST arrays [nrays][nup+next-2*kext] (the module
+ * arrays u, mu, dt, dphi, lam, tpmi, tpri per ray; entries behind a ray's npts are zero), ncase[nrays], npts[nrays] (0 = the
+ * ray never enters uout, GEOKERR's NUP=0 return).  usegeor != 0 (mu as the independent variable) and phit == 0 are refused.
+ * Runs the same set-up and geodesic kernels as grt_trace_tile. */
+int grt_camera_pixels(const grt_camera *cam, int64_t i1, int64_t i2, double *alpha, double *beta, double *q2, double *l,
+                      double *su, double *sm, double *uf, double *muf, int32_t *tpm, int32_t *tpr);
+int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a, double offset, int nup, int phit, int usegeor,
+                     int mufill, int kext, int next, const double *uf, const double *l, const double *q2, const double *alpha,
+                     const double *beta, const int32_t *tpr, const double *su, const double *sm, double *ufi, double *mufi,
+                     double *dti, double *dphi, double *lambdai, int32_t *tpmi, int32_t *tpri, int32_t *ncase, int32_t *npts);
+
+/* tstep of the loaded HARM slices: t(1)-t(2) of the dump headers when several are loaded, the module default 20. otherwise
+ * (fluid_model_harm.f90:493-500); advance_harm_timestep (:511-521) steps the dump index with it. */
+int grt_get_harm_tstep(float *tstep);
+
+/* ---- multi-GPU (one process per GPU; each calls grt_init with its own device first) ------------------------------------
+ * Replaces nothing in the reference, which assembles ivals in one process (pgrtrans.f90:221-242): the pixel ranges of the
+ * image are shared out over the ranks by the reference's own i1..i2 key, and the only exchange is one gather of the fp32
+ * cameras to the root (RCCL point-to-point over xGMI, ragged sizes, no collective on the data path).
+ *
+ * Communicator owned by the library:
+ *   grt_comm_unique_id  128 bytes of an ncclUniqueId, made by one rank and handed to all by the launcher's own channel
+ *   grt_comm_init       every rank, same id bytes
+ *   grt_comm_init_file  the same with a file rendezvous (rank 0 writes `path`, the others poll it for timeout_s seconds):
+ *                       for hosts without a channel of their own (the Fortran executable)
+ *   grt_comm_allreduce  sum (op 0) / max (op 1) of <= 64 doubles, in place on the host: run statistics only
+ * Rank-level image [ncams][npix_rank][nvals] in HBM, zeroed by grt_stage_reset; grt_stage_resident copies the tile of the
+ * last grt_trace_tile / grt_trace_tile_resident call (cameras cam0 .. cam0+nfreq-1, npix_tile pixels) into it at pixel
+ * offset pix_offset, device to device; grt_gather_stage sends every rank's image to `root`, whose HOST buffer host_full
+ * receives [ncams][sum npix_of_rank][nvals], a camera's pixels in rank order (other ranks pass NULL).  With one rank and
+ * no communicator the three stage calls still work (a plain copy). */
+int grt_comm_unique_id(char *id128);
+int grt_comm_init(int rank, int nranks, const char *id128);
+int grt_comm_init_file(int rank, int nranks, const char *path, double timeout_s);
+int grt_comm_rank(int *rank, int *nranks);
+int grt_comm_handle(void **comm, void **stream);     /* the library's ncclComm_t and hipStream_t, e.g. for grt_gather */
+int grt_comm_allreduce(double *vals, int n, int op);
+int grt_comm_free(void);
+int grt_stage_reset(int ncams, int nvals, int64_t npix_rank);
+int grt_stage_resident(int cam0, int nfreq, int64_t npix_tile, int64_t pix_offset);
+int grt_gather_stage(const int64_t *npix_of_rank, int root, float *host_full);
+/* Caller-owned communicator (an ncclComm_t) and device buffers: every rank's flat tile of `count` floats to `root`, whose
+ * d_full receives them rank after rank (counts[nranks]). */
+int grt_gather(const float *d_tile, int64_t count, float *d_full, const int64_t *counts, int nranks, int rank, int root,
+               void *comm, void *stream);
 
 const char *grt_version(void);
 

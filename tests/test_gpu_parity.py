@@ -25,6 +25,23 @@ def dev():
     d.close()
 
 
+@pytest.fixture
+def fdev():
+    # a context that is certainly up: the host tests (./grtrans in-process through module pgrtrans) end with grt_free
+    from grtrans_amd import capi
+    d = capi.Device(0)
+    d.load_ffjet()
+    d.load_tables()
+    return d
+
+
+def free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
 def run(nn, iname, i1=None, i2=None, freqs=(FREQ,)):
     from grtrans_amd import capi
     cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
@@ -425,13 +442,15 @@ def test_edge_cases_single_pixel_dead_tile_small_nup_and_max_nfreq():
     ref, rn, _ = o.trace(1, 256, [FREQ], nthreads=0)
     pix, _, status, _ = run(nn, "delo")
     assert np.array_equal(status, rn) and stokes_err(pix, ref) < STOKES_TOL
-    # (d) the ABI's frequency limit (32) and one past it
+    # (d) 32 frequencies (round 1's limit) and one more: there is no limit (pgrtrans.f90:87-91)
     freqs = list(2.41e10 * np.exp(np.arange(32) * np.log(6.31e14 / 2.41e10) / 31))
     multi, _, _, _ = run((12, 12, 60), "formal", freqs=freqs)
     single, _, _, _ = run((12, 12, 60), "formal", freqs=[freqs[17]])
     assert multi.shape == (32, 144, 4) and np.array_equal(multi[17], single[0])
+    more, _, _, _ = run((12, 12, 60), "formal", freqs=freqs + [1e15])
+    assert more.shape == (33, 144, 4) and np.array_equal(more[:32], multi)
     with pytest.raises(capi.GrtError):
-        run((12, 12, 60), "formal", freqs=freqs + [1e15])
+        run((12, 12, 60), "formal", freqs=[])
     dev.close()
 
 
@@ -601,6 +620,23 @@ def test_fits_output_cflag1_through_fortran_host(tmp_path, monkeypatch):
     x.run_grtrans()
     raw = open('grtrans.fits', 'rb').read()
     assert len(raw) % 2880 == 0 and raw[:30].decode() == "SIMPLE  =                    T"
+    # (1) container grammar by an independent strict FITS 4.0 reader (tests/fits_check.py: card grammar, END, blank/zero
+    # fill, 2880-byte blocks, mandatory keyword order, big-endian data)
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fits_check
+    strict = fits_check.check(raw)
+    assert len(strict) == 3 and strict[0][1].size == 2 * 1024 and strict[1][1].size == 4 * 1024
+    # (2) the cards behind the six mandatory ones: names, order and value kinds of the reference's writer
+    # (tests/golden/fits_keys.json, parsed from camera.f90:216-312 + pgrtrans.f90:229-238 by tests/extract_fits_keys.py)
+    want = json.load(open(os.path.join(G, "fits_keys.json")))
+    for h in strict[1:]:
+        got = h[0][6:]
+        assert [k.upper() for k, _, _ in got] == [w["name"].upper() for w in want]
+        for (k, v, _), w in zip(got, want):
+            assert isinstance(v, {"j": int, "d": float, "e": float, "s": str}[w["kind"]]), (k, v, w)
+    assert np.array_equal(strict[1][1], gb.read_fits('grtrans.fits')[1][1])        # both readers see the same numbers
     hdus = gb.read_fits('grtrans.fits')
     assert len(hdus) == 3 and [k for k, _ in hdus[1][0][:9]] == ['XTENSION', 'BITPIX', 'NAXIS', 'NAXIS1', 'PCOUNT', 'GCOUNT', 'NX', 'NY', 'NU']
     assert dict(hdus[1][0])['gridvals(3)'].startswith('-2.0') and dict(hdus[2][0])['FNAME'] == 'FFJET'
@@ -908,13 +944,97 @@ def test_bench_distributed_path_through_rccl_single_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GRT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
                           "--nn", "256", "256", "200", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["metric"] == "ray-steps/sec" and j["n_gpus"] == 1 and j["value"] > 1e8 and j["scaling"] == "weak"
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert j["config"]["gather_ms"] is not None and "grt_gather_stage" in j["config"]["gather_via"], j["config"]["gather_via"]
+    # strong-scaling mode (BASELINE config 5's shape: one camera shared out in column tiles) through the same launcher; with
+    # GRT_BENCH_CHECK_IMAGE the gathered, un-permuted image must equal a whole-image trace bit for bit.  Three frequencies.
+    env["GRT_BENCH_CHECK_IMAGE"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--nn", "128", "96", "200", "--nfreq", "3", "--scaling", "strong", "--no-cpu-baseline"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["scaling"] == "strong" and "grt_gather_stage" in j["config"]["gather_via"]
+    # and the fall-back (the process group's own gather) gives the same image
+    env["GRT_BENCH_GATHER"] = "torch"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--nn", "128", "96", "200", "--nfreq", "3", "--scaling", "strong", "--no-cpu-baseline"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "torch.distributed.gather" in j["config"]["gather_via"]
+
+
+def test_hosts_gather_path_with_a_one_rank_communicator(tmp_path, monkeypatch):
+    # The N-GPU mode of module pgrtrans (one process per GPU; pixel ranges = strips or column tiles; tiles staged device to
+    # device into the rank's image; ONE RCCL gather; rank 0 assembles ivals) on this 1-GPU box: GRT_FORCE_COMM=1 runs all of it
+    # with a one-rank communicator, GRT_TILE_COLS=5 makes seven ranges of the 32 columns.  Must equal the plain run exactly,
+    # through ./grtrans and through run_pgrtrans (the same Fortran module), two frequencies, two mdots (geodesic re-use).
+    from grtrans_amd import grtrans_batch as gb
+    kw = dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=2, nmu=1, fmin=FREQ, fmax=2 * FREQ,
+              ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1, nn=[32, 32, 100], uout=0.01, mbh=3.4e9, nmdot=2, mdotmin=1e15,
+              mdotmax=2e15, mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], ntscl=2., nrscl=70., iname='delo', cflag=0,
+              i1=37, i2=1000)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='plain.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    plain = x.ivals.copy()
+    assert plain.shape == (1024, 4, 4) and (plain[:36] == 0).all() and (plain[1000:] == 0).all() and np.abs(plain[36:1000]).max() > 0
+    monkeypatch.setenv("GRT_FORCE_COMM", "1")
+    monkeypatch.setenv("GRT_COMM_FILE", str(tmp_path / "comm_id"))
+    for cols in ("0", "5"):
+        monkeypatch.setenv("GRT_TILE_COLS", cols)
+        if os.path.exists(str(tmp_path / "comm_id")):
+            os.remove(str(tmp_path / "comm_id"))
+        x.write_grtrans_inputs('inputs.in', oname='comm%s.out' % cols, **kw)
+        x.run_grtrans()
+        x.read_grtrans_output(bin=1)
+        assert np.array_equal(x.ivals, plain), cols
+        os.remove(str(tmp_path / "comm_id"))
+        y = gb.grtrans()
+        y.run_pgrtrans(**kw)
+        assert y.ivals.shape == (4, 1024, 4)
+        assert np.array_equal(y.ivals.transpose(1, 0, 2).astype(np.float32), plain), cols
+        assert np.array_equal(y.ab.T.astype(np.float32)[36:1000], x.ab[36:1000])
+
+
+def test_grt_gather_with_a_caller_side_view_of_the_communicator():
+    # grt_gather (caller-owned ncclComm_t + device buffers) on a one-rank communicator: the root's own tile lands in d_full
+    import ctypes as C
+    import torch
+    from grtrans_amd import capi
+    L = capi.lib()
+    dev = capi.Device(0)
+    idb = C.create_string_buffer(128)
+    capi.check(L.grt_comm_unique_id(idb), "grt_comm_unique_id")
+    capi.check(L.grt_comm_init(C.c_int(0), C.c_int(1), idb), "grt_comm_init")
+    comm, stream = C.c_void_p(), C.c_void_p()
+    capi.check(L.grt_comm_handle(C.byref(comm), C.byref(stream)), "grt_comm_handle")
+    assert comm.value
+    tile = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+    full = torch.zeros(1000, dtype=torch.float32, device="cuda")
+    cnt = (C.c_int64 * 1)(1000)
+    capi.check(L.grt_gather(C.c_void_p(tile.data_ptr()), C.c_int64(1000), C.c_void_p(full.data_ptr()), cnt, C.c_int(1), C.c_int(0),
+                            C.c_int(0), comm, stream), "grt_gather")
+    vals = (C.c_double * 2)(3.0, -1.0)
+    capi.check(L.grt_comm_allreduce(vals, C.c_int(2), C.c_int(0)), "grt_comm_allreduce")     # also synchronises the library stream
+    assert torch.equal(full, tile) and list(vals) == [3.0, -1.0]
+    assert L.grt_gather(C.c_void_p(tile.data_ptr()), C.c_int64(1000), C.c_void_p(full.data_ptr()), cnt, C.c_int(1), C.c_int(3),
+                        C.c_int(0), comm, stream) != 0          # bad rank: refused before any RCCL call, no group left open
+    capi.check(L.grt_gather(C.c_void_p(tile.data_ptr()), C.c_int64(1000), C.c_void_p(full.data_ptr()), cnt, C.c_int(1), C.c_int(0),
+                            C.c_int(0), comm, stream), "grt_gather")
+    L.grt_comm_free()
+    dev.close()
 
 
 def test_koral3d_device_and_both_hosts_vs_reference_golden(tmp_path, monkeypatch):
@@ -1224,7 +1344,7 @@ CONFIG5_FREQS = list(2.41e10 * np.exp(np.arange(25) * np.log(6.31e14 / 2.41e10) 
 
 
 @pytest.mark.parametrize("iname", ["formal", "delo"])
-def test_config5_frequency_grid_vs_compiled_reference(dev, iname):
+def test_config5_frequency_grid_vs_compiled_reference(fdev, iname):
     # BASELINE config 5's 25 frequencies 2.41e10 .. 6.31e14 Hz through the frequency-batch kernels (FB = 13 formal / 8 DELO)
     # against the reference's own grtrans_main (tests/make_golden.py:config5).  Bar per frequency: 2e-6 of each Stokes
     # peak, or 10x the reference's own response to one-ulp input changes at that frequency where that is larger.
@@ -1242,7 +1362,7 @@ def test_config5_frequency_grid_vs_compiled_reference(dev, iname):
     assert (err < bar).all(), np.argwhere(err >= bar)
 
 
-def test_config5_full_size_properties(dev):
+def test_config5_full_size_properties(fdev):
     # 1024 x 1024 x 400, 25 frequencies, image only: size-independent properties at BASELINE's full size
     from grtrans_amd import capi
     nn = (1024, 1024, 400)
@@ -1266,3 +1386,80 @@ def test_config5_full_size_properties(dev):
     flux_full = full[:, :, 0].astype(float).sum(axis=1) / (1024.0 * 1024.0)
     flux_gold = g["ivals_formal"][:, :, 0].astype(float).sum(axis=1) / (64.0 * 64.0)
     assert np.allclose(flux_full, flux_gold, rtol=0.02), np.abs(flux_full / flux_gold - 1).max()
+
+
+def test_geokerr_rays_abi_vs_reference_geokerr(fdev):
+    # G-10, class_geokerr's f2py surface (class_geokerr.f90:69-144): `pixel` -> per-pixel constants, `call_geokerr` ->
+    # GEOKERR's raw arrays u, mu, dt, dphi, lam, tpmi, tpri for caller-given rays.  Goldens: the compiled reference's
+    # GEOKERR on the FFJET regression camera (raw arrays of nine rays; tpmi, tpri, ncase of all 10000).
+    from grtrans_amd import capi
+    nn = (100, 100, 400)
+    g = np.load(os.path.join(G, "ffjet_100x100x400.npz"))
+    gr = np.load(os.path.join(G, "ffjet_rays_100x100x400.npz"))
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
+    px = capi.camera_pixels(cam, 1, 10000)
+    for k in ("alpha", "beta", "q2", "l", "su", "sm", "uf"):
+        assert np.array_equal(px[k], g["cam_" + k]), k
+    assert np.array_equal(px["tpr"], g["cam_tpr"]) and px["u0"] == g["cam_scal"][0] and px["offset"] == g["cam_scal"][2]
+    out = capi.geokerr_rays(px["u0"], cam.uout, cam.mu0, cam.a, px["offset"], nn[2], px["uf"], px["l"], px["q2"], px["alpha"],
+                            px["beta"], px["tpr"], px["su"], px["sm"], mufill=cam.mufill, kext=cam.kext, next=cam.next)
+    assert np.array_equal(out["npts"], g["npts"]) and np.array_equal(out["ncase"], g["ncase"])
+    m = out["tpmi"].shape[1]
+    assert np.array_equal(out["tpmi"], g["tpmi"][:, :m]) and np.array_equal(out["tpri"], g["tpri"][:, :m])      # bit-exact integers
+    for i in gr["rays"]:
+        n = int(gr["ray%d_npts" % i])
+        for k, tol in (("u", 1e-12), ("mu", 1e-10), ("dphi", 1e-9), ("dt", 1e-13), ("lam", 1e-13)):
+            ref = gr["ray%d_raw_%s" % (i, k)]
+            err = np.abs(out[k][i - 1, :n] - ref).max() / np.abs(ref).max()
+            assert err < tol, (i, k, err)
+        assert (out["u"][i - 1, n:] == 0).all()
+    # a caller's own subset in its own order (not a camera): rays 5051, 1, 3366 -> the same rows
+    sel = np.array([5051, 1, 3366]) - 1
+    sub = capi.geokerr_rays(px["u0"], cam.uout, cam.mu0, cam.a, px["offset"], nn[2], px["uf"][sel], px["l"][sel], px["q2"][sel],
+                            px["alpha"][sel], px["beta"][sel], px["tpr"][sel], px["su"][sel], px["sm"][sel], mufill=cam.mufill,
+                            kext=cam.kext, next=cam.next)
+    for k in ("u", "mu", "dt", "dphi", "lam", "tpmi", "tpri"):
+        assert np.array_equal(sub[k], out[k][sel]), k
+    with pytest.raises(capi.GrtError):      # mu as the independent variable is refused, not emulated
+        capi.geokerr_rays(px["u0"], cam.uout, cam.mu0, cam.a, 0.5, 10, px["uf"][:4], px["l"][:4], px["q2"][:4], px["alpha"][:4],
+                          px["beta"][:4], px["tpr"][:4], px["su"][:4], px["sm"][:4], usegeor=1, mufill=0)
+
+
+def test_resident_geodesic_is_reused_for_the_next_parameter_set(fdev):
+    # grtrans_driver.f90:134: one geodesic serves every m = 1..nparams.  A second trace of the same camera and pixel range
+    # (other emissivity parameters, other frequencies) re-launches only the transfer kernels and gives the bits of a cold run.
+    import ctypes as C
+    from grtrans_amd import capi
+    nn = (48, 48, 200)
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
+    em1 = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    em2 = capi.make_emis("POLSYNCHPL", 3.4e9, 3.0, 40.0, 50., 1e5, 3.5)
+    L = capi.lib()
+    L.grt_geo_passes.restype = C.c_longlong
+    for rec in (False, True):
+        capi.record_steps(rec)
+        n0 = L.grt_geo_passes()
+        capi.trace_tile(cam, 1, 2304, "FFJET", em1, [FREQ], "formal")
+        warm, _, sw, stw = capi.trace_tile(cam, 1, 2304, "FFJET", em2, [FREQ, 2 * FREQ], "delo")
+        assert L.grt_geo_passes() == n0 + 1                      # the second call ran no set-up / geodesic kernel
+        capi.geo_reuse(False)
+        cold, _, sc, stc = capi.trace_tile(cam, 1, 2304, "FFJET", em2, [FREQ, 2 * FREQ], "delo")
+        capi.geo_reuse(True)
+        assert L.grt_geo_passes() == n0 + 2
+        assert np.array_equal(warm, cold) and np.array_equal(sw, sc) and stw.ray_steps == stc.ray_steps
+        # another pixel range or camera drops the record
+        capi.trace_tile(cam, 1, 2304, "FFJET", em1, [FREQ], "formal")
+        other, _, _, sto = capi.trace_tile(cam, 1, 1000, "FFJET", em2, [FREQ], "delo")
+        assert L.grt_geo_passes() == n0 + 4 and np.array_equal(other[0], cold[0, :1000])
+    capi.record_steps(False)
+
+
+def test_more_frequencies_than_any_batch_limit(fdev):
+    # pgrtrans.f90:87-91 has no limit on nfreq; 40 cameras of one geodesic in one call equal their own single runs
+    nn = (12, 12, 60)
+    freqs = list(1e10 * np.exp(np.arange(40) * np.log(1e15 / 1e10) / 39))
+    multi, _, _, _ = run(nn, "formal", freqs=freqs)
+    assert multi.shape[0] == 40
+    for k in (0, 13, 31, 32, 39):
+        single, _, _, _ = run(nn, "formal", freqs=[freqs[k]])
+        assert np.array_equal(multi[k], single[0]), k

@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
 
@@ -101,6 +103,13 @@ def test_strips_tile_the_image():
             assert all(edges[r][1] + 1 == edges[r + 1][0] for r in range(world - 1))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
 def test_two_rank_gloo_gather_equals_single_image(tmp_path):
     # N>1 path on CPU: two processes (gloo), each traces its strip with the CPU oracle standing in for
     # the device, tiles gathered with the same helper bench.py uses; must equal the one-process image exactly.
@@ -126,6 +135,81 @@ dist.destroy_process_group()
 ''' % (ROOT, str(tmp_path / "ok")))
     env = dict(os.environ, OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)], env=env,
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=env,
                           timeout=600)
     assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_fits_grammar_checker_accepts_and_rejects():
+    # the independent FITS reader the GPU test holds host/fits_min.f90's output against (tests/fits_check.py)
+    import fits_check
+
+    def card(k, v, c=""):
+        return ("%-8s= %20s%s" % (k, v, (" / " + c) if c else "")).ljust(80)
+
+    def hdr(cards):
+        t = "".join(cards) + "END".ljust(80)
+        return (t + " " * ((2880 - len(t) % 2880) % 2880)).encode()
+
+    data = np.arange(6, dtype=">f4").tobytes()
+    ext = np.arange(3, dtype=">f4").tobytes()
+    good = hdr([card("SIMPLE", "T"), card("BITPIX", -32), card("NAXIS", 1), card("NAXIS1", 6), card("EXTEND", "T")]) + data + b"\0" * (2880 - 24) + \
+        hdr(["XTENSION= 'IMAGE   '".ljust(80), card("BITPIX", -32), card("NAXIS", 1), card("NAXIS1", 3), card("PCOUNT", 0), card("GCOUNT", 1),
+             card("NX", "3.000000E+00", "# x pixels"), "HIERARCH gridvals(3) = -2.000000E+01 / gridvals(3)".ljust(80),
+             "FNAME   = 'FFJET   '           / fname".ljust(80)]) + ext + b"\0" * (2880 - 12)
+    h = fits_check.check(good)
+    assert len(h) == 2 and np.array_equal(h[0][1], np.arange(6)) and dict((k, v) for k, v, _ in h[1][0])["gridvals(3)"] == -20.0
+    assert dict((k, v) for k, v, _ in h[1][0])["FNAME"] == "FFJET"
+    for bad in (good[:-1], good.replace(b"BITPIX  =", b"bitpix  =", 1), good.replace(b"END" + b" " * 77, b"END x" + b" " * 75, 1),
+                good.replace(b"XTENSION= 'IMAGE   '", b"XTENSION= 'IMAGE'   ", 1), good[:100] + b"\1" + good[101:],
+                good.replace(b"PCOUNT  =                    0", b"PCOUNT  =                    1", 1)):
+        with pytest.raises(AssertionError):
+            fits_check.check(bad)
+
+
+def test_pixel_share_out_fortran_equals_python():
+    # module pgrtrans's pixel_ranges (the share-out of an N-GPU run) against grtrans_amd/tiling.py:ranges, which the 2-rank
+    # gloo test and bench.py use: strips and round-robin column tiles, every pixel of i1..i2 exactly once
+    from grtrans_amd import capi, tiling
+    capi.lib()
+    L = C.CDLL(os.path.join(ROOT, "grtrans_amd", "host", "libpgrtrans.so"))
+
+    def f(r, w, i1, i2, nphi, tc):
+        n = C.c_int(0); lo = (C.c_int * 4096)(); hi = (C.c_int * 4096)()
+        L.pgrtrans_pixel_ranges(r, w, i1, i2, nphi, tc, 4096, C.byref(n), lo, hi)
+        return [(lo[k], hi[k]) for k in range(n.value)]
+    for (i1, i2, nphi) in ((1, 1024 * 1024, 1024), (1, 100, 10), (37, 911, 13), (5, 5, 7)):
+        for w in (1, 2, 3, 8):
+            for tc in (0, 1, 4, 32):
+                seen = []
+                for r in range(w):
+                    a, b = f(r, w, i1, i2, nphi, tc), tiling.ranges(r, w, i1, i2, nphi, tc)
+                    assert a == b, (i1, i2, nphi, w, tc, r)
+                    seen += a
+                seen.sort()
+                assert seen[0][0] == i1 and seen[-1][1] == i2 and all(seen[k][1] + 1 == seen[k + 1][0] for k in range(len(seen) - 1))
+
+
+def test_pgrtrans_module_surface_without_a_device():
+    # grtrans_amd/pgrtrans.py = the f2py-shaped view of the Fortran module in host/libpgrtrans.so: 85 positional arguments,
+    # module arrays, del_pgrtrans_data.  Without a GPU the call must fail loudly (grt_init) -- as a GrtError, not a dead
+    # interpreter, and never through a CPU path.
+    from grtrans_amd import capi, grtrans_batch as gb
+    from grtrans_amd.pgrtrans import pgrtrans, _ARGS
+    ref_order = re.findall(r"[a-z_0-9]+", "standard,mumin,mumax,nmu,phi0,spin,uout,uin,rcut,nrotype,gridvals,nn,i1,i2,fname,dt,nt,nload,"
+                           "nmdot,mdotmin,mdotmax,ename,mbh,nfreq,fmin,fmax,muval,gmin,gmax,p1,p2,jetalpha,stype,use_geokerr,nvals,iname,"
+                           "cflag,extra,debug,outfile,fdfile,fhfile,fgfile,fsim,fnt,findf,fnfiles,fjonfix,fnw,fnfreq_tab,fnr,foffset,fdindf,"
+                           "fmagcrit,frspot,fr0spot,fn0spot,ftscl,frscl,fwmin,fwmax,ffmin,ffmax,frmax,fsigt,ffcol,fmdot,fnscl,fnnthscl,fnnthp,"
+                           "fbeta,fbl06,fnp,ftp,frin,frout,fthin,fthout,fphiin,fphiout,fscalefac,sigcut,epcoefindx,epotherargs,nepotherargs")
+    assert [n for n, _ in _ARGS] == ref_order                       # pgrtrans.f90:12-19
+    assert np.shape(pgrtrans.ivals) == ()
+    with pytest.raises(TypeError):
+        pgrtrans.grtrans_main(1, 2, 3)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the GPU tests drive this surface end to end")
+    x = gb.grtrans()
+    with pytest.raises(capi.GrtError):
+        x.run_pgrtrans(fname='FFJET', nfreq=1, nmu=1, fmin=3.45e11, fmax=3.45e11, ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1,
+                       nn=[8, 8, 40], uout=0.01, mbh=3.4e9, mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], iname='formal')
+    assert np.shape(pgrtrans.ivals) == ()

@@ -32,6 +32,7 @@ else:
         dev.load_harm3d(dfile, hfile, 40, 0.9375)
         em = capi.make_emis(os.environ.get("GRT_ENAME", "POLSYNCHTH"), 4e6, 1.0, 6.0, 1.0, 1e5, 3.5, mdot=1e20)
 capi.record_steps(os.environ.get("GRT_RECORD", "0") == "1")
+capi.geo_reuse(False)
 best = None
 for it in range(3):
     _, _, _, st = capi.trace_tile(cam, 1, nn[0] * nn[1], fluid, em, [freq], iname, resident=True)
