@@ -11,7 +11,7 @@ LIB = os.environ.get("GRTRANS_AMD_LIB", os.path.join(PKG, "libgrtrans_amd.so"))
 DATA = os.path.join(PKG, "data")
 
 FLUID = {"SPHACC": 1, "THINDISK": 2, "HARM": 12, "FFJET": 13, "HARM3D": 19, "KORAL3D": 25, "KORAL3D_DISK": 26, "IHARM": 29}       # fluid.f90:40-43
-EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8, "HYBRIDTHPL": 20, "HYBRIDTH": 21, "HYBRIDPL": 22, "MAXJUTT": 23, "MAXCOMP": 24,
+EMIS = {"POLSYNCHTH": 2, "SYNCHPL": 3, "POLSYNCHPL": 4, "BB": 8, "BBPOL": 9, "HYBRIDTHPL": 20, "HYBRIDTH": 21, "HYBRIDPL": 22, "MAXJUTT": 23, "MAXCOMP": 24,
         "POLSYNCHSYMTH": 15, "SYNCHTHAV": 13, "SYNCHTHAVNOABS": 14, "BREMS": 5, "SYNCHTHBREMS": 27, "RHO": 12}    # emis.f90:11-18
 INTEG = {"lsoda": 0, "delo": 1, "formal": 2, "lsodasph": 3}          # rad_trans.f90:29-37
 
@@ -97,6 +97,10 @@ class Device:
 
     def set_thindisk(self, mdot, rin, rout):
         check(lib().grt_set_thindisk(C.c_double(mdot), C.c_double(rin), C.c_double(rout)), "grt_set_thindisk")
+
+    def load_chandra(self, path=None):
+        path = path or os.path.join(DATA, "ch24_vals.txt")
+        check(lib().grt_load_chandra_file(path.encode()), "grt_load_chandra_file")
 
     def load_tables(self, path=None):
         path = path or os.path.join(DATA, "polsynchpl_tables.bin")

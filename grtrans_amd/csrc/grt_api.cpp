@@ -26,9 +26,10 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const unsigned long long *flags, long long ray_stride, long long field_stride,
                                           int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back);
 
-extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mbh, float mdot, float rin, float rout, long long i1,
+extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const void *disk, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
-                                      unsigned long long *step_counter);
+                                      unsigned long long *step_counter, int nvals, int nextra, int bbpol);
+extern "C" size_t grt_sizeof_disk(void);
 
 namespace {
 
@@ -61,8 +62,9 @@ struct Ctx {
   double *d_t0 = nullptr;        // per-ray time origin of the current tile (nload > 1), or unset
   size_t cap_t0 = 0;
   long long t0_n = 0;
-  float disk_mdot = 0.f, disk_rin = -1.f, disk_rout = 1e8f;
-  bool have_disk = false;
+  // GrtDisk as the kernel takes it (grt_dev_disk.hpp): mbh, mdot, rin, rout, nch, ch_mu[32], ch_I[32], ch_del[32]
+  struct DiskArgs { float mbh, mdot, rin, rout; int nch; float ch_mu[32], ch_I[32], ch_del[32]; } disk{};
+  bool have_disk = false, have_chandra = false;
   double *d_tables = nullptr;
   GrtTables tables{};
   double h_tables[2020] = {0};
@@ -405,9 +407,31 @@ int grt_set_t0(const double *t0_host, int64_t n) {
 
 int grt_set_thindisk(double mdot, double rin, double rout) {
   if (!C.init) return GRT_E_NOTINIT;
-  C.disk_mdot = (float)mdot; C.disk_rin = (float)rin; C.disk_rout = (float)rout;   // init_thindisk takes REAL(4)
+  C.disk.mdot = (float)mdot; C.disk.rin = (float)rin; C.disk.rout = (float)rout;   // init_thindisk takes REAL(4)
   C.have_disk = true;
   return 0;
+}
+
+int grt_upload_chandra(int n, const float *mu, const float *I, const float *delta) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (n < 2 || n > 32 || !mu || !I || !delta) return GRT_E_BADARG;
+  C.disk.nch = n;
+  for (int i = 0; i < n; ++i) { C.disk.ch_mu[i] = mu[i]; C.disk.ch_I[i] = I[i]; C.disk.ch_del[i] = delta[i]; }
+  C.have_chandra = true;
+  return 0;
+}
+
+int grt_load_chandra_file(const char *path) {      // load_chandra_tab24 (chandra_tab24.f90:11-22): list-directed npts [ncols], mu, I, delta
+  FILE *f = std::fopen(path, "r");
+  if (!f) return GRT_E_IO;
+  int n = 0, ncol = 0;
+  float v[96];
+  char line[256];
+  bool ok = std::fgets(line, sizeof line, f) && std::sscanf(line, "%d %d", &n, &ncol) >= 1 && n >= 2 && n <= 32;
+  for (int i = 0; ok && i < 3 * n; ++i) ok = std::fscanf(f, "%f", &v[i]) == 1;
+  std::fclose(f);
+  if (!ok) return GRT_E_IO;
+  return grt_upload_chandra(n, v, v + n, v + 2 * n);
 }
 
 int grt_upload_polsynchpl_tables(const double *t) {
@@ -481,22 +505,28 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (!cam || !em || !freqs || nfreq < 1 || i2 < i1 || i1 < 1) return GRT_E_BADARG;     // any nfreq (pgrtrans.f90:87-91 has no limit)
   if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
   if (cam->standard == 2) {
-    // the one standard=2 problem on the device: one point per ray on a thin disk (BASELINE config 1)
-    if (cam->nup != 1 || fluid_model != GRT_FLUID_THINDISK || em->type != GRT_EMIS_BB || nvals != 1 || nextra != 0)
-      return GRT_E_UNSUPPORTED;
+    // standard=2 on the device: one point per ray on a thin disk -- BB (Stokes I; BASELINE config 1) or BBPOL (the
+    // polarized atmosphere, nvals = 4, with the 7 one-point diagnostics when extra=1; the reference's `thindisk` problem)
+    const bool bb = em->type == GRT_EMIS_BB && nvals == 1 && nextra == 0;
+    const bool bbpol = em->type == GRT_EMIS_BBPOL && nvals == 4 && (nextra == 0 || nextra == 7);
+    if (cam->nup != 1 || fluid_model != GRT_FLUID_THINDISK || !(bb || bbpol)) return GRT_E_UNSUPPORTED;
     if (!C.have_disk) return GRT_E_NOFLUID;
+    if (bbpol && !C.have_chandra) return GRT_E_NOTABLES;
+    if (sizeof(C.disk) != grt_sizeof_disk()) return GRT_E_BADARG;
     HIPCHK(hipSetDevice(C.device));
     C.geo.valid = false;
     const int nrays = (int)(i2 - i1 + 1);
     int rc;
     if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
-    if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq))) return rc;
+    if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
     if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;
-    HIPCHK(hipMemcpyAsync(C.d_freqs, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
+    C.h_freqs.assign(freqs, freqs + nfreq);
+    HIPCHK(hipMemcpyAsync(C.d_freqs, C.h_freqs.data(), nfreq * sizeof(double), hipMemcpyHostToDevice, C.stream));
     HIPCHK(hipMemsetAsync(C.d_stepcount, 0, sizeof(unsigned long long), C.stream));
     HIPCHK(hipEventRecord(C.ev[1], C.stream));
-    HIPCHK(grt_launch_disk(C.stream, cam, (float)em->mbh, C.disk_mdot, C.disk_rin, C.disk_rout, (long long)i1, nrays, nfreq,
-                           C.d_freqs, C.d_pixvals, C.d_npts, C.d_stepcount));
+    C.disk.mbh = (float)em->mbh;
+    HIPCHK(grt_launch_disk(C.stream, cam, &C.disk, (long long)i1, nrays, nfreq, C.d_freqs, C.d_pixvals, C.d_npts, C.d_stepcount, nvals, nextra,
+                           bbpol ? 1 : 0));
     HIPCHK(hipEventRecord(C.ev[2], C.stream));
     HIPCHK(hipStreamSynchronize(C.stream));
     if (st) {

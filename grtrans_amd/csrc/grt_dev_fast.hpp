@@ -102,11 +102,25 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     delta[k] = (pt[k] - x) * (pt[k] - y) * (pt[k] - z);
   }
   double avef, aved, avej[NA];
-  bool more;
 #ifdef GRT_COUNT
   g_calls[NJ]++;
 #endif
-  do {
+  // The convergence test comes BEFORE a duplication (the reference's loops duplicate first): arguments that are already
+  // within the series' tolerance -- the Carlson arguments of a segment between neighbouring stored points -- cost no step.
+  for (;;) {
+    avef = (1.0 / 3.0) * (xt + yt + zt);
+    aved = .2 * (xt + yt + 3.0 * zt);
+    bool more = dmax(dmax(fabs(avef - xt), fabs(avef - yt)), fabs(avef - zt)) > TOL * avef ||
+                dmax(dmax(fabs(aved - xt), fabs(aved - yt)), fabs(aved - zt)) > TOL * aved;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NJ; ++k) {
+      avej[k] = .2 * (xt + yt + zt + pt[k] + pt[k]);
+      more = more || dmax(dmax(fabs(avej[k] - xt), fabs(avej[k] - yt)), dmax(fabs(avej[k] - zt), fabs(avej[k] - pt[k]))) >
+                         TOL * avej[k];
+    }
+    if (!more) break;
 #ifdef GRT_COUNT
     g_it[NJ]++;
 #endif
@@ -136,19 +150,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     xt = .25 * (xt + alamb);
     yt = .25 * (yt + alamb);
     zt = .25 * (zt + alamb);
-    avef = (1.0 / 3.0) * (xt + yt + zt);
-    aved = .2 * (xt + yt + 3.0 * zt);
-    more = dmax(dmax(fabs(avef - xt), fabs(avef - yt)), fabs(avef - zt)) > TOL * avef ||
-           dmax(dmax(fabs(aved - xt), fabs(aved - yt)), fabs(aved - zt)) > TOL * aved;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int k = 0; k < NJ; ++k) {
-      avej[k] = .2 * (xt + yt + zt + pt[k] + pt[k]);
-      more = more || dmax(dmax(fabs(avej[k] - xt), fabs(avej[k] - yt)), dmax(fabs(avej[k] - zt), fabs(avej[k] - pt[k]))) >
-                         TOL * avej[k];
-    }
-  } while (more);
+  }
   {  // R_F (DLMF 19.36.1)
     double inv = frcp(avef), X = (avef - xt) * inv, Y = (avef - yt) * inv, Z = -X - Y;
     double E2 = X * Y - Z * Z, E3 = X * Y * Z;
@@ -194,6 +196,7 @@ struct RealRay {
   double siu0m, siu0e, isqee, ii3mu, id15[3], imuplus, imposneg, ifac2facm;   // reciprocals of per-ray constants used per point
   double iu0, tu0, phiu0, tu01;                  // u0-side pieces (cached by the set-up kernel)
   double jfac, m1u, sqmee;                       // geor (Table 2 rows 7/8)
+  double anc[4];                                 // segment scheme: iu1, tu11, phiu1, tu1 of the ray's top stored point
   // M(mu)
   int sym;
   double mneg, mpos, muplus, muminus, mposR, muplusR;
@@ -325,25 +328,22 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   for (int k = 0; k < 3; ++k) K.id15[k] = 1.0 / K.d15[k];
   agm_ladder(K.m1m, K.agm_mu);
   agm_ladder(K.m1u, K.agm_u);
+  K.anc[0] = K.anc[1] = K.anc[2] = K.anc[3] = 0.0;
 }
 
 // u end-point: I_u1 and the four uf-side integrals of Eq. 47-49 for the pair (uf, root).
 struct UPart { double iu1, phiu1, tu11, tu1; };   // tu1: Eq. 47 combination (only with the coordinate time)
 
-// PHI=false drops the two R_J integrals that only feed the azimuth (Eq. 48): a stationary axisymmetric
-// fluid never reads phi, so they are evaluated only when the per-step record is requested.  The
-// coordinate-time integral (Eq. 47, one more R_J) is never evaluated: t is not an output of this path
-// for nt=nload=1 (grtrans_driver.f90 uses x(1) only through time-dependent fluid models).
-// NPH: 0 = neither, 2 = the two azimuth integrals (Eq. 48), 3 = azimuth + the third [-2] integral, (a5,b5) = (0,1),
-// that only the coordinate time needs (Eq. 47; slow-light fluid models read t)
+// The four integrals between two arbitrary points y < x of one monotonic stretch of the ray, sign +1 (Carlson 1988's
+// formulas hold for any pair of limits inside the interval where the four factors are positive).  real_upart is the pair
+// (uf, root); the segment scheme of grt_geo_kernel uses it for NEIGHBOURING stored points, whose Carlson arguments
+// (U12^2, U13^2, U14^2 ~ 1/(x-y)^2 with constant differences d_ij) are equal to a relative (x-y)^2: the duplication loop
+// then runs once or not at all and the integrals cost their power series only.
 template <int NPH>
-GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
+GRT_HD void real_upair(const RealRay &K, double x, double y, UPart &o, bool endterms = true) {
   const double two = 2.0;
-  const bool c7 = (K.ncase == 7);
-  const double root = c7 ? K.u2 : K.u3;
   o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
-  if (uf == root) return;
-  const double y = c7 ? uf : K.u3, x = c7 ? K.u2 : uf, sg = c7 ? 1.0 : -1.0;
+  if (x == y) return;
   double X1 = fsqrt(K.a1 + K.b1 * x), X2 = fsqrt(K.a2 + K.b2 * x), X3 = fsqrt(K.a3 + K.b3 * x), X4 = fsqrt(K.a4 + K.b4 * x);
   double Y1 = fsqrt(K.a1 + K.b1 * y), Y2 = fsqrt(K.a2 + K.b2 * y), Y3 = fsqrt(K.a3 + K.b3 * y), Y4 = fsqrt(K.a4 + K.b4 * y);
   double idxy = frcp(x - y);
@@ -376,12 +376,11 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
   }
   carlson_bundle<NJ>(U122, U132, U142, W22, rff, rdd, rj2);
   double I1 = two * rff;
-  o.iu1 = sg * I1;
-  // GEOPHITIME skips the end-point terms when uf sits on the turning point (:2200, :2258)
-  if (c7 ? !(fabs(uf - K.u2) > 1e-12) : false) return;
+  o.iu1 = I1;
+  if (!endterms) return;
   // [-1,-1,-1,-1,-4] with (a5,b5)=(0,1), Carlson (1988) 2.48
   double I2 = K.cRD * rdd + tI2;
-  o.tu11 = sg * (K.cI2 * I2 + K.cI1 * I1 - K.cA4 * A111m1m2);
+  o.tu11 = K.cI2 * I2 + K.cI1 * I1 - K.cA4 * A111m1m2;
   if (NPH > 0) {
     double v[NA];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -389,23 +388,39 @@ GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
 #endif
     for (int k = 0; k < NPH; ++k) {   // [-1,-1,-1,-1,-2], Carlson (1988) 2.35
       double I3 = K.jk[k] * rj2[k] + two * rc7(P22[k], Q22[k]);
-      v[k] = sg * (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
+      v[k] = (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
     }
     o.phiu1 = -K.cP * v[0] + K.cQ * v[1];
     if (NPH == 3) o.tu1 = K.cA * o.tu11 + K.cB * v[2] - K.cC * v[0] + K.cD * v[1];   // :2215-2219
   }
 }
 
+// PHI=false drops the two R_J integrals that only feed the azimuth (Eq. 48): a stationary axisymmetric
+// fluid never reads phi, so they are evaluated only when the per-step record is requested.  The
+// coordinate-time integral (Eq. 47, one more R_J) is never evaluated: t is not an output of this path
+// for nt=nload=1 (grtrans_driver.f90 uses x(1) only through time-dependent fluid models).
+// NPH: 0 = neither, 2 = the two azimuth integrals (Eq. 48), 3 = azimuth + the third [-2] integral, (a5,b5) = (0,1),
+// that only the coordinate time needs (Eq. 47; slow-light fluid models read t)
+template <int NPH>
+GRT_HD void real_upart(const RealRay &K, double uf, UPart &o) {
+  const bool c7 = (K.ncase == 7);
+  const double root = c7 ? K.u2 : K.u3;
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
+  if (uf == root) return;
+  const double y = c7 ? uf : K.u3, x = c7 ? K.u2 : uf, sg = c7 ? 1.0 : -1.0;
+  // GEOPHITIME skips the end-point terms when uf sits on the turning point (:2200, :2258)
+  real_upair<NPH>(K, x, y, o, !(c7 ? !(fabs(uf - K.u2) > 1e-12) : false));
+  o.iu1 = sg * o.iu1; o.tu11 = sg * o.tu11; o.phiu1 = sg * o.phiu1; o.tu1 = sg * o.tu1;
+}
+
 // ncase 5: the same four uf-side quantities from ELLQUARTICCOMPLEX (Carlson 1991), integrals between u0 and uf.
 // Signs are arranged so that ray_point_real's assembly (written for "root-side minus uf-side" with the root-side
 // caches zero) reproduces GEOMU / GEOPHITIME (geokerr_wrapper.f:1005-1030, :2236-2262): iu = su sg I1 / sqrt|ee| etc.
 template <int NPH>
-GRT_HD void cplx_upart(const RealRay &K, double uf, UPart &o) {
+GRT_HD void cplx_upair(const RealRay &K, double x, double y, UPart &o) {    // y < x, sign +1 (see real_upair)
   const double two = 2.0;
   o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
-  const double u0 = K.u0;
-  if (uf == u0) return;
-  const double sg = (u0 < uf) ? 1.0 : -1.0, y = (u0 < uf) ? u0 : uf, x = (u0 < uf) ? uf : u0;
+  if (x == y) return;
   const double X1 = fsqrt(K.a1 + K.b1 * x), X4 = fsqrt(K.a4 + K.b4 * x), Y1 = fsqrt(K.a1 + K.b1 * y), Y4 = fsqrt(K.a4 + K.b4 * y);
   const double xi = fsqrt(K.cf + K.cg * x + x * x), eta = fsqrt(K.cf + K.cg * y + y * y);
   const double idxy = frcp(x - y);
@@ -434,10 +449,10 @@ GRT_HD void cplx_upart(const RealRay &K, double uf, UPart &o) {
   }
   carlson_bundle<NJ>(M2, Lm2, Lp2, Wp2, rff, rdd, rj2);
   const double I1 = 4.0 * rff;
-  o.iu1 = -sg * I1;
+  o.iu1 = I1;
   const double I2 = K.ci2a * (K.ci2b * rdd - 6.0 * rff) + tI2;
   const double tu1v = K.ct1 * I2 + K.ct2 * I1 - K.ct3 * A111m1m2;
-  o.tu11 = -sg * tu1v;
+  o.tu11 = tu1v;
   if (NPH > 0) {
     double v[NA];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -447,9 +462,95 @@ GRT_HD void cplx_upart(const RealRay &K, double uf, UPart &o) {
       const double I3 = K.ci3a[k] * (K.ci3b[k] * rj2[k] - 6.0 * rff + 3.0 * rc7(U2, W2[k])) + two * rc7(P2[k], Q2[k]);
       v[k] = (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
     }
-    o.phiu1 = sg * (K.cP * v[0] - K.cQ * v[1]);
-    if (NPH == 3) o.tu1 = -sg * (K.cA * tu1v + K.cB * v[2] - K.cC * v[0] + K.cD * v[1]);
+    o.phiu1 = -K.cP * v[0] + K.cQ * v[1];
+    if (NPH == 3) o.tu1 = K.cA * tu1v + K.cB * v[2] - K.cC * v[0] + K.cD * v[1];
   }
+}
+
+template <int NPH>
+GRT_HD void cplx_upart(const RealRay &K, double uf, UPart &o) {
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
+  const double u0 = K.u0;
+  if (uf == u0) return;
+  const double sg = (u0 < uf) ? -1.0 : 1.0;       // the four quantities are MINUS the integrals from u0 to uf
+  cplx_upair<NPH>(K, (u0 < uf) ? uf : u0, (u0 < uf) ? u0 : uf, o);
+  o.iu1 = sg * o.iu1; o.tu11 = sg * o.tu11; o.phiu1 = sg * o.phiu1; o.tu1 = sg * o.tu1;
+}
+
+// ---- segment scheme ------------------------------------------------------------------------------------------------
+// S(u) = what real_upart / cplx_upart return for end point u: (sign) x the integrals between u and a FIXED reference
+// point of the ray (the radial turning point, or u0 for the complex-pair class).  For two points of one monotonic
+// stretch S(ua) - S(ub) = sign(ub - ua) x J(min, max) with J = the pair integrals above -- the same for every class.
+// grt_geo_kernel gives lane k (stored point k) the difference to its upper neighbour k+1 of the same leg and sums the
+// differences down the wave (segmented suffix scan + a carry from the chunk above); a leg starts ("reset") at
+//   * the top point of the ray (idx = npts): S = the anchor the set-up kernel evaluated once per ray (RealRay.anc),
+//   * the last inbound point before the mu-fill segment / the turning point: its upper neighbour is the reference
+//     point itself, S(reference) = 0,
+//   * a point clamped onto the turning point (geokerr_wrapper.f:1079,1089): S = 0.
+// Points of the mu-fill segment (mu is their independent variable) keep the one-point evaluation.
+template <int NPH>
+GRT_HD void upair_diff(const RealRay &K, double ua, double ub, UPart &o) {     // S(ua) - S(ub)
+  const double lo = dmin(ua, ub), hi = dmax(ua, ub), sg = (ub >= ua) ? 1.0 : -1.0;
+  if (K.cplx) cplx_upair<NPH>(K, hi, lo, o); else real_upair<NPH>(K, hi, lo, o);
+  o.iu1 = sg * o.iu1; o.tu11 = sg * o.tu11; o.phiu1 = sg * o.phiu1; o.tu1 = sg * o.tu1;
+}
+
+// u of stored point j on the inbound (inb) or outbound leg (geokerr_wrapper.f:498,519,576), clamped onto the turning
+// point as GEOMU does (:1079,1089)
+GRT_HD double leg_u(const GrtCam &cam, const GrtRay &R, const RealRay &K, int j, bool inb) {
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const bool c7 = (K.ncase == 7);
+  const double root = c7 ? K.u2 : K.u3;
+  double un;
+  if (inb) un = cam.uout + (j - cam.offset) * R.du;
+  else { const int Kk = fill ? (j - (cam.next - 2 * cam.kext)) : j; un = 2.0 * R.ub - (cam.uout + (Kk - cam.offset) * R.du); }
+  if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;
+  return un;
+}
+
+// the per-ray anchor: the four quantities at the ray's top stored point, evaluated once per ray by the set-up kernel
+// (one lane per ray there, so the full duplication loops run lane-parallel over 64 rays)
+GRT_HD void realray_anchor(const GrtCam &cam, const GrtRay &R, RealRay &K) {
+  K.anc[0] = K.anc[1] = K.anc[2] = K.anc[3] = 0.0;
+  const int n = R.npts;
+  if (n < 1) return;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const int lo = fill ? (R.kmax - cam.kext) : R.kmax;
+  if (fill && n > lo && n <= lo + cam.next) return;          // (a ray that ends inside its mu-fill segment: never the case)
+  const double un = leg_u(cam, R, K, n, n <= lo || R.tpr == 0);
+  UPart U;
+  if (K.cplx) cplx_upart<3>(K, un, U); else real_upart<3>(K, un, U);
+  K.anc[0] = U.iu1; K.anc[1] = U.tu11; K.anc[2] = U.phiu1; K.anc[3] = U.tu1;
+}
+
+// Lane classification and segment difference of stored point idx.  reset: S(idx) = o as it stands (no neighbour term).
+// usable = false: a mu-fill point (o = 0, reset): ray_point_real evaluates it on its own.
+template <int NPH>
+GRT_HD void useg_lane(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, UPart &o, bool &reset, bool &usable) {
+  const int kext = cam.kext, next = cam.next, kmax = R.kmax, n = R.npts;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const int lo = fill ? (kmax - kext) : kmax;
+  const bool c7 = (K.ncase == 7);
+  const double root = K.cplx ? K.u0 : (c7 ? K.u2 : K.u3);     // the reference point: S(root) = 0
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
+  reset = true; usable = false;
+  if (idx < 1 || idx > n) return;
+  const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
+  if (isfill) return;
+  usable = true;
+  const bool inb = (idx <= lo || R.tpr == 0);
+  const double ua = leg_u(cam, R, K, idx, inb);
+  if (idx == n) {                       // top of the ray: the per-ray anchor
+    o.iu1 = K.anc[0]; o.tu11 = K.anc[1]; o.phiu1 = K.anc[2]; o.tu1 = K.anc[3];
+    return;
+  }
+  if (!K.cplx && ua == root) return;    // clamped onto the turning point: S = 0
+  if (inb && R.tpr != 0 && idx == lo) { // last inbound point: its upper neighbour is the turning point itself
+    upair_diff<NPH>(K, ua, root, o);
+    return;
+  }
+  reset = false;
+  upair_diff<NPH>(K, ua, leg_u(cam, R, K, idx + 1, inb), o);
 }
 
 // mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)
@@ -507,8 +608,9 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
 // two "integral" stages around one inversion, so the function is written as a two-pass loop whose body holds
 // ONE copy of each stage (the earlier if/else form inlined every stage twice: twice the code, and the register
 // allocator spilled inside the duplication loops).
+// pre: the u-side quantities of a non-fill point, summed from segments by the caller (grt_geo_kernel); NULL = evaluate here
 template <int NPH>
-GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P) {
+GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr) {
   constexpr bool PHI = NPH > 0;
   const double one = 1.0, two = 2.0;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
@@ -537,7 +639,10 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 #endif
   for (int pass = 0; pass < 2; ++pass) {
     const bool doU = (pass == 0) != isfill;
-    if (doU) { if (K.cplx) cplx_upart<NPH>(K, un, U); else real_upart<NPH>(K, un, U); }   // (one ray per wave: a uniform branch)
+    if (doU) {
+      if (pre && !isfill) U = *pre;
+      else if (K.cplx) cplx_upart<NPH>(K, un, U); else real_upart<NPH>(K, un, U);   // (one ray per wave: a uniform branch)
+    }
     else real_mupart<PHI>(K, mun, M, isfill);
     if (pass == 0) {
       // argument of the Jacobi inversion
@@ -604,7 +709,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 // image-only build (PHI=false), where its extra instruction-level parallelism wins over the smaller
 // two-pass form: 11.0 ms against 12.8 ms for 1.19e8 points (tools/run_variants.sh).
 template <bool PHI>
-GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P) {
+GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr) {
   const double one = 1.0, two = 2.0;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
   const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
@@ -624,7 +729,8 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
     }
     if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;        // geokerr_wrapper.f:1079,1089
-    if (K.cplx) cplx_upart<(PHI ? 2 : 0)>(K, un, U); else real_upart<(PHI ? 2 : 0)>(K, un, U);   // wave-uniform
+    if (pre) U = *pre;
+    else if (K.cplx) cplx_upart<(PHI ? 2 : 0)>(K, un, U); else real_upart<(PHI ? 2 : 0)>(K, un, U);   // wave-uniform
     iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
     // mu_f from I_u (Eq. 30-42)
     double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;

@@ -24,7 +24,9 @@ GRT_HD double sq(double x) { return x * x; }
 GRT_HD double frcp(double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
+#if !defined(GRT_RCP_1NR)
   r = fma(fma(-b, r, 1.0), r, r);
+#endif
   return r;
 }
 GRT_HD double fdiv(double a, double b) {
@@ -37,7 +39,9 @@ GRT_HD double fsqrt(double x) {
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);
+#if !defined(GRT_SQRT_1NR)
   g = fma(fma(-g, g, x), h, g);
+#endif
   return (x == 0.0) ? 0.0 : g;
 }
 #else

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
     RealRay K;
     realray_init(cam, R, K);
+    realray_anchor(cam, R, K);       // the segment scheme's per-ray anchor (u-side integrals of the top stored point)
     *reinterpret_cast<RealRay *>(rrays + (size_t)tid * GRT_RR_STRIDE) = K;
   } else if (cubic) {
     CubRay K;
@@ -130,6 +131,27 @@ extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long 
   return hipGetLastError();
 }
 
+// Segmented suffix sum over the 64 lanes of a wave for the segment scheme (grt_dev_fast.hpp:useg_lane): lane k ends with
+// v_k + v_k+1 + ... up to and including the first lane >= k whose flag is set; the flag ends as "a reset lies at or above me
+// in this chunk" (lanes without one take the carry of the chunk above).  Kogge-Stone with the operator
+// (v,f)_k o (v,f)_k+d = (v_k + (f_k ? 0 : v_k+d), f_k | f_k+d).
+template <int NQ>
+__device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const bool have = lane + d < 64;
+    const int fo = __shfl_down((int)f, d);
+    double o[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) o[q] = __shfl_down(v[q], d);
+    if (have && !f) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[q] += o[q];
+      f = (fo != 0);
+    }
+  }
+}
+
 // FAST: 0 generic (every root case), 1 four real roots, 2 Schwarzschild cubic
 // NPH : 0 no azimuth, 2 azimuth (per-step record / extra=1), 3 azimuth + coordinate time (slow-light fluid models)
 template <int FAST, int NPH>
@@ -153,6 +175,10 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const int n = Rp->npts;
   const int nchunk = (int)(ray_stride >> 6);      // ray_stride is a multiple of 64 points: every chunk row is a
   double LamN = 0.0;                              // 512-byte aligned, fully used run of four 128-byte lines
+  constexpr int NQ = (NPH == 3) ? 4 : (NPH == 2 ? 3 : 2);   // u-side quantities of the segment scheme: iu1, tu11[, phiu1[, tu1]]
+  double carry[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) carry[q] = 0.0;
   // chunk c holds stored points 64c+1 .. 64c+64; the top (partial) chunk first: it owns Lambda(npts)
   for (int c = (n - 1) >> 6; c >= 0; --c) {
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
@@ -168,14 +194,37 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     const bool valid = idx <= n;
     GeoPoint P;
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
+    UPart S;
+    bool usable = false;
+#if !defined(GRT_NO_USEG)
+    if (FAST == 1) {
+      // u-side integrals from segments between neighbouring points, summed down the wave (grt_dev_fast.hpp:useg_lane)
+      bool reset;
+      useg_lane<NPH>(cam, *Rp, *Kp, idx, S, reset, usable);
+      double v[NQ];
+      v[0] = S.iu1; v[1] = S.tu11;
+      if (NQ > 2) v[2] = S.phiu1;
+      if (NQ > 3) v[3] = S.tu1;
+      seg_suffix_scan<NQ>(v, reset, lane);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (!reset) v[q] += carry[q];
+        carry[q] = __shfl(v[q], 0);
+      }
+      S.iu1 = v[0]; S.tu11 = v[1];
+      if (NQ > 2) S.phiu1 = v[2];
+      if (NQ > 3) S.tu1 = v[3];
+    }
+#endif
     if (valid) {
+      const UPart *pre = usable ? &S : nullptr;
       if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
-      else if (FAST == 1 && NPH == 3) ray_point_real<3>(cam, *Rp, *Kp, idx, P);
-      else if (FAST == 1 && NPH == 2) ray_point_real<2>(cam, *Rp, *Kp, idx, P);
+      else if (FAST == 1 && NPH == 3) ray_point_real<3>(cam, *Rp, *Kp, idx, P, pre);
+      else if (FAST == 1 && NPH == 2) ray_point_real<2>(cam, *Rp, *Kp, idx, P, pre);
 #if defined(GRT_GEO0_TWOPASS)
-      else if (FAST == 1) ray_point_real<0>(cam, *Rp, *Kp, idx, P);
+      else if (FAST == 1) ray_point_real<0>(cam, *Rp, *Kp, idx, P, pre);
 #else
-      else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P);
+      else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
 #endif
       else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
     }
@@ -629,26 +678,27 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
   }
 }
 
-// standard=2 / nup=1 / THINDISK / BB: one lane per pixel, one point per ray (grt_dev_disk.hpp)
+// standard=2 / nup=1 / THINDISK / BB or BBPOL: one lane per pixel, one point per ray (grt_dev_disk.hpp)
 __global__ __launch_bounds__(256) void grt_disk_kernel(GrtCam cam, GrtDisk disk, long long i1, int nrays, int nfreq,
                                                        const double *__restrict__ freqs, float *__restrict__ pixvals,
-                                                       int *__restrict__ ray_status, unsigned long long *__restrict__ step_counter) {
+                                                       int *__restrict__ ray_status, unsigned long long *__restrict__ step_counter,
+                                                       int nvals, int nextra, int bbpol) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nrays) return;
-  const int st = disk_pixel(cam, disk, (int)(i1 + tid), nfreq, freqs, pixvals + tid, nrays);
+  const int nv = nvals + nextra;
+  const int st = disk_pixel(cam, disk, (int)(i1 + tid), nfreq, freqs, pixvals + (long long)tid * nv, (long long)nrays * nv, nvals, nextra, bbpol);
   ray_status[tid] = st;
   if (st > 0) atomicAdd(step_counter, 1ull);
 }
 
-extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, float mbh, float mdot, float rin, float rout, long long i1,
+extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const void *disk, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
-                                      unsigned long long *step_counter) {
-  GrtDisk d;
-  d.mbh = mbh; d.mdot = mdot; d.rin = rin; d.rout = rout;
-  hipLaunchKernelGGL(grt_disk_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, d, i1, nrays, nfreq, freqs, pixvals,
-                     ray_status, step_counter);
+                                      unsigned long long *step_counter, int nvals, int nextra, int bbpol) {
+  hipLaunchKernelGGL(grt_disk_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, *(const GrtDisk *)disk, i1, nrays, nfreq, freqs, pixvals,
+                     ray_status, step_counter, nvals, nextra, bbpol);
   return hipGetLastError();
 }
+extern "C" size_t grt_sizeof_disk(void) { return sizeof(GrtDisk); }
 
 // ---- host-side launch helpers (called from grt_api.cpp) ----
 // pixel constants of camera pixel ii on the host (the same camera_pixel the set-up kernel runs): alpha, beta, l, q2, su, sm

@@ -9,7 +9,7 @@ module grt_cabi
        GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM3D = 19, GRT_FLUID_IHARM = 29, &
        GRT_FLUID_KORAL3D = 25, GRT_FLUID_KORAL3D_DISK = 26
   integer(c_int), parameter :: GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, &
-       GRT_EMIS_BB = 8, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22, &
+       GRT_EMIS_BB = 8, GRT_EMIS_BBPOL = 9, GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22, &
        GRT_EMIS_MAXJUTT = 23, GRT_EMIS_MAXCOMP = 24, GRT_EMIS_SYNCHTHAV = 13, GRT_EMIS_SYNCHTHAVNOABS = 14, &
        GRT_EMIS_BREMS = 5, GRT_EMIS_SYNCHTHBREMS = 27, GRT_EMIS_RHO = 12, GRT_EMIS_POLSYNCHSYMTH = 15
 
@@ -154,6 +154,11 @@ module grt_cabi
        real(c_float), intent(out) :: tstep
        integer(c_int) :: rc
      end function grt_get_harm_tstep
+     function grt_load_chandra_file(path) bind(C, name='grt_load_chandra_file') result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), dimension(*), intent(in) :: path
+       integer(c_int) :: rc
+     end function grt_load_chandra_file
      function grt_load_sphacc_tables_file(path) bind(C, name='grt_load_sphacc_tables_file') result(rc)
        import :: c_int, c_char
        character(kind=c_char), dimension(*), intent(in) :: path

@@ -115,8 +115,10 @@ contains
     if (debug /= 0) then
        call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps'); goto 999
     end if
-    if (extra == 1 .and. nup <= 1) then
-       call die('extra=1 with nup=1 is not supported yet'); goto 999
+    ! extra=1 with one point per ray: the 7 diagnostics of grtrans_driver.f90:298-311 go through transpol, which reads the
+    ! Chandrasekhar table -- loaded only for nvals = 4 (pgrtrans.f90:154), so the reference itself needs BBPOL here
+    if (extra == 1 .and. nup <= 1 .and. .not. (trim(ename) == 'BBPOL' .and. nvals == 4)) then
+       call die('extra=1 with nup=1 needs ename=BBPOL, nvals=4 (the one-point diagnostics read the Chandrasekhar table)'); goto 999
     end if
     select case (trim(fname))
     case ('FFJET'); fluid_id = GRT_FLUID_FFJET
@@ -135,6 +137,7 @@ contains
     case ('SYNCHPL'); emis_id = GRT_EMIS_SYNCHPL
     case ('POLSYNCHTH'); emis_id = GRT_EMIS_POLSYNCHTH
     case ('BB'); emis_id = GRT_EMIS_BB
+    case ('BBPOL'); emis_id = GRT_EMIS_BBPOL
     case ('HYBRIDTHPL'); emis_id = GRT_EMIS_HYBRIDTHPL
     case ('HYBRIDTH'); emis_id = GRT_EMIS_HYBRIDTH
     case ('HYBRIDPL'); emis_id = GRT_EMIS_HYBRIDPL
@@ -250,6 +253,17 @@ contains
        ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
        rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) then
           call die_rc('grt_set_thindisk', rc); goto 999
+       end if
+       if (nup == 1 .and. nvals == 4) then
+          ! load_chandra_tab24 (pgrtrans.f90:154): ch24_vals.txt from the working directory, as the reference; else the shipped copy
+          rc = grt_load_chandra_file(cstr('ch24_vals.txt'))
+          if (rc /= 0) then
+             path = trim(datadir)//'/ch24_vals.txt'
+             rc = grt_load_chandra_file(cstr(path))
+          end if
+          if (rc /= 0) then
+             call die_rc('grt_load_chandra_file ch24_vals.txt', rc); goto 999
+          end if
        end if
     else if (fluid_id == GRT_FLUID_SPHACC) then
        ! the reference holds these tables as DATA statements (fluid_model_sphacc.f90:40-448)

@@ -36,6 +36,7 @@ extern "C" {
 enum { GRT_FLUID_SPHACC = 1, GRT_FLUID_THINDISK = 2, GRT_FLUID_HARM = 12, GRT_FLUID_FFJET = 13, GRT_FLUID_HARM3D = 19, GRT_FLUID_KORAL3D = 25, GRT_FLUID_KORAL3D_DISK = 26,
        GRT_FLUID_IHARM = 29 };
 enum { GRT_EMIS_POLSYNCHTH = 2, GRT_EMIS_POLSYNCHSYMTH = 15 /* sympolemisth, polsynchemis.f90:915-1010: Pandya et al. fits */, GRT_EMIS_SYNCHPL = 3, GRT_EMIS_POLSYNCHPL = 4, GRT_EMIS_BB = 8,
+       GRT_EMIS_BBPOL = 9 /* fbbpolemis, emis.f90:170-184: colour-corrected black body times Chandrasekhar's limb darkening and polarization degree */,
        /* thermal + power-law electron populations (emis.f90:16-17, :473-490): K = Kth + Kpl; HYBRIDTH / HYBRIDPL keep
           one population's emission with the total absorption and Faraday coefficients */
        GRT_EMIS_HYBRIDTHPL = 20, GRT_EMIS_HYBRIDTH = 21, GRT_EMIS_HYBRIDPL = 22,
@@ -161,9 +162,16 @@ int grt_set_iharm_mmks(int metric, double mks_smooth, double poly_xt, double pol
 int grt_load_iharm_files(const char *dfile, const char *hfile, int indf, double spin);
 
 /* replaces init_thindisk(a, ifile, mdot, mbh, rin, rout) (fluid_model_thindisk.f90:31-49, called from
- * fluid.f90:226-227 with fargs%mdot, %rin, %rout; the mass comes with grt_emis.mbh).  Only the reference's
- * harm.in.dist problem is on the device for this model: standard=2 camera, nup=1, ename BB, nvals=1. */
+ * fluid.f90:226-227 with fargs%mdot, %rin, %rout; the mass comes with grt_emis.mbh).  On the device for this model: the
+ * standard=2 camera with nup=1 -- ename BB, nvals=1 (the reference's harm.in.dist problem) and ename BBPOL, nvals=4 (its
+ * `thindisk` regression problem). */
 int grt_set_thindisk(double mdot, double rin, double rout);
+/* replaces load_chandra_tab24 (chandra_tab24.f90:11-22; the reference reads ch24_vals.txt from the working directory when
+ * nup = 1 and nvals = 4, pgrtrans.f90:154): n <= 32 tabulated mu, I, delta of the semi-infinite scattering atmosphere,
+ * REAL(4).  Needed by ename BBPOL (THINDISK, standard=2, nup=1, nvals=4; extra=1 adds the 7 one-point diagnostics of
+ * grtrans_driver.f90:298-311). */
+int grt_upload_chandra(int n, const float *mu, const float *I, const float *delta);
+int grt_load_chandra_file(const char *path);
 
 /* replaces initialize_polsynchpl (polsynchemis.f90:107-525): 2020 doubles,
  * gxvals[181] gyvals[543] xvals[81] yavals[243] ypvals[243] yvvals[243] yapvals[243] yavvals[243] */

@@ -51,6 +51,49 @@ int hs_ray_points_fast(const GrtCam *cam, int ii, int maxn, double *u, double *m
   return fast ? R.npts : -R.npts;
 }
 
+// The segment scheme of grt_geo_kernel (grt_dev_fast.hpp:useg_lane), emulated chunk by chunk: the per-lane differences are
+// summed down each 64-point chunk (segmented suffix sum, carry from the chunk above) exactly as the wave does, then handed
+// to ray_point_real / ray_point_real_branchy.  nph = 3, 2 or 0 (0: the branchy image-only form).
+int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, double *mu, double *dt, double *dphi, double *lam,
+                      int *tpm, int *tpr, int *ncase) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  *ncase = R.ncase;
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
+  if (!fast || R.npts < 1) return -R.npts;
+  RealRay K;
+  realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  UPart carry; carry.iu1 = carry.tu11 = carry.phiu1 = carry.tu1 = 0.0;
+  for (int c = (R.npts - 1) >> 6; c >= 0; --c) {
+    UPart S[64]; bool reset[64], usable[64];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int idx = 64 * c + lane + 1;
+      if (nph == 3) useg_lane<3>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
+      else if (nph == 2) useg_lane<2>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
+      else useg_lane<0>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
+    }
+    for (int lane = 63; lane >= 0; --lane) {
+      if (reset[lane]) continue;
+      const UPart &up = (lane < 63) ? S[lane + 1] : carry;
+      S[lane].iu1 += up.iu1; S[lane].tu11 += up.tu11; S[lane].phiu1 += up.phiu1; S[lane].tu1 += up.tu1;
+    }
+    carry = S[0];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int idx = 64 * c + lane + 1;
+      if (idx > R.npts || idx > maxn) continue;
+      GeoPoint P;
+      const UPart *pre = usable[lane] ? &S[lane] : nullptr;
+      if (nph == 3) ray_point_real<3>(*cam, R, K, idx, P, pre);
+      else if (nph == 2) ray_point_real<2>(*cam, R, K, idx, P, pre);
+      else ray_point_real_branchy<false>(*cam, R, K, idx, P, pre);
+      u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
+      tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
+    }
+  }
+  return R.npts;
+}
+
 // PHI=false variant: only u, mu, lambda, tpm, tpr are meaningful
 int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *lam, int *tpm, int *tpr) {
   GrtRay R;
@@ -304,7 +347,14 @@ void hs_formal_step(const double *j4, const double *K7, double dx, const double 
 
 // standard=2 / nup=1 thin-disk pixel (BASELINE config 1)
 int hs_disk_pixel(const GrtCam *cam, float mbh, float mdot, float rin, float rout, int ii, double freq, float *pix) {
-  GrtDisk d; d.mbh = mbh; d.mdot = mdot; d.rin = rin; d.rout = rout;
-  return disk_pixel(*cam, d, ii, 1, &freq, pix, 1);
+  GrtDisk d; d.mbh = mbh; d.mdot = mdot; d.rin = rin; d.rout = rout; d.nch = 0;
+  return disk_pixel(*cam, d, ii, 1, &freq, pix, 1, 1, 0, 0);
+}
+// BBPOL (nvals = 4) with nextra = 0 or 7: pix receives [nfreq][4 + nextra]
+int hs_disk_pixel_pol(const GrtCam *cam, float mbh, float mdot, float rin, float rout, int nch, const float *mu, const float *I,
+                      const float *del, int ii, int nfreq, const double *freqs, int nextra, float *pix) {
+  GrtDisk d; d.mbh = mbh; d.mdot = mdot; d.rin = rin; d.rout = rout; d.nch = nch;
+  for (int i = 0; i < nch; ++i) { d.ch_mu[i] = mu[i]; d.ch_I[i] = I[i]; d.ch_del[i] = del[i]; }
+  return disk_pixel(*cam, d, ii, nfreq, freqs, pix, 4 + nextra, 4, nextra, 1);
 }
 }

@@ -556,6 +556,23 @@ def config5(nx=64, nup=400):
     np.savez_compressed(os.path.join(G, "ffjet_nfreq25_%dx%dx%d.npz" % (nx, nx, nup)), fmin=2.41e10, fmax=6.31e14, **out)
 
 
+def thindisk_pol():
+    # the reference's `thindisk` regression problem (run_grtrans_test_problems_public.py:111-129; its pickle is not shipped):
+    # THINDISK + BBPOL, nvals = 4, standard = 2, nup = 1, three of its 25 frequencies; and the same with extra=1 (7 one-point
+    # diagnostics, grtrans_driver.f90:298-311).  Through the reference's own main (needs ch24_vals.txt in the working directory).
+    from oracle import refmain
+    ch = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "grtrans_amd", "data", "ch24_vals.txt")
+    kw = dict(fname='THINDISK', nfreq=3, nmu=1, fmin=2.41e16, fmax=6.31e18, ename='BBPOL', nvals=4, spin=0.9, standard=2, nn=[100, 100, 1],
+              uout=0.01, mbh=10, mumin=.26, mumax=.26, gridvals=[-21, 21, -21, 21])
+    out = {}
+    r = refmain.run(kw, nthreads=8, links=[ch])
+    out["ivals"], out["nu"] = r["ivals"], r["nu"]
+    r = refmain.run(dict(kw, extra=1), nthreads=8, links=[ch])
+    out["ivals_extra"] = r["ivals"]
+    assert r["nvals"] == 11 and np.array_equal(r["ivals"][:, :, :4], out["ivals"], equal_nan=True)
+    np.savez_compressed(os.path.join(G, "thindisk_bbpol_100x100x1.npz"), **out)
+
+
 def crosscheck_main():
     # the image goldens above were produced through oracle/ref_driver.f90 (per-stage probes + a restated pixel loop);
     # assert that the reference's own main gives the same bits, and record it
@@ -609,5 +626,6 @@ if __name__ == "__main__":
     unpolarized()
     sympol()
     config5()
+    thindisk_pol()
     crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

@@ -1463,3 +1463,39 @@ def test_more_frequencies_than_any_batch_limit(fdev):
     for k in (0, 13, 31, 32, 39):
         single, _, _, _ = run(nn, "formal", freqs=[freqs[k]])
         assert np.array_equal(multi[k], single[0]), k
+
+
+def test_polarized_thindisk_bbpol_and_one_point_diagnostics(fdev, tmp_path, monkeypatch):
+    # The reference's `thindisk` regression problem (run_grtrans_test_problems_public.py:111-129): THINDISK + BBPOL, nvals = 4,
+    # standard = 2, nup = 1 -- Chandrasekhar's limb darkening and polarization degree, rotated by the transported basis --
+    # and with extra=1 the 7 one-point diagnostics of grtrans_driver.f90:298-311.  Golden = the compiled reference's own
+    # grtrans_main.  Through the C ABI, ./grtrans and run_pgrtrans.
+    from grtrans_amd import capi, grtrans_batch as gb
+    g = np.load(os.path.join(G, "thindisk_bbpol_100x100x1.npz"))
+    fdev.set_thindisk(0.1, -1., 1e8)
+    fdev.load_chandra()
+    cam = capi.make_camera(2, (-21., 21., -21., 21.), (100, 100, 1), 0.9, 0.26, 0.01, -0.5)
+    em = capi.make_emis("BBPOL", 10., 1.0, 6.0, 100., 1e5, 3.5)
+    freqs = list(2.41e16 * np.exp(np.arange(3) * np.log(6.31e18 / 2.41e16) / 2))
+    pix, _, status, st = capi.trace_tile(cam, 1, 10000, "THINDISK", em, freqs, "lsoda", nvals=4)
+    assert pix.shape == (3, 10000, 4) and st.ray_steps == int((status > 0).sum())
+    assert stokes_err(pix[:, :, :3], g["ivals"][:, :, :3]) < STOKES_TOL
+    assert (pix[:, :, 3] == 0).all() and (g["ivals"][:, :, 3] == 0).all()
+    pix7, _, _, _ = capi.trace_tile(cam, 1, 10000, "THINDISK", em, freqs, "lsoda", nvals=4, nextra=7)
+    assert np.array_equal(pix7[:, :, :4], pix)
+    ref = g["ivals_extra"].astype(float)
+    for k in range(4, 11):
+        assert np.abs(pix7[:, :, k] - ref[:, :, k]).max() / np.abs(ref[:, :, k]).max() < 2e-5, k
+    with pytest.raises(capi.GrtError):      # nvals = 1 with extra=1: the reference reads an unloaded table there
+        capi.trace_tile(cam, 1, 100, "THINDISK", capi.make_emis("BB", 10., 1.0, 6.0, 100., 1e5, 3.5), freqs, "lsoda", nvals=1, nextra=7)
+    kw = dict(fname='THINDISK', nfreq=3, nmu=1, fmin=2.41e16, fmax=6.31e18, ename='BBPOL', nvals=4, spin=0.9, standard=2, nn=[100, 100, 1],
+              uout=0.01, mbh=10, mumin=.26, mumax=.26, gridvals=[-21, 21, -21, 21], extra=1, cflag=0)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (10000, 11, 3) and np.array_equal(x.ivals.transpose(2, 0, 1), pix7)
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert y.ivals.shape == (11, 10000, 3) and np.array_equal(y.ivals.transpose(2, 1, 0).astype(np.float32), pix7)

@@ -504,3 +504,69 @@ def test_polsynchsymth_matches_oracle(L):
     scale = np.abs(want[:, [0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 10]]) + np.abs(want[:, [0] * 4 + [4] * 4 + [10, 10, 8]]) * np.array([0] * 8 + [1, 1, 1]) + 1e-300
     err = np.abs(got - want) / scale
     assert err.max() < 1e-9, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_polarized_thindisk_bbpol_and_one_point_diagnostics_vs_reference_golden(L):
+    # the reference's `thindisk` regression problem (THINDISK + BBPOL, nvals = 4, standard = 2, nup = 1) with extra=1: Stokes
+    # I, Q, U, V and the 7 one-point diagnostics (s2xi, s2psi, cosne of calc_polar_psi, ang, cosne, c2xi, c2psi); golden = the
+    # compiled reference's own grtrans_main (tests/make_golden.py:thindisk_pol); device function compiled for the host
+    g = np.load(os.path.join(ROOT, "tests", "golden", "thindisk_bbpol_100x100x1.npz"))
+    cam = (C.c_char * L.hs_sizeof_cam())()
+    gv = np.array([-21., 21., -21., 21.]); nn = np.array([100, 100, 1], dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    L.hs_make_cam(cam, 2, dp(gv), nn.ctypes.data_as(C.POINTER(C.c_int)), C.c_double(0.9), C.c_double(0.26), C.c_double(0.01), C.c_double(-0.5))
+    txt = open(os.path.join(ROOT, "grtrans_amd", "data", "ch24_vals.txt")).read().split()
+    n = int(txt[0]); v = np.array(txt[2:], dtype=np.float32)
+    mu, chI, chd = v[:n].copy(), v[n:2 * n].copy(), v[2 * n:3 * n].copy()
+    freqs = np.array(2.41e16 * np.exp(np.arange(3) * np.log(6.31e18 / 2.41e16) / 2))
+    L.hs_disk_pixel_pol.argtypes = [C.c_void_p] + [C.c_float] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    out = np.zeros((10000, 3, 11), dtype=np.float32)
+    for i in range(0, 10000, 3):
+        pix = np.zeros((3, 11), dtype=np.float32)
+        L.hs_disk_pixel_pol(cam, 10., 0.1, -1., 1e8, n, mu.ctypes.data, chI.ctypes.data, chd.ctypes.data, i + 1, 3, freqs.ctypes.data, 7, pix.ctypes.data)
+        out[i] = pix
+    ref = g["ivals_extra"].transpose(1, 0, 2)[::3]
+    got = out[::3]
+    for k in range(11):
+        sc = np.abs(ref[:, :, k]).max()
+        if sc > 0:
+            assert np.abs(got[:, :, k].astype(float) - ref[:, :, k]).max() / sc < (2e-6 if k < 4 else 2e-5), k
+    assert (ref[:, :, 3] == 0).all() and (got[:, :, 3] == 0).all()
+
+
+SEG_CAMS = [(0.998, 0.906, (-40., 20., -20., 40.), (100, 100, 400), 0.01, 83),
+            (0.9375, 0.6428, (-13., 13., -13., 13.), (64, 64, 400), 0.04, 37),      # 11 % of these rays plunge (complex-pair class)
+            (0.5, -0.3, (-20., 20., -20., 20.), (48, 48, 200), 0.02, 23),
+            (0.7, 0.0, (-15., 15., -15., 15.), (32, 32, 1000), 0.03, 13),           # 16 chunks per ray
+            (0.9, 1.0, (-10., 10., -10., 10.), (32, 32, 64), 0.05, 11)]             # one chunk per ray, pole-on
+
+
+@pytest.mark.parametrize("spin,mu0,gv,nn,uout,stride", SEG_CAMS)
+def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin, mu0, gv, nn, uout, stride):
+    # grt_geo_kernel's segment scheme (grt_dev_fast.hpp:useg_lane): u-side integrals of a stored point = sum of the integrals
+    # between neighbouring points down from a per-ray anchor, emulated chunk by chunk as the wave does it
+    # (hostsim.cpp:hs_ray_points_seg), for the three kernel forms (azimuth + time, azimuth, image only).  Integers exact.
+    cam = (C.c_char * L.hs_sizeof_cam())()
+    gva = np.array(gv, dtype=float); nna = np.array(nn, dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    L.hs_make_cam(cam, 1, dp(gva), ip(nna), C.c_double(spin), C.c_double(mu0), C.c_double(uout), C.c_double(-0.5))
+    o = O.Oracle(nn=nn, spin=spin, mu0=mu0, gridvals=gv, uout=uout)
+    maxn = nn[2] * 2 + 64
+    nfast = 0
+    for i in range(1, nn[0] * nn[1] + 1, stride):
+        g = o.geokerr_ray(i)
+        for nph in (3, 2, 0):
+            d = [np.zeros(maxn) for _ in range(5)]
+            tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
+            n = L.hs_ray_points_seg(cam, i, maxn, nph, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc))
+            if n <= 0:
+                continue
+            nfast += 1
+            assert n == g["n"] and nc.value == g["ncase"]
+            assert np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"]), (i, nph)
+            for key in ["u", "mu", "lam"] + (["dphi"] if nph else []) + (["dt"] if nph == 3 else []):
+                k = ("u", "mu", "dt", "dphi", "lam").index(key)
+                assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, nph, key)
+    assert nfast > 100
