@@ -18,6 +18,9 @@ extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps, unsigned long long *flags,
                                      long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw);
+extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
+                                      double *steps, unsigned long long *flags, long long ray_stride, long long field_stride, int nfields,
+                                      int tfield);
 extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long i1, int nrays, double *t0);
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
@@ -504,7 +507,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (!C.init) return GRT_E_NOTINIT;
   if (!cam || !em || !freqs || nfreq < 1 || i2 < i1 || i1 < 1) return GRT_E_BADARG;     // any nfreq (pgrtrans.f90:87-91 has no limit)
   if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
-  if (cam->standard == 2) {
+  if (cam->standard == 2 && cam->nup == 1) {
     // standard=2 on the device: one point per ray on a thin disk -- BB (Stokes I; BASELINE config 1) or BBPOL (the
     // polarized atmosphere, nvals = 4, with the 7 one-point diagnostics when extra=1; the reference's `thindisk` problem)
     const bool bb = em->type == GRT_EMIS_BB && nvals == 1 && nextra == 0;
@@ -563,7 +566,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (!pair_ok && !scalar_ok && !sym_ok && !synchpl_ok) return GRT_E_UNSUPPORTED;
   if (iflag != GRT_INT_DELO && iflag != GRT_INT_FORMAL) return GRT_E_UNSUPPORTED;   // LSODA is CPU-only in the reference
   // nextra: 0, or the 19 ray diagnostics of extra=1 for nup>1 (pgrtrans.f90:108-114)
-  if (cam->standard != 1 || cam->nup < 2 || (nvals != 4 && nvals != 1) || (nextra != 0 && nextra != 19)) return GRT_E_UNSUPPORTED;
+  // standard=2 with nup > 1: GEOKERR's USEGEOR branch (mu as the independent variable, geokerr_wrapper.f:421-461) on the
+  // generic class, ends trimmed as geodesics.f90:298-323 does
+  if ((cam->standard != 1 && cam->standard != 2) || cam->nup < 2 || (nvals != 4 && nvals != 1) || (nextra != 0 && nextra != 19)) return GRT_E_UNSUPPORTED;
+  if (cam->standard == 2 && (!cam->usegeor || cam->mufill || cam->kext || cam->next)) return GRT_E_BADARG;
   // nvals=1: both iname=delo and iname=formal fall through to the quadrature (radtrans_integrate.f90:176-189)
   const int kflag = (nvals == 1) ? 4 /* GRT_INT_QUAD */ : iflag;
   if (fluid_model == GRT_FLUID_FFJET && !C.have_ffjet) return GRT_E_NOFLUID;
@@ -666,6 +672,9 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps, C.d_flags,
                                    rstride, fstride, nfields, tfield, t0c, 0));
+        if (!reuse && cam->usegeor)
+          LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, C.d_flags, rstride, fstride,
+                                    nfields, tfield));
         // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
         LAUNCHCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc,
                                       nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,

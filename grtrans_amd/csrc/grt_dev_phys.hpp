@@ -1387,22 +1387,6 @@ struct Affine {   // I -> A I + b
   double A[4][4], b[4];
 };
 
-GRT_HD void affine_identity(Affine &m) {
-  for (int i = 0; i < 4; ++i) {
-    for (int j = 0; j < 4; ++j) m.A[i][j] = (i == j) ? 1.0 : 0.0;
-    m.b[i] = 0.0;
-  }
-}
-
-// later o earlier: (L.A, L.b) o (E.A, E.b) = (L.A E.A, L.A E.b + L.b)
-GRT_HD void affine_compose(const Affine &L, const Affine &E, Affine &out) {
-  for (int i = 0; i < 4; ++i) {
-    for (int j = 0; j < 4; ++j)
-      out.A[i][j] = L.A[i][0] * E.A[0][j] + L.A[i][1] * E.A[1][j] + L.A[i][2] * E.A[2][j] + L.A[i][3] * E.A[3][j];
-    out.b[i] = L.A[i][0] * E.b[0] + L.A[i][1] * E.b[1] + L.A[i][2] * E.b[2] + L.A[i][3] * E.b[3] + L.b[i];
-  }
-}
-
 // formal step at point k: I <- O_k (j_k dx_k + I)   (radtrans_integrate.f90:863-871)
 GRT_HD void formal_map(const double *j, const double *K, double dx, Affine &m) {
   calc_O(K, K + 4, dx, m.A);

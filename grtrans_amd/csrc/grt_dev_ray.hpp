@@ -128,6 +128,49 @@ GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
   setup_ray_core(cam, R, 1.0 / (1.0 + sqrt(1.0 - a * a)), 1);
 }
 
+// standard=2 (USEGEOR, geokerr_wrapper.f:421-461): mu is the independent variable, nup points at equal steps of mu from
+// mu0 to mu_f = 0; pixel constants as INITIALIZE_CAMERA_GEOKERR's standard=2 branch (:167-234).  The first GEOR call
+// (FIRSTPT) finds the roots and caches; every stored point is then GEOR + GEOPHITIME on that cache.
+GRT_HD double usegeor_mu(const GrtCam &cam, int k) { return cam.mu0 + (k - cam.offset) * (0.0 - cam.mu0) / (double)cam.nup; }
+
+GRT_HD void setup_ray_usegeor(const GrtCam &cam, int ii, GrtRay &R) {
+  camera_pixel(cam, ii, R);
+  const double a = cam.a, mu0 = cam.mu0, l = R.l, q2 = R.q2;
+  R.sm = (R.beta > 0.0 && mu0 < 1.0) ? 1.0 : -1.0;
+  R.npts = 0; R.kmax = 0; R.tpr = 0; R.tpr_out = 0; R.fill_tpm0 = 0; R.fill_tpm1 = 0;
+  R.fill_muminus = R.fill_muplus = R.fill_mu0 = R.fill_muf = 0.0; R.dt1 = 0.0; R.lam1 = 0.0;
+  R.ub = 0.0; R.du = 0.0; R.uf = 0.0;
+  GKCache c;
+  int tpm = (int)((fsign(1.0, mu0) * R.sm + 1.0) / 2.0), tpr = 0;
+  double u0 = cam.u0, uf = 0.0, imu = 0.0;
+  const double mun = usegeor_mu(cam, 1);
+  double phimu = 0.0, tmu = 0.0, phiu = 0.0, tu = 0.0, lambda = 0.0;
+  if (mu0 != 0.0 || R.beta != 0.0) {
+    geor(u0, uf, mu0, mun, a, l, l * l, q2, imu, tpm, tpr, R.su, R.sm, c, true, true);
+    geophitime(u0, uf, mu0, mun, a, l, l * l, q2, tpm, tpr, R.su, R.sm, imu, c, phimu, tmu, phiu, tu, lambda, true);
+  }
+  cache_to_ray(c, R);
+  R.dt1 = tmu + tu; R.lam1 = lambda;
+  R.npts = cam.nup;
+}
+
+GRT_HD void ray_point_usegeor(const GrtCam &cam, const GrtRay &R, int idx, double &un, double &mun, double &dt, double &dphi, double &lam,
+                              int &tpm, int &tpr) {
+  const double a = cam.a, mu0 = cam.mu0, l = R.l, q2 = R.q2;
+  GKCache c;
+  cache_from_ray(R, c);
+  mun = usegeor_mu(cam, idx);
+  tpm = (int)((fsign(1.0, mu0) * R.sm + 1.0) / 2.0); tpr = 0;       // :445 (and the camera's TPM for K = 1)
+  // UF is an in/out argument threaded through GEOKERR's K loop: a ray GEOR rejected at its first point (NCASE = 0, UF = -1)
+  // keeps UF = -1 at every later point, whose GEOR calls find no case to evaluate
+  double u0 = cam.u0, uf = (R.ncase == 0) ? -1.0 : u0, imu = 0.0, phimu = 0.0, tmu = 0.0, phiu = 0.0, tu = 0.0, lambda = 0.0;
+  if (mu0 != 0.0 || R.beta != 0.0) {
+    geor(u0, uf, mu0, mun, a, l, l * l, q2, imu, tpm, tpr, R.su, R.sm, c, true, idx == 1);
+    geophitime(u0, uf, mu0, mun, a, l, l * l, q2, tpm, tpr, R.su, R.sm, imu, c, phimu, tmu, phiu, tu, lambda, true);
+  }
+  un = uf; dt = tmu + tu; dphi = phimu + phiu; lam = lambda;
+}
+
 struct GeoPoint {
   double u, mu, dt, dphi, lam;
   int tpm, tpr;
@@ -141,6 +184,10 @@ GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P, 
   const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
   GKCache c;
   cache_from_ray(R, c);
+  if (cam.usegeor) {
+    ray_point_usegeor(cam, R, idx, P.u, P.mu, P.dt, P.dphi, P.lam, P.tpm, P.tpr);
+    return;
+  }
   double l2 = l * l, iu = 0.0, mun = 0.0, un, phimu, tmu, phiu, tu, lambda;
   int tpm = 0, tprp;
   const int lo = fill ? (kmax - kext) : kmax;          // last pure inbound index

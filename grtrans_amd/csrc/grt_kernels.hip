@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
       R.alpha = rin.alpha[tid]; R.beta = rin.beta[tid]; R.l = rin.l[tid]; R.q2 = rin.q2[tid]; R.su = rin.su[tid]; R.sm = rin.sm[tid];
       R.pix = tid + 1;
       setup_ray_core(cam, R, rin.uf[tid], rin.tpr[tid]);
+    } else if (cam.usegeor) {
+      setup_ray_usegeor(cam, (int)(i1 + tid), R);      // standard=2: mu is the independent variable (generic class)
     } else {
       setup_ray(cam, (int)(i1 + tid), R);
     }
@@ -72,13 +74,13 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   // near-polar rays (l^2 below polar_l2 (q2 + a^2): the characteristic of the azimuthal Pi integrals within ~polar_l2 of 1) stay on the generic, reference-literal path: tools/fuzz_cameras.py found
   // one such ray (l = -4e-5) whose azimuth came out of the fast path 1.49 rad off after crossing the equator on the device
   const bool polar = R.l * R.l < polar_l2 * (R.q2 + cam.a * cam.a);
-  const bool quart = alive && !polar && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
+  const bool quart = alive && !polar && !cam.usegeor && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
 #if !defined(GRT_NO_CPLX_FAST)
                                (R.ncase == 5 && R.tpr == 0 && cam.a != 0.0 && R.q2 != 0.0));
 #else
                                false);
 #endif
-  const bool cubic = alive && !need_time && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool cubic = alive && !need_time && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
@@ -238,7 +240,12 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       sp[GRT_F_R * field_stride] = 1.0 / P.u;
       sp[GRT_F_TH * field_stride] = acos(P.mu);
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
-      if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = cam.phi0 - P.dphi;
+      if (nfields > GRT_F_PHI) {
+        double ph = cam.phi0 - P.dphi;
+        // pole-on cameras (geodesics.f90:339-341): phi is measured from the pixel's own position angle
+        if (fabs(cam.mu0) == 1.0) ph += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
+        sp[GRT_F_PHI * field_stride] = ph;
+      }
       if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)
     }
     // turning-point parities of the chunk as two 64-bit lane masks (tpm, tpr): 0.25 bit-pairs per byte instead of a byte per point
@@ -250,6 +257,60 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
   } while (FAST == 0 && slot0 < *nlive_dev);     // only the generic class strides (capped grid); a fast-class wave serves one ray
+}
+
+// standard=2 with nup > 1 (geodesics.f90:298-347): GEOR returns u_f < 0 where the ray does not reach the requested mu; such
+// points are cut from both ENDS of the ray, the survivors i1..i2 are re-indexed from 1, and lambda is referred to
+// LAMBDAI(npts') -- the element of the UNTRIMMED array at the trimmed count, as the reference writes it.  One lane per ray of
+// the generic class, after its geodesic kernel; shifts r, theta, lambda (+ phi, t) and the turning-point parities in place.
+__global__ __launch_bounds__(256) void grt_trim_kernel(GrtRay *__restrict__ rays, const int *__restrict__ live, const int *__restrict__ nlive_dev,
+                                                       int nrays, int *__restrict__ ray_npts, double *__restrict__ steps,
+                                                       unsigned long long *__restrict__ flags, long long ray_stride, long long field_stride,
+                                                       int nfields, int tfield) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= *nlive_dev) return;
+  const int ray = live[nrays - 1 - slot];
+  const int n = rays[ray].npts;
+  if (n <= 1) return;
+  double *rr = steps + GRT_F_R * field_stride + (long long)ray * ray_stride;
+  int i1 = 1, i2 = n;
+  if (rr[0] < 0.0)
+    for (int ii = 2; ii <= n; ++ii)
+      if (!(rr[ii - 1] < 0.0)) { i1 = ii; break; }
+  if (rr[n - 1] < 0.0)
+    for (int ii = 1; ii <= n - 1; ++ii)
+      if (!(rr[n - ii - 1] < 0.0)) { i2 = n - ii; break; }
+  const int np = i2 - i1 + 1;
+  if (np == n) return;
+  double *lam = steps + GRT_F_LAM * field_stride + (long long)ray * ray_stride;
+  const double lref = lam[np - 1];                     // LAMBDAI(npts') of the untrimmed array, in the stored form LamN - Lambda
+  const int nchunk = (int)(ray_stride >> 6);
+  unsigned long long *fl = flags + (long long)ray * nchunk * 2;
+  const int sh = i1 - 1;
+  for (int j = 0; j < np; ++j) {
+    const int s = j + sh;
+    for (int f = 0; f < nfields && f < 4; ++f) {
+      double *p = steps + (long long)f * field_stride + (long long)ray * ray_stride;
+      p[j] = (f == GRT_F_LAM) ? (p[s] - lref) : p[s];
+    }
+    if (tfield >= 0) { double *p = steps + (long long)tfield * field_stride + (long long)ray * ray_stride; p[j] = p[s]; }
+    if (sh) {
+      const unsigned long long bm = (fl[(s >> 6) * 2] >> (s & 63)) & 1ull, br = (fl[(s >> 6) * 2 + 1] >> (s & 63)) & 1ull;
+      fl[(j >> 6) * 2] = (fl[(j >> 6) * 2] & ~(1ull << (j & 63))) | (bm << (j & 63));
+      fl[(j >> 6) * 2 + 1] = (fl[(j >> 6) * 2 + 1] & ~(1ull << (j & 63))) | (br << (j & 63));
+    }
+  }
+  rays[ray].npts = np;
+  ray_npts[ray] = np;
+}
+
+extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
+                                      double *steps, unsigned long long *flags, long long ray_stride, long long field_stride, int nfields,
+                                      int tfield) {
+  if (nrays <= 0) return hipSuccess;
+  hipLaunchKernelGGL(grt_trim_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, rays, live, nlive_dev, nrays, ray_npts, steps, flags, ray_stride,
+                     field_stride, nfields, tfield);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -132,7 +132,7 @@ int hs_ray_points_cubic(const GrtCam *cam, int ii, int maxn, double *u, double *
 int hs_ray_points(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *dt, double *dphi, double *lam,
                   int *tpm, int *tpr, int *ncase) {
   GrtRay R;
-  setup_ray(*cam, ii, R);
+  if (cam->usegeor) setup_ray_usegeor(*cam, ii, R); else setup_ray(*cam, ii, R);
   *ncase = R.ncase;
   for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
     GeoPoint P;

@@ -573,6 +573,81 @@ def thindisk_pol():
     np.savez_compressed(os.path.join(G, "thindisk_bbpol_100x100x1.npz"), **out)
 
 
+SLOWMOVIE_DUMPS = {k: (20261010 + k, 2000.0 + 10.0 * (k - 38)) for k in (40, 41, 43, 44, 47, 48)}      # 10 M apart
+
+
+def write_slowmovie_dumps(outdir, nzone=48):
+    import make_harm_dump
+    return {k: make_harm_dump.write(outdir, n=nzone, name="dump%03d" % k, seed=s, time=t) for k, (s, t) in SLOWMOVIE_DUMPS.items()}
+
+
+def harm_slowmovie():
+    # nt = 3 movie frames of a SLOW-LIGHT run (hnt = 2 slices loaded) whose dumps are 10 M apart, dt = 35: load_harm_data sets
+    # tstep = t(1) - t(2) = 10 (fluid_model_harm.f90:493-500), so advance_harm_timestep walks the dump index 41 -> 44 -> 48
+    # (with the default 20 it would go 41 -> 42 -> 44).  Through the reference's own grtrans_main.  dt is chosen so that every
+    # advance exceeds hnt: for nupdate <= hnt update_harm_data (:523-546) shifts its arrays with sections of unequal length
+    # and the compiled reference aborts.
+    import hashlib
+    import tempfile
+    from oracle import refmain
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_slowmovie_dumps(td)
+        out["dump_sha256"] = np.array([hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)])
+        kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=1,
+                  nn=[24, 24, 80], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428, mumax=.6428,
+                  gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', hdfile='dump', hhfile='dump041', hindf=41, hnt=2,
+                  nt=3, dt=35.)
+        r = refmain.run(kw, nthreads=8, links=[paths[k] for k in sorted(paths)])
+        out["ivals"] = r["ivals"]
+        print(r["log"][-900:])
+    np.savez_compressed(os.path.join(G, "harm_slowmovie_24x24x80.npz"), freq=FREQ_HARM, dt=35.0, **out)
+
+
+def standard2():
+    # standard=2 with nup > 1 (GEOKERR's USEGEOR branch, geokerr_wrapper.f:421-461: mu steps from mu0 to the equatorial plane;
+    # ends with u_f < 0 trimmed, geodesics.f90:298-323) on the FFJET problem: images through the reference's own main, trimmed
+    # point counts and the raw GEOKERR arrays of a few rays through the per-stage probe.
+    from oracle import refmain
+    out = {}
+    cams = {"a": dict(spin=0.998, mu0=0.906, gridvals=(-40., 20., -20., 40.), nn=(32, 32, 80)),
+            "b": dict(spin=0.5, mu0=0.3, gridvals=(-15., 15., -15., 15.), nn=(24, 24, 64))}
+    for key, cm in cams.items():
+        nn = cm["nn"]
+        for iname in ("formal", "delo"):
+            r = refmain.run(dict(FFJET_KW, standard=2, spin=cm["spin"], mumin=cm["mu0"], mumax=cm["mu0"], gridvals=list(cm["gridvals"]),
+                                 nn=list(nn), iname=iname), nthreads=8)
+            out["%s_ivals_%s" % (key, iname)] = r["ivals"][0]
+        rb = R.Ref(iname="formal", **dict(FFJET, standard=2, spin=cm["spin"], mu0=cm["mu0"], gridvals=cm["gridvals"], nn=nn))
+        pix, npts, _ = rb.trace(1, nn[0] * nn[1], [FREQ], nthreads=8)
+        assert np.array_equal(pix[0], out["%s_ivals_formal" % key], equal_nan=True)
+        out[key + "_npts"] = npts
+        out[key + "_cam"] = np.array([cm["spin"], cm["mu0"], *cm["gridvals"], *nn], dtype=float)
+        pick = sorted(set([1, 7, nn[1] * (nn[0] // 2) + nn[1] // 2, nn[1] * (nn[0] // 3) + 2, nn[0] * nn[1]] +
+                          [int(i) + 1 for i in np.where(npts < nn[2])[0][:4]]))
+        for i in pick:
+            g = rb.geokerr_ray(i)
+            for k in ("u", "mu", "dt", "dphi", "lam", "tpm", "tpr"):
+                out["%s_ray%d_%s" % (key, i, k)] = g[k]
+        out[key + "_rays"] = np.array(pick)
+    # an image on the synthetic HARM dump (the far points of a standard=2 ray start at r = 1/u0 >= 1e4, outside every table:
+    # FFJET reads past its arrays there in the reference, the HARM sampler has a defined answer)
+    import tempfile
+    import make_harm_dump
+    with tempfile.TemporaryDirectory() as td:
+        path = make_harm_dump.write(td, n=64)
+        hk = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=2,
+                  nn=[24, 24, 64], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, mumin=.6428, mumax=.6428, gridvals=[-13, 13, -13, 13],
+                  muval=0.25, gmin=1., hdfile='dump', hhfile='dump040', hindf=40, hnt=1)
+        for iname in ("formal", "delo"):
+            out["harm_ivals_" + iname] = refmain.run(dict(hk, iname=iname), nthreads=8, links=[path])["ivals"][0]
+        rb = R.Ref(iname="formal", datadir=td, **dict(HARM, standard=2, nn=(24, 24, 64)))
+        pix, npts, _ = rb.trace(1, 576, [FREQ_HARM], nthreads=8)
+        assert np.array_equal(pix[0], out["harm_ivals_formal"], equal_nan=True)
+        out["harm_npts"] = npts
+    np.savez_compressed(os.path.join(G, "standard2_ffjet.npz"), freq=FREQ, **out)
+
+
 def crosscheck_main():
     # the image goldens above were produced through oracle/ref_driver.f90 (per-stage probes + a restated pixel loop);
     # assert that the reference's own main gives the same bits, and record it
@@ -627,5 +702,7 @@ if __name__ == "__main__":
     sympol()
     config5()
     thindisk_pol()
+    harm_slowmovie()
+    standard2()
     crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

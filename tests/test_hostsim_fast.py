@@ -570,3 +570,30 @@ def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin
                 k = ("u", "mu", "dt", "dphi", "lam").index(key)
                 assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, nph, key)
     assert nfast > 100
+
+
+@pytest.mark.parametrize("key", ["a", "b"])
+def test_standard2_mu_stepping_points_vs_reference_geokerr(L, key):
+    # standard=2 with nup > 1: GEOKERR's USEGEOR branch (geokerr_wrapper.f:421-461; mu steps from mu0 to the equatorial plane,
+    # GEOR + GEOPHITIME per point).  Golden = raw arrays of the compiled reference's GEOKERR (tests/make_golden.py:standard2);
+    # device functions compiled for the host.  u_f = -1 marks points GEOR finds no solution for (trimmed later).
+    g = np.load(os.path.join(ROOT, "tests", "golden", "standard2_ffjet.npz"))
+    spin, mu0, a1, a2, b1, b2, nx, ny, nup = g[key + "_cam"]
+    cam = (C.c_char * L.hs_sizeof_cam())()
+    gva = np.array([a1, a2, b1, b2]); nna = np.array([nx, ny, nup], dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    L.hs_make_cam(cam, 2, dp(gva), ip(nna), C.c_double(spin), C.c_double(mu0), C.c_double(0.01), C.c_double(-0.5))
+    maxn = int(nup) * 2 + 64
+    for i in g[key + "_rays"]:
+        d = [np.zeros(maxn) for _ in range(5)]
+        tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
+        n = L.hs_ray_points(cam, int(i), maxn, *[dp(x) for x in d], ip(tpm), ip(tpr), C.byref(nc))
+        ref = {k: g["%s_ray%d_%s" % (key, i, k)] for k in ("u", "mu", "dt", "dphi", "lam", "tpm", "tpr")}
+        assert n == len(ref["u"]) == int(nup)
+        assert np.array_equal(tpm[:n], ref["tpm"]) and np.array_equal(tpr[:n], ref["tpr"])
+        assert np.array_equal(d[0][:n] < 0, ref["u"] < 0)
+        ok = ref["u"] > 0
+        for k, name in enumerate(("u", "mu", "dt", "dphi", "lam")):
+            if ok.any():
+                assert np.max(np.abs(d[k][:n][ok] - ref[name][ok])) <= 1e-10 * (np.max(np.abs(ref[name][ok])) + 1e-300), (i, name)
