@@ -41,7 +41,7 @@ struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // the generic-class launches run beside the fast-class ones
-  hipEvent_t evj[2] = {nullptr, nullptr};
+  hipEvent_t evj[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   // fluid + tables
   float *d_cells = nullptr, *d_uniq = nullptr;
@@ -160,11 +160,13 @@ int grt_init(int device) {
     // stream of the highest priority, so that its waves are placed ahead of the fast-class kernels' backlog
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char *po = std::getenv("GRT_CLASS_ORDER");     // experiment knob: bit 0 = generic chain first, bit 1 = high priority
-    C.class_order = po ? std::atoi(po) : 3;
+    // experiment knob: bit 0 = generic chain launched first, bit 1 = on a high-priority stream, bit 2 = the fast-class chain
+    // waits for the generic geodesic kernel
+    const char *po = std::getenv("GRT_CLASS_ORDER");
+    C.class_order = po ? std::atoi(po) : 7;
     HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
   }
-  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
+  for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&C.evk[i]));
   HIPCHK(hipMalloc((void **)&C.d_counters, 4 * sizeof(int)));
@@ -187,7 +189,7 @@ int grt_free(void) {
     if (C.evk[i]) (void)hipEventDestroy(C.evk[i]);
   if (C.stream) (void)hipStreamDestroy(C.stream);
   if (C.stream2) (void)hipStreamDestroy(C.stream2);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (C.evj[i]) (void)hipEventDestroy(C.evj[i]);
   C = Ctx();
   return 0;
@@ -675,6 +677,14 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, C.d_flags, rstride, fstride,
                                     nfields, tfield));
+        if (!reuse && (C.class_order & 4) && turn == 0) {
+          // The generic geodesic kernel is ~1.4 ms of work for this camera but starves beside the fast-class kernel (it needs a
+          // whole SIMD per wave plus scratch: profiles/r02_a timeline, 73-114 ms when overlapped), and its transfer kernel -- a
+          // few blocks, but 454 sequential steps per lane = 3.4 ms of latency -- then trails the whole trace.  Let the
+          // fast-class chain start when the generic GEODESICS are done: the generic transfer hides under the fast geodesics.
+          LAUNCHCHK(hipEventRecord(C.evj[2], C.stream2));
+          LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evj[2], 0));
+        }
         // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
         LAUNCHCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc,
                                       nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,

@@ -222,7 +222,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       const UPart *pre = usable ? &S : nullptr;
       if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
       else if (FAST == 1 && NPH == 3) ray_point_real<3>(cam, *Rp, *Kp, idx, P, pre);
+#if defined(GRT_GEO2_BRANCHY)
+      else if (FAST == 1 && NPH == 2) ray_point_real_branchy<true>(cam, *Rp, *Kp, idx, P, pre);
+#else
       else if (FAST == 1 && NPH == 2) ray_point_real<2>(cam, *Rp, *Kp, idx, P, pre);
+#endif
 #if defined(GRT_GEO0_TWOPASS)
       else if (FAST == 1) ray_point_real<0>(cam, *Rp, *Kp, idx, P, pre);
 #else

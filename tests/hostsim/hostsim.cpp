@@ -94,6 +94,49 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
   return R.npts;
 }
 
+// exploration / test access to the mu-side internals of the fast path: per stored point (non-fill points only, others zero)
+// out[12] = iu, jarg, sn, cn, dn, tpm, tmuf, T = c1 tmu1 + c2 tmuf + c3 tmu3, facm, k2 = 1 - m1m, sym, isfill
+int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12);
+  if (!fast || R.npts < 1) return -R.npts;
+  RealRay K;
+  realray_init(*cam, R, K);
+  const bool fill = (R.tpr == 1 && cam->mufill && cam->nup > 1);
+  const int lo = fill ? (R.kmax - cam->kext) : R.kmax;
+  for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
+    double *o = out + (size_t)(idx - 1) * 12;
+    for (int k = 0; k < 12; ++k) o[k] = 0.0;
+    const bool isfill = fill && idx > lo && idx <= lo + cam->next && R.tpr != 0;
+    o[11] = isfill;
+    if (isfill) continue;
+    GeoPoint P;
+    ray_point_real<3>(*cam, R, K, idx, P);
+    const bool inb = (idx <= lo || R.tpr == 0);
+    const int tprs = inb ? 0 : R.tpr_out;
+    UPart U;
+    real_upart<3>(K, P.u, U);
+    const double iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
+    int tpm;
+    double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
+    if (K.sm == 1) tpm = fint(r1) + (K.sym ? fint((1 + fsign(1.0, r1)) / 2.0) : fint(fabs((1 + fsign(1.0, r1)) / 2.0)));
+    else tpm = fint((iu + K.i1mu) * K.ii3mu);
+    double a2 = K.sm * powm1(tpm);
+    double a3 = 2.0 * fint((2.0 * (double)tpm + 3.0 - K.sm) / 4.0) - 1.0;
+    double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
+    double jarg = (K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus)) * iarg;
+    double sn, cn, dn;
+    sncndn_ladder(K.agm_mu, jarg, K.m1m, sn, cn, dn);
+    MuPart M;
+    real_mupart<true>(K, P.mu, M, false);
+    double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+    o[0] = iu; o[1] = jarg; o[2] = sn; o[3] = cn; o[4] = dn; o[5] = tpm; o[6] = M.tmuf;
+    o[7] = c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3; o[8] = K.facm; o[9] = 1.0 - K.m1m; o[10] = K.sym;
+  }
+  return R.npts;
+}
+
 // PHI=false variant: only u, mu, lambda, tpm, tpr are meaningful
 int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *lam, int *tpm, int *tpr) {
   GrtRay R;

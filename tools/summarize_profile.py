@@ -55,11 +55,21 @@ if not args:
                              "8 B/lane accesses), WRITE_SIZE as reported; both in KB",
                "source": "profiles/%s_pmc.json (separate --pmc passes, tools/profile_round.sh)" % tag},
               open(os.path.join(S, "traffic.json"), "w"), indent=1)
+    # shader clock while the dominant kernel runs: GRBM_GUI_ACTIVE counts busy cycles summed over the 8 XCDs
     gui = mx("grt_geo_kernel<1, 2>", "GRBM_GUI_ACTIVE")
+    dur_ns = None
+    try:
+        for r in csv.DictReader(open(os.path.join(S, tag + "_kernel_stats.csv"))):
+            if "grt_geo_kernel<1, 2>" in r["Name"]:
+                dur_ns = float(r["AverageNs"])
+    except Exception:
+        pass
+    sclk = gui / 8.0 / (dur_ns * 1e-9) if (gui and dur_ns) else 2.4e9
     json.dump({"scope": "trace phase of one record-mode step at 1024x1024x400 (same dispatches as traffic.json)",
                "fma_f64_wave_insts": rec("SQ_INSTS_VALU_FMA_F64"), "mul_f64_wave_insts": rec("SQ_INSTS_VALU_MUL_F64"),
                "add_f64_wave_insts": rec("SQ_INSTS_VALU_ADD_F64"), "trans_f64_wave_insts": rec("SQ_INSTS_VALU_TRANS_F64"),
-               "valu_wave_insts": rec("SQ_INSTS_VALU"), "sclk_hz": 2.4e9,
+               "valu_wave_insts": rec("SQ_INSTS_VALU"), "sclk_hz": sclk,
+               "sclk_note": "GRBM_GUI_ACTIVE of grt_geo_kernel<1,2> / 8 XCDs / its average duration in the kernel trace",
                "per_kernel": {k: {c: v[c]["max"] for c in v if c.startswith("SQ_INSTS_VALU")} for k, v in out.items() if "geo_kernel" in k or "transfer" in k},
                "source": "profiles/%s_pmc.json" % tag},
               open(os.path.join(S, "valu.json"), "w"), indent=1)
