@@ -75,7 +75,7 @@ GRT_HD double rc1p(double e, double b) {
 // and lambda per iteration for all of them), a division-free convergence test and the 7th-order
 // series of Carlson (1995) / DLMF 19.36.1-2 (tolerance 0.015 instead of 0.0015-0.0025: ~1.5 fewer
 // iterations; values agree with the reference's 5th-order evaluation to rounding, ~7e-16).
-template <int NJ>
+template <int NJ, bool WD = true>
 GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double &orf, double &ord, double *orj) {
   const double TOL = 0.015;
   constexpr int NA = NJ > 0 ? NJ : 1;
@@ -111,7 +111,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     avef = (1.0 / 3.0) * (xt + yt + zt);
     aved = .2 * (xt + yt + 3.0 * zt);
     bool more = dmax(dmax(fabs(avef - xt), fabs(avef - yt)), fabs(avef - zt)) > TOL * avef ||
-                dmax(dmax(fabs(aved - xt), fabs(aved - yt)), fabs(aved - zt)) > TOL * aved;
+                (WD && dmax(dmax(fabs(aved - xt), fabs(aved - yt)), fabs(aved - zt)) > TOL * aved);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -126,7 +126,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
 #endif
     double sx = fsqrt(xt), sy = fsqrt(yt), sz = fsqrt(zt);
     double alamb = sx * (sy + sz) + sy * sz;
-    sumd = sumd + fac * frcp(sz * (zt + alamb));
+    if (WD) sumd = sumd + fac * frcp(sz * (zt + alamb));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -157,7 +157,8 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     orf = (1.0 - E2 * (1.0 / 10.0) + E3 * (1.0 / 14.0) + E2 * E2 * (1.0 / 24.0) - (3.0 / 44.0) * E2 * E3 - 5.0 / 208.0 * E2 * E2 * E2 +
            3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 * (1.0 / 16.0)) * fsqrt(inv);
   }
-  {  // R_D (DLMF 19.36.2 with the elementary symmetric functions of X,Y,Z,Z,Z)
+  ord = 0.0;
+  if (WD) {  // R_D (DLMF 19.36.2 with the elementary symmetric functions of X,Y,Z,Z,Z)
     double inv = frcp(aved), X = (aved - xt) * inv, Y = (aved - yt) * inv, Z = -(X + Y) * (1.0 / 3.0);
     double E2 = X * Y - 6.0 * Z * Z, E3 = (3.0 * X * Y - 8.0 * Z * Z) * Z, E4 = 3.0 * (X * Y - Z * Z) * Z * Z, E5 = X * Y * Z * Z * Z;
     double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
@@ -197,6 +198,9 @@ struct RealRay {
   double iu0, tu0, phiu0, tu01;                  // u0-side pieces (cached by the set-up kernel)
   double jfac, m1u, sqmee;                       // geor (Table 2 rows 7/8)
   double anc[4];                                 // segment scheme: iu1, tu11, phiu1, tu1 of the ray's top stored point
+  // mu side of the segment scheme (symmetric M(mu) only): Taylor coefficients in d^2 of sn(d)/d and eps(d)/d (Jacobi's epsilon,
+  // int_0^d dn^2) at the ray's modulus k^2 = 1 - m1m, and the anchor T, I_u, signed sn of the top stored point
+  double k2, sn_c[7], eps_c[7], ancT, anc_iu, anc_s;
   // M(mu)
   int sym;
   double mneg, mpos, muplus, muminus, mposR, muplusR;
@@ -329,6 +333,31 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   agm_ladder(K.m1m, K.agm_mu);
   agm_ladder(K.m1u, K.agm_u);
   K.anc[0] = K.anc[1] = K.anc[2] = K.anc[3] = 0.0;
+  // Taylor coefficients of sn(x|m) and eps(x|m) = int_0^x dn^2: x^(2j+3) terms, j = 0..6, polynomials in m (from the ODE
+  // system sn' = cn dn, cn' = -sn dn, dn' = -m sn cn in exact rationals)
+  static const double SN_SER[7][9] = {
+    {-0.16666666666666666, -0.16666666666666666, 0, 0, 0, 0, 0, 0, 0},
+    {0.0083333333333333332, 0.11666666666666667, 0.0083333333333333332, 0, 0, 0, 0, 0, 0},
+    {-0.00019841269841269841, -0.026785714285714284, -0.026785714285714284, -0.00019841269841269841, 0, 0, 0, 0, 0},
+    {2.7557319223985893e-06, 0.0033840388007054674, 0.015095899470899472, 0.0033840388007054674, 2.7557319223985893e-06, 0, 0, 0, 0},
+    {-2.505210838544172e-08, -0.00027730178771845441, -0.0041542909251242582, -0.0041542909251242582, -0.00027730178771845441, -2.505210838544172e-08, 0, 0, 0},
+    {1.6059043836821613e-10, 1.6001552459885793e-05, 0.00072174979727063064, 0.0021166250159305715, 0.00072174979727063064, 1.6001552459885793e-05, 1.6059043836821613e-10, 0, 0},
+    {-7.6471637318198164e-13, -6.8579993761872067e-07, -8.8932440556944531e-05, -0.0006382989522663795, -0.0006382989522663795, -8.8932440556944531e-05, -6.8579993761872067e-07, -7.6471637318198164e-13, 0}};
+  static const double EPS_SER[7][9] = {
+    {0, -0.33333333333333331, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0.066666666666666666, 0.066666666666666666, 0, 0, 0, 0, 0, 0},
+    {0, -0.0063492063492063492, -0.041269841269841269, -0.0063492063492063492, 0, 0, 0, 0, 0},
+    {0, 0.00035273368606701942, 0.010582010582010581, 0.010582010582010581, 0.00035273368606701942, 0, 0, 0, 0},
+    {0, -1.2826679493346161e-05, -0.0016097482764149431, -0.0056180856180856184, -0.0016097482764149431, -1.2826679493346161e-05, 0, 0, 0},
+    {0, 3.2888921777810664e-07, 0.0001674046118490563, 0.0016283305172194061, 0.0016283305172194061, 0.0001674046118490563, 3.2888921777810664e-07, 0, 0},
+    {0, -6.2645565291067936e-09, -1.280788582375884e-05, -0.00031267028092424917, -0.00080486552444224407, -0.00031267028092424917, -1.280788582375884e-05, -6.2645565291067936e-09, 0}};
+  K.k2 = 1.0 - K.m1m;
+  for (int j = 0; j < 7; ++j) {
+    double a_ = 0.0, b_ = 0.0;
+    for (int q = 8; q >= 0; --q) { a_ = a_ * K.k2 + SN_SER[j][q]; b_ = b_ * K.k2 + EPS_SER[j][q]; }
+    K.sn_c[j] = a_; K.eps_c[j] = b_;
+  }
+  K.ancT = 0.0; K.anc_iu = 0.0; K.anc_s = 0.0;
 }
 
 // u end-point: I_u1 and the four uf-side integrals of Eq. 47-49 for the pair (uf, root).
@@ -556,7 +585,8 @@ GRT_HD void useg_lane(const GrtCam &cam, const GrtRay &R, const RealRay &K, int 
 // mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)
 struct MuPart { double i2mu, tmuf, phimuf; };
 
-template <bool PHI>
+// NOE: the E piece (t_mu) comes from the segment scheme (tseg_*): R_D is not evaluated and tmuf is left 0
+template <bool PHI, bool NOE = false>
 GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
   double sf;
   bool past;     // phi_f > pi/2  <=>  tan(phi_f) < 0  (phi_f = acos(muf/muplus) in [0,pi])
@@ -570,7 +600,7 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
   }
   double qf = (1.0 - sf * K.akm) * (1.0 + sf * K.akm);
   double pj[1] = {1.0 - K.nn * sf * sf}, rff, rdf, rjf[1] = {0.0};
-  carlson_bundle<PHI ? 1 : 0>(1.0 - sf * sf, qf, 1.0, pj, rff, rdf, rjf);
+  carlson_bundle<PHI ? 1 : 0, !NOE>(1.0 - sf * sf, qf, 1.0, pj, rff, rdf, rjf);
   // I_mu piece (calcimusymf / calcimuasymf, geokerr_wrapper.f:3175-3274)
   double imuf = sf * rff;
   if (K.sym) {
@@ -597,7 +627,7 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
       ellpif = ellpic - ellpif;
     }
   }
-  o.tmuf = K.facm * ellef;
+  o.tmuf = NOE ? 0.0 : K.facm * ellef;
   o.phimuf = PHI ? ellpif * K.ifac2facm : 0.0;
 }
 
@@ -703,6 +733,161 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
   double dt = 0.0;
   if (NPH == 3) dt = K.su * (K.tu0 - s * U.tu1) * K.isqee * K.ur + tmu;      // DTI = tu + tmu (:2220, :2351)
   P.u = un; P.mu = mun; P.dt = dt; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
+}
+
+// ---- ray_point_real in two stages, for callers that sum the mu-side t integral from segments between the stages ---------
+// Stage A = pass 0 above (first integral stage + Jacobi inversion), stage B = pass 1 + the assembly.  Between them
+// grt_geo_kernel has, for every lane, I_u, mu and tpm -- all the segment scheme of the mu side needs:
+//   T = c1 tmu1 + c2 tmuf + c3 tmu3 (the E-type part of t_mu and lambda) is facm x Jacobi's epsilon function of the continuous
+//   Jacobi argument v = facm I_u + const of mu = -mu+ cn(v) (symmetric M(mu)), so for neighbouring points, by the addition
+//   theorem eps(x + d) = eps(x) + eps(d) - k^2 sn(x) sn(d) sn(x + d):
+//       T(k) - T(k+1) = -facm [ eps(d) - k^2 s_k s_k+1 sn(d) ],   d = facm (I_u(k+1) - I_u(k)),   s = |sn| (-1)^tpm,
+//   with |sn| = sqrt(1 - (mu/mu+)^2) and eps(d), sn(d) from their Taylor series at the ray's modulus (RealRay.eps_c, sn_c;
+//   |d| <= GRT_TSEG_DMAX, else the lane evaluates its own Legendre integrals as before).  Points of the mu-fill segment and
+//   the top point of the ray (anchor from the set-up kernel) start the chains.  No R_D, and without the azimuth no
+//   Carlson loop at all, is left on the mu side of a regular point.
+#ifndef GRT_TSEG_DMAX
+#define GRT_TSEG_DMAX 0.12
+#endif
+struct RPState {
+  double un, mun, iu;
+  int tpm, tprs, tprp;
+  bool isfill, mu_done;
+  UPart U;
+  MuPart M;
+};
+
+template <int NPH>
+GRT_HD void rp_stage_a(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, const UPart *pre, RPState &S) {
+  constexpr bool PHI = NPH > 0;
+  const double one = 1.0, two = 2.0;
+  const int kext = cam.kext, next = cam.next, kmax = R.kmax;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const int lo = fill ? (kmax - kext) : kmax;
+  const bool c7 = (K.ncase == 7);
+  const double root = c7 ? K.u2 : K.u3;
+  const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
+  double un = 0.0, mun = 0.0, iu = 0.0, jarg = 0.0;
+  int tpm = 0, tprs = 0, tprp = 0;
+  S.U.iu1 = 0.0; S.U.phiu1 = 0.0; S.U.tu11 = 0.0; S.U.tu1 = 0.0;
+  S.M.i2mu = 0.0; S.M.tmuf = 0.0; S.M.phimuf = 0.0;
+  S.mu_done = false;
+  if (!isfill) {
+    if (idx <= lo || R.tpr == 0) {
+      un = cam.uout + (idx - cam.offset) * R.du; tprs = 0; tprp = 0;
+    } else {
+      int Kk = fill ? (idx - (next - 2 * kext)) : idx;
+      un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
+    }
+    if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;        // geokerr_wrapper.f:1079,1089
+    if (pre) S.U = *pre;
+    else if (K.cplx) cplx_upart<NPH>(K, un, S.U); else real_upart<NPH>(K, un, S.U);
+    iu = K.su * (K.iu0 - powm1(tprs) * S.U.iu1) * K.isqee;
+    double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
+    if (K.sm == 1) tpm = fint(r1) + (K.sym ? fint((1 + fsign(1.0, r1)) / 2.0) : fint(fabs((1 + fsign(1.0, r1)) / 2.0)));
+    else tpm = fint((iu + K.i1mu) * K.ii3mu);
+    double a2 = K.sm * powm1(tpm);
+    double a3 = two * fint((two * (double)tpm + 3.0 - K.sm) / 4.0) - one;
+    double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
+    jarg = (K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus)) * iarg;
+  } else {
+    indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, K.sm, idx - lo, next, cam.offset, mun, tpm);
+    real_mupart<PHI>(K, mun, S.M, true);
+    S.mu_done = true;
+    double b1 = K.sm, b2 = K.sm * powm1(tpm + 1), b3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+    iu = b1 * K.i1mu + b2 * S.M.i2mu + b3 * K.i3mu;                      // I_mu
+    jarg = K.jfac * (c7 ? iu - K.siu0m : iu + K.siu0m);
+  }
+  double sn = 0.0, cn = 0.0, dn = 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang loop unroll(disable)
+#endif
+  for (int w = 0; w < 2; ++w) {      // one copy of the ascending recurrence (see ray_point_real)
+    const bool mine = (w == 0) ? !isfill : isfill;
+    const AgmLadder &L = (w == 0) ? K.agm_mu : K.agm_u;
+    const double emmc = (w == 0) ? K.m1m : K.m1u;
+    if (mine) sncndn_ladder(L, jarg, emmc, sn, cn, dn);
+  }
+  if (!isfill) {
+    mun = K.sym ? K.muminus * cn : fdiv(K.muminus, dn);
+  } else {
+    if (c7) {
+      un = fdiv((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1), (K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
+      tprs = (int)((fsign(1.0, K.su * (iu - K.siu0e)) + 1.0) / 2.0);
+    } else {
+      un = fdiv((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2), (K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
+      tprs = (int)((-fsign(1.0, K.su * (iu + K.siu0m)) + 1.0) / 2.0);
+    }
+    tprp = tprs;
+  }
+  S.un = un; S.mun = mun; S.iu = iu; S.tpm = tpm; S.tprs = tprs; S.tprp = tprp; S.isfill = isfill;
+}
+
+// signed sn of the continuous Jacobi argument of a point (symmetric M(mu)): |sn| = sqrt(1 - (mu/mu+)^2), sign (-1)^tpm
+GRT_HD double tseg_s(const RealRay &K, const RPState &S) {
+  const double c = S.mun * K.imuplus, q = (1.0 - c) * (1.0 + c);
+  const double sf = (q > 0.0) ? fsqrt(q) : 0.0;
+  return (S.tpm & 1) ? -sf : sf;
+}
+// T of a point whose own E piece has been evaluated (S.M.tmuf)
+GRT_HD double tseg_T(const RealRay &K, const RPState &S) {
+  const double c1 = K.sm, c2 = K.sm * powm1(S.tpm + 1), c3 = 2.0 * fint((2 * S.tpm - K.sm + 1) / 4.0);
+  return c1 * K.tmu1 + c2 * S.M.tmuf + c3 * K.tmu3;
+}
+// T(this) - T(neighbour) from the addition theorem; d = facm (I_u(neighbour) - I_u(this))
+GRT_HD double tseg_diff(const RealRay &K, double d, double s, double nb_s) {
+  const double d2 = d * d;
+  double e = K.eps_c[6], n = K.sn_c[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 5; j >= 0; --j) { e = e * d2 + K.eps_c[j]; n = n * d2 + K.sn_c[j]; }
+  const double eps = d + d * d2 * e, snd = d + d * d2 * n;
+  return -K.facm * (eps - K.k2 * s * nb_s * snd);
+}
+
+// preT: T summed from segments by the caller (regular points of a symmetric-M ray); NULL = evaluate the E piece here
+template <int NPH>
+GRT_HD void rp_stage_b(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, RPState &S, const double *preT, GeoPoint &P) {
+  constexpr bool PHI = NPH > 0;
+  if (S.isfill) {
+    if (K.cplx) cplx_upart<NPH>(K, S.un, S.U); else real_upart<NPH>(K, S.un, S.U);
+  } else if (!S.mu_done) {
+    if (preT) { if (PHI) real_mupart<PHI, true>(K, S.mun, S.M, false); }
+    else real_mupart<PHI>(K, S.mun, S.M, false);
+  }
+  const int tpm = S.tpm;
+  const double iu = S.iu;
+  // Eq. 48-49, 45-46 (geokerr_wrapper.f:2229-2234, 2313-2351)
+  const double s = powm1(S.tprs);
+  double lambdau = K.su * (K.tu01 - s * S.U.tu11) * K.isqee;
+  double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+  const double Tsum = (preT && !S.isfill && !S.mu_done) ? *preT : (c1 * K.tmu1 + c2 * S.M.tmuf + c3 * K.tmu3);
+  double tmu;
+  if (K.sym) tmu = K.a * K.a * K.mneg * iu + Tsum;
+  else tmu = Tsum;
+  double dphi = 0.0;
+  if (PHI) {
+    double phiu = K.su * (K.phiu0 - s * S.U.phiu1) * K.isqee * K.ur;
+    double phimu = -K.l * iu + K.l * (c1 * K.phimu1 + c2 * S.M.phimuf + c3 * K.phimu3);
+    if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
+    dphi = phimu + phiu;
+  }
+  double dt = 0.0;
+  if (NPH == 3) dt = K.su * (K.tu0 - s * S.U.tu1) * K.isqee * K.ur + tmu;      // DTI = tu + tmu (:2220, :2351)
+  P.u = S.un; P.mu = S.mun; P.dt = dt; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = S.tprp;
+}
+
+// mu-side anchor of the segment scheme: T, I_u and signed sn of the ray's top stored point (set-up kernel, after realray_anchor)
+GRT_HD void realray_anchor_mu(const GrtCam &cam, const GrtRay &R, RealRay &K) {
+  K.ancT = 0.0; K.anc_iu = 0.0; K.anc_s = 0.0;
+  if (R.npts < 1 || !K.sym) return;
+  UPart U; U.iu1 = K.anc[0]; U.tu11 = K.anc[1]; U.phiu1 = K.anc[2]; U.tu1 = K.anc[3];
+  RPState S;
+  rp_stage_a<0>(cam, R, K, R.npts, &U, S);
+  if (S.isfill) return;
+  real_mupart<false>(K, S.mun, S.M, false);
+  K.ancT = tseg_T(K, S); K.anc_iu = S.iu; K.anc_s = tseg_s(K, S);
 }
 
 // Branch-per-segment form of ray_point_real (each stage inlined once per segment type).  Kept for the

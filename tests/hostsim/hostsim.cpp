@@ -64,7 +64,9 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
   RealRay K;
   realray_init(*cam, R, K);
   realray_anchor(*cam, R, K);
+  realray_anchor_mu(*cam, R, K);
   UPart carry; carry.iu1 = carry.tu11 = carry.phiu1 = carry.tu1 = 0.0;
+  double carryT = 0.0, carry_iu = 0.0, carry_s = 0.0;
   for (int c = (R.npts - 1) >> 6; c >= 0; --c) {
     UPart S[64]; bool reset[64], usable[64];
     for (int lane = 0; lane < 64; ++lane) {
@@ -79,14 +81,50 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
       S[lane].iu1 += up.iu1; S[lane].tu11 += up.tu11; S[lane].phiu1 += up.phiu1; S[lane].tu1 += up.tu1;
     }
     carry = S[0];
+    // stage A, the mu-side segment sums (symmetric M(mu)), stage B: as grt_geo_kernel orders them
+    RPState St[64]; bool valid[64]; double my_iu[64], my_s[64], T[64]; bool treset[64];
     for (int lane = 0; lane < 64; ++lane) {
       const int idx = 64 * c + lane + 1;
-      if (idx > R.npts || idx > maxn) continue;
-      GeoPoint P;
+      valid[lane] = idx <= R.npts;
+      my_iu[lane] = 0.0; my_s[lane] = 0.0;
+      if (!valid[lane]) continue;
       const UPart *pre = usable[lane] ? &S[lane] : nullptr;
-      if (nph == 3) ray_point_real<3>(*cam, R, K, idx, P, pre);
-      else if (nph == 2) ray_point_real<2>(*cam, R, K, idx, P, pre);
-      else ray_point_real_branchy<false>(*cam, R, K, idx, P, pre);
+      if (nph == 3) rp_stage_a<3>(*cam, R, K, idx, pre, St[lane]);
+      else if (nph == 2) rp_stage_a<2>(*cam, R, K, idx, pre, St[lane]);
+      else rp_stage_a<0>(*cam, R, K, idx, pre, St[lane]);
+      my_iu[lane] = St[lane].iu; my_s[lane] = tseg_s(K, St[lane]);
+    }
+    const bool tuse = K.sym != 0;
+    if (tuse) {
+      for (int lane = 0; lane < 64; ++lane) {
+        const int idx = 64 * c + lane + 1;
+        const double nb_iu = (lane < 63) ? my_iu[lane + 1] : carry_iu, nb_s = (lane < 63) ? my_s[lane + 1] : carry_s;
+        treset[lane] = true; T[lane] = 0.0;
+        if (!valid[lane]) continue;
+        if (St[lane].isfill) { T[lane] = tseg_T(K, St[lane]); continue; }
+        if (idx == R.npts) { T[lane] = K.ancT; continue; }
+        const double d = K.facm * (nb_iu - my_iu[lane]);
+        if (!(fabs(d) <= GRT_TSEG_DMAX)) {
+          if (nph) real_mupart<true>(K, St[lane].mun, St[lane].M, false); else real_mupart<false>(K, St[lane].mun, St[lane].M, false);
+          St[lane].mu_done = true;
+          T[lane] = tseg_T(K, St[lane]);
+          continue;
+        }
+        treset[lane] = false;
+        T[lane] = tseg_diff(K, d, my_s[lane], nb_s);
+      }
+      for (int lane = 63; lane >= 0; --lane)
+        if (!treset[lane]) T[lane] += (lane < 63) ? T[lane + 1] : carryT;
+      carryT = T[0]; carry_iu = my_iu[0]; carry_s = my_s[0];
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+      const int idx = 64 * c + lane + 1;
+      if (!valid[lane] || idx > maxn) continue;
+      GeoPoint P;
+      const double *preT = tuse ? &T[lane] : nullptr;
+      if (nph == 3) rp_stage_b<3>(*cam, R, K, idx, St[lane], preT, P);
+      else if (nph == 2) rp_stage_b<2>(*cam, R, K, idx, St[lane], preT, P);
+      else rp_stage_b<0>(*cam, R, K, idx, St[lane], preT, P);
       u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
       tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
     }
