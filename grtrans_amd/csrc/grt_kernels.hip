@@ -184,6 +184,9 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   double carry[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) carry[q] = 0.0;
+  // phi = phi0 - dphi; pole-on cameras (geodesics.f90:339-341) measure it from the pixel's own position angle.  Once per ray.
+  double phi_ref = cam.phi0;
+  if (PHI && fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
   double carryT = 0.0, carry_iu = 0.0, carry_s = 0.0;      // mu-side segment sums: T, I_u and signed sn of the chunk above's first lane
   // chunk c holds stored points 64c+1 .. 64c+64; the top (partial) chunk first: it owns Lambda(npts)
   for (int c = (n - 1) >> 6; c >= 0; --c) {
@@ -286,12 +289,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       sp[GRT_F_R * field_stride] = 1.0 / P.u;
       sp[GRT_F_TH * field_stride] = acos(P.mu);
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
-      if (nfields > GRT_F_PHI) {
-        double ph = cam.phi0 - P.dphi;
-        // pole-on cameras (geodesics.f90:339-341): phi is measured from the pixel's own position angle
-        if (fabs(cam.mu0) == 1.0) ph += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
-        sp[GRT_F_PHI * field_stride] = ph;
-      }
+      if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
       if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)
     }
     // turning-point parities of the chunk as two 64-bit lane masks (tpm, tpr): 0.25 bit-pairs per byte instead of a byte per point
