@@ -213,3 +213,43 @@ def test_pgrtrans_module_surface_without_a_device():
         x.run_pgrtrans(fname='FFJET', nfreq=1, nmu=1, fmin=3.45e11, fmax=3.45e11, ename='POLSYNCHPL', nvals=4, spin=0.998, standard=1,
                        nn=[8, 8, 40], uout=0.01, mbh=3.4e9, mumin=.906, mumax=.906, gridvals=[-40, 20, -20, 40], iname='formal')
     assert np.shape(pgrtrans.ivals) == ()
+
+
+def test_two_rank_gloo_interleaved_column_tiles_equal_single_image(tmp_path):
+    # The strong-scaling share-out (bench.py --scaling strong, module pgrtrans with GRT_TILE_COLS): column tiles dealt round-robin
+    # (tiling.ranges), every rank traces its ranges, rank-ordered gather, rank 0 un-permutes -- with two gloo ranks on CPU and the
+    # oracle standing in for the device (no GPU here); must equal the one-process image exactly, three frequencies.
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from grtrans_amd.tiling import ranges, gather_tiles
+from oracle import orabind
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+nn = (12, 11, 60)
+freqs = [2.3e11, 3.45e11, 6.9e11]
+o = orabind.Oracle(nn=nn, iname="delo")
+npix = nn[0] * nn[1]
+mine = ranges(rank, world, 5, npix - 3, nn[1], 2)          # i1 = 5, i2 = npix - 3: ragged first and last tiles
+tiles = [o.trace(a, b, freqs, nthreads=1)[0] for (a, b) in mine]
+tile = torch.from_numpy(np.concatenate(tiles, axis=1))
+full = gather_tiles(tile, dist, 0)
+if rank == 0:
+    img = np.zeros((3, npix, 4), dtype=np.float32)
+    pre = 0
+    for r in range(world):
+        for (a, b) in ranges(r, world, 5, npix - 3, nn[1], 2):
+            img[:, a - 1:b] = full.numpy()[:, pre:pre + b - a + 1]
+            pre += b - a + 1
+    ref, _, _ = o.trace(5, npix - 3, freqs, nthreads=1)
+    assert pre == npix - 7 and np.array_equal(img[:, 4:npix - 3], ref) and (img[:, :4] == 0).all(), "gathered image differs"
+    open(%r, "w").write("ok")
+dist.destroy_process_group()
+''' % (ROOT, str(tmp_path / "ok")))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=env,
+                          timeout=600)
+    assert (tmp_path / "ok").read_text() == "ok"
