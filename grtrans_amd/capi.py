@@ -22,7 +22,7 @@ class GrtCam(C.Structure):
                 ("offset", C.c_double), ("phi0", C.c_double),
                 ("standard", C.c_int32), ("nro", C.c_int32), ("nphi", C.c_int32), ("nup", C.c_int32),
                 ("usegeor", C.c_int32), ("phit", C.c_int32), ("mufill", C.c_int32), ("kext", C.c_int32),
-                ("next", C.c_int32), ("pad0", C.c_int32)]
+                ("next", C.c_int32), ("nrotype", C.c_int32), ("rcut", C.c_double)]
 
 
 class GrtEmis(C.Structure):
@@ -110,12 +110,14 @@ class Device:
         lib().grt_free()
 
 
-def make_camera(standard, gridvals, nn, spin, mu0, uout, phi0=-0.5):
+def make_camera(standard, gridvals, nn, spin, mu0, uout, phi0=-0.5, nrotype=2, rcut=1.0):
     cam = GrtCam()
     gv = (C.c_double * 4)(*[float(v) for v in gridvals])
     n3 = (C.c_int * 3)(*[int(v) for v in nn])
     check(lib().grt_make_camera(C.byref(cam), C.c_int(standard), gv, n3, C.c_double(spin), C.c_double(mu0),
                                 C.c_double(uout), C.c_double(phi0)), "grt_make_camera")
+    if int(nrotype) == 1:       # polar alpha/beta grid: gridvals[0] = inner radius, rcut = outer radius
+        check(lib().grt_set_camera_polar(C.byref(cam), C.c_double(rcut)), "grt_set_camera_polar")
     return cam
 
 

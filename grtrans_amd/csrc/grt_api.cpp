@@ -34,6 +34,8 @@ extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const vo
                                       unsigned long long *step_counter, int nvals, int nextra, int bbpol);
 extern "C" size_t grt_sizeof_disk(void);
 
+extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *out6);
+
 namespace {
 
 struct Ctx {
@@ -493,6 +495,14 @@ int grt_make_camera(grt_camera *cam, int standard, const double gridvals[4], con
 
 long long grt_geo_passes(void) { return C.geo_passes; }
 
+int grt_set_camera_polar(grt_camera *cam, double rcut) {
+  if (!cam || !(rcut > 0.0) || !(cam->a1 > 0.0)) return GRT_E_BADARG;
+  cam->nrotype = 1;
+  cam->rcut = rcut;
+  cam->u0 = std::fmin(1.e-4, 1.0 / (100.0 * rcut * rcut));          // ABMAX = RCUT**2 (geokerr_wrapper.f:142,163)
+  return 0;
+}
+
 int grt_set_geo_reuse(int enable) {
   C.geo_reuse = enable ? 1 : 0;
   C.geo.valid = false;
@@ -770,20 +780,18 @@ int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_mode
   const size_t nrays = (size_t)(i2 - i1 + 1);
   if (pixvals) HIPCHK(hipMemcpy(pixvals, C.d_pixvals, nrays * nfreq * (nvals + nextra) * sizeof(float), hipMemcpyDeviceToHost));
   if (ray_status) HIPCHK(hipMemcpy(ray_status, C.d_npts, nrays * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (pixloc) {   // camera.f90:36: pixloc(:,i) = real(alpha), real(beta); pure host arithmetic (geokerr_wrapper.f:258-262)
+  if (pixloc) {   // camera.f90:36: pixloc(:,i) = real(alpha), real(beta); pure host arithmetic (geokerr_wrapper.f:258-272)
     for (size_t t = 0; t < nrays; ++t) {
-      long long ii = (long long)i1 + (long long)t;
-      int i = (int)((double)(ii - 1) / (double)cam->nphi) + 1;
-      int j = (int)((ii - 1) % cam->nphi) + 1;
-      pixloc[2 * t] = (float)(cam->a1 + (cam->a2 - cam->a1) * ((double)(i - 1) + 0.5) / (double)cam->nro);
-      pixloc[2 * t + 1] = (float)(cam->b1 + (cam->b2 - cam->b1) * ((double)(j - 1) + 0.5) / (double)cam->nphi);
+      double v[6];
+      grt_host_camera_pixel(cam, (long long)i1 + (long long)t, v);
+      pixloc[2 * t] = (float)v[0];
+      pixloc[2 * t + 1] = (float)v[1];
     }
   }
   return 0;
 }
 
 // ---- G-10: class_geokerr's f2py surface (class_geokerr.f90:69-144) --------------------------------------------------
-extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *out6);
 
 int grt_camera_pixels(const grt_camera *cam, int64_t i1, int64_t i2, double *alpha, double *beta, double *q2, double *l,
                       double *su, double *sm, double *uf, double *muf, int32_t *tpm, int32_t *tpr) {

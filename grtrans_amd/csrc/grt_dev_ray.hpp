@@ -33,8 +33,16 @@ GRT_HD void camera_pixel(const GrtCam &cam, int ii, GrtRay &R) {
   const double INPUT_LIMIT = 1.e-5;
   int i = (int)((double)(ii - 1) / (double)cam.nphi) + 1;
   int j = (ii - 1) % cam.nphi + 1;
-  double alpha = cam.a1 + (cam.a2 - cam.a1) * ((double)(i - 1) + 0.5) / (double)cam.nro;
-  double beta = cam.b1 + (cam.b2 - cam.b1) * ((double)(j - 1) + 0.5) / (double)cam.nphi;
+  double alpha, beta;
+  if (cam.nrotype == 1) {     // polar grid (geokerr_wrapper.f:138-149, 263-272): ro_i = r1 (rcut/r1)**(float(i)/nro), r1 = a1
+    const double ro = cam.a1 * pow(cam.rcut / cam.a1, (double)((float)i / (float)cam.nro));
+    const double phi = (cam.nphi != 1) ? 2.0 * acos(-1.0) * ((double)(j - 1) + 0.5) / (double)cam.nphi : 0.0;
+    alpha = ro * cos(phi);
+    beta = ro * sin(phi);
+  } else {
+    alpha = cam.a1 + (cam.a2 - cam.a1) * ((double)(i - 1) + 0.5) / (double)cam.nro;
+    beta = cam.b1 + (cam.b2 - cam.b1) * ((double)(j - 1) + 0.5) / (double)cam.nphi;
+  }
   double mu0 = cam.mu0, a = cam.a;
   double l = -alpha * sqrt(1.0 - mu0 * mu0);
   double q2 = beta * beta - (a * a - alpha * alpha) * mu0 * mu0;

@@ -17,7 +17,8 @@ module grt_cabi
      real(c_double) :: a1, a2, b1, b2
      real(c_double) :: a, mu0, uout, u0, offset, phi0
      integer(c_int32_t) :: standard, nro, nphi, nup
-     integer(c_int32_t) :: usegeor, phit, mufill, kext, next, pad0
+     integer(c_int32_t) :: usegeor, phit, mufill, kext, next, nrotype
+     real(c_double) :: rcut
   end type grt_camera
 
   type, bind(C) :: grt_emis            ! GrtEmis
@@ -179,6 +180,12 @@ module grt_cabi
        real(c_double), value :: spin, mu0, uout, phi0
        integer(c_int) :: rc
      end function grt_make_camera
+     function grt_set_camera_polar(cam, rcut) bind(C, name='grt_set_camera_polar') result(rc)
+       import :: c_int, c_double, grt_camera
+       type(grt_camera), intent(inout) :: cam
+       real(c_double), value :: rcut
+       integer(c_int) :: rc
+     end function grt_set_camera_polar
      function grt_trace_tile(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, pixvals, pixloc, &
           ray_status, st) bind(C, name='grt_trace_tile') result(rc)
        import :: c_int, c_int64_t, c_double, c_float, c_int32_t, grt_camera, grt_emis, grt_stats

@@ -107,11 +107,8 @@ contains
     if (.not. use_geokerr) then
        call die('use_geokerr=F is not supported'); goto 999
     end if
-    ! nrotype=1 is the polar alpha/beta grid of geokerr_wrapper.f:138-149,181-195 (rcut = its outer radius); the device
-    ! builds the rectangular grid (nrotype > 1) only.  uin never reaches GEOKERR in the reference either (geodesics.f90:71-75).
-    if (nrotype <= 1) then
-       call die('nrotype=1 (polar camera grid, rcut) is not supported: use nrotype=2 with gridvals'); goto 999
-    end if
+    ! uin never reaches GEOKERR in the reference either (geodesics.f90:71-75); rcut is the outer radius of the polar pixel grid
+    ! of nrotype=1 (geokerr_wrapper.f:138-149), gridvals(1) its inner radius
     if (debug /= 0) then
        call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps'); goto 999
     end if
@@ -306,6 +303,12 @@ contains
        if (rc /= 0) then
           call die_rc('grt_make_camera', rc); goto 999
        end if
+       if (nrotype == 1) then
+          rc = grt_set_camera_polar(cam, rcut)
+          if (rc /= 0) then
+             call die_rc('grt_set_camera_polar', rc); goto 999
+          end if
+       end if
        if (nload > 1) then
           ! pgrtrans.f90:172-189: time origin of every ray from a one-point geodesic, normalised over the image
           ! (over all ranks: two max-reductions of statistics, not a data-path collective);
@@ -447,6 +450,7 @@ contains
     ntile = i2 - i1 + 1
     allocate(alpha_all(ntile), beta_all(ntile))
     rc = grt_make_camera(cam, int(standard, c_int), gridvals, int(nn, c_int), spin, mu0(nmu), uout, phi0)
+    if (nrotype == 1) rc = grt_set_camera_polar(cam, rcut)
     rc = grt_camera_pixels_ab(cam, int(i1, c_int64_t), int(i2, c_int64_t), alpha_all, beta_all)
     if (rc /= 0) then
        call die_rc('grt_camera_pixels', rc); goto 999

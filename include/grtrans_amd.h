@@ -57,7 +57,9 @@ typedef struct GrtCam {
   double a1, a2, b1, b2;                  /* gridvals: alpha min/max, beta min/max */
   double a, mu0, uout, u0, offset, phi0;  /* phi0 = acos(-1.)*phi0 (single-precision pi), geodesics.f90:218 */
   int32_t standard, nro, nphi, nup;
-  int32_t usegeor, phit, mufill, kext, next, pad0;
+  int32_t usegeor, phit, mufill, kext, next;
+  int32_t nrotype;                        /* 0 or 2: rectangular alpha/beta grid (gridvals); 1: polar grid (grt_set_camera_polar) */
+  double rcut;                            /* nrotype = 1: outer radius of the polar grid */
 } grt_camera;
 
 /* source_params + emis_params for one mdot (pgrtrans.f90:117-136, emis.f90:32-39) */
@@ -181,6 +183,11 @@ int grt_load_polsynchpl_tables_file(const char *path);
 /* replaces initialize_pixels (geodesics.f90:64-111) + the scalar part of INITIALIZE_CAMERA_GEOKERR */
 int grt_make_camera(grt_camera *cam, int standard, const double gridvals[4], const int nn[3], double spin,
                     double mu0, double uout, double phi0);
+
+/* nrotype = 1 (geokerr_wrapper.f:138-149, 181-195, 258-272): the polar pixel grid alpha = ro_i cos(phi_j), beta = ro_i sin(phi_j)
+ * with ro_i = r1 (rcut/r1)^(i/nro), r1 = gridvals(1), phi_j = 2 pi (j - 1/2)/nphi, and u0 from rcut^2.  Call after
+ * grt_make_camera. */
+int grt_set_camera_polar(grt_camera *cam, double rcut);
 
 /* nload > 1 (pgrtrans.f90:172-189): grt_compute_t0 replaces the loop over initialize_geo_tabs (geodesics.f90:113-128)
  * and returns the RAW per-ray time origins of pixels i1..i2; the caller normalises them over the image exactly as

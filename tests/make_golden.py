@@ -648,6 +648,19 @@ def standard2():
     np.savez_compressed(os.path.join(G, "standard2_ffjet.npz"), freq=FREQ, **out)
 
 
+def polar_camera():
+    # nrotype = 1: the polar pixel grid (geokerr_wrapper.f:138-149, 263-272): ro_i = r1 (rcut/r1)**(i/nro), r1 = gridvals(1),
+    # phi_j = 2 pi (j - 1/2)/nphi; FFJET problem, through the reference's own main
+    from oracle import refmain
+    out = {}
+    kw = dict(FFJET_KW, nn=[24, 16, 100], gridvals=[2., 0., 0., 0.], rcut=30., nrotype=1)
+    for iname in ("formal", "delo"):
+        r = refmain.run(dict(kw, iname=iname), nthreads=8)
+        out["ivals_" + iname] = r["ivals"][0]
+        out["ab"] = r["ab"]
+    np.savez_compressed(os.path.join(G, "ffjet_polar_24x16x100.npz"), freq=FREQ, **out)
+
+
 def crosscheck_main():
     # the image goldens above were produced through oracle/ref_driver.f90 (per-stage probes + a restated pixel loop);
     # assert that the reference's own main gives the same bits, and record it
@@ -704,5 +717,6 @@ if __name__ == "__main__":
     thindisk_pol()
     harm_slowmovie()
     standard2()
+    polar_camera()
     crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

@@ -1556,3 +1556,28 @@ def test_standard2_with_many_points_vs_reference(fdev, key):
         emh = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1.0, 1e5, 3.5, mdot=1.57e15)
         _, _, sh, _ = capi.trace_tile(camh, 1, 576, "HARM", emh, [FREQ_HARM], "formal")
         assert np.array_equal(sh, g["harm_npts"])
+
+
+def test_polar_camera_grid_nrotype1(fdev, tmp_path, monkeypatch):
+    # nrotype = 1 (geokerr_wrapper.f:138-149, 263-272): pixels on rings ro_i = r1 (rcut/r1)^(i/nro), r1 = gridvals(1), at azimuths
+    # 2 pi (j - 1/2)/nphi; u0 from rcut^2.  Golden = the reference's own main.  C ABI, ./grtrans and run_pgrtrans.
+    from grtrans_amd import capi, grtrans_batch as gb
+    g = np.load(os.path.join(G, "ffjet_polar_24x16x100.npz"))
+    cam = capi.make_camera(1, (2., 0., 0., 0.), (24, 16, 100), 0.998, 0.906, 0.01, -0.5, nrotype=1, rcut=30.)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    for iname in ("formal", "delo"):
+        pix, loc, status, _ = capi.trace_tile(cam, 1, 384, "FFJET", em, [FREQ], iname)
+        assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL, iname
+        assert np.array_equal(loc, g["ab"])
+    kw = dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=1, nmu=1, fmin=FREQ, fmax=FREQ, ename='POLSYNCHPL', nvals=4,
+              spin=0.998, standard=1, nn=[24, 16, 100], uout=0.01, mbh=3.4e9, mumin=.906, mumax=.906, gridvals=[2., 0., 0., 0.], rcut=30.,
+              nrotype=1, ntscl=2., nrscl=70., iname='formal', cflag=0)
+    monkeypatch.chdir(tmp_path)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert stokes_err(x.ivals[:, :, 0], g["ivals_formal"]) < STOKES_TOL and np.array_equal(x.ab, g["ab"])
+    y = gb.grtrans()
+    y.run_pgrtrans(**kw)
+    assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0])

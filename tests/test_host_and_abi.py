@@ -64,7 +64,7 @@ def test_abi_library_exports_every_declared_symbol():
 
 def test_abi_struct_layouts_match_header():
     from grtrans_amd import capi
-    assert C.sizeof(capi.GrtCam) == 10 * 8 + 10 * 4
+    assert C.sizeof(capi.GrtCam) == 10 * 8 + 10 * 4 + 8          # ... + rcut
     assert C.sizeof(capi.GrtEmis) == 11 * 8 + 8 * 4 + 2 * 4 + 8 * 8
     assert C.sizeof(capi.GrtStats) == 3 * 8 + 5 * 8
 
