@@ -91,9 +91,9 @@ class Device:
     def load_iharm(self, dfile, hfile, indf, spin):
         check(lib().grt_load_iharm_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin)), "grt_load_iharm_files")
 
-    def load_koral3d(self, dfile, hfile, indf, spin, scalefac=1.0):
-        check(lib().grt_load_koral3d_files(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_double(spin), C.c_double(scalefac)),
-              "grt_load_koral3d_files")
+    def load_koral3d(self, dfile, hfile, indf, spin, scalefac=1.0, nt=1):
+        check(lib().grt_load_koral3d_files_nt(dfile.encode(), hfile.encode(), C.c_int(indf), C.c_int(nt), C.c_double(spin),
+                                              C.c_double(scalefac)), "grt_load_koral3d_files_nt")
 
     def set_thindisk(self, mdot, rin, rout):
         check(lib().grt_set_thindisk(C.c_double(mdot), C.c_double(rin), C.c_double(rout)), "grt_set_thindisk")
@@ -202,6 +202,13 @@ def harm_tstep():
     """tstep of the loaded HARM slices (fluid_model_harm.f90:493-500)."""
     t = C.c_float(0)
     check(lib().grt_get_harm_tstep(C.byref(t)), "grt_get_harm_tstep")
+    return np.float32(t.value)
+
+
+def koral3d_tstep():
+    """tstep of the loaded KORAL3D slices (fluid_model_koral3d.f90:617-619)."""
+    t = C.c_float(0)
+    check(lib().grt_get_koral3d_tstep(C.byref(t)), "grt_get_koral3d_tstep")
     return np.float32(t.value)
 
 

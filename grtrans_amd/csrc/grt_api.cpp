@@ -327,18 +327,19 @@ int grt_upload_harm3d(int nx1, int nx2, int nx3, const float *x1_arr, const floa
   return 0;
 }
 
-int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, float bb, float pp, const float *x1_arr,
-                       const float *x2_arr, const float *x3_arr, const float *rho, const float *p, const float *b0,
-                       const float *br, const float *bth, const float *bph, const float *u0, const float *vrl,
-                       const float *vtl, const float *vpl, const float *be) {
+int grt_upload_koral3d_slices(int nx1, int nx2, int nx3, int nt, float tstep, float r0, float h, float aa, float bb, float pp,
+                              const float *x1_arr, const float *x2_arr, const float *x3_arr, const float *rho, const float *p,
+                              const float *b0, const float *br, const float *bth, const float *bph, const float *u0,
+                              const float *vrl, const float *vtl, const float *vpl, const float *be) {
   if (!C.init) return GRT_E_NOTINIT;
-  if (nx1 < 2 || nx2 < 4 || nx3 < 2 || nx3 > nx1 || 2 * nx1 + nx2 + nx3 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr || !be)
+  if (nx1 < 2 || nx2 < 4 || nx3 < 2 || nx3 > nx1 || nt < 1 || 2 * nx1 + nx2 + nx3 > 2 * GRT_HARM_MAXCOORD || !x1_arr || !x2_arr || !x3_arr || !be)
     return GRT_E_BADARG;
+  if (nt > 1 && !(tstep > 0.f)) return GRT_E_BADARG;
   const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
   for (const float *q : src)
     if (!q) return GRT_E_BADARG;
   std::vector<float> cells, crd;
-  grt_koral3d_pack(nx1, nx2, nx3, r0, x1_arr, x2_arr, x3_arr, src, be, cells, crd);
+  grt_koral3d_pack(nx1, nx2, nx3, r0, x1_arr, x2_arr, x3_arr, src, be, cells, crd, nt);
   if (C.d_ko_cells) { (void)hipFree(C.d_ko_cells); C.d_ko_cells = nullptr; }
   if (C.d_ko_coords) { (void)hipFree(C.d_ko_coords); C.d_ko_coords = nullptr; }
   HIPCHK(hipMalloc((void **)&C.d_ko_cells, cells.size() * sizeof(float)));
@@ -349,7 +350,23 @@ int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, f
   C.koral.cells = C.d_ko_cells; C.koral.coords = C.d_ko_coords;
   C.koral.nx1 = nx1; C.koral.nx2 = nx2; C.koral.nx3 = nx3;
   C.koral.kr0 = r0; C.koral.kh = h; C.koral.kaa = aa; C.koral.kbb = bb; C.koral.kpp = pp;
+  C.koral.nt = nt; C.koral.tstep = tstep;
   C.have_koral = true;
+  return 0;
+}
+
+int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, float bb, float pp, const float *x1_arr,
+                       const float *x2_arr, const float *x3_arr, const float *rho, const float *p, const float *b0,
+                       const float *br, const float *bth, const float *bph, const float *u0, const float *vrl,
+                       const float *vtl, const float *vpl, const float *be) {
+  return grt_upload_koral3d_slices(nx1, nx2, nx3, 1, 20.f, r0, h, aa, bb, pp, x1_arr, x2_arr, x3_arr, rho, p, b0, br, bth, bph, u0, vrl,
+                                   vtl, vpl, be);
+}
+
+int grt_get_koral3d_tstep(float *tstep) {
+  if (!tstep) return GRT_E_BADARG;
+  if (!C.have_koral) return GRT_E_NOFLUID;
+  *tstep = C.koral.tstep;
   return 0;
 }
 
@@ -609,7 +626,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   // extra=1 weights by phi as well; a 3-D fluid model is sampled at the point's azimuth
   const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || is_koral) ? 4 : 3);
   // several HARM slices loaded ("slow light"): every point also carries its coordinate time, one more field
-  const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1);
+  const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1) || (is_koral && C.koral.nt > 1);
   if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;
   const int tfield = need_time ? nfields : -1;
   if (need_time && C.t0_n != 0 && C.t0_n != (long long)(i2 - i1 + 1)) return GRT_E_BADARG;   // t0 table of another tile

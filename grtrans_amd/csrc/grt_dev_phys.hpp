@@ -879,13 +879,18 @@ GRT_HD double bl2ks_time(double r, double x, double a) {      // kerr.f90:147-15
   const double sq1 = sqrt(1. - a * a);
   return x + log(r * r - 2 * r + a * a) + 1. / (2.0 * sq1) * log((r - 1. - sq1) / (r - 1 + sq1));
 }
-GRT_HD int harm_time_index(const GrtHarm &t, double r, double tcoord, double r1, float a) {
-  if (t.nt <= 1) return 0;
+// slice of a point from its Kerr-Schild look-back time relative to the ray's first point (fluid_model_harm.f90:134-137, 175-186;
+// the same statements in fluid_model_koral3d.f90:126-128, 212-219): REAL(4) tt = -tt + 1d-8, floor(tt/tstep), oldest slice beyond
+GRT_HD int slice_time_index(int nt, float tstep, double r, double tcoord, double r1, float a) {
+  if (nt <= 1) return 0;
   float tt = (float)(bl2ks_time((double)(float)r, (double)(float)tcoord, (double)a) - bl2ks_time((double)(float)r1, 0.0, (double)a));
   tt = (float)(-(double)tt + 1e-8);
-  const int fl = (int)floorf(tt / t.tstep);
-  int tindx = (fl <= t.nt - 2) ? fl : t.nt - 1;
+  const int fl = (int)floorf(tt / tstep);
+  int tindx = (fl <= nt - 2) ? fl : nt - 1;
   return tindx < 0 ? 0 : tindx;                         // (negative: out of bounds in the reference)
+}
+GRT_HD int harm_time_index(const GrtHarm &t, double r, double tcoord, double r1, float a) {
+  return slice_time_index(t.nt, t.tstep, r, tcoord, r1, a);
 }
 
 // theta -> zone index of harm_vals (fluid_model_harm.f90:58-71, :141-143), see harm_sample.  brent_only: the
@@ -1263,10 +1268,11 @@ GRT_HD float koral_theta_of_x2(float x2, float r, float h, float a, float b, flo
   return (float)(0.5 * PH_pi * (1 + tan((double)h * PH_pi * (double)inner) / tan((double)(0.5f * h) * PH_pi)));
 }
 
-// koral3d_vals (:83-341), one loaded slice: closed-form theta -> x2, azimuth folded into (-pi, pi] WITHOUT the Kerr-Schild
+// koral3d_vals (:83-341), slice tindx of the loaded ones: closed-form theta -> x2, azimuth folded into (-pi, pi] WITHOUT the Kerr-Schild
 // shift, eight corners (x2 fastest, then x1, then x3), 1e-3 scaling of rho and T_e in the innermost radial zone, the
 // polar trust region (minpolecell = 2 zones; 0.25 rad for the disc variant).  Be (Bernoulli parameter) rides along.
-GRT_NI void koral3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &Be) {
+GRT_NI void koral3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &Be,
+                           int tindx = 0) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqx3 = crd + 2 * nx1 + nx2;
@@ -1304,10 +1310,11 @@ GRT_NI void koral3d_sample(const GrtHarm3d &t, const float *crd, double r, doubl
   const float thone = koral_theta_of_x2(uniqx2[0], uniqr[lx1c - 1], t.kh, t.kaa, t.kbb, t.kpp);
   const float td = (ux2c != lx2c) ? fabsf((theta - thl) / (thu - thl)) : fabsf((theta - thl) / thone);
   const size_t plane = (size_t)nx1 * nx2 * 12;
-  const float *c_ll = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(lx1c - 1) * nx2 + (lx2c - 1)) * 12;     // (x1l, x2l, x3l)
-  const float *c_lu = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(lx1c - 1) * nx2 + (ux2c - 1)) * 12;     // (x1l, x2u, x3l)
-  const float *c_ul = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(ux1c - 1) * nx2 + (lx2c - 1)) * 12;     // (x1u, x2l, x3l)
-  const float *c_uu = t.cells + (size_t)(lx3c - 1) * plane + ((size_t)(ux1c - 1) * nx2 + (ux2c - 1)) * 12;     // (x1u, x2u, x3l)
+  const float *cells = t.cells + (size_t)tindx * nx3 * plane;          // slice tindx (time weight zero, :248)
+  const float *c_ll = cells + (size_t)(lx3c - 1) * plane + ((size_t)(lx1c - 1) * nx2 + (lx2c - 1)) * 12;     // (x1l, x2l, x3l)
+  const float *c_lu = cells + (size_t)(lx3c - 1) * plane + ((size_t)(lx1c - 1) * nx2 + (ux2c - 1)) * 12;     // (x1l, x2u, x3l)
+  const float *c_ul = cells + (size_t)(lx3c - 1) * plane + ((size_t)(ux1c - 1) * nx2 + (lx2c - 1)) * 12;     // (x1u, x2l, x3l)
+  const float *c_uu = cells + (size_t)(lx3c - 1) * plane + ((size_t)(ux1c - 1) * nx2 + (ux2c - 1)) * 12;     // (x1u, x2u, x3l)
   const long long o3 = ((long long)(ux3 - 1) - (long long)(lx3c - 1)) * (long long)plane;                      // to the x3u plane
   float q[11], m1[11];
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -252,11 +252,11 @@ extern "C" int grt_load_iharm_files(const char *dfile, const char *hfile, int in
 }
 
 // KORAL 3-D dumps: read_koral3d_data_header / read_koral3d_data_file ("shortfile" layout) / load_koral3d_data
-// (fluid_model_koral3d.f90:357-388, 397-507, 567-633).  11-number header; `dfile`//I4.4(indf) = that header line + one
+// (fluid_model_koral3d.f90:357-388, 397-507, 567-633), nt slices.  11-number header; `dfile`//I4.4(indf) = that header line + one
 // 23-column line per zone, x2 fastest, then x1, then x3: grid columns 4-9, rho 10, u^mu 12-15 and b^mu 16-19 (already
 // Boyer-Lindquist), T_e 21, Be 22.  rho * scalefac, b * sqrt(scalefac), LNRF velocities in REAL(4).
-extern "C" int grt_load_koral3d_files(const char *dfile, const char *hfile, int indf, double spin, double scalefac) {
-  if (!dfile || !hfile) return GRT_E_BADARG;
+extern "C" int grt_load_koral3d_files_nt(const char *dfile, const char *hfile, int indf, int nt, double spin, double scalefac) {
+  if (!dfile || !hfile || nt < 1) return GRT_E_BADARG;
   const size_t nhead = 11, dlen = 23;
   std::vector<double> head;
   if (!slurp_numbers(hfile, nhead, head)) return GRT_E_IO;
@@ -267,25 +267,39 @@ extern "C" int grt_load_koral3d_files(const char *dfile, const char *hfile, int 
     std::fprintf(stderr, "grtrans_amd: ERROR -- Different simulation and grtrans spin values! (%g vs %g)\n", (double)asim, spin);
     return GRT_E_BADARG;
   }
-  const size_t n = (size_t)nx1 * nx2 * nx3;
-  char suffix[16];
-  std::snprintf(suffix, sizeof suffix, "%04d", indf);          // write(append, fmt='(I4.4)')
-  std::vector<double> all;
-  if (!slurp_numbers(std::string(dfile) + suffix, nhead + n * dlen, all)) return GRT_E_IO;
-  const double *z = all.data() + nhead;
+  const size_t n = (size_t)nx1 * nx2 * nx3, ntot = n * (size_t)nt;
   const double sq = std::sqrt(scalefac);
-  std::vector<float> x1(n), x2(n), x3(n), rho(n), p(n), be(n), u0(n), vrl(n), vtl(n), vpl(n), b0(n), br(n), bth(n), bph(n);
-  for (size_t i = 0; i < n; ++i, z += dlen) {
-    x1[i] = (float)z[3]; x2[i] = (float)z[4]; x3[i] = (float)z[5];
-    const float r = (float)z[6], th = (float)z[7];
-    const double *u = z + 11, *b = z + 15;
-    lnrf_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r, asim, th, vrl[i], vtl[i], vpl[i]);
-    rho[i] = (float)(z[9] * scalefac);
-    p[i] = (float)z[20];
-    be[i] = (float)z[21];
-    b0[i] = (float)(b[0] * sq); br[i] = (float)(b[1] * sq); bth[i] = (float)(b[2] * sq); bph[i] = (float)(b[3] * sq);
-    u0[i] = (float)u[0];
+  std::vector<float> x1(n), x2(n), x3(n), rho(ntot), p(ntot), be(ntot), u0(ntot), vrl(ntot), vtl(ntot), vpl(ntot), b0(ntot), br(ntot),
+      bth(ntot), bph(ntot), tdump((size_t)nt);
+  for (int ks = 0; ks < nt; ++ks) {                // load_koral3d_data: slice k <- file indf-(k-1), t(k) = its header time (:583-588)
+    char suffix[16];
+    std::snprintf(suffix, sizeof suffix, "%04d", indf - ks);          // write(append, fmt='(I4.4)')
+    std::vector<double> all;
+    if (!slurp_numbers(std::string(dfile) + suffix, nhead + n * dlen, all)) return GRT_E_IO;
+    tdump[ks] = (float)all[0];
+    const double *z = all.data() + nhead;
+    const size_t o = (size_t)ks * n;
+    for (size_t i = 0; i < n; ++i, z += dlen) {
+      x1[i] = (float)z[3]; x2[i] = (float)z[4]; x3[i] = (float)z[5];
+      const float r = (float)z[6], th = (float)z[7];
+      const double *u = z + 11, *b = z + 15;
+      lnrf_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r, asim, th, vrl[o + i], vtl[o + i], vpl[o + i]);
+      rho[o + i] = (float)(z[9] * scalefac);
+      p[o + i] = (float)z[20];
+      be[o + i] = (float)z[21];
+      b0[o + i] = (float)(b[0] * sq); br[o + i] = (float)(b[1] * sq); bth[o + i] = (float)(b[2] * sq); bph[o + i] = (float)(b[3] * sq);
+      u0[o + i] = (float)u[0];
+    }
   }
-  return grt_upload_koral3d(nx1, nx2, nx3, r0, h, aa, bb, pp, x1.data(), x2.data(), x3.data(), rho.data(), p.data(), b0.data(),
-                            br.data(), bth.data(), bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data(), be.data());
+  const float tstep = (nt > 1) ? (tdump[0] - tdump[1]) : 20.f;        // :617-624 (module default 20. for one slice, :23)
+  if (nt > 1 && !(tstep > 0.f)) {
+    std::fprintf(stderr, "grtrans_amd: KORAL3D dumps %d and %d are %g apart in time: no usable time step\n", indf, indf - 1, (double)tstep);
+    return GRT_E_BADARG;
+  }
+  return grt_upload_koral3d_slices(nx1, nx2, nx3, nt, tstep, r0, h, aa, bb, pp, x1.data(), x2.data(), x3.data(), rho.data(), p.data(),
+                                   b0.data(), br.data(), bth.data(), bph.data(), u0.data(), vrl.data(), vtl.data(), vpl.data(), be.data());
+}
+
+extern "C" int grt_load_koral3d_files(const char *dfile, const char *hfile, int indf, double spin, double scalefac) {
+  return grt_load_koral3d_files_nt(dfile, hfile, indf, 1, spin, scalefac);
 }

@@ -95,11 +95,12 @@ inline void grt_iharm_pack_mmks(int nx1, int nx2, int nx3, double hslope, float 
   }
 }
 
-// KORAL3D: cells [x3][x1][x2][12] (x2 fastest) with Be in slot 10; crd: [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqx3 nx3]
-// (koral3d_vals :111-115: uniqr = r0 + exp(uniqx1) in REAL(4))
+// KORAL3D: cells [nt][x3][x1][x2][12] (x2 fastest) with Be in slot 10; crd: [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqx3 nx3]
+// (koral3d_vals :111-115: uniqr = r0 + exp(uniqx1) in REAL(4)); the field arrays hold nt slices back to back
 inline void grt_koral3d_pack(int nx1, int nx2, int nx3, float r0, const float *x1_arr, const float *x2_arr, const float *x3_arr,
-                             const float *const src[10], const float *be, std::vector<float> &cells, std::vector<float> &crd) {
-  const size_t n = (size_t)nx1 * nx2 * nx3;
+                             const float *const src[10], const float *be, std::vector<float> &cells, std::vector<float> &crd,
+                             int nt = 1) {
+  const size_t n = (size_t)nx1 * nx2 * nx3 * (size_t)nt;
   cells.assign(n * 12, 0.f);
   crd.assign((size_t)2 * nx1 + nx2 + nx3, 0.f);
   for (size_t i = 0; i < n; ++i) {

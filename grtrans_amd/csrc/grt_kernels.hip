@@ -468,7 +468,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
   const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
   const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
   const double lam_1 = has_ray ? steps[GRT_F_LAM * field_stride + base] : 0.0;   // g%lambda(1)
-  const bool slowlight = (FLUID == GRT_FLUID_HARM) && !EXTRA && tfield >= 0;    // several HARM slices: the point's time picks one
+  const bool slowlight = (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_KORAL3D) && !EXTRA && tfield >= 0;    // several slices: the point's time picks one
   const double r_1 = (slowlight && has_ray) ? steps[GRT_F_R * field_stride + base] : 10.0;
   double I[FB][4], facs[FB];
   double jn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][4], Kn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][7];
@@ -539,7 +539,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
       const int fl8 = (int)((fmm >> (ip & 63)) & 1ull) | ((int)((fmr >> (ip & 63)) & 1ull) << 1);
       const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? tl3[lane * GRT_TS + e] : 0.0;
-      const double t_i = (slowlight && valid) ? tl3[lane * GRT_TS + e] : 0.0;
+      // HARM: the time rides in the fourth tile; KORAL3D needs that tile for phi and reads its time straight from the record
+      const double t_i = !(slowlight && valid) ? 0.0 : (FLUID == GRT_FLUID_KORAL3D ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * GRT_TS + e]);
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);
       calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
@@ -554,7 +555,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
         harm3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl);
       float kela = 0.f;
       if (FLUID == GRT_FLUID_IHARM) iharm_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela);
-      if (FLUID == GRT_FLUID_KORAL3D) koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela);   // kela carries Be
+      if (FLUID == GRT_FLUID_KORAL3D)
+        koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela,                                  // kela carries Be
+                       slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0);
       double s2xi, c2xi, ang, g;
       comoving_ortho(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)

@@ -54,8 +54,8 @@ struct GrtHarm {                // device pointers; nt 2-D HARM slices, fluid_mo
   float h, tstep;               // tstep: time between loaded slices (t(1)-t(2); module default 20. when nt = 1)
   int32_t nt, pad;              // loaded time slices: slice k = dump indf-(k-1), cells [nt][nx1*nx2][12]
 };
-struct GrtHarm3d {              // device pointers; one 3-D HARM slice, fluid_model_harm3d.f90:14-22
-  const float *cells;           // [nx1][nx2][nx3][12], x3 (phi) fastest: rho,p,b0,br,bth,bph,u0,vrl,vtl,vpl,pad,pad
+struct GrtHarm3d {              // device pointers; 3-D slices (HARM3D, IHARM: one; KORAL3D: nt), fluid_model_harm3d.f90:14-22
+  const float *cells;           // [nt][nx1][nx2][nx3][12], x3 (phi) fastest: rho,p,b0,br,bth,bph,u0,vrl,vtl,vpl,pad,pad
   const float *coords;          // [uniqx1 nx1][uniqr nx1][uniqx2 nx2][uniqth nx2][uniqx3 nx3] (staged in LDS)
   int32_t nx1, nx2, nx3, eheat;  // eheat (IHARM): slot 10 of a cell holds the electron entropy
   double hslope;                // IHARM, metric 0: theta = pi x2 + (1-hslope)/2 sin(2 pi x2) (REAL(8) in the reference)
@@ -65,6 +65,8 @@ struct GrtHarm3d {              // device pointers; one 3-D HARM slice, fluid_mo
   double startx1;               // MMKS (REAL(8) there)
   float kr0, kh, kaa, kbb, kpp;  // KORAL3D: r = r0 + exp(x1), MKSH3 theta(x2, r) parameters (fluid_model_koral3d.f90:64-82)
   int32_t ktype;                // KORAL3D: 0 whole flow, 1 disc (KORAL3D_DISK)
+  int32_t nt;                   // KORAL3D: loaded time slices, slice k = dump indf-(k-1) (fluid_model_koral3d.f90:583-616); 0 or 1 = one
+  float tstep;                  // KORAL3D: t(1)-t(2) of the loaded dumps (REAL(4), :618-619; module default 20.)
 };
 #define GRT_HARM_MAXCOORD 1024  // nx1+nx2 limit for the LDS copy of the coordinate vectors (2*(nx1+nx2) floats = 8 KB)
 

@@ -85,6 +85,18 @@ module grt_cabi
        real(c_double), value :: spin, scalefac
        integer(c_int) :: rc
      end function grt_load_koral3d_files
+     function grt_load_koral3d_files_nt(dfile, hfile, indf, nt, spin, scalefac) bind(C, name='grt_load_koral3d_files_nt') result(rc)
+       import :: c_char, c_int, c_double
+       character(kind=c_char), dimension(*), intent(in) :: dfile, hfile
+       integer(c_int), value :: indf, nt
+       real(c_double), value :: spin, scalefac
+       integer(c_int) :: rc
+     end function grt_load_koral3d_files_nt
+     function grt_get_koral3d_tstep(tstep) bind(C, name='grt_get_koral3d_tstep') result(rc)
+       import :: c_int, c_float
+       real(c_float), intent(out) :: tstep
+       integer(c_int) :: rc
+     end function grt_get_koral3d_tstep
      function grt_load_iharm_files(dfile, hfile, indf, spin) bind(C, name='grt_load_iharm_files') result(rc)
        import :: c_char, c_int, c_double
        character(kind=c_char), dimension(*), intent(in) :: dfile, hfile

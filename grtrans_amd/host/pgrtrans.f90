@@ -22,7 +22,7 @@ module pgrtrans
   ! HARM time-stepping state (module variables of fluid_model_harm.f90:12-16)
   integer, save :: cur_fluid = 0, harm_indf = 0, harm_nt = 1
   real, save :: harm_tstep = 20., harm_toffset = 0.
-  real(8), save :: harm_spin = 0d0
+  real(8), save :: harm_spin = 0d0, harm_scalefac = 1d0
   character(len=256), save :: harm_dfile = ' ', harm_hfile = ' ' 
 
 contains
@@ -214,7 +214,9 @@ contains
        harm_tstep = 20.
        ! initialize_harm3d_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:195-196; one loaded slice
        if (fnt /= 1 .or. nload /= 1) then
-          call die('HARM3D with several loaded slices (fnt, nload > 1) is not supported'); goto 999
+          ! read_harm3d_data_file never assigns the dump time on its binary branch (fluid_model_harm3d.f90:383, 402-449): the
+          ! reference's tstep is whatever the stack held ("WARNING -- Time step changes over dumps!")
+          call die('HARM3D with several loaded slices (fnt, nload > 1): undefined in the reference (dump time never read), refused'); goto 999
        end if
        rc = grt_load_harm3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) then
@@ -223,22 +225,27 @@ contains
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
     else if (fluid_id == GRT_FLUID_KORAL3D .or. fluid_id == GRT_FLUID_KORAL3D_DISK) then
-       ! initialize_koral3d_model(a,ifile,.false.,fdfile,fhfile,fnt,findf,fscalefac,...), fluid.f90:205-210; one loaded slice
-       if (fnt /= 1 .or. nload /= 1) then
-          call die('KORAL3D with several loaded slices (fnt, nload > 1) is not supported'); goto 999
+       ! initialize_koral3d_model(a,ifile,.false.,fdfile,fhfile,fnt,findf,fscalefac,...), fluid.f90:205-210.  fnt > 1: that many
+       ! slices are loaded and each point reads the one its look-back time selects (fluid_model_koral3d.f90:126-128, 212-228)
+       if (fnt > 1 .and. extra /= 0) then
+          call die('extra=1 with several KORAL3D slices (fnt > 1) is not supported'); goto 999
        end if
-       if (nt > 1) then
-          call die('KORAL3D movie frames (nt > 1) are not supported'); goto 999
-       end if
-       rc = grt_load_koral3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin, fscalefac)
+       rc = grt_load_koral3d_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(max(fnt, 1), c_int), spin, fscalefac)
        if (rc /= 0) then
           call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+       end if
+       harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
+       harm_nt = max(fnt, 1); harm_scalefac = fscalefac
+       ! tstep = t(1)-t(2) of the loaded dumps when fnt > 1, the module default 20. otherwise (fluid_model_koral3d.f90:23, 617-619)
+       rc = grt_get_koral3d_tstep(harm_tstep); if (rc /= 0) then
+          call die_rc('grt_get_koral3d_tstep', rc); goto 999
        end if
     else if (fluid_id == GRT_FLUID_IHARM) then
        harm_tstep = 20.
        ! initialize_iharm_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:199-200; one loaded slice, metric 0
        if (fnt /= 1 .or. nload /= 1) then
-          call die('IHARM with several loaded slices (fnt, nload > 1) is not supported'); goto 999
+          ! load_iharm_data stores the HEADER's time for every slice (fluid_model_iharm.f90:745): tstep = t(1)-t(2) = 0 (:778)
+          call die('IHARM with several loaded slices (fnt, nload > 1): undefined in the reference (tstep = 0), refused'); goto 999
        end if
        rc = grt_load_iharm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) then
@@ -550,12 +557,14 @@ contains
 
   ! advance_fluid_timestep (fluid.f90:246-262): only HARM-family models step (advance_harm_timestep,
   ! fluid_model_harm.f90:511-521: REAL(4) tstep -- the dumps' own spacing when several slices are loaded, 20. otherwise --
-  ! and toffset kept across calls); the other device models are static
+  ! and toffset kept across calls; advance_koral3d_timestep, fluid_model_koral3d.f90:635-645, is the same statement for
+  ! statement); the other device models are static
   subroutine advance_fluid_timestep(dtobs)
     use grt_cabi
     real(8), intent(in) :: dtobs
     integer :: nupdate, rc
-    if (cur_fluid /= GRT_FLUID_HARM .and. cur_fluid /= GRT_FLUID_HARM3D .and. cur_fluid /= GRT_FLUID_IHARM) return
+    if (cur_fluid /= GRT_FLUID_HARM .and. cur_fluid /= GRT_FLUID_HARM3D .and. cur_fluid /= GRT_FLUID_IHARM .and. &
+        cur_fluid /= GRT_FLUID_KORAL3D .and. cur_fluid /= GRT_FLUID_KORAL3D_DISK) return
     nupdate = floor(dtobs / harm_tstep)
     harm_toffset = harm_toffset + dtobs - harm_tstep*nupdate
     nupdate = nupdate + floor(harm_toffset/harm_tstep)
@@ -566,6 +575,10 @@ contains
     if (nupdate > 0 .and. cur_fluid == GRT_FLUID_IHARM) then
        rc = grt_load_iharm_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
        if (rc /= 0) call die_rc('grt_load_iharm_files (advance) '//trim(harm_dfile), rc)
+    else if (nupdate > 0 .and. (cur_fluid == GRT_FLUID_KORAL3D .or. cur_fluid == GRT_FLUID_KORAL3D_DISK)) then
+       rc = grt_load_koral3d_files_nt(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), int(harm_nt, c_int), &
+                                      harm_spin, harm_scalefac)
+       if (rc /= 0) call die_rc('grt_load_koral3d_files (advance) '//trim(harm_dfile), rc)
     else if (nupdate > 0 .and. cur_fluid == GRT_FLUID_HARM3D) then
        rc = grt_load_harm3d_files(cstr(trim(harm_dfile)), cstr(trim(harm_hfile)), int(harm_indf, c_int), harm_spin)
        if (rc /= 0) call die_rc('grt_load_harm3d_files (advance) '//trim(harm_dfile), rc)

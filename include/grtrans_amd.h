@@ -146,6 +146,18 @@ int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, f
 /* replaces initialize_koral3d_model (fluid_model_koral3d.f90:513-565): 11-number header file and the text dump
  * `dfile`//I4.4(indf) in the reader's 23-column layout (:397-507); scalefac = fargs%scalefac. */
 int grt_load_koral3d_files(const char *dfile, const char *hfile, int indf, double spin, double scalefac);
+/* several loaded slices (slow light): the eleven field arrays hold nt*n values, slice k (1-based) = dump indf-(k-1)
+ * (load_koral3d_data, fluid_model_koral3d.f90:583-616); tstep = t(1)-t(2) of the dumps' header times (:618-619).  A point reads
+ * the slice its Kerr-Schild look-back time selects (:126-128, :212-228), the time weight is zero (:248).  Only KORAL3D has this
+ * among the 3-D models: HARM3D never assigns the dump time on its binary branch (fluid_model_harm3d.f90:383, 402-449) and IHARM
+ * stores the header's time for every slice (fluid_model_iharm.f90:745, 778: tstep = 0) -- both are refused with nt > 1. */
+int grt_upload_koral3d_slices(int nx1, int nx2, int nx3, int nt, float tstep, float r0, float h, float aa, float bb, float pp,
+                              const float *x1_arr, const float *x2_arr, const float *x3_arr, const float *rho, const float *p,
+                              const float *b0, const float *br, const float *bth, const float *bph, const float *u0,
+                              const float *vrl, const float *vtl, const float *vpl, const float *be);
+int grt_load_koral3d_files_nt(const char *dfile, const char *hfile, int indf, int nt, double spin, double scalefac);
+/* tstep of the loaded KORAL3D slices (module default 20. for one slice); advance_koral3d_timestep (:635-645) steps with it */
+int grt_get_koral3d_tstep(float *tstep);
 
 /* iharm-format 3-D dumps (fname IHARM, fluid.f90:199-200), header metric = 0 (MKS with hslope) or 1 (MMKS: theta also
  * depends on x1, calcthmmks fluid_model_iharm.f90:111-122; select it with grt_set_iharm_mmks BEFORE the upload; the

@@ -71,7 +71,7 @@ void ray_stages(int ii, double freq, RayWork &w, double *pix, double &fac, doubl
     else if (S.fluid == 2) thindisk_point(S.disk, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 19) harm3d_vals(S.harm3d, x, (float)S.cam.a, w.f[i]);
     else if (S.fluid == 29) iharm_vals(S.iharm, x, (float)S.cam.a, w.f[i], kela);
-    else if (S.fluid == 25) koral3d_vals(S.koral, x, (float)S.cam.a, S.koral_type, w.f[i], kela);     // kela carries Be here
+    else if (S.fluid == 25) koral3d_vals(S.koral, x, (float)S.cam.a, S.koral_type, w.f[i], kela, w.g.x[1]);     // kela carries Be here
     else harm_vals(S.harm, x, (float)S.cam.a, w.f[i], w.g.x[1]);
     comoving_ortho(x[1], x[2], S.cam.a, px.alpha, px.beta, S.cam.mu0, w.f[i].u, w.f[i].b, k, w.s2xi[i], w.c2xi[i],
                    w.ang[i], w.rshift[i], w.cosne[i]);
@@ -287,7 +287,7 @@ int grto_setup(int standard, double mu0, double phi0, double spin, double uout, 
   if (S.fluid == 12 && harm_load(dfile, hfile, indf, spin, S.harm, fnt > 0 ? fnt : 1) != 0) return -4;
   if (S.fluid == 19 && harm3d_load(dfile, hfile, indf, spin, S.harm3d, 1) != 0) return -4;
   if (S.fluid == 29 && iharm_load(dfile, hfile, indf, spin, S.iharm) != 0) return -4;
-  if (S.fluid == 25 && koral3d_load(dfile, hfile, indf, spin, 1.0, S.koral) != 0) return -4;
+  if (S.fluid == 25 && koral3d_load(dfile, hfile, indf, spin, 1.0, S.koral, fnt > 0 ? fnt : 1) != 0) return -4;
   if (!pltables_load(pltab, S.pl)) return -5;
   S.ok = true;
   return 0;

@@ -8,14 +8,16 @@
 //                 andrew_sigcut; type 1 zeroes Be >= 0.05).  Types 2, 3 read an uninitialised array there (sigmacgs) and
 //                 are not restated.
 #pragma once
+#include "grto_harm.hpp"
 #include "grto_harm3d.hpp"
 
 namespace grto {
 
 struct Koral3dTable {
-  int nx1 = 0, nx2 = 0, nx3 = 0;
+  int nx1 = 0, nx2 = 0, nx3 = 0, nt = 1;
   float asim = 0, r0 = 0, h = 0, aa = 0, bb = 0, pp = 0;
-  std::vector<float> rho, p, be, u0, vrl, vpl, vtl, b0, br, bth, bph;     // [n], x2 fastest, then x1, then x3
+  float tstep = 20.f;                                                    // module default (:23); t(1)-t(2) when nt > 1 (:618-619)
+  std::vector<float> rho, p, be, u0, vrl, vpl, vtl, b0, br, bth, bph;     // [nt][n], x2 fastest, then x1, then x3; slice k = dump indf-(k-1)
   std::vector<float> uniqx1, uniqx2, uniqx3, uniqr;
 };
 
@@ -30,7 +32,7 @@ inline float koral_theta_of_x2(float x2, float r, float h, float a, float b, flo
 }
 
 // returns 0 ok, -1 io, -2 spin mismatch
-inline int koral3d_load(const char *dfile, const char *hfile, int indf, double a, double scalefac, Koral3dTable &t) {
+inline int koral3d_load(const char *dfile, const char *hfile, int indf, double a, double scalefac, Koral3dTable &t, int nt = 1) {
   const int nhead = 11, dlen = 23;
   FILE *f = std::fopen(hfile, "r");
   if (!f) return -1;
@@ -43,31 +45,37 @@ inline int koral3d_load(const char *dfile, const char *hfile, int indf, double a
   t.pp = (float)header[10];
   if (std::fabs((double)t.asim - a) > 1e-4) return -2;
   const size_t n = (size_t)t.nx1 * t.nx2 * t.nx3;
-  char name[512];
-  std::snprintf(name, sizeof name, "%s%04d", dfile, indf);
-  f = std::fopen(name, "r");
-  if (!f) return -1;
-  for (int i = 0; i < nhead; ++i)
-    if (std::fscanf(f, "%lf", &header[i]) != 1) { std::fclose(f); return -1; }
-  std::vector<double> data(n * dlen);
-  for (size_t i = 0; i < data.size(); ++i)
-    if (std::fscanf(f, "%lf", &data[i]) != 1) { std::fclose(f); return -1; }
-  std::fclose(f);
-  for (auto *w : {&t.rho, &t.p, &t.be, &t.u0, &t.vrl, &t.vpl, &t.vtl, &t.b0, &t.br, &t.bth, &t.bph}) w->assign(n, 0.f);
-  std::vector<float> x1(n), x2(n), x3(n);
+  t.nt = nt;
+  for (auto *w : {&t.rho, &t.p, &t.be, &t.u0, &t.vrl, &t.vpl, &t.vtl, &t.b0, &t.br, &t.bth, &t.bph}) w->assign(n * (size_t)nt, 0.f);
+  std::vector<float> x1(n), x2(n), x3(n), tdump(nt);
   const double sq = std::sqrt(scalefac);
-  for (size_t i = 0; i < n; ++i) {
-    const double *row = &data[i * dlen];
-    x1[i] = (float)row[3]; x2[i] = (float)row[4]; x3[i] = (float)row[5];
-    const float r_f = (float)row[6], th_f = (float)row[7];
-    const double *u = row + 11, *b = row + 15;
-    lnrf_frame_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r_f, t.asim, th_f, t.vrl[i], t.vtl[i], t.vpl[i]);
-    t.rho[i] = (float)(row[9] * scalefac);
-    t.p[i] = (float)row[20];
-    t.be[i] = (float)row[21];
-    t.b0[i] = (float)(b[0] * sq); t.br[i] = (float)(b[1] * sq); t.bth[i] = (float)(b[2] * sq); t.bph[i] = (float)(b[3] * sq);
-    t.u0[i] = (float)u[0];
+  for (int ks = 0; ks < nt; ++ks) {              // load_koral3d_data (:583-616): slice k <- file indf-(k-1), t(k) = its header time
+    char name[512];
+    std::snprintf(name, sizeof name, "%s%04d", dfile, indf - ks);
+    f = std::fopen(name, "r");
+    if (!f) return -1;
+    for (int i = 0; i < nhead; ++i)
+      if (std::fscanf(f, "%lf", &header[i]) != 1) { std::fclose(f); return -1; }
+    tdump[ks] = (float)header[0];
+    std::vector<double> data(n * dlen);
+    for (size_t i = 0; i < data.size(); ++i)
+      if (std::fscanf(f, "%lf", &data[i]) != 1) { std::fclose(f); return -1; }
+    std::fclose(f);
+    const size_t o = (size_t)ks * n;
+    for (size_t i = 0; i < n; ++i) {
+      const double *row = &data[i * dlen];
+      x1[i] = (float)row[3]; x2[i] = (float)row[4]; x3[i] = (float)row[5];
+      const float r_f = (float)row[6], th_f = (float)row[7];
+      const double *u = row + 11, *b = row + 15;
+      lnrf_frame_real((float)(u[1] / u[0]), (float)(u[2] / u[0]), (float)(u[3] / u[0]), r_f, t.asim, th_f, t.vrl[o + i], t.vtl[o + i], t.vpl[o + i]);
+      t.rho[o + i] = (float)(row[9] * scalefac);
+      t.p[o + i] = (float)row[20];
+      t.be[o + i] = (float)row[21];
+      t.b0[o + i] = (float)(b[0] * sq); t.br[o + i] = (float)(b[1] * sq); t.bth[o + i] = (float)(b[2] * sq); t.bph[o + i] = (float)(b[3] * sq);
+      t.u0[o + i] = (float)u[0];
+    }
   }
+  t.tstep = (nt > 1) ? (tdump[0] - tdump[1]) : 20.f;
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
   t.uniqx2.assign(x2.begin(), x2.begin() + nx2);
   t.uniqx1.resize(nx1); t.uniqr.resize(nx1); t.uniqx3.resize(nx3);
@@ -77,8 +85,19 @@ inline int koral3d_load(const char *dfile, const char *hfile, int indf, double a
 }
 
 // x = (t, r, th, phi); type 0 / 1
-inline void koral3d_vals(const Koral3dTable &t, const double *x, float a, int type, FluidPoint &f, float &Be) {
+// r1 = r of the ray's first stored point (zr(1) of the array call); several slices: tindx = floor(tt/tstep) of the
+// Kerr-Schild look-back time (:126-128, :212-219), time weight zeroed (rttd=0., :248)
+inline void koral3d_vals(const Koral3dTable &t, const double *x, float a, int type, FluidPoint &f, float &Be, double r1 = 0.0) {
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
+  int tindx = 0;
+  if (t.nt > 1) {
+    float tt = (float)(bl2ks_time((double)(float)x[1], (double)(float)x[0], (double)a) - bl2ks_time((double)(float)r1, 0.0, (double)a));
+    tt = (float)(-(double)tt + 1e-8);
+    const int fl = (int)std::floor(tt / t.tstep);
+    tindx = (fl <= t.nt - 2) ? fl : t.nt - 1;
+    if (tindx < 0) tindx = 0;                                  // (out-of-bounds in the reference)
+  }
+  const size_t toff = (size_t)tindx * ((size_t)nx1 * nx2 * nx3);
   const float theta = (float)x[2], zr = (float)x[1], zpp = (float)x[3];
   float zphi = zpp;
   zphi = (float)std::fmod((double)zphi, 2. * PH_pi);
@@ -116,10 +135,10 @@ inline void koral3d_vals(const Koral3dTable &t, const double *x, float a, int ty
   const size_t idx[8] = {x1l + x2l + x3l, x1l + x2u + x3l, x1u + x2l + x3l, x1u + x2u + x3l,
                          x1l + x2l + x3u, x1l + x2u + x3u, x1u + x2l + x3u, x1u + x2u + x3u};
   auto g = [&](const std::vector<float> &arr) {
-    float i1 = arr[idx[0]] * (1.f - td) + arr[idx[1]] * td;
-    float i2 = arr[idx[2]] * (1.f - td) + arr[idx[3]] * td;
-    float j1 = arr[idx[4]] * (1.f - td) + arr[idx[5]] * td;
-    float j2 = arr[idx[6]] * (1.f - td) + arr[idx[7]] * td;
+    float i1 = arr[toff + idx[0]] * (1.f - td) + arr[toff + idx[1]] * td;
+    float i2 = arr[toff + idx[2]] * (1.f - td) + arr[toff + idx[3]] * td;
+    float j1 = arr[toff + idx[4]] * (1.f - td) + arr[toff + idx[5]] * td;
+    float j2 = arr[toff + idx[6]] * (1.f - td) + arr[toff + idx[7]] * td;
     float m1 = i1 * (1.f - rd) + i2 * rd;
     float m2 = j1 * (1.f - rd) + j2 * rd;
     float w1 = m1 * (1.f - pd) + m2 * pd;

@@ -358,22 +358,25 @@ void hs_iharm_point(double r, double th, double phi, double a, double mbh, doubl
 // KORAL 3-D dumps: capture of the loader's arrays and the point sampler + unit conversion
 static GrtHarm3d g_ko;
 static std::vector<float> g_cellsk, g_crdk;
-int grt_upload_koral3d(int nx1, int nx2, int nx3, float r0, float h, float aa, float bb, float pp, const float *x1_arr,
-                       const float *x2_arr, const float *x3_arr, const float *rho, const float *p, const float *b0,
-                       const float *br, const float *bth, const float *bph, const float *u0, const float *vrl,
-                       const float *vtl, const float *vpl, const float *be) {
+int grt_upload_koral3d_slices(int nx1, int nx2, int nx3, int nt, float tstep, float r0, float h, float aa, float bb, float pp,
+                              const float *x1_arr, const float *x2_arr, const float *x3_arr, const float *rho, const float *p,
+                              const float *b0, const float *br, const float *bth, const float *bph, const float *u0,
+                              const float *vrl, const float *vtl, const float *vpl, const float *be) {
   const float *src[10] = {rho, p, b0, br, bth, bph, u0, vrl, vtl, vpl};
-  grt_koral3d_pack(nx1, nx2, nx3, r0, x1_arr, x2_arr, x3_arr, src, be, g_cellsk, g_crdk);
+  grt_koral3d_pack(nx1, nx2, nx3, r0, x1_arr, x2_arr, x3_arr, src, be, g_cellsk, g_crdk, nt);
   g_ko = GrtHarm3d{};
   g_ko.cells = g_cellsk.data(); g_ko.coords = g_crdk.data(); g_ko.nx1 = nx1; g_ko.nx2 = nx2; g_ko.nx3 = nx3;
-  g_ko.kr0 = r0; g_ko.kh = h; g_ko.kaa = aa; g_ko.kbb = bb; g_ko.kpp = pp;
+  g_ko.kr0 = r0; g_ko.kh = h; g_ko.kaa = aa; g_ko.kbb = bb; g_ko.kpp = pp; g_ko.nt = nt; g_ko.tstep = tstep;
   return 0;
 }
-void hs_koral3d_point(double r, double th, double phi, double a, int type, double nfac, double gminval, double sigcut, double *out15) {
+float hs_koral3d_tstep() { return g_ko.tstep; }
+// t, r1: coordinate time of the point and radius of the ray's first point (slice selection when several are loaded)
+void hs_koral3d_point(double r, double th, double phi, double a, int type, double nfac, double gminval, double sigcut, double *out15,
+                      double t, double r1) {
   FluidPoint f;
   float be = 0.f;
   g_ko.ktype = type;
-  koral3d_sample(g_ko, g_crdk.data(), r, th, phi, (float)a, f, be);
+  koral3d_sample(g_ko, g_crdk.data(), r, th, phi, (float)a, f, be, slice_time_index(g_ko.nt, g_ko.tstep, r, t, r1, (float)a));
   out15[0] = f.rho; out15[1] = f.p; out15[2] = f.bmag;
   for (int i = 0; i < 4; ++i) { out15[3 + i] = f.u[i]; out15[7 + i] = f.b[i]; }
   koral3d_convert(f, be, type, nfac, gminval, sigcut, out15[11], out15[14], out15[12], out15[13]);

@@ -604,6 +604,44 @@ def harm_slowmovie():
     np.savez_compressed(os.path.join(G, "harm_slowmovie_24x24x80.npz"), freq=FREQ_HARM, dt=35.0, **out)
 
 
+KORAL_SLOW_DUMPS = {41: (20261103, 2040.0, 0.12), 40: (20261102, 2020.0, 0.2), 39: (20261101, 2000.0, 0.3),
+                    44: (20261104, 2100.0, 0.16), 43: (20261105, 2080.0, 0.26), 42: (20261106, 2060.0, 0.09)}
+
+
+def write_koral_slow_dumps(outdir, zones=None):
+    import make_koral3d_dump
+    zones = zones or dict(n1=32, n2=32, n3=16)
+    return {k: make_koral3d_dump.write(outdir, indf=k, seed=s, time=t, b0=b, **zones)[0] + "%04d" % k for k, (s, t, b) in KORAL_SLOW_DUMPS.items()}
+
+
+def koral3d_slowlight():
+    # KORAL3D with several loaded slices (fnt = 3, dumps 41, 40, 39 20 M apart with different field strengths): every point reads
+    # the slice its Kerr-Schild look-back time selects (fluid_model_koral3d.f90:126-128, 212-228; time weight zeroed :248).
+    # Of the 3-D samplers only KORAL3D's has a defined time step: read_harm3d_data_file never assigns tcur on its BINARY branch
+    # (fluid_model_harm3d.f90:383, 402-449; the compiled reference warns "Time step changes over dumps"), load_iharm_data
+    # stores the HEADER's time for every slice (fluid_model_iharm.f90:745, 778: tstep = 0).  Through the reference's own
+    # grtrans_main: fast light (fnt=1), slow light (fnt=3, formal and delo), nload=2 (per-ray time origin) and two movie frames
+    # of a slow-light run (fnt=2, nt=2, dt=65: tstep = 20 from the dumps, advance_koral3d_timestep steps 41 -> 44 and, because
+    # nupdate = 3 > fnt, reloads both slices; the shift branch of update_koral3d_data assigns sections of unequal length).
+    import hashlib
+    import tempfile
+    from oracle import refmain
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_koral_slow_dumps(td)
+        out["dump_sha256"] = np.array([hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)])
+        links = [paths[k] for k in sorted(paths)] + [os.path.join(td, "koral_header")]
+        kw = dict(fname='KORAL3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=1,
+                  nn=[24, 24, 100], uout=0.04, mbh=4e6, nmdot=1, mumin=.5, mumax=.5, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=-1.,
+                  iname='formal', hdfile='koral', hhfile='koral_header', hindf=41, hnt=3, ntscl=1.5)
+        for key, extra in (("slow", {}), ("fast", dict(hnt=1)), ("nload", dict(nload=2)), ("slow_delo", dict(iname='delo')),
+                           ("movie", dict(hnt=2, nt=2, dt=65.))):
+            r = refmain.run(dict(kw, **extra), nthreads=8, links=links)
+            out["ivals_" + key] = r["ivals"]
+            print(key, r["ivals"].shape, float(np.nansum(r["ivals"][..., 0])), r["log"][-300:])
+    np.savez_compressed(os.path.join(G, "koral3d_slowlight_24x24x100.npz"), freq=FREQ_HARM, **out)
+
+
 def standard2():
     # standard=2 with nup > 1 (GEOKERR's USEGEOR branch, geokerr_wrapper.f:421-461: mu steps from mu0 to the equatorial plane;
     # ends with u_f < 0 trimmed, geodesics.f90:298-323) on the FFJET problem: images through the reference's own main, trimmed

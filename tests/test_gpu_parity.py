@@ -601,6 +601,73 @@ def test_harm_slow_light_three_slices_device_and_fortran_host(tmp_path, monkeypa
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
 
 
+def test_koral3d_several_slices_slow_light_nload_and_movie(tmp_path, monkeypatch):
+    # KORAL3D with fnt = 3 loaded slices (each point reads the dump its Kerr-Schild look-back time selects,
+    # fluid_model_koral3d.f90:126-128, 212-228), nload = 2 (per-ray time origin) and two movie frames of a two-slice run
+    # (advance_koral3d_timestep :635-645 with tstep from the dumps).  Golden = the reference's own grtrans_main.  HARM3D and IHARM
+    # with several slices are undefined in the reference (dump time never read / tstep = 0) and refused.
+    import hashlib
+    import subprocess
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    if not os.path.exists(gb.HOST_EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "host")])
+    g = np.load(os.path.join(G, "koral3d_slowlight_24x24x100.npz"))
+    monkeypatch.chdir(tmp_path)
+    paths = make_golden.write_koral_slow_dumps(str(tmp_path))
+    assert [hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)] == list(g["dump_sha256"])
+
+    def cmp(pix, key, frame=0):
+        ref = g["ivals_" + key][frame].astype(float)
+        bad = np.isnan(ref).any(axis=1)                 # DELO: three pixels are NaN in the reference
+        assert np.array_equal(bad, np.isnan(pix).any(axis=1)), key
+        return stokes_err(pix[~bad][None], ref[~bad][None])
+
+    dev = capi.Device(0)
+    dev.load_tables()
+    cam = capi.make_camera(1, (-13., 13., -13., 13.), (24, 24, 100), 0.9375, 0.5, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 4e6, 1.5, 6.0, -1., 1e5, 3.5, muval=0.25)
+    dev.load_koral3d("koral", "koral_header", 41, 0.9375, nt=3)
+    assert capi.koral3d_tstep() == 20.0
+    for key, iname in (("slow", "formal"), ("slow_delo", "delo")):
+        for rec in (False, True):
+            capi.record_steps(rec)
+            pix, _, status, _ = capi.trace_tile(cam, 1, 576, "KORAL3D", em, [FREQ_HARM], iname)
+            assert cmp(pix[0], key) < STOKES_TOL, (key, rec)
+    capi.record_steps(False)
+    with pytest.raises(capi.GrtError):
+        capi.trace_tile(cam, 1, 576, "KORAL3D", em, [FREQ_HARM], "formal", nextra=19)    # extra=1 with several slices: refused
+    dev.load_koral3d("koral", "koral_header", 41, 0.9375)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 576, "KORAL3D", em, [FREQ_HARM], "formal")
+    assert cmp(pix[0], "fast") < STOKES_TOL
+    assert np.abs(g["ivals_slow"] - g["ivals_fast"]).max() > 0.1 * np.abs(g["ivals_slow"]).max()
+    with pytest.raises(capi.GrtError):
+        dev.load_koral3d("koral", "koral_header", 41, 0.9375, nt=5)                        # dump 37 does not exist
+    dev.close()
+    kw = dict(fname='KORAL3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=1,
+              nn=[24, 24, 100], uout=0.04, mbh=4e6, nmdot=1, mumin=.5, mumax=.5, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=-1.,
+              iname='formal', cflag=0, hdfile='koral', hhfile='koral_header', hindf=41, hnt=3, ntscl=1.5)
+    for key, extra in (("slow", {}), ("nload", dict(nload=2)), ("movie", dict(hnt=2, nt=2, dt=65.))):
+        x = gb.grtrans()
+        x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **dict(kw, **extra))
+        x.run_grtrans()
+        x.read_grtrans_output(bin=1)
+        y = gb.grtrans()
+        y.run_pgrtrans(**dict(kw, **extra))
+        for l in range(g["ivals_" + key].shape[0]):
+            assert cmp(x.ivals[:, :, l], key, l) < STOKES_TOL, (key, l)
+            assert np.array_equal(y.ivals[:, :, l].T.astype(np.float32), x.ivals[:, :, l].astype(np.float32))
+    assert np.abs(g["ivals_movie"][1] - g["ivals_movie"][0]).max() > 0.1 * np.abs(g["ivals_movie"][0]).max()      # the dumps moved on
+    # the other 3-D readers with several slices: no defined time step in the reference
+    for fname in ("HARM3D", "IHARM"):
+        with pytest.raises(Exception):
+            z = gb.grtrans()
+            z.run_pgrtrans(**dict(kw, fname=fname, hnt=2))
+
+
 def test_fits_output_cflag1_through_fortran_host(tmp_path, monkeypatch):
     # cflag=1: the reference's default on-disk format.  The host writes FITS with its own emitter (no cfitsio here),
     # the harness reads it back without astropy; nx, ny, nu sit at header positions 6, 7, 8 as the reference's reader

@@ -298,27 +298,41 @@ def test_koral3d_loader_sampler_and_units_match_oracle(L, tmp_path, fname, gmin)
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_koral3d_dump
+    import make_golden
     dfile, hfile = make_koral3d_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+    nt = 3 if gmin == 3.0 else 1          # one of the cases with several loaded slices (slow light): dumps 41, 40, 39
+    if nt > 1:
+        make_golden.write_koral_slow_dumps(str(tmp_path))
     kw = dict(fname=fname, ename="POLSYNCHTH", spin=0.9375, standard=1, uout=0.04, mbh=4e6, mu0=0.5,
-              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=gmin, dfile="koral", hfile="koral_header", findf=40,
-              nn=(24, 24, 200), ftscl=1.5, sigcut=1e10)
+              gridvals=(-13., 13., -13., 13.), muval=0.25, gmin=gmin, dfile="koral", hfile="koral_header", findf=41 if nt > 1 else 40,
+              fnt=nt, nn=(24, 24, 200), ftscl=1.5, sigcut=1e10)
     o = O.Oracle(iname="formal", datadir=str(tmp_path), **kw)
     L.grt_load_koral3d_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_double]
-    assert L.grt_load_koral3d_files(dfile.encode(), hfile.encode(), 40, 0.9375, 1.0) == 0
+    L.grt_load_koral3d_files_nt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double]
     assert L.grt_load_koral3d_files(dfile.encode(), hfile.encode(), 40, 0.5, 1.0) != 0          # spin check
-    L.hs_koral3d_point.argtypes = [C.c_double] * 4 + [C.c_int] + [C.c_double] * 3 + [C.c_void_p]
+    assert L.grt_load_koral3d_files_nt(dfile.encode(), hfile.encode(), 38, 2, 0.9375, 1.0) != 0   # dumps 38, 37 do not exist
+    assert L.grt_load_koral3d_files_nt(dfile.encode(), hfile.encode(), kw["findf"], nt, 0.9375, 1.0) == 0
+    L.hs_koral3d_tstep.restype = C.c_float
+    assert L.hs_koral3d_tstep() == 20.0
+    L.hs_koral3d_point.argtypes = [C.c_double] * 4 + [C.c_int] + [C.c_double] * 3 + [C.c_void_p] + [C.c_double] * 2
+    moved = 0
     for i in (293, 92, 300, 5, 570, 130, 12, 276, 280, 284):
         d = o.ray_dump(i, 2.3e11)
         for k in range(0, d["npts"], 3):
             out = np.zeros(15)
             L.hs_koral3d_point(float(d["x"][k, 1]), float(d["x"][k, 2]), float(d["x"][k, 3]), 0.9375, int(fname.endswith("DISK")), 1.5, gmin,
-                               1e10, out.ctypes.data)
+                               1e10, out.ctypes.data, float(d["x"][k, 0]), float(d["x"][0, 1]))
             want = np.concatenate([[d["rho"][k], d["p"][k], d["bmag"][k]], d["u"][k], d["b"][k],
                                    [d["ncgs"][k], d["bcgs"][k], d["tcgs"][k], d["ncgsnth"][k]]])
             tol = np.full(15, 1e-12); tol[2:7] = 3e-7; tol[12] = 3e-7; tol[13] = 3e-7
             with np.errstate(all="ignore"):
                 err = np.abs(out - want) / np.abs(want)
             assert np.array_equal(np.isnan(out), np.isnan(want)) and np.all(np.nan_to_num(err) <= tol), (i, k, err)
+            first = np.zeros(15)          # the newest slice at the same place
+            L.hs_koral3d_point(float(d["x"][k, 1]), float(d["x"][k, 2]), float(d["x"][k, 3]), 0.9375, int(fname.endswith("DISK")), 1.5, gmin,
+                               1e10, first.ctypes.data, 0.0, float(d["x"][k, 1]))
+            moved += int(first[0] != out[0])
+    assert (moved > 50) if nt > 1 else (moved == 0)
 
 
 def test_frame_coefficients_and_formal_step_match_oracle(L):

@@ -264,6 +264,32 @@ def test_harm_slow_light_three_slices(tmp_path):
     assert (np.abs(pix[0] - ref).max(axis=0) / np.abs(ref).max(axis=0)).max() < 1e-6
 
 
+def test_koral3d_several_slices_slow_light(tmp_path):
+    # KORAL3D with fnt = 3 loaded slices and with nload = 2 (per-ray time origin): fluid_model_koral3d.f90:126-128, 212-228, 248;
+    # golden = the reference's own grtrans_main (tests/make_golden.py koral3d_slowlight)
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_golden
+    g = load("koral3d_slowlight_24x24x100.npz")
+    paths = make_golden.write_koral_slow_dumps(str(tmp_path))
+    assert [hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)] == list(g["dump_sha256"])
+    kw = dict(make_golden.KORAL3D, findf=41, mu0=0.5)
+    for key, iname, fnt in (("slow", "formal", 3), ("slow_delo", "delo", 3), ("fast", "formal", 1)):
+        o = O.Oracle(nn=(24, 24, 100), iname=iname, datadir=str(tmp_path), **dict(kw, fnt=fnt))
+        pix, npts, _ = o.trace(1, 576, [float(g["freq"])], nthreads=8)
+        ref = g["ivals_" + key][0].astype(float)
+        bad = np.isnan(ref).any(axis=1)           # DELO: three pixels are NaN in the reference (and here)
+        assert np.array_equal(bad, np.isnan(pix[0]).any(axis=1)) and bad.sum() == (3 if iname == "delo" else 0)
+        assert (np.abs(pix[0][~bad] - ref[~bad]).max(axis=0) / np.abs(ref[~bad]).max(axis=0)).max() < 2e-6, key
+    assert np.abs(g["ivals_slow"] - g["ivals_fast"]).max() / np.abs(g["ivals_slow"]).max() > 0.1      # the slices differ
+    o = O.Oracle(nn=(24, 24, 100), iname="formal", datadir=str(tmp_path), **dict(kw, fnt=3))
+    o.nload_t0()
+    pix, npts, _ = o.trace(1, 576, [float(g["freq"])], nthreads=8)
+    ref = g["ivals_nload"][0].astype(float)
+    assert (np.abs(pix[0] - ref).max(axis=0) / np.abs(ref).max(axis=0)).max() < 2e-6
+
+
 def test_harm3d_polsynchth_image_rays_and_sigcut(tmp_path):
     # 3-D HARM sampler (periodic phi, eight-corner interpolation, fluid.f90:975-993 units and
     # electron model, magnetisation cut) on the synthetic binary dump; golden = compiled reference
