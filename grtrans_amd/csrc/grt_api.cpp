@@ -685,7 +685,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
       C.geo_passes++;
       LAUNCHCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
       LAUNCHCHK(hipEventRecord(C.ev[0], C.stream));
-      LAUNCHCHK(grt_launch_setup(C.stream, cam, (long long)i1 + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays, need_time ? 1 : 0, nullptr));
+      LAUNCHCHK(grt_launch_setup(C.stream, cam, (long long)i1 + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays, (need_time ? 1 : 0) | (nfields > 3 ? 2 : 0), nullptr));
     }
     LAUNCHCHK(hipEventRecord(C.ev[1], C.stream));
     // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back; their sizes stay on the device
@@ -888,7 +888,7 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   const long long fstride = (long long)n * rstride;
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
-  hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 1, &rin);
+  hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin);
   if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, C.d_flags, rstride, fstride, nf, 4, nullptr, 1);
   if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, C.d_flags, rstride, fstride, nf, 4, nullptr, 1);
   if (e != hipSuccess) { drain(); return (int)e; }

@@ -198,9 +198,19 @@ struct RealRay {
   double iu0, tu0, phiu0, tu01;                  // u0-side pieces (cached by the set-up kernel)
   double jfac, m1u, sqmee;                       // geor (Table 2 rows 7/8)
   double anc[4];                                 // segment scheme: iu1, tu11, phiu1, tu1 of the ray's top stored point
-  // mu side of the segment scheme (symmetric M(mu) only): Taylor coefficients in d^2 of sn(d)/d and eps(d)/d (Jacobi's epsilon,
-  // int_0^d dn^2) at the ray's modulus k^2 = 1 - m1m, and the anchor T, I_u, signed sn of the top stored point
-  double k2, sn_c[7], eps_c[7], ancT, anc_iu, anc_s;
+  // mu-side second-kind integral from the Jacobi ladder (symmetric M(mu), sncndn_ladder_z): T = c1 tmu1 + c2 tmuf + c3 tmu3 of a
+  // regular point is facm Z(v) + tbeta I_u + tC with Z Jacobi's Zeta of the continuous argument v = facm I_u + const,
+  // tbeta = tmu3/i3mu (the mean rate: facm^2 E/K) and tC fixed at the ray's top stored point by the set-up kernel
+  double tbeta, tC;
+  // and the third-kind one, P = c1 phimu1 + c2 phimuf + c3 phimu3 = ifac2facm Pi(v) + const, from Jacobi's theta function: for the
+  // negative characteristic alpha^2 = -mpos/(1-mpos) of this integral (A&S 17.7 "circular case", a = i b in Jacobi's
+  // Pi(u,a) = u Z(a) + (1/2) ln[Theta(u-a)/Theta(u+a)])
+  //     Pi(v) = (Pi_c/K) v + (s' c'/d') arg Theta(v + i b),   s',c',d' = sn,cn,dn(b,k'),  tan am(b,k') = sqrt(n)/k,
+  //     Theta(v + i b) = 1 + 2 sum_j (-1)^j q^(j^2) [cosh(2 j z_b) cos(2 j z) - i sinh(2 j z_b) sin(2 j z)],  z = pi v/2K, z_b = pi b/2K:
+  // pcs, psn hold the 2 (-1)^j q^(j^2) cosh / -sinh factors of the pn terms that matter at double precision (q^(j^2 - j b/K') <
+  // 1e-17 beyond), pG = ifac2facm s'c'/d', pbeta = phimu3/i3mu the mean rate, pC fixed at the top stored point like tC
+  double pbeta, pC, pG, pcs[8], psn[8], pomt1;   // pomt1 = 1 + pcs[0] formed without cancellation (b close to K': rays near the axis)
+  int zok, pok, pn, zpad;
   // M(mu)
   int sym;
   double mneg, mpos, muplus, muminus, mposR, muplusR;
@@ -333,31 +343,9 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   agm_ladder(K.m1m, K.agm_mu);
   agm_ladder(K.m1u, K.agm_u);
   K.anc[0] = K.anc[1] = K.anc[2] = K.anc[3] = 0.0;
-  // Taylor coefficients of sn(x|m) and eps(x|m) = int_0^x dn^2: x^(2j+3) terms, j = 0..6, polynomials in m (from the ODE
-  // system sn' = cn dn, cn' = -sn dn, dn' = -m sn cn in exact rationals)
-  static const double SN_SER[7][9] = {
-    {-0.16666666666666666, -0.16666666666666666, 0, 0, 0, 0, 0, 0, 0},
-    {0.0083333333333333332, 0.11666666666666667, 0.0083333333333333332, 0, 0, 0, 0, 0, 0},
-    {-0.00019841269841269841, -0.026785714285714284, -0.026785714285714284, -0.00019841269841269841, 0, 0, 0, 0, 0},
-    {2.7557319223985893e-06, 0.0033840388007054674, 0.015095899470899472, 0.0033840388007054674, 2.7557319223985893e-06, 0, 0, 0, 0},
-    {-2.505210838544172e-08, -0.00027730178771845441, -0.0041542909251242582, -0.0041542909251242582, -0.00027730178771845441, -2.505210838544172e-08, 0, 0, 0},
-    {1.6059043836821613e-10, 1.6001552459885793e-05, 0.00072174979727063064, 0.0021166250159305715, 0.00072174979727063064, 1.6001552459885793e-05, 1.6059043836821613e-10, 0, 0},
-    {-7.6471637318198164e-13, -6.8579993761872067e-07, -8.8932440556944531e-05, -0.0006382989522663795, -0.0006382989522663795, -8.8932440556944531e-05, -6.8579993761872067e-07, -7.6471637318198164e-13, 0}};
-  static const double EPS_SER[7][9] = {
-    {0, -0.33333333333333331, 0, 0, 0, 0, 0, 0, 0},
-    {0, 0.066666666666666666, 0.066666666666666666, 0, 0, 0, 0, 0, 0},
-    {0, -0.0063492063492063492, -0.041269841269841269, -0.0063492063492063492, 0, 0, 0, 0, 0},
-    {0, 0.00035273368606701942, 0.010582010582010581, 0.010582010582010581, 0.00035273368606701942, 0, 0, 0, 0},
-    {0, -1.2826679493346161e-05, -0.0016097482764149431, -0.0056180856180856184, -0.0016097482764149431, -1.2826679493346161e-05, 0, 0, 0},
-    {0, 3.2888921777810664e-07, 0.0001674046118490563, 0.0016283305172194061, 0.0016283305172194061, 0.0001674046118490563, 3.2888921777810664e-07, 0, 0},
-    {0, -6.2645565291067936e-09, -1.280788582375884e-05, -0.00031267028092424917, -0.00080486552444224407, -0.00031267028092424917, -1.280788582375884e-05, -6.2645565291067936e-09, 0}};
-  K.k2 = 1.0 - K.m1m;
-  for (int j = 0; j < 7; ++j) {
-    double a_ = 0.0, b_ = 0.0;
-    for (int q = 8; q >= 0; --q) { a_ = a_ * K.k2 + SN_SER[j][q]; b_ = b_ * K.k2 + EPS_SER[j][q]; }
-    K.sn_c[j] = a_; K.eps_c[j] = b_;
-  }
-  K.ancT = 0.0; K.anc_iu = 0.0; K.anc_s = 0.0;
+  K.tbeta = K.tmu3 * K.ii3mu; K.tC = 0.0; K.zok = 0; K.zpad = 0;
+  K.pbeta = K.phimu3 * K.ii3mu; K.pC = 0.0; K.pG = 0.0; K.pok = 0; K.pn = 0; K.pomt1 = 1.0;
+  for (int j = 0; j < 8; ++j) { K.pcs[j] = 0.0; K.psn[j] = 0.0; }
 }
 
 // u end-point: I_u1 and the four uf-side integrals of Eq. 47-49 for the pair (uf, root).
@@ -585,8 +573,7 @@ GRT_HD void useg_lane(const GrtCam &cam, const GrtRay &R, const RealRay &K, int 
 // mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)
 struct MuPart { double i2mu, tmuf, phimuf; };
 
-// NOE: the E piece (t_mu) comes from the segment scheme (tseg_*): R_D is not evaluated and tmuf is left 0
-template <bool PHI, bool NOE = false>
+template <bool PHI>
 GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
   double sf;
   bool past;     // phi_f > pi/2  <=>  tan(phi_f) < 0  (phi_f = acos(muf/muplus) in [0,pi])
@@ -600,7 +587,7 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
   }
   double qf = (1.0 - sf * K.akm) * (1.0 + sf * K.akm);
   double pj[1] = {1.0 - K.nn * sf * sf}, rff, rdf, rjf[1] = {0.0};
-  carlson_bundle<PHI ? 1 : 0, !NOE>(1.0 - sf * sf, qf, 1.0, pj, rff, rdf, rjf);
+  carlson_bundle<PHI ? 1 : 0>(1.0 - sf * sf, qf, 1.0, pj, rff, rdf, rjf);
   // I_mu piece (calcimusymf / calcimuasymf, geokerr_wrapper.f:3175-3274)
   double imuf = sf * rff;
   if (K.sym) {
@@ -627,8 +614,91 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
       ellpif = ellpic - ellpif;
     }
   }
-  o.tmuf = NOE ? 0.0 : K.facm * ellef;
+  o.tmuf = K.facm * ellef;
   o.phimuf = PHI ? ellpif * K.ifac2facm : 0.0;
+}
+
+// T = c1 tmu1 + c2 tmuf + c3 tmu3 of a regular point of a symmetric-M ray from the ladder's Zeta (RealRay.tbeta): z = Zeta of the
+// reduced Jacobi argument jarg = a2 (v - shift) with a2 = sm (-1)^tpm = +-1 and the shift a multiple of the period, v = facm I_u
+// + const the continuous argument; Zeta is odd and periodic, so Z(v) = a2 z.
+GRT_HD double zeta_T(const RealRay &K, double z, int tpm, double iu) {
+  const double zs = ((K.sm < 0) != ((tpm & 1) != 0)) ? -z : z;
+  return K.facm * zs + K.tbeta * iu + K.tC;
+}
+
+// P = c1 phimu1 + c2 phimuf + c3 phimu3 of a regular point from the theta series (RealRay.pcs): s0, c0 = sin, cos of z = pi jarg/2K
+// (the first step of the ladder).  arg Theta(v + i b) is odd and periodic in v like Zeta: same orientation rule as zeta_T.
+GRT_HD double theta_P(const RealRay &K, double s0, double c0, int tpm, double iu) {
+  // Re Theta = 1 + pcs[0] cos 2z + ... written as (1 + pcs[0]) - 2 pcs[0] sin^2 z + ...: the first coefficient approaches -1 for rays
+  // close to the axis (b -> K'), and 1 + pcs[0] is a per-ray constant formed without the cancellation
+  const double c2 = 1.0 - 2.0 * s0 * s0, s2 = 2.0 * s0 * c0;
+  double re = K.pomt1 - 2.0 * K.pcs[0] * s0 * s0, im = K.psn[0] * s2;
+  double cjm = c2, sjm = s2, cj = 2.0 * c2 * c2 - 1.0, sj = 2.0 * c2 * s2;
+  for (int j = 1; j < K.pn; ++j) {               // wave-uniform trip count (two to four terms for most rays)
+    re += K.pcs[j] * cj; im += K.psn[j] * sj;
+    const double cn_ = 2.0 * c2 * cj - cjm, sn_ = 2.0 * c2 * sj - sjm;
+    cjm = cj; sjm = sj; cj = cn_; sj = sn_;
+  }
+  const double A = fast_atan2(im, re);
+  const double As = ((K.sm < 0) != ((tpm & 1) != 0)) ? -A : A;
+  return K.pG * As + K.pbeta * iu + K.pC;
+}
+
+// Fixes RealRay.tC (and pC, with the theta-series constants) at the ray's top stored point (set-up kernel, after realray_anchor):
+// there T and P are evaluated once with the Legendre/Carlson forms, every other regular point of the ray takes them from the ladder.
+// want_phi: the azimuth is asked for (the image-only trace does not need the series).
+GRT_HD void realray_anchor_z(const GrtCam &cam, const GrtRay &R, RealRay &K, bool want_phi = true) {
+  K.zok = 0; K.tC = 0.0; K.pok = 0; K.pC = 0.0;
+  const int n = R.npts;
+  if (n < 1 || !K.sym || K.agm_mu.l == 0 || K.agm_mu.bo) return;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const int lo = fill ? (R.kmax - cam.kext) : R.kmax;
+  if (fill && n > lo && n <= lo + cam.next && R.tpr != 0) return;     // the top point lies inside the mu-fill segment
+  const int tprs = (n <= lo || R.tpr == 0) ? 0 : R.tpr_out;
+  const double iu = K.su * (K.iu0 - powm1(tprs) * K.anc[0]) * K.isqee;
+  int tpm;
+  const double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
+  if (K.sm == 1) tpm = fint(r1) + fint((1 + fsign(1.0, r1)) / 2.0);
+  else tpm = fint((iu + K.i1mu) * K.ii3mu);
+  const double a2 = K.sm * powm1(tpm), a3 = 2.0 * fint((2.0 * (double)tpm + 3.0 - K.sm) / 4.0) - 1.0;
+  const double jarg = sqrt(K.mpos - K.mneg) * (fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu));
+  double sn, cn, dn, z, s0, c0;
+  sncndn_ladder_z(K.agm_mu, jarg, K.m1m, sn, cn, dn, z, s0, c0);
+  MuPart M;
+  real_mupart<true>(K, K.muminus * cn, M, false);
+  const double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+  K.tC = (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3) - zeta_T(K, z, tpm, iu);
+  K.zok = 1;
+  if (!want_phi || K.nn == 1.0 || !(K.mpos < 1.0)) return;            // mpos = 1: the phi terms are switched off (geokerr_wrapper.f:2408-2412)
+  // theta-series constants: nome q = exp(-pi K'/K) from the two means AGM(1,k') (the ladder's) and AGM(1,k)
+  const double k2 = 1.0 - K.m1m, k = sqrt(k2), agp = K.agm_mu.c;
+  double ga = 1.0, gb = k;
+  for (int it = 0; it < 40 && fabs(ga - gb) > 1e-16 * ga; ++it) { const double t = 0.5 * (ga + gb); gb = sqrt(ga * gb); ga = t; }
+  const double lnq = -3.141592653589793 * agp / ga;                   // K'/K = AGM(1,k')/AGM(1,k)
+  const double nchar = -K.nn;                                         // n = mpos/(1-mpos) > 0
+  const double h = sqrt(nchar + k2), sp = sqrt(nchar) / h, cp = k / h, dp = sqrt(1.0 - K.m1m * sp * sp);
+  // K' - b = F(psi, k') with tan psi = 1/sqrt(n) (tan am tan psi = 1/k): the small quantity when the ray runs close to the axis
+  const double h1 = sqrt(1.0 + nchar), spsi = 1.0 / h1, cpsi = sqrt(nchar) / h1;
+  const double delta = spsi * rf(cpsi * cpsi, 1.0 - K.m1m * spsi * spsi, 1.0);
+  const double eps2 = 2.0 * agp * delta;                               // 2 (z_K' - z_b) = (pi/K)(K' - b)
+  // 2 (-1)^j q^(j^2) cosh / sinh (2 j z_b) = (-1)^j [q^(j^2-j) exp(-j eps2) +- q^(j^2+j) exp(j eps2)]
+  int np = 0;
+  double sgn = 1.0;
+  for (int j = 1; j <= 9; ++j) {
+    sgn = -sgn;
+    const double lo_ = exp(lnq * (double)(j * j - j) - (double)j * eps2), hi_ = exp(lnq * (double)(j * j + j) + (double)j * eps2);
+    if (lo_ + hi_ < 1e-17) break;
+    if (j == 9) return;                                               // nome too close to 1 for a short series: Carlson stays
+    K.pcs[j - 1] = sgn * (lo_ + hi_); K.psn[j - 1] = -sgn * (lo_ - hi_);
+    if (j == 1) K.pomt1 = -expm1(-eps2) - hi_;
+    np = j;
+  }
+  if (np < 1) return;
+  K.pn = np;
+  K.pG = K.ifac2facm * sp * cp / dp;
+  K.pC = 0.0;
+  K.pC = (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3) - theta_P(K, s0, c0, tpm, iu);
+  K.pok = 1;
 }
 
 // Stored point idx of a real-quartic ray (same contract as ray_point).
@@ -649,7 +719,10 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
   const bool c7 = (K.ncase == 7);
   const double root = c7 ? K.u2 : K.u3;
   const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
-  double un = 0.0, mun = 0.0, iu = 0.0, jarg = 0.0;
+  double un = 0.0, mun = 0.0, iu = 0.0, jarg = 0.0, Tz = 0.0, Pz = 0.0;
+  // regular points of a symmetric-M ray take the second- and third-kind integrals of the mu side from the Jacobi ladder
+  // (zeta_T, theta_P): no Carlson loop on that side
+  const bool need_mu = isfill || !K.zok || (PHI && !K.pok);
   int tpm = 0, tprs = 0, tprp = 0;
   UPart U; U.iu1 = 0.0; U.phiu1 = 0.0; U.tu11 = 0.0; U.tu1 = 0.0;
   MuPart M; M.i2mu = 0.0; M.tmuf = 0.0; M.phimuf = 0.0;
@@ -673,7 +746,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
       if (pre && !isfill) U = *pre;
       else if (K.cplx) cplx_upart<NPH>(K, un, U); else real_upart<NPH>(K, un, U);   // (one ray per wave: a uniform branch)
     }
-    else real_mupart<PHI>(K, mun, M, isfill);
+    else if (need_mu) real_mupart<PHI>(K, mun, M, isfill);
     if (pass == 0) {
       // argument of the Jacobi inversion
       if (!isfill) {
@@ -692,7 +765,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
         jarg = K.jfac * (c7 ? iu - K.siu0m : iu + K.siu0m);
       }
       // one copy of the ascending recurrence; the ladder (mu or u modulus) is wave-uniform per trip
-      double sn = 0.0, cn = 0.0, dn = 1.0;
+      double sn = 0.0, cn = 0.0, dn = 1.0, zz = 0.0, s0 = 0.0, c0 = 1.0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang loop unroll(disable)
 #endif
@@ -700,10 +773,12 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
         const bool mine = (w == 0) ? !isfill : isfill;
         const AgmLadder &L = (w == 0) ? K.agm_mu : K.agm_u;
         const double emmc = (w == 0) ? K.m1m : K.m1u;
-        if (mine) sncndn_ladder(L, jarg, emmc, sn, cn, dn);
+        if (mine) sncndn_ladder_z(L, jarg, emmc, sn, cn, dn, zz, s0, c0);
       }
       if (!isfill) {
         mun = K.sym ? K.muminus * cn : fdiv(K.muminus, dn);
+        Tz = zeta_T(K, zz, tpm, iu);
+        if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);
       } else {
         if (c7) {
           un = fdiv((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1), (K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
@@ -720,174 +795,21 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
   const double s = powm1(tprs);
   double lambdau = K.su * (K.tu01 - s * U.tu11) * K.isqee;
   double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+  const double T = (isfill || !K.zok) ? (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3) : Tz;
   double tmu;
-  if (K.sym) tmu = K.a * K.a * K.mneg * iu + (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
-  else tmu = (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
+  if (K.sym) tmu = K.a * K.a * K.mneg * iu + T;
+  else tmu = T;
   double dphi = 0.0;
   if (PHI) {
     double phiu = K.su * (K.phiu0 - s * U.phiu1) * K.isqee * K.ur;
-    double phimu = -K.l * iu + K.l * (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3);
+    const double Pm = (isfill || !K.zok || !K.pok) ? (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3) : Pz;
+    double phimu = -K.l * iu + K.l * Pm;
     if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
     dphi = phimu + phiu;
   }
   double dt = 0.0;
   if (NPH == 3) dt = K.su * (K.tu0 - s * U.tu1) * K.isqee * K.ur + tmu;      // DTI = tu + tmu (:2220, :2351)
   P.u = un; P.mu = mun; P.dt = dt; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
-}
-
-// ---- ray_point_real in two stages, for callers that sum the mu-side t integral from segments between the stages ---------
-// Stage A = pass 0 above (first integral stage + Jacobi inversion), stage B = pass 1 + the assembly.  Between them
-// grt_geo_kernel has, for every lane, I_u, mu and tpm -- all the segment scheme of the mu side needs:
-//   T = c1 tmu1 + c2 tmuf + c3 tmu3 (the E-type part of t_mu and lambda) is facm x Jacobi's epsilon function of the continuous
-//   Jacobi argument v = facm I_u + const of mu = -mu+ cn(v) (symmetric M(mu)), so for neighbouring points, by the addition
-//   theorem eps(x + d) = eps(x) + eps(d) - k^2 sn(x) sn(d) sn(x + d):
-//       T(k) - T(k+1) = -facm [ eps(d) - k^2 s_k s_k+1 sn(d) ],   d = facm (I_u(k+1) - I_u(k)),   s = |sn| (-1)^tpm,
-//   with |sn| = sqrt(1 - (mu/mu+)^2) and eps(d), sn(d) from their Taylor series at the ray's modulus (RealRay.eps_c, sn_c;
-//   |d| <= GRT_TSEG_DMAX, else the lane evaluates its own Legendre integrals as before).  Points of the mu-fill segment and
-//   the top point of the ray (anchor from the set-up kernel) start the chains.  No R_D, and without the azimuth no
-//   Carlson loop at all, is left on the mu side of a regular point.
-#ifndef GRT_TSEG_DMAX
-#define GRT_TSEG_DMAX 0.12
-#endif
-struct RPState {
-  double un, mun, iu;
-  int tpm, tprs, tprp;
-  bool isfill, mu_done;
-  UPart U;
-  MuPart M;
-};
-
-template <int NPH>
-GRT_HD void rp_stage_a(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, const UPart *pre, RPState &S) {
-  constexpr bool PHI = NPH > 0;
-  const double one = 1.0, two = 2.0;
-  const int kext = cam.kext, next = cam.next, kmax = R.kmax;
-  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
-  const int lo = fill ? (kmax - kext) : kmax;
-  const bool c7 = (K.ncase == 7);
-  const double root = c7 ? K.u2 : K.u3;
-  const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
-  double un = 0.0, mun = 0.0, iu = 0.0, jarg = 0.0;
-  int tpm = 0, tprs = 0, tprp = 0;
-  S.U.iu1 = 0.0; S.U.phiu1 = 0.0; S.U.tu11 = 0.0; S.U.tu1 = 0.0;
-  S.M.i2mu = 0.0; S.M.tmuf = 0.0; S.M.phimuf = 0.0;
-  S.mu_done = false;
-  if (!isfill) {
-    if (idx <= lo || R.tpr == 0) {
-      un = cam.uout + (idx - cam.offset) * R.du; tprs = 0; tprp = 0;
-    } else {
-      int Kk = fill ? (idx - (next - 2 * kext)) : idx;
-      un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
-    }
-    if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;        // geokerr_wrapper.f:1079,1089
-    if (pre) S.U = *pre;
-    else if (K.cplx) cplx_upart<NPH>(K, un, S.U); else real_upart<NPH>(K, un, S.U);
-    iu = K.su * (K.iu0 - powm1(tprs) * S.U.iu1) * K.isqee;
-    double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
-    if (K.sm == 1) tpm = fint(r1) + (K.sym ? fint((1 + fsign(1.0, r1)) / 2.0) : fint(fabs((1 + fsign(1.0, r1)) / 2.0)));
-    else tpm = fint((iu + K.i1mu) * K.ii3mu);
-    double a2 = K.sm * powm1(tpm);
-    double a3 = two * fint((two * (double)tpm + 3.0 - K.sm) / 4.0) - one;
-    double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
-    jarg = (K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus)) * iarg;
-  } else {
-    indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, K.sm, idx - lo, next, cam.offset, mun, tpm);
-    real_mupart<PHI>(K, mun, S.M, true);
-    S.mu_done = true;
-    double b1 = K.sm, b2 = K.sm * powm1(tpm + 1), b3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
-    iu = b1 * K.i1mu + b2 * S.M.i2mu + b3 * K.i3mu;                      // I_mu
-    jarg = K.jfac * (c7 ? iu - K.siu0m : iu + K.siu0m);
-  }
-  double sn = 0.0, cn = 0.0, dn = 1.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma clang loop unroll(disable)
-#endif
-  for (int w = 0; w < 2; ++w) {      // one copy of the ascending recurrence (see ray_point_real)
-    const bool mine = (w == 0) ? !isfill : isfill;
-    const AgmLadder &L = (w == 0) ? K.agm_mu : K.agm_u;
-    const double emmc = (w == 0) ? K.m1m : K.m1u;
-    if (mine) sncndn_ladder(L, jarg, emmc, sn, cn, dn);
-  }
-  if (!isfill) {
-    mun = K.sym ? K.muminus * cn : fdiv(K.muminus, dn);
-  } else {
-    if (c7) {
-      un = fdiv((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1), (K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
-      tprs = (int)((fsign(1.0, K.su * (iu - K.siu0e)) + 1.0) / 2.0);
-    } else {
-      un = fdiv((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2), (K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
-      tprs = (int)((-fsign(1.0, K.su * (iu + K.siu0m)) + 1.0) / 2.0);
-    }
-    tprp = tprs;
-  }
-  S.un = un; S.mun = mun; S.iu = iu; S.tpm = tpm; S.tprs = tprs; S.tprp = tprp; S.isfill = isfill;
-}
-
-// signed sn of the continuous Jacobi argument of a point (symmetric M(mu)): |sn| = sqrt(1 - (mu/mu+)^2), sign (-1)^tpm
-GRT_HD double tseg_s(const RealRay &K, const RPState &S) {
-  const double c = S.mun * K.imuplus, q = (1.0 - c) * (1.0 + c);
-  const double sf = (q > 0.0) ? fsqrt(q) : 0.0;
-  return (S.tpm & 1) ? -sf : sf;
-}
-// T of a point whose own E piece has been evaluated (S.M.tmuf)
-GRT_HD double tseg_T(const RealRay &K, const RPState &S) {
-  const double c1 = K.sm, c2 = K.sm * powm1(S.tpm + 1), c3 = 2.0 * fint((2 * S.tpm - K.sm + 1) / 4.0);
-  return c1 * K.tmu1 + c2 * S.M.tmuf + c3 * K.tmu3;
-}
-// T(this) - T(neighbour) from the addition theorem; d = facm (I_u(neighbour) - I_u(this))
-GRT_HD double tseg_diff(const RealRay &K, double d, double s, double nb_s) {
-  const double d2 = d * d;
-  double e = K.eps_c[6], n = K.sn_c[6];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int j = 5; j >= 0; --j) { e = e * d2 + K.eps_c[j]; n = n * d2 + K.sn_c[j]; }
-  const double eps = d + d * d2 * e, snd = d + d * d2 * n;
-  return -K.facm * (eps - K.k2 * s * nb_s * snd);
-}
-
-// preT: T summed from segments by the caller (regular points of a symmetric-M ray); NULL = evaluate the E piece here
-template <int NPH>
-GRT_HD void rp_stage_b(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, RPState &S, const double *preT, GeoPoint &P) {
-  constexpr bool PHI = NPH > 0;
-  if (S.isfill) {
-    if (K.cplx) cplx_upart<NPH>(K, S.un, S.U); else real_upart<NPH>(K, S.un, S.U);
-  } else if (!S.mu_done) {
-    if (preT) { if (PHI) real_mupart<PHI, true>(K, S.mun, S.M, false); }
-    else real_mupart<PHI>(K, S.mun, S.M, false);
-  }
-  const int tpm = S.tpm;
-  const double iu = S.iu;
-  // Eq. 48-49, 45-46 (geokerr_wrapper.f:2229-2234, 2313-2351)
-  const double s = powm1(S.tprs);
-  double lambdau = K.su * (K.tu01 - s * S.U.tu11) * K.isqee;
-  double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
-  const double Tsum = (preT && !S.isfill && !S.mu_done) ? *preT : (c1 * K.tmu1 + c2 * S.M.tmuf + c3 * K.tmu3);
-  double tmu;
-  if (K.sym) tmu = K.a * K.a * K.mneg * iu + Tsum;
-  else tmu = Tsum;
-  double dphi = 0.0;
-  if (PHI) {
-    double phiu = K.su * (K.phiu0 - s * S.U.phiu1) * K.isqee * K.ur;
-    double phimu = -K.l * iu + K.l * (c1 * K.phimu1 + c2 * S.M.phimuf + c3 * K.phimu3);
-    if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
-    dphi = phimu + phiu;
-  }
-  double dt = 0.0;
-  if (NPH == 3) dt = K.su * (K.tu0 - s * S.U.tu1) * K.isqee * K.ur + tmu;      // DTI = tu + tmu (:2220, :2351)
-  P.u = S.un; P.mu = S.mun; P.dt = dt; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = S.tprp;
-}
-
-// mu-side anchor of the segment scheme: T, I_u and signed sn of the ray's top stored point (set-up kernel, after realray_anchor)
-GRT_HD void realray_anchor_mu(const GrtCam &cam, const GrtRay &R, RealRay &K) {
-  K.ancT = 0.0; K.anc_iu = 0.0; K.anc_s = 0.0;
-  if (R.npts < 1 || !K.sym) return;
-  UPart U; U.iu1 = K.anc[0]; U.tu11 = K.anc[1]; U.phiu1 = K.anc[2]; U.tu1 = K.anc[3];
-  RPState S;
-  rp_stage_a<0>(cam, R, K, R.npts, &U, S);
-  if (S.isfill) return;
-  real_mupart<false>(K, S.mun, S.M, false);
-  K.ancT = tseg_T(K, S); K.anc_iu = S.iu; K.anc_s = tseg_s(K, S);
 }
 
 // Branch-per-segment form of ray_point_real (each stage inlined once per segment type).  Kept for the
@@ -901,7 +823,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
   const int lo = fill ? (kmax - kext) : kmax;
   const bool c7 = (K.ncase == 7);
   const double root = c7 ? K.u2 : K.u3;
-  double un, mun, iu;
+  double un, mun, iu, Tz = 0.0, Pz = 0.0;
   int tpm, tprs, tprp;
   UPart U;
   MuPart M;
@@ -926,13 +848,17 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
     double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);   // a2 = +-1: 1/a2 == a2
     double sn, cn, dn;
     if (K.sym) {
-      sncndn_ladder(K.agm_mu, fsqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn);
+      double zz, s0, c0;
+      sncndn_ladder_z(K.agm_mu, fsqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn, zz, s0, c0);
       mun = K.muminus * cn;
+      Tz = zeta_T(K, zz, tpm, iu);
+      if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);
     } else {
       sncndn_ladder(K.agm_mu, fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
       mun = fdiv(K.muminus, dn);
     }
-    real_mupart<PHI>(K, mun, M, false);
+    M.i2mu = 0.0; M.tmuf = 0.0; M.phimuf = 0.0;
+    if (!K.zok || (PHI && !K.pok)) real_mupart<PHI>(K, mun, M, false);      // (wave-uniform: one ray per wave)
   } else {
     int k = idx - lo;
     indep_muf(R.fill_muminus, R.fill_muplus, R.fill_mu0, R.fill_muf, R.fill_tpm0, R.fill_tpm1, K.sm, k, next, cam.offset, mun, tpm);
@@ -959,13 +885,15 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
   const double s = powm1(tprs);
   double lambdau = K.su * (K.tu01 - s * U.tu11) * K.isqee;
   double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
+  const double T = (isfill || !K.zok) ? (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3) : Tz;
   double tmu;
-  if (K.sym) tmu = K.a * K.a * K.mneg * iu + (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
-  else tmu = (c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3);
+  if (K.sym) tmu = K.a * K.a * K.mneg * iu + T;
+  else tmu = T;
   double dphi = 0.0;
   if (PHI) {
     double phiu = K.su * (K.phiu0 - s * U.phiu1) * K.isqee * K.ur;
-    double phimu = -K.l * iu + K.l * (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3);
+    const double Pm = (isfill || !K.zok || !K.pok) ? (c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3) : Pz;
+    double phimu = -K.l * iu + K.l * Pm;
     if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
     dphi = phimu + phiu;
   }

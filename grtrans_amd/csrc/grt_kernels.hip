@@ -45,7 +45,7 @@ using namespace grtd;
 
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
-                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time, double polar_l2,
+                                                         int *__restrict__ counters, char *__restrict__ rrays, int need_time /* bit 0: coordinate time wanted (no cubic class), bit 1: azimuth wanted */, double polar_l2,
                                                          GrtRayIn rin) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
@@ -80,16 +80,14 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
 #else
                                false);
 #endif
-  const bool cubic = alive && !need_time && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool cubic = alive && !(need_time & 1) && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
     RealRay K;
     realray_init(cam, R, K);
     realray_anchor(cam, R, K);       // the segment scheme's per-ray anchor: u-side integrals of the top stored point
-#if defined(GRT_TSEG)
-    realray_anchor_mu(cam, R, K);    // and its T, I_u, sn for the mu side
-#endif
+    realray_anchor_z(cam, R, K, (need_time & 2) != 0);   // and the constants of the mu-side integrals taken from the Jacobi ladder
     *reinterpret_cast<RealRay *>(rrays + (size_t)tid * GRT_RR_STRIDE) = K;
   } else if (cubic) {
     CubRay K;
@@ -187,7 +185,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   // phi = phi0 - dphi; pole-on cameras (geodesics.f90:339-341) measure it from the pixel's own position angle.  Once per ray.
   double phi_ref = cam.phi0;
   if (PHI && fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
-  double carryT = 0.0, carry_iu = 0.0, carry_s = 0.0;      // mu-side segment sums: T, I_u and signed sn of the chunk above's first lane
   // chunk c holds stored points 64c+1 .. 64c+64; the top (partial) chunk first: it owns Lambda(npts)
   for (int c = (n - 1) >> 6; c >= 0; --c) {
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
@@ -224,44 +221,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       if (NQ > 2) S.phiu1 = v[2];
       if (NQ > 3) S.tu1 = v[3];
     }
-#endif
-#if defined(GRT_TSEG) && !defined(GRT_NO_USEG)
-    // EXPERIMENT (build with -DGRT_TSEG; tools/build_variant.sh): the mu side from segments too.  Measured on MI355X
-    // (1024^2 x 400): fp64 FMA -14 %, MUL -20 % per point, but +7 % VALU instructions in this two-stage form (v_add_f64 and
-    // moves) -- image-only geodesic kernel 38.3 -> 41.0 ms, with the azimuth 72.9 -> 72.4 ms.  Not in the product build.
-    if (FAST == 1) {
-      // stage A (first integral stage + Jacobi inversion), the mu-side segment sums, stage B (grt_dev_fast.hpp:rp_stage_a)
-      RPState St;
-      St.iu = 0.0; St.mun = 0.0; St.tpm = 0; St.isfill = false; St.mu_done = false;
-      if (valid) rp_stage_a<NPH>(cam, *Rp, *Kp, idx, usable ? &S : nullptr, St);
-      const bool tuse = Kp->sym != 0;          // wave-uniform: the ray's M(mu) is symmetric
-      double T[1] = {0.0};
-      if (tuse) {
-        const double my_iu = valid ? St.iu : 0.0, my_s = valid ? tseg_s(*Kp, St) : 0.0;
-        double nb_iu = __shfl_down(my_iu, 1), nb_s = __shfl_down(my_s, 1);
-        if (lane == 63) { nb_iu = carry_iu; nb_s = carry_s; }
-        bool treset = true;
-        if (valid) {
-          if (St.isfill) T[0] = tseg_T(*Kp, St);              // mu-fill points evaluated their own E piece in stage A
-          else if (idx == n) T[0] = Kp->ancT;                 // top of the ray: the set-up kernel's anchor
-          else {
-            const double d = Kp->facm * (nb_iu - my_iu);
-            if (!(fabs(d) <= GRT_TSEG_DMAX)) {                // coarse rays: the Taylor series of eps(d), sn(d) would not do
-              real_mupart<PHI>(*Kp, St.mun, St.M, false);
-              St.mu_done = true;
-              T[0] = tseg_T(*Kp, St);
-            } else {
-              treset = false;
-              T[0] = tseg_diff(*Kp, d, my_s, nb_s);
-            }
-          }
-        }
-        seg_suffix_scan<1>(T, treset, lane);
-        if (!treset) T[0] += carryT;
-        carryT = __shfl(T[0], 0); carry_iu = __shfl(my_iu, 0); carry_s = __shfl(my_s, 0);
-      }
-      if (valid) rp_stage_b<NPH>(cam, *Rp, *Kp, idx, St, tuse ? &T[0] : nullptr, P);
-    } else
 #endif
     if (valid) {
       const UPart *pre = usable ? &S : nullptr;

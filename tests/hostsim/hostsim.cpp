@@ -64,9 +64,8 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
   RealRay K;
   realray_init(*cam, R, K);
   realray_anchor(*cam, R, K);
-  realray_anchor_mu(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
   UPart carry; carry.iu1 = carry.tu11 = carry.phiu1 = carry.tu1 = 0.0;
-  double carryT = 0.0, carry_iu = 0.0, carry_s = 0.0;
   for (int c = (R.npts - 1) >> 6; c >= 0; --c) {
     UPart S[64]; bool reset[64], usable[64];
     for (int lane = 0; lane < 64; ++lane) {
@@ -81,50 +80,14 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
       S[lane].iu1 += up.iu1; S[lane].tu11 += up.tu11; S[lane].phiu1 += up.phiu1; S[lane].tu1 += up.tu1;
     }
     carry = S[0];
-    // stage A, the mu-side segment sums (symmetric M(mu)), stage B: as grt_geo_kernel orders them
-    RPState St[64]; bool valid[64]; double my_iu[64], my_s[64], T[64]; bool treset[64];
     for (int lane = 0; lane < 64; ++lane) {
       const int idx = 64 * c + lane + 1;
-      valid[lane] = idx <= R.npts;
-      my_iu[lane] = 0.0; my_s[lane] = 0.0;
-      if (!valid[lane]) continue;
-      const UPart *pre = usable[lane] ? &S[lane] : nullptr;
-      if (nph == 3) rp_stage_a<3>(*cam, R, K, idx, pre, St[lane]);
-      else if (nph == 2) rp_stage_a<2>(*cam, R, K, idx, pre, St[lane]);
-      else rp_stage_a<0>(*cam, R, K, idx, pre, St[lane]);
-      my_iu[lane] = St[lane].iu; my_s[lane] = tseg_s(K, St[lane]);
-    }
-    const bool tuse = K.sym != 0;
-    if (tuse) {
-      for (int lane = 0; lane < 64; ++lane) {
-        const int idx = 64 * c + lane + 1;
-        const double nb_iu = (lane < 63) ? my_iu[lane + 1] : carry_iu, nb_s = (lane < 63) ? my_s[lane + 1] : carry_s;
-        treset[lane] = true; T[lane] = 0.0;
-        if (!valid[lane]) continue;
-        if (St[lane].isfill) { T[lane] = tseg_T(K, St[lane]); continue; }
-        if (idx == R.npts) { T[lane] = K.ancT; continue; }
-        const double d = K.facm * (nb_iu - my_iu[lane]);
-        if (!(fabs(d) <= GRT_TSEG_DMAX)) {
-          if (nph) real_mupart<true>(K, St[lane].mun, St[lane].M, false); else real_mupart<false>(K, St[lane].mun, St[lane].M, false);
-          St[lane].mu_done = true;
-          T[lane] = tseg_T(K, St[lane]);
-          continue;
-        }
-        treset[lane] = false;
-        T[lane] = tseg_diff(K, d, my_s[lane], nb_s);
-      }
-      for (int lane = 63; lane >= 0; --lane)
-        if (!treset[lane]) T[lane] += (lane < 63) ? T[lane + 1] : carryT;
-      carryT = T[0]; carry_iu = my_iu[0]; carry_s = my_s[0];
-    }
-    for (int lane = 0; lane < 64; ++lane) {
-      const int idx = 64 * c + lane + 1;
-      if (!valid[lane] || idx > maxn) continue;
+      if (idx > R.npts || idx > maxn) continue;
       GeoPoint P;
-      const double *preT = tuse ? &T[lane] : nullptr;
-      if (nph == 3) rp_stage_b<3>(*cam, R, K, idx, St[lane], preT, P);
-      else if (nph == 2) rp_stage_b<2>(*cam, R, K, idx, St[lane], preT, P);
-      else rp_stage_b<0>(*cam, R, K, idx, St[lane], preT, P);
+      const UPart *pre = usable[lane] ? &S[lane] : nullptr;
+      if (nph == 3) ray_point_real<3>(*cam, R, K, idx, P, pre);
+      else if (nph == 2) ray_point_real<2>(*cam, R, K, idx, P, pre);
+      else ray_point_real_branchy<false>(*cam, R, K, idx, P, pre);
       u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
       tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
     }
@@ -132,20 +95,56 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
   return R.npts;
 }
 
+double hs_fast_atan2(double y, double x) { return fast_atan2(y, x); }
+
+// per-ray constants of the mu side (exploration / tests): m1m, nn, facm, ifac2facm, phimu3, i3mu, tmu3, pbeta, pG, tbeta
+int hs_ray_consts(const GrtCam *cam, int ii, double *out) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
+  if (!fast || R.npts < 1) return -1;
+  RealRay K;
+  realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
+  out[0] = K.m1m; out[1] = K.nn; out[2] = K.facm; out[3] = K.ifac2facm; out[4] = K.phimu3; out[5] = K.i3mu; out[6] = K.tmu3;
+  out[7] = K.pbeta; out[8] = K.pG; out[9] = K.tbeta;
+  return K.pok;
+}
+
+// 1: the ray takes the mu-side second-kind integral from the Jacobi ladder (RealRay.zok), 0: it does not, -1: not a fast-path ray
+int hs_ray_zok(const GrtCam *cam, int ii) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
+  if (!fast || R.npts < 1) return -1;
+  RealRay K;
+  realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
+  return K.zok;
+}
+
 // exploration / test access to the mu-side internals of the fast path: per stored point (non-fill points only, others zero)
-// out[12] = iu, jarg, sn, cn, dn, tpm, tmuf, T = c1 tmu1 + c2 tmuf + c3 tmu3, facm, k2 = 1 - m1m, sym, isfill
+// out[12] = iu, jarg, sn, cn, dn, tpm, tmuf, T = c1 tmu1 + c2 tmuf + c3 tmu3, facm, the same T from the Jacobi ladder's Zeta
+// (zeta_T; 0 when the ray does not use it), sym, isfill, P = c1 phimu1 + c2 phimuf + c3 phimu3, the same from the theta series
+// (theta_P), pok, number of series terms   -- 16 columns
 int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
   GrtRay R;
   setup_ray(*cam, ii, R);
-  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12);
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
   if (!fast || R.npts < 1) return -R.npts;
   RealRay K;
   realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
+  const int zok = K.zok, pok = K.pok;
+  K.zok = 0;                    // the points below: the Legendre/Carlson evaluation
   const bool fill = (R.tpr == 1 && cam->mufill && cam->nup > 1);
   const int lo = fill ? (R.kmax - cam->kext) : R.kmax;
   for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
-    double *o = out + (size_t)(idx - 1) * 12;
-    for (int k = 0; k < 12; ++k) o[k] = 0.0;
+    double *o = out + (size_t)(idx - 1) * 16;
+    for (int k = 0; k < 16; ++k) o[k] = 0.0;
     const bool isfill = fill && idx > lo && idx <= lo + cam->next && R.tpr != 0;
     o[11] = isfill;
     if (isfill) continue;
@@ -154,7 +153,7 @@ int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
     const bool inb = (idx <= lo || R.tpr == 0);
     const int tprs = inb ? 0 : R.tpr_out;
     UPart U;
-    real_upart<3>(K, P.u, U);
+    if (K.cplx) cplx_upart<3>(K, P.u, U); else real_upart<3>(K, P.u, U);
     const double iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
     int tpm;
     double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
@@ -164,13 +163,15 @@ int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
     double a3 = 2.0 * fint((2.0 * (double)tpm + 3.0 - K.sm) / 4.0) - 1.0;
     double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
     double jarg = (K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus)) * iarg;
-    double sn, cn, dn;
-    sncndn_ladder(K.agm_mu, jarg, K.m1m, sn, cn, dn);
+    double sn, cn, dn, zz = 0.0, s0 = 0.0, c0 = 1.0;
+    if (zok) sncndn_ladder_z(K.agm_mu, jarg, K.m1m, sn, cn, dn, zz, s0, c0);
+    else sncndn_ladder(K.agm_mu, jarg, K.m1m, sn, cn, dn);
     MuPart M;
     real_mupart<true>(K, P.mu, M, false);
     double c1 = K.sm, c2 = K.sm * powm1(tpm + 1), c3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
     o[0] = iu; o[1] = jarg; o[2] = sn; o[3] = cn; o[4] = dn; o[5] = tpm; o[6] = M.tmuf;
-    o[7] = c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3; o[8] = K.facm; o[9] = 1.0 - K.m1m; o[10] = K.sym;
+    o[7] = c1 * K.tmu1 + c2 * M.tmuf + c3 * K.tmu3; o[8] = K.facm; o[9] = zok ? zeta_T(K, zz, tpm, iu) : 0.0; o[10] = K.sym;
+    o[12] = c1 * K.phimu1 + c2 * M.phimuf + c3 * K.phimu3; o[13] = (zok && pok) ? theta_P(K, s0, c0, tpm, iu) : 0.0; o[14] = pok; o[15] = K.pn;
   }
   return R.npts;
 }

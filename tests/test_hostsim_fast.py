@@ -556,6 +556,23 @@ SEG_CAMS = [(0.998, 0.906, (-40., 20., -20., 40.), (100, 100, 400), 0.01, 83),
             (0.9, 1.0, (-10., 10., -10., 10.), (32, 32, 64), 0.05, 11)]             # one chunk per ray, pole-on
 
 
+def test_one_division_atan2_of_the_theta_series(L):
+    # fast_atan2 (grt_dev_special.hpp): all quadrants, axes, tiny and huge ratios, against libm
+    L.hs_fast_atan2.restype = C.c_double
+    L.hs_fast_atan2.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(7)
+    ys = np.concatenate([rng.standard_normal(4000) * 10.0 ** rng.uniform(-12, 12, 4000), [0.0, 0.0, 1.0, -1.0, 1e-200, 3.0, -0.0]])
+    xs = np.concatenate([rng.standard_normal(4000) * 10.0 ** rng.uniform(-12, 12, 4000), [1.0, -1.0, 0.0, 0.0, 1e-200, 3.0, 2.0]])
+    worst = 0.0
+    for y, x in zip(ys, xs):
+        got, want = L.hs_fast_atan2(float(y), float(x)), np.arctan2(y, x)
+        worst = max(worst, abs(got - want) / max(abs(want), 1e-300) if want != 0 else abs(got))
+    assert worst < 4e-16, worst
+    for k in range(0, 801):          # across every breakpoint of the reduction
+        t = k / 800.0
+        assert abs(L.hs_fast_atan2(t, 1.0) - np.arctan(t)) <= 2.3e-16 * max(np.arctan(t), 1e-300) + 0 * t
+
+
 @pytest.mark.parametrize("spin,mu0,gv,nn,uout,stride", SEG_CAMS)
 def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin, mu0, gv, nn, uout, stride):
     # grt_geo_kernel's segment scheme (grt_dev_fast.hpp:useg_lane): u-side integrals of a stored point = sum of the integrals
@@ -568,9 +585,33 @@ def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin
     L.hs_make_cam(cam, 1, dp(gva), ip(nna), C.c_double(spin), C.c_double(mu0), C.c_double(uout), C.c_double(-0.5))
     o = O.Oracle(nn=nn, spin=spin, mu0=mu0, gridvals=gv, uout=uout)
     maxn = nn[2] * 2 + 64
-    nfast = 0
+    nfast = nzeta = nphi = nterms = 0
     for i in range(1, nn[0] * nn[1] + 1, stride):
         g = o.geokerr_ray(i)
+        # the mu-side second-kind integral of regular points comes from the Jacobi ladder's Zeta (sncndn_ladder_z) on these rays
+        zok = L.hs_ray_zok(cam, i)
+        nzeta += int(zok == 1)
+        if zok == 1:          # against the product's own Legendre/Carlson evaluation of T at every regular point
+            dbg = np.zeros((maxn, 16))
+            n0 = L.hs_mu_debug(cam, i, maxn, dbg.ctypes.data_as(C.c_void_p))
+            reg = dbg[:n0, 11] == 0
+            assert reg.sum() > 0.8 * n0 and np.all(dbg[:n0, 10][reg] == 1)
+            # (next to a mu turning point the LEGENDRE form loses digits -- sin(phi) = sqrt(1 - (mu/mu+)^2) from a rounded mu --
+            #  about 1e-15 facm / |sn| in T, and next to the equatorial plane 1 - sin^2(phi) cancels, 1e-15 facm / |cn|; the ladder
+            #  has neither)
+            err = np.abs(dbg[:n0, 7] - dbg[:n0, 9])
+            lose = 2e-15 / np.maximum(np.abs(dbg[:n0, 2]), 1e-300) + 1e-15 / np.maximum(np.abs(dbg[:n0, 3]), 1e-300)
+            bar = 2e-13 * max(1.0, np.max(np.abs(dbg[:n0, 7]))) + dbg[:n0, 8] * lose
+            assert np.all(err[reg] <= bar[reg]), (i, np.max(err[reg] / bar[reg]))
+            # the third-kind integral from the theta series (theta_P) against the R_J form
+            if dbg[0, 14] == 1:
+                nphi += 1
+                nterms = max(nterms, int(dbg[0, 15]))
+                errp = np.abs(dbg[:n0, 12] - dbg[:n0, 13])
+                rc = np.zeros(10)
+                L.hs_ray_consts(cam, i, rc.ctypes.data_as(C.c_void_p))
+                barp = 2e-13 * max(1.0, np.max(np.abs(dbg[:n0, 12]))) + rc[3] * lose        # (ifac2facm x the same loss of the R_J form)
+                assert np.all(errp[reg] <= barp[reg]), (i, np.max(errp[reg] / barp[reg]), int(dbg[0, 15]))
         for nph in (3, 2, 0):
             d = [np.zeros(maxn) for _ in range(5)]
             tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
@@ -583,7 +624,10 @@ def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin
             for key in ["u", "mu", "lam"] + (["dphi"] if nph else []) + (["dt"] if nph == 3 else []):
                 k = ("u", "mu", "dt", "dphi", "lam").index(key)
                 assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, nph, key)
-    assert nfast > 100
+    if mu0 == 1.0:          # pole-on: mpos = 1 on every ray, the reference switches the phi terms of the mu side off
+        assert nfast > 100 and nzeta > 30 and nphi == 0
+    else:
+        assert nfast > 100 and nzeta > 30 and nphi > 30 and 2 <= nterms <= 8
 
 
 @pytest.mark.parametrize("key", ["a", "b"])
