@@ -229,6 +229,57 @@ GRT_NI void sncndn(double uu, double emmc, double &sn, double &cn, double &dn) {
 // The descending-Landen ladder of sncndn depends only on the complementary parameter emmc, which is a
 // constant of the ray (M(mu) or U(u) modulus): build it once per ray, run only the ascending recurrence
 // (and one sincos) per point.  Same operations in the same order as sncndn above -> identical values.
+// sin and cos for the arguments of this path (Jacobi arguments scaled to [0, pi], polar angles, Faraday angles of a step; the absolute
+// error stays at 1e-16 while |x| < 1e9 and grows as ulp(x) beyond, which is the uncertainty of such an argument anyway): Cody-Waite
+// reduction by pi/2 in two fused steps and the fdlibm kernels on [-pi/4, pi/4].  No large-argument path, no special cases -- the
+// library routine carries both, and their registers, into every kernel that calls it.  (Geodesic kernels only: measured on the
+// transfer kernel, lean exp / log / sincos / acos of the same kind were 3-7 % SLOWER than the library's there.)
+GRT_HD void fast_sincos(double x, double *sn, double *cs) {
+  const double n = rint(x * 0.63661977236758138);
+  double r = fma(-n, 1.5707963267948966, x);
+  r = fma(-n, 6.123233995736766e-17, r);
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double s = r + r * z * ps;
+  const double c = 1.0 - 0.5 * z + z * z * pc;
+  const int q = (int)((long long)n & 3);
+  const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// atan2 for the theta-series argument (theta_P): one division.  atan(p/q), 0 <= p <= q, = atan(c) + atan((p - c q)/(q + c p)) with
+// c = i/8 the breakpoint nearest to p/q (picked from an approximate quotient: any neighbour keeps the reduced argument below
+// 1/15), seven terms of the series for the remainder (truncation 1/15^15/15 < 1e-18).  (The library atan2 costs this kernel a quarter
+// of its time: measured 76.5 -> 58.7 ms without it on the 1024^2 x 400 record-mode geodesics.)
+GRT_HD double fast_atan2(double y, double x) {
+  const double ATAN_I8[9] = {0.0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.46364760900080609,
+                             0.55859931534356244, 0.64350110879328437, 0.71882999962162453, 0.78539816339744831};
+  const double ax = fabs(x), ay = fabs(y);
+  const double p = dmin(ax, ay), q = dmax(ax, ay);
+  if (!(q > 0.0)) return 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  int i = (int)(8.0 * p * __builtin_amdgcn_rcp(q) + 0.5);      // (the hardware's approximate reciprocal: the index only)
+#else
+  int i = (int)(8.0 * p / q + 0.5);
+#endif
+  i = i < 0 ? 0 : (i > 8 ? 8 : i);
+  const double c = 0.125 * (double)i;
+  const double r = fdiv(p - c * q, q + c * p), r2 = r * r;
+  double t = 1.0 / 13.0;
+  t = t * r2 - 1.0 / 11.0; t = t * r2 + 1.0 / 9.0; t = t * r2 - 1.0 / 7.0; t = t * r2 + 1.0 / 5.0; t = t * r2 - 1.0 / 3.0;
+  double a = ATAN_I8[i] + (r + r * r2 * t);
+  if (ay > ax) a = 1.5707963267948966 - a;
+  if (x < 0.0) a = 3.141592653589793 - a;
+  return (y < 0.0) ? -a : a;
+}
+
+// acos through the one-division arctangent: acos(x) = atan2(sqrt((1-x)(1+x)), x), |x| <= 1
+GRT_HD double fast_acos(double x) { return fast_atan2(fsqrt((1.0 - x) * (1.0 + x)), x); }
+
 struct AgmLadder {
   int l, bo;            // l = 0: emmc == 0 (hyperbolic limit), handled by the generic routine
   double d, c;          // sqrt(1-emmc) for emmc<0 ; final mean (scale of u)
@@ -269,11 +320,7 @@ GRT_HD void sncndn_ladder(const AgmLadder &L, double uu, double emmc, double &sn
   double a, b, c = L.c;
   dn = 1.0;
   u = c * u;
-#if defined(__HIP_DEVICE_COMPILE__)
-  sincos(u, &sn, &cn);
-#else
-  sn = sin(u); cn = cos(u);
-#endif
+  fast_sincos(u, &sn, &cn);
   if (sn != 0.0) {
     a = fdiv(cn, sn);
     c = a * c;
@@ -310,11 +357,7 @@ GRT_HD void sncndn_ladder_z(const AgmLadder &L, double uu, double emmc, double &
   double a, b, c = L.c;
   dn = 1.0;
   u = c * u;
-#if defined(__HIP_DEVICE_COMPILE__)
-  sincos(u, &sn, &cn);
-#else
-  sn = sin(u); cn = cos(u);
-#endif
+  fast_sincos(u, &sn, &cn);
   s0 = sn; c0 = cn;          // sin, cos of pi uu / (2K): the argument of the theta series (L.c is AGM(1,k') = pi/(2K))
   if (sn != 0.0) {
     a = fdiv(cn, sn);
@@ -340,32 +383,6 @@ GRT_HD void sncndn_ladder_z(const AgmLadder &L, double uu, double emmc, double &
     cn = a;
     sn = fdiv(sn, L.d);
   }
-}
-
-// atan2 for the theta-series argument (theta_P): one division.  atan(p/q), 0 <= p <= q, = atan(c) + atan((p - c q)/(q + c p)) with
-// c = i/8 the breakpoint nearest to p/q (picked from an approximate quotient: any neighbour keeps the reduced argument below
-// 1/15), seven terms of the series for the remainder (truncation 1/15^15/15 < 1e-18).  (The library atan2 costs this kernel a quarter
-// of its time: measured 76.5 -> 58.7 ms without it on the 1024^2 x 400 record-mode geodesics.)
-GRT_HD double fast_atan2(double y, double x) {
-  const double ATAN_I8[9] = {0.0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.46364760900080609,
-                             0.55859931534356244, 0.64350110879328437, 0.71882999962162453, 0.78539816339744831};
-  const double ax = fabs(x), ay = fabs(y);
-  const double p = dmin(ax, ay), q = dmax(ax, ay);
-  if (!(q > 0.0)) return 0.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  int i = (int)(8.0 * p * __builtin_amdgcn_rcp(q) + 0.5);      // (the hardware's approximate reciprocal: the index only)
-#else
-  int i = (int)(8.0 * p / q + 0.5);
-#endif
-  i = i < 0 ? 0 : (i > 8 ? 8 : i);
-  const double c = 0.125 * (double)i;
-  const double r = fdiv(p - c * q, q + c * p), r2 = r * r;
-  double t = 1.0 / 13.0;
-  t = t * r2 - 1.0 / 11.0; t = t * r2 + 1.0 / 9.0; t = t * r2 - 1.0 / 7.0; t = t * r2 + 1.0 / 5.0; t = t * r2 - 1.0 / 3.0;
-  double a = ATAN_I8[i] + (r + r * r2 * t);
-  if (ay > ax) a = 1.5707963267948966 - a;
-  if (x < 0.0) a = 3.141592653589793 - a;
-  return (y < 0.0) ? -a : a;
 }
 
 GRT_HD double asech(double x) { return (x > 0.0) ? log((1.0 + sqrt(1.0 - x * x)) / x) : 0.0; }

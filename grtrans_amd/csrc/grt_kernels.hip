@@ -245,8 +245,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       sp[4 * field_stride] = P.dt; sp[5 * field_stride] = (double)P.tpm; sp[6 * field_stride] = (double)P.tpr;
     } else if (valid) {   // geodesics.f90:333-347
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
-      sp[GRT_F_R * field_stride] = 1.0 / P.u;
-      sp[GRT_F_TH * field_stride] = acos(P.mu);
+      sp[GRT_F_R * field_stride] = frcp(P.u);
+      sp[GRT_F_TH * field_stride] = fast_acos(P.mu);
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
       if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
       if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)

@@ -96,6 +96,8 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
 }
 
 double hs_fast_atan2(double y, double x) { return fast_atan2(y, x); }
+double hs_fast_acos(double x) { return fast_acos(x); }
+void hs_fast_sincos(double x, double *s, double *c) { fast_sincos(x, s, c); }
 
 // per-ray constants of the mu side (exploration / tests): m1m, nn, facm, ifac2facm, phimu3, i3mu, tmu3, pbeta, pG, tbeta
 int hs_ray_consts(const GrtCam *cam, int ii, double *out) {

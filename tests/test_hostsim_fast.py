@@ -573,6 +573,23 @@ def test_one_division_atan2_of_the_theta_series(L):
         assert abs(L.hs_fast_atan2(t, 1.0) - np.arctan(t)) <= 2.3e-16 * max(np.arctan(t), 1e-300) + 0 * t
 
 
+def test_lean_sincos_and_acos(L):
+    # fast_sincos (moderate arguments, Cody-Waite + fdlibm kernels) and fast_acos against libm
+    L.hs_fast_acos.restype = C.c_double
+    L.hs_fast_acos.argtypes = [C.c_double]
+    L.hs_fast_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-7, 7, 6000), rng.uniform(-1e4, 1e4, 2000), np.arange(-8, 9) * (np.pi / 4), [0.0, 1e-9, -1e-300]])
+    s, c = C.c_double(), C.c_double()
+    for x in xs:
+        L.hs_fast_sincos(float(x), C.byref(s), C.byref(c))
+        assert abs(s.value - np.sin(x)) <= 2.3e-16 * max(abs(np.sin(x)), 1e-300) + 1.2e-16 * (abs(x) > 10) * abs(x) * 1e-4 + 2e-17, x
+        assert abs(c.value - np.cos(x)) <= 2.3e-16 * max(abs(np.cos(x)), 1e-300) + 1.2e-16 * (abs(x) > 10) * abs(x) * 1e-4 + 2e-17, x
+    for x in np.concatenate([rng.uniform(-1, 1, 6000), [1.0, -1.0, 0.0, 1 - 1e-15, -1 + 1e-15, 1 - 1e-9]]):
+        want = np.arccos(x)
+        assert abs(L.hs_fast_acos(float(x)) - want) <= 4.5e-16 * max(want, 2e-8), x
+
+
 @pytest.mark.parametrize("spin,mu0,gv,nn,uout,stride", SEG_CAMS)
 def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin, mu0, gv, nn, uout, stride):
     # grt_geo_kernel's segment scheme (grt_dev_fast.hpp:useg_lane): u-side integrals of a stored point = sum of the integrals

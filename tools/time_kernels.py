@@ -31,6 +31,8 @@ else:
         dfile, hfile = make_harm3d_dump.write(td, n1=128, n2=128, n3=64); fluid = "HARM3D"
         dev.load_harm3d(dfile, hfile, 40, 0.9375)
         em = capi.make_emis(os.environ.get("GRT_ENAME", "POLSYNCHTH"), 4e6, 1.0, 6.0, 1.0, 1e5, 3.5, mdot=1e20)
+if os.environ.get("GRT_NOFILL"):          # experiment: no mu-fill segment (different stored points: timing only)
+    cam.mufill, cam.kext, cam.next = 0, 0, 0
 capi.record_steps(os.environ.get("GRT_RECORD", "0") == "1")
 capi.geo_reuse(False)
 best = None
