@@ -16,17 +16,17 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
                                        int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin);
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
-                                     const int *live, const int *nlive_dev, int nrays, double *steps, unsigned long long *flags,
+                                     const int *live, const int *nlive_dev, int nrays, double *steps,
                                      long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw);
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
-                                      double *steps, unsigned long long *flags, long long ray_stride, long long field_stride, int nfields,
+                                      double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield);
 extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long i1, int nrays, double *t0);
 extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, int emis, int extra, const GrtCam *cam, const GrtRay *rays,
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
-                                          const unsigned long long *flags, long long ray_stride, long long field_stride,
+                                          long long ray_stride, long long field_stride,
                                           int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back);
 
 extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const void *disk, long long i1,
@@ -82,16 +82,14 @@ struct Ctx {
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
-  unsigned long long *d_flags = nullptr;
   long long steps_stride = 0;
-  size_t cap_flags = 0;
   int steps_fields = 0;
   hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long *d_stepcount = nullptr;
   int record_steps = 0;
   long long steps_rays = 0, steps_maxpts = 0;
   std::vector<double> h_freqs;          // host staging of (freqs, log freqs): must outlive the async copy
-  // The geodesic record resident in d_rays / d_live / d_steps / d_flags / d_counters, and what it was computed for.  A trace
+  // The geodesic record resident in d_rays / d_live / d_steps / d_counters, and what it was computed for.  A trace
   // call with the same key (e.g. the next mdot of grtrans_main's loop, grtrans_driver.f90:134: one geodesic serves every
   // m = 1..nparams; or the next movie frame of a fast-light run) re-launches only the transfer kernels.
   struct GeoKey {
@@ -181,7 +179,7 @@ int grt_free(void) {
   if (!C.init) return 0;
   drain();
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
-                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_flags, C.d_sphacc,
+                  C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_sphacc,
                   C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -637,7 +635,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   // ray_status always cover the whole tile.  With the per-step record on, the record itself must be resident: one pass.
   int chunk = nrays;
   {
-    const size_t per_ray = (size_t)nalloc * rstride * sizeof(double) + (size_t)(rstride / 64) * 16 + sizeof(GrtRay) + grt_sizeof_realray() + 8;
+    const size_t per_ray = (size_t)nalloc * rstride * sizeof(double) + sizeof(GrtRay) + grt_sizeof_realray() + 8;
     size_t cap_bytes = (size_t)96 << 30;
     if (const char *e = std::getenv("GRT_MAX_WORK_BYTES")) { const double v = std::atof(e); if (v > 0) cap_bytes = (size_t)v; }
     const size_t fit = cap_bytes / per_ray;
@@ -655,7 +653,6 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * chunk * rstride))) return rc;
-  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)chunk * (rstride / 64) * 2))) return rc;
   C.steps_rays = (chunk == nrays) ? nrays : 0; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride;
   const long long fstride = (long long)chunk * rstride;
   GrtPLConst plc{};
@@ -699,10 +696,10 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
       const bool generic = ((C.class_order & 1) != 0) == (turn == 0);
       if (generic) {
         if (!reuse)
-          LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps, C.d_flags,
+          LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps,
                                    rstride, fstride, nfields, tfield, t0c, 0));
         if (!reuse && cam->usegeor)
-          LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, C.d_flags, rstride, fstride,
+          LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
         if (!reuse && (C.class_order & 4) && turn == 0) {
           // The generic geodesic kernel is ~1.4 ms of work for this camera but starves beside the fast-class kernel (it needs a
@@ -715,15 +712,15 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
         // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
         LAUNCHCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc,
                                       nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,
-                                      C.d_flags, rstride, fstride, nfields, tfield, C.d_stepcount, C.d_counters + 1, nch));
+                                      rstride, fstride, nfields, tfield, C.d_stepcount, C.d_counters + 1, nch));
         LAUNCHCHK(hipEventRecord(C.evj[1], C.stream2));
       } else {
         if (!reuse)
-          LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, C.d_flags, rstride, fstride,
+          LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
                                    nfields, tfield, t0c, 0));
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
-                                      C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps, C.d_flags, rstride,
+                                      C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps, rstride,
                                       fstride, nfields, tfield, C.d_stepcount, C.d_counters, 0));
       }
     }
@@ -874,7 +871,6 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)n))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)n))) return rc;
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nf * n * rstride))) return rc;
-  if ((rc = grow(C.d_flags, C.cap_flags, (size_t)n * (rstride / 64) * 2))) return rc;
   C.steps_rays = 0;
   struct Tmp { void *p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } din, dtpr;
   HIPCHK(hipMalloc(&din.p, (size_t)7 * n * sizeof(double)));
@@ -889,8 +885,8 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
   hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, C.d_flags, rstride, fstride, nf, 4, nullptr, 1);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, C.d_flags, rstride, fstride, nf, 4, nullptr, 1);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
   if (e != hipSuccess) { drain(); return (int)e; }
   HIPCHK(hipStreamSynchronize(C.stream));
   // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them
@@ -934,6 +930,10 @@ int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
     HIPCHK(hipMemcpy2D(out + (size_t)f * nrays * maxpts, (size_t)maxpts * sizeof(double),
                        C.d_steps + ((size_t)src[f] * C.steps_rays + ray0) * C.steps_stride, (size_t)C.steps_stride * sizeof(double),
                        (size_t)maxpts * sizeof(double), (size_t)nrays, hipMemcpyDeviceToHost));
+  // on the device r and theta carry the turning-point parities of the point in their sign bits (grt_geo_kernel): not part of the record
+  // (r = 0 marks a standard=2 point GEOR found no solution for: 1/u_f = -1 in the reference's arrays)
+  for (size_t q = 0; q < (size_t)nrays * maxpts; ++q) out[q] = (out[q] == 0.0) ? -1.0 : std::fabs(out[q]);
+  for (size_t q = (size_t)nrays * maxpts; q < (size_t)2 * nrays * maxpts; ++q) out[q] = std::fabs(out[q]);
   return 0;
 }
 

@@ -701,6 +701,18 @@ GRT_HD void realray_anchor_z(const GrtCam &cam, const GrtRay &R, RealRay &K, boo
   K.pok = 1;
 }
 
+// mu-fill segment of a ray: stored points lo+1 .. lo+nfill (nfill = 0: none)
+struct RealLeg { int lo, nfill; bool fill; };
+GRT_HD RealLeg real_leg(const GrtCam &cam, const GrtRay &R) {
+  RealLeg g;
+  g.fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  g.lo = g.fill ? (R.kmax - cam.kext) : R.kmax;
+  int nf = 0;
+  if (g.fill && R.tpr != 0) { const int hi = (g.lo + cam.next < R.npts) ? g.lo + cam.next : R.npts; nf = hi - g.lo; }
+  g.nfill = nf > 0 ? nf : 0;
+  return g;
+}
+
 // Stored point idx of a real-quartic ray (same contract as ray_point).
 //
 // A regular point goes u -> (U integrals) -> I_u -> Jacobi inversion -> mu -> (mu integrals); a point of the

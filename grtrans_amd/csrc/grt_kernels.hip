@@ -74,12 +74,16 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   // near-polar rays (l^2 below polar_l2 (q2 + a^2): the characteristic of the azimuthal Pi integrals within ~polar_l2 of 1) stay on the generic, reference-literal path: tools/fuzz_cameras.py found
   // one such ray (l = -4e-5) whose azimuth came out of the fast path 1.49 rad off after crossing the equator on the device
   const bool polar = R.l * R.l < polar_l2 * (R.q2 + cam.a * cam.a);
-  const bool quart = alive && !polar && !cam.usegeor && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
+  bool quart = alive && !polar && !cam.usegeor && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
 #if !defined(GRT_NO_CPLX_FAST)
                                (R.ncase == 5 && R.tpr == 0 && cam.a != 0.0 && R.q2 != 0.0));
 #else
                                false);
 #endif
+  // (a ray that ENDS inside its mu-fill segment -- never seen -- would have Lambda(npts) in the second phase: generic class)
+  bool topfill = false;
+  if (quart) { const RealLeg lg = real_leg(cam, R); topfill = lg.nfill > 0 && R.npts <= lg.lo + lg.nfill; }
+  quart = quart && !topfill;
   const bool cubic = alive && !(need_time & 1) && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
@@ -160,7 +164,7 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
-    const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, unsigned long long *__restrict__ flags, long long ray_stride,
+    const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
     long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
   constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -176,8 +180,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)(FAST ? rayidx : 0) * GRT_RR_STRIDE);
   const CubRay *Cp = reinterpret_cast<const CubRay *>(Kp);
   const int n = Rp->npts;
-  const int nchunk = (int)(ray_stride >> 6);      // ray_stride is a multiple of 64 points: every chunk row is a
-  double LamN = 0.0;                              // 512-byte aligned, fully used run of four 128-byte lines
+  double LamN = 0.0;                              // (ray_stride is a multiple of 64 points: every full chunk row is a 512-byte aligned run of four 128-byte lines)
   constexpr int NQ = (NPH == 3) ? 4 : (NPH == 2 ? 3 : 2);   // u-side quantities of the segment scheme: iu1, tu11[, phiu1[, tu1]]
   double carry[NQ];
 #pragma unroll
@@ -185,8 +188,19 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   // phi = phi0 - dphi; pole-on cameras (geodesics.f90:339-341) measure it from the pixel's own position angle.  Once per ray.
   double phi_ref = cam.phi0;
   if (PHI && fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
-  // chunk c holds stored points 64c+1 .. 64c+64; the top (partial) chunk first: it owns Lambda(npts)
-  for (int c = (n - 1) >> 6; c >= 0; --c) {
+  // Stored points are served in 64-point chunks, top chunk first (it owns Lambda(npts)).  A four-real-root ray with a mu-fill
+  // segment is walked in two phases: its regular points COMPACTED into chunks (position r -> point r below the segment, r + nfill
+  // above it), then the segment on its own.  The two kinds of point run their stages in opposite orders (grt_dev_fast.hpp:
+  // ray_point_real), and a chunk that mixed them made the whole wave execute both (9.5 of 58.6 ms on the 1024^2 x 400 record-mode
+  // camera); a chunk of one kind runs each stage once.
+  RealLeg leg;
+  leg.lo = n; leg.nfill = 0; leg.fill = false;
+  if (FAST == 1) leg = real_leg(cam, *Rp);
+  const int nreg = n - leg.nfill;
+  for (int ph = 0; ph < (leg.nfill > 0 ? 2 : 1); ++ph) {
+  const bool fillph = (ph == 1);
+  const int cnt = fillph ? leg.nfill : nreg;
+  for (int c = (cnt - 1) >> 6; c >= 0; --c) {
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
     {
@@ -196,79 +210,71 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       asm volatile("" : "+s"(r_), "+s"(k_));
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
     }
-    const int idx = 64 * c + lane + 1;
-    const bool valid = idx <= n;
+    const int pos = 64 * c + lane + 1;
+    const bool valid = pos <= cnt;
+    const int idx = fillph ? leg.lo + pos : ((pos <= leg.lo) ? pos : pos + leg.nfill);
     GeoPoint P;
     P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
-    UPart S;
-    bool usable = false;
+    {
+      UPart S;
+      bool usable = false;
 #if !defined(GRT_NO_USEG)
-    if (FAST == 1) {
-      // u-side integrals from segments between neighbouring points, summed down the wave (grt_dev_fast.hpp:useg_lane)
-      bool reset;
-      useg_lane<NPH>(cam, *Rp, *Kp, idx, S, reset, usable);
-      double v[NQ];
-      v[0] = S.iu1; v[1] = S.tu11;
-      if (NQ > 2) v[2] = S.phiu1;
-      if (NQ > 3) v[3] = S.tu1;
-      seg_suffix_scan<NQ>(v, reset, lane);
+      if (FAST == 1 && !fillph) {
+        // u-side integrals from segments between neighbouring points, summed down the wave (grt_dev_fast.hpp:useg_lane)
+        bool reset;
+        useg_lane<NPH>(cam, *Rp, *Kp, valid ? idx : 0, S, reset, usable);
+        double v[NQ];
+        v[0] = S.iu1; v[1] = S.tu11;
+        if (NQ > 2) v[2] = S.phiu1;
+        if (NQ > 3) v[3] = S.tu1;
+        seg_suffix_scan<NQ>(v, reset, lane);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (!reset) v[q] += carry[q];
-        carry[q] = __shfl(v[q], 0);
+        for (int q = 0; q < NQ; ++q) {
+          if (!reset) v[q] += carry[q];
+          carry[q] = __shfl(v[q], 0);
+        }
+        S.iu1 = v[0]; S.tu11 = v[1];
+        if (NQ > 2) S.phiu1 = v[2];
+        if (NQ > 3) S.tu1 = v[3];
       }
-      S.iu1 = v[0]; S.tu11 = v[1];
-      if (NQ > 2) S.phiu1 = v[2];
-      if (NQ > 3) S.tu1 = v[3];
+#endif
+      if (valid) {
+        const UPart *pre = usable ? &S : nullptr;
+        if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
+        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
+        else if (FAST == 1) ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre);
+        else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
+      }
     }
-#endif
-    if (valid) {
-      const UPart *pre = usable ? &S : nullptr;
-      if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
-      else if (FAST == 1 && NPH == 3) ray_point_real<3>(cam, *Rp, *Kp, idx, P, pre);
-#if defined(GRT_GEO2_BRANCHY)
-      else if (FAST == 1 && NPH == 2) ray_point_real_branchy<true>(cam, *Rp, *Kp, idx, P, pre);
-#else
-      else if (FAST == 1 && NPH == 2) ray_point_real<2>(cam, *Rp, *Kp, idx, P, pre);
-#endif
-#if defined(GRT_GEO0_TWOPASS)
-      else if (FAST == 1) ray_point_real<0>(cam, *Rp, *Kp, idx, P, pre);
-#else
-      else if (FAST == 1) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
-#endif
-      else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
-    }
-    if (c == ((n - 1) >> 6)) LamN = __shfl(P.lam, (n - 1) & 63);
+    if (ph == 0 && c == ((cnt - 1) >> 6)) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel)
+    // the turning-point parities ride in the sign bits of r (radial) and theta (polar): both are positive quantities
     if (NPH == 3 && valid && raw) {   // grt_geokerr_rays: GEOKERR's own output arrays UFI, MUFI, LAMBDAI, DPHI, DTI, TPMI, TPRI
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
       sp[0] = P.u; sp[field_stride] = P.mu; sp[2 * field_stride] = P.lam; sp[3 * field_stride] = P.dphi;
       sp[4 * field_stride] = P.dt; sp[5 * field_stride] = (double)P.tpm; sp[6 * field_stride] = (double)P.tpr;
     } else if (valid) {   // geodesics.f90:333-347
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
-      sp[GRT_F_R * field_stride] = frcp(P.u);
-      sp[GRT_F_TH * field_stride] = fast_acos(P.mu);
+      const double rr = (P.u > 0.0) ? frcp(P.u) : 0.0;            // u_f = -1 (GEOR found no solution, standard=2): r = 0 marks the point for grt_trim_kernel
+      const double th = fast_acos(P.mu);
+      sp[GRT_F_R * field_stride] = (P.tpr & 1) ? -rr : rr;
+      sp[GRT_F_TH * field_stride] = (P.tpm & 1) ? -th : th;
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
       if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
       if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)
     }
-    // turning-point parities of the chunk as two 64-bit lane masks (tpm, tpr): 0.25 bit-pairs per byte instead of a byte per point
-    const unsigned long long mm = __ballot(valid && (P.tpm & 1)), mr = __ballot(valid && (P.tpr & 1));
-    if (lane == 0) {
-      unsigned long long *fp = flags + ((long long)rayidx * nchunk + c) * 2;
-      fp[0] = mm; fp[1] = mr;
-    }
+  }
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
   } while (FAST == 0 && slot0 < *nlive_dev);     // only the generic class strides (capped grid); a fast-class wave serves one ray
 }
 
 // standard=2 with nup > 1 (geodesics.f90:298-347): GEOR returns u_f < 0 where the ray does not reach the requested mu; such
-// points are cut from both ENDS of the ray, the survivors i1..i2 are re-indexed from 1, and lambda is referred to
-// LAMBDAI(npts') -- the element of the UNTRIMMED array at the trimmed count, as the reference writes it.  One lane per ray of
-// the generic class, after its geodesic kernel; shifts r, theta, lambda (+ phi, t) and the turning-point parities in place.
+// points (stored with r = 0) are cut from both ENDS of the ray, the survivors i1..i2 are re-indexed from 1, and lambda is referred
+// to LAMBDAI(npts') -- the element of the UNTRIMMED array at the trimmed count, as the reference writes it.  One lane per ray of
+// the generic class, after its geodesic kernel; shifts r, theta (with the turning-point parities in their signs), lambda (+ phi, t).
 __global__ __launch_bounds__(256) void grt_trim_kernel(GrtRay *__restrict__ rays, const int *__restrict__ live, const int *__restrict__ nlive_dev,
                                                        int nrays, int *__restrict__ ray_npts, double *__restrict__ steps,
-                                                       unsigned long long *__restrict__ flags, long long ray_stride, long long field_stride,
+                                                       long long ray_stride, long long field_stride,
                                                        int nfields, int tfield) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= *nlive_dev) return;
@@ -277,18 +283,16 @@ __global__ __launch_bounds__(256) void grt_trim_kernel(GrtRay *__restrict__ rays
   if (n <= 1) return;
   double *rr = steps + GRT_F_R * field_stride + (long long)ray * ray_stride;
   int i1 = 1, i2 = n;
-  if (rr[0] < 0.0)
+  if (rr[0] == 0.0)
     for (int ii = 2; ii <= n; ++ii)
-      if (!(rr[ii - 1] < 0.0)) { i1 = ii; break; }
-  if (rr[n - 1] < 0.0)
+      if (!(rr[ii - 1] == 0.0)) { i1 = ii; break; }
+  if (rr[n - 1] == 0.0)
     for (int ii = 1; ii <= n - 1; ++ii)
-      if (!(rr[n - ii - 1] < 0.0)) { i2 = n - ii; break; }
+      if (!(rr[n - ii - 1] == 0.0)) { i2 = n - ii; break; }
   const int np = i2 - i1 + 1;
   if (np == n) return;
   double *lam = steps + GRT_F_LAM * field_stride + (long long)ray * ray_stride;
   const double lref = lam[np - 1];                     // LAMBDAI(npts') of the untrimmed array, in the stored form LamN - Lambda
-  const int nchunk = (int)(ray_stride >> 6);
-  unsigned long long *fl = flags + (long long)ray * nchunk * 2;
   const int sh = i1 - 1;
   for (int j = 0; j < np; ++j) {
     const int s = j + sh;
@@ -297,21 +301,16 @@ __global__ __launch_bounds__(256) void grt_trim_kernel(GrtRay *__restrict__ rays
       p[j] = (f == GRT_F_LAM) ? (p[s] - lref) : p[s];
     }
     if (tfield >= 0) { double *p = steps + (long long)tfield * field_stride + (long long)ray * ray_stride; p[j] = p[s]; }
-    if (sh) {
-      const unsigned long long bm = (fl[(s >> 6) * 2] >> (s & 63)) & 1ull, br = (fl[(s >> 6) * 2 + 1] >> (s & 63)) & 1ull;
-      fl[(j >> 6) * 2] = (fl[(j >> 6) * 2] & ~(1ull << (j & 63))) | (bm << (j & 63));
-      fl[(j >> 6) * 2 + 1] = (fl[(j >> 6) * 2 + 1] & ~(1ull << (j & 63))) | (br << (j & 63));
-    }
   }
   rays[ray].npts = np;
   ray_npts[ray] = np;
 }
 
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
-                                      double *steps, unsigned long long *flags, long long ray_stride, long long field_stride, int nfields,
+                                      double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield) {
   if (nrays <= 0) return hipSuccess;
-  hipLaunchKernelGGL(grt_trim_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, rays, live, nlive_dev, nrays, ray_npts, steps, flags, ray_stride,
+  hipLaunchKernelGGL(grt_trim_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, rays, live, nlive_dev, nrays, ray_npts, steps, ray_stride,
                      field_stride, nfields, tfield);
   return hipGetLastError();
 }
@@ -351,7 +350,7 @@ template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
 __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive_arg, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
-    int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps, const unsigned long long *__restrict__ flags,
+    int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps,
     long long ray_stride, long long field_stride, int nfields, int tfield, unsigned long long *__restrict__ step_counter,
     const int *__restrict__ nlive_dev, int from_back) {
   constexpr int NW = GRT_XFER_THREADS / 64;
@@ -428,7 +427,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
   const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
   const double lam_1 = has_ray ? steps[GRT_F_LAM * field_stride + base] : 0.0;   // g%lambda(1)
   const bool slowlight = (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_KORAL3D) && !EXTRA && tfield >= 0;    // several slices: the point's time picks one
-  const double r_1 = (slowlight && has_ray) ? steps[GRT_F_R * field_stride + base] : 10.0;
+  const double r_1 = (slowlight && has_ray) ? fabs(steps[GRT_F_R * field_stride + base]) : 10.0;
   double I[FB][4], facs[FB];
   double jn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][4], Kn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][7];
 #pragma unroll
@@ -459,8 +458,6 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
   // the ray is walked in tiles of 8 points aligned to 8 (64-byte segments that never straddle a 128-byte line);
   // tile m holds 0-based points 8m..8m+7, the top tile mt may be partial
   const int mt = (n - 1) >> 3;
-  const int nchunk = (int)(ray_stride >> 6);
-  unsigned long long fmm = 0ull, fmr = 0ull;     // parity masks of the current 64-point chunk
 
   const int ntile = ((nmax - 1) >> 3) + 1;
   for (int t = 0; t < ntile; ++t) {
@@ -489,14 +486,13 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       const int ip = 8 * m + e;                            // 0-based stored point of this lane's ray
       const bool valid = has_ray && m >= 0 && ip < n;
       const int k = ip + 1;
-      if (valid && ((ip & 63) == 63 || ip == n - 1)) {     // entering a new 64-point chunk (walking downwards)
-        const unsigned long long *fp = flags + ((long long)rayidx * nchunk + (ip >> 6)) * 2;
-        fmm = fp[0]; fmr = fp[1];
-      }
-      const double r = valid ? tl0[lane * GRT_TS + e] : 10.0;    // idle lanes (shorter rays) keep benign inputs
-      const double th = valid ? tl1[lane * GRT_TS + e] : 1.0;
+      // r and theta carry the turning-point parities of the point in their sign bits (grt_geo_kernel)
+      const double rs_ = valid ? tl0[lane * GRT_TS + e] : 10.0;  // idle lanes (shorter rays) keep benign inputs
+      const double ths_ = valid ? tl1[lane * GRT_TS + e] : 1.0;
+      // (r = 0 marks a point GEOR found no solution for, standard=2 only; inside a ray it is sampled at r = 1/u_f = -1 as before)
+      const double r = (rs_ == 0.0) ? -1.0 : fabs(rs_), th = fabs(ths_);
       const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
-      const int fl8 = (int)((fmm >> (ip & 63)) & 1ull) | ((int)((fmr >> (ip & 63)) & 1ull) << 1);
+      const int fl8 = (int)(__double2hiint(ths_) < 0) | ((int)(__double2hiint(rs_) < 0) << 1);
       const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? tl3[lane * GRT_TS + e] : 0.0;
       // HARM: the time rides in the fourth tile; KORAL3D needs that tile for phi and reads its time straight from the record
       const double t_i = !(slowlight && valid) ? 0.0 : (FLUID == GRT_FLUID_KORAL3D ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * GRT_TS + e]);
@@ -794,7 +790,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 // nlive_dev: device counter of the class (counters[0] fast, counters[1] generic); nrays: rays of the pass = worst case
 // the grid is sized for, and the length of live[] (the generic class is read from its back)
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
-                                     const int *live, const int *nlive_dev, int nrays, double *steps, unsigned long long *flags,
+                                     const int *live, const int *nlive_dev, int nrays, double *steps,
                                      long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
@@ -806,7 +802,7 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   const int kind = !fast ? 0 : (cam->a == 0.0 ? 2 : 1);
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P)                                                                                            \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, flags, ray_stride, field_stride, nfields, tfield, t0, raw);
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw);
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE
   return hipGetLastError();
@@ -816,16 +812,16 @@ template <int IFLAG, int FLUID, int EMIS>
 static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
-                              double *steps, const unsigned long long *flags, long long ray_stride, long long field_stride,
+                              double *steps, long long ray_stride, long long field_stride,
                               int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
-                       rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags,
+                       rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps,
                        ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   } else if (nfreq == 1) {
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
-                       *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, flags, ray_stride,
+                       *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
                        field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   } else {
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
@@ -834,7 +830,7 @@ static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
                        dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
-                       nvals, ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+                       nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   }
 }
 
@@ -843,7 +839,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
                                           const int *live, int nlive, const GrtFluidDev *fd, const GrtTables *tb,
                                           const GrtEmis *em, const GrtPLConst *plc, int nfreq, const double *freqs,
                                           float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1, double *steps,
-                                          const unsigned long long *flags, long long ray_stride, long long field_stride,
+                                          long long ray_stride, long long field_stride,
                                           int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   if (nlive <= 0) return hipSuccess;
   if (emis == GRT_EMIS_HYBRIDTH || emis == GRT_EMIS_HYBRIDPL) emis = GRT_EMIS_HYBRIDTHPL;   // one instantiation, em->type selects
@@ -853,7 +849,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
     launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
-                               ray_status, i1, steps, flags, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);   \
+                               ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);   \
     return hipGetLastError();                                                                                           \
   }
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)

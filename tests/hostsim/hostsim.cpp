@@ -66,10 +66,16 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
   realray_anchor(*cam, R, K);
   realray_anchor_z(*cam, R, K);
   UPart carry; carry.iu1 = carry.tu11 = carry.phiu1 = carry.tu1 = 0.0;
-  for (int c = (R.npts - 1) >> 6; c >= 0; --c) {
-    UPart S[64]; bool reset[64], usable[64];
+  // as grt_geo_kernel walks a ray: the regular points compacted into 64-point chunks (segment sums down each chunk, carry from
+  // the chunk above), then the mu-fill segment on its own
+  const RealLeg leg = real_leg(*cam, R);
+  const int nreg = R.npts - leg.nfill;
+  for (int c = (nreg - 1) >> 6; c >= 0; --c) {
+    UPart S[64]; bool reset[64], usable[64]; int idxs[64];
     for (int lane = 0; lane < 64; ++lane) {
-      const int idx = 64 * c + lane + 1;
+      const int pos = 64 * c + lane + 1;
+      const int idx = (pos > nreg) ? 0 : (pos <= leg.lo ? pos : pos + leg.nfill);
+      idxs[lane] = idx;
       if (nph == 3) useg_lane<3>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
       else if (nph == 2) useg_lane<2>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
       else useg_lane<0>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
@@ -81,8 +87,8 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
     }
     carry = S[0];
     for (int lane = 0; lane < 64; ++lane) {
-      const int idx = 64 * c + lane + 1;
-      if (idx > R.npts || idx > maxn) continue;
+      const int idx = idxs[lane];
+      if (idx < 1 || idx > maxn) continue;
       GeoPoint P;
       const UPart *pre = usable[lane] ? &S[lane] : nullptr;
       if (nph == 3) ray_point_real<3>(*cam, R, K, idx, P, pre);
@@ -91,6 +97,14 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
       u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
       tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
     }
+  }
+  for (int idx = leg.lo + 1; idx <= leg.lo + leg.nfill && idx <= maxn; ++idx) {
+    GeoPoint P;
+    if (nph == 3) ray_point_real<3>(*cam, R, K, idx, P);
+    else if (nph == 2) ray_point_real<2>(*cam, R, K, idx, P);
+    else ray_point_real_branchy<false>(*cam, R, K, idx, P);
+    u[idx - 1] = P.u; mu[idx - 1] = P.mu; dt[idx - 1] = P.dt; dphi[idx - 1] = P.dphi; lam[idx - 1] = P.lam;
+    tpm[idx - 1] = P.tpm; tpr[idx - 1] = P.tpr;
   }
   return R.npts;
 }
