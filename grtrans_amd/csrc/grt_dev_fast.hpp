@@ -866,7 +866,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       Tz = zeta_T(K, zz, tpm, iu);
       if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);
     } else {
-      sncndn_ladder(K.agm_mu, fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
+      sncndn_ladder<true>(K.agm_mu, fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
       mun = fdiv(K.muminus, dn);
     }
     M.i2mu = 0.0; M.tmuf = 0.0; M.phimuf = 0.0;
@@ -880,12 +880,12 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
     double sn, cn, dn;
     if (c7) {
       double arg = imu - K.siu0m;
-      sncndn_ladder(K.agm_u, K.jfac * arg, K.m1u, sn, cn, dn);
+      sncndn_ladder<true>(K.agm_u, K.jfac * arg, K.m1u, sn, cn, dn);
       un = fdiv((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1), (K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));
       tprs = (int)((fsign(1.0, K.su * (imu - K.siu0e)) + 1.0) / 2.0);
     } else {
       double arg = imu + K.siu0m;
-      sncndn_ladder(K.agm_u, K.jfac * arg, K.m1u, sn, cn, dn);
+      sncndn_ladder<true>(K.agm_u, K.jfac * arg, K.m1u, sn, cn, dn);
       un = fdiv((K.u4 - K.u3) * K.u2 * sn * sn - K.u3 * (K.u4 - K.u2), (K.u4 - K.u3) * sn * sn - (K.u4 - K.u2));
       tprs = (int)((-fsign(1.0, K.su * (imu + K.siu0m)) + 1.0) / 2.0);
     }

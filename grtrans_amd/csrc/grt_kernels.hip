@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     } else if (valid) {   // geodesics.f90:333-347
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
       const double rr = (P.u > 0.0) ? frcp(P.u) : 0.0;            // u_f = -1 (GEOR found no solution, standard=2): r = 0 marks the point for grt_trim_kernel
-      const double th = fast_acos(P.mu);
+      const double th = (FAST == 1) ? fast_acos(P.mu) : acos(P.mu);     // (the lean one pays in the four-real-root kernels only: measured)
       sp[GRT_F_R * field_stride] = (P.tpr & 1) ? -rr : rr;
       sp[GRT_F_TH * field_stride] = (P.tpm & 1) ? -th : th;
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
