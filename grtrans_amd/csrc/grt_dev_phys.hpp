@@ -138,8 +138,11 @@ GRT_HD void transport_perpk(const double *k, double r, double sth, double cth, d
 }
 
 // kerr.f90:586.  u,b,k: contravariant BL components (t,r,th,phi).
+// cang: cos of the angle between field and wave vector (always); ang = acos(cang) only when WANT_ANG (the power-law emissivity needs
+// sin and cos alone: sin = sqrt(1 - cos^2) exactly where acos followed by sincos gave it to rounding)
+template <bool WANT_ANG = true>
 GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double alpha, double beta, double mus, const double *u,
-                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang, double &g) {
+                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang, double &g, double *cang = nullptr) {
   Metric m = blmetric_cov_sc(r, sth, cth, a);
   double gtt = m.g[0], gtp = m.g[3], grr = m.g[4], gmm = m.g[7], gpp = m.g[9];
   double ut = u[0], ur = u[1], um = u[2], up = u[3];
@@ -191,7 +194,8 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
   const double angmin = -0.99, angmax = 0.99;
   double t = (angnorm <= angmax) ? angnorm : angmax;
   t = (angnorm >= angmin) ? t : angmin;
-  ang = acos(t);
+  ang = WANT_ANG ? acos(t) : 0.0;
+  if (cang) *cang = t;
   g = ikt;
 }
 
@@ -291,15 +295,10 @@ GRT_HD double interp_fast(double lx, int ix, int iy, const double *xv, int nx, c
 struct PLPoint { double itanth, nubperp, lnub, A, kperp, omega0; };
 
 // plain: SYNCHPL (synchpl, polsynchemis.f90:657) forms nu_B,perp with sin(th) itself, POLSYNCHPL with sin(th) + 1e-10
-GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P, bool plain = false) {
+// (s0, c0) = sin, cos of the angle between field and wave vector
+GRT_HD void polsynchpl_point_sc(const GrtPLConst &C, double nnth, double B, double s0, double c0, PLPoint &P, bool plain = false) {
   const double nufloor = 1e-10, thsafe = 1e-10;
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
-  double s0, c0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  sincos(th, &s0, &c0);
-#else
-  s0 = sin(th); c0 = cos(th);
-#endif
   double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe;
   P.itanth = frcp(tanth);
   double sinth = s0 + (plain ? 0.0 : thsafe);
@@ -308,6 +307,16 @@ GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double 
   P.A = C.A0 * nnth;
   P.kperp = P.A * (ec * ec / m / c) * frcp(P.nubperp);
   P.omega0 = P.nubperp * 2.0 * pi;
+}
+
+GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P, bool plain = false) {
+  double s0, c0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(th, &s0, &c0);
+#else
+  s0 = sin(th); c0 = cos(th);
+#endif
+  polsynchpl_point_sc(C, nnth, B, s0, c0, P, plain);
 }
 
 // lnu = log(nu): log x = log(nub/nu) = lnub - lnu, so a frequency costs exponentials only

@@ -513,8 +513,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       if (FLUID == GRT_FLUID_KORAL3D)
         koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela,                                  // kela carries Be
                        slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0);
-      double s2xi, c2xi, ang, g;
-      comoving_ortho(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g);
+      double s2xi, c2xi, ang, g, cang;
+      // the power-law emissivity takes sin and cos of the field / wave-vector angle, not the angle: no acos + sincos pair per step
+      constexpr bool WANT_ANG = EXTRA || !(EMIS == GRT_EMIS_POLSYNCHPL && FLUID == GRT_FLUID_FFJET);
+      comoving_ortho<WANT_ANG>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
       double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
       const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
@@ -525,7 +527,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       else if (FLUID == GRT_FLUID_IHARM) iharm_convert(fl, kela, fd.h3.gam, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       else if (FLUID == GRT_FLUID_HARM3D) harm3d_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       PLPoint plp;
-      if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
+      if (!WANT_ANG)
+        polsynchpl_point_sc(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, fsqrt((1.0 - cang) * (1.0 + cang)), cang, plp,
+                            IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
+      else if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
         polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp,
                          IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
       const double lg = log(g);
