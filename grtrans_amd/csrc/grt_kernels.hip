@@ -88,11 +88,10 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
-    RealRay K;
+    RealRay &K = *reinterpret_cast<RealRay *>(rrays + (size_t)tid * GRT_RR_STRIDE);     // built in place: 2 KB less scratch per lane
     realray_init(cam, R, K);
     realray_anchor(cam, R, K);       // the segment scheme's per-ray anchor: u-side integrals of the top stored point
     realray_anchor_z(cam, R, K, (need_time & 2) != 0);   // and the constants of the mu-side integrals taken from the Jacobi ladder
-    *reinterpret_cast<RealRay *>(rrays + (size_t)tid * GRT_RR_STRIDE) = K;
   } else if (cubic) {
     CubRay K;
     cubray_init(cam, R, K);
