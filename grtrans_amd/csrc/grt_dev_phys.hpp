@@ -520,16 +520,20 @@ GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, do
 // seed+Newton division.  Values agree with the literal routine to rounding (tests/test_hostsim_fast.py).
 // SYM: POLSYNCHSYMTH (sympolemisth, polsynchemis.f90:915-969) -- the Pandya et al. (2016) fitting functions replace the
 // emissivities (absorption by Kirchhoff's law as before), the Faraday coefficients are the same.
-template <bool SYM = false>
-GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double theta, double *e) {
+// HAVE_SC: the caller hands sin and cos of the field / wave-vector angle over (sth_in, cth_in) and theta is not looked at
+template <bool SYM = false, bool HAVE_SC = false>
+GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double theta, double *e, double sth_in = 0.0, double cth_in = 1.0) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
   const double nucminval = 1.0, thetaemin = 1e-10, s3 = 1.7320508075688772;
   double sth, cth;
+  if (HAVE_SC) { sth = sth_in; cth = cth_in; }
+  else {
 #if defined(__HIP_DEVICE_COMPILE__)
-  sincos(theta, &sth, &cth);
+    sincos(theta, &sth, &cth);
 #else
-  sth = sin(theta); cth = cos(theta);
+    sth = sin(theta); cth = cos(theta);
 #endif
+  }
   const double thetae = k * T / m / c / c + thetaemin, th2 = thetae * thetae;
   const double nuc = 3.0 * ec * B * sth / 4.0 / pi / m / c * th2 + nucminval;
   const double xm = fdiv(nu, nuc);
@@ -551,7 +555,9 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
     const double pf = 1.4142135623730951 * pi / 27.0 * sth;
     const double jis = pf * sq(sqx + c1112 * x16);
     const double jqs = -pf * sq(sqx + (7.0 * t2425 + 35.0) / (10.0 * t2425 + 75.0) * c1112 * x16);
-    const double jvs = -(37.0 - 87.0 * sin(theta - 28.0 / 25.0)) / 100.0 / (thetae + 1.0) *
+    // sin(theta - 28/25) from sin and cos of theta when the caller handed those over
+    const double sshift = HAVE_SC ? (sth * 0.4356824462767121 - cth * 0.9001004421765051) : sin(theta - 28.0 / 25.0);
+    const double jvs = -(37.0 - 87.0 * sshift) / 100.0 / (thetae + 1.0) *
                        exp(5.0 / 3.0 * log(1.0 + (exp(0.6 * lte) / 25.0 + 7.0 / 10.0) * exp(0.36 * lxs)));
     const double fac = n * (ec * ec) / c * nucs * exp(-x13s);
     ji = fac * jis; jq = -fac * jqs; jv = -fac * jvs;

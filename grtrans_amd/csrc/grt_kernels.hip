@@ -514,7 +514,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
                        slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0);
       double s2xi, c2xi, ang, g, cang;
       // the power-law emissivity takes sin and cos of the field / wave-vector angle, not the angle: no acos + sincos pair per step
-      constexpr bool WANT_ANG = EXTRA || !(EMIS == GRT_EMIS_POLSYNCHPL && FLUID == GRT_FLUID_FFJET);
+      constexpr bool WANT_ANG = EXTRA || !((EMIS == GRT_EMIS_POLSYNCHPL && FLUID == GRT_FLUID_FFJET) || EMIS == GRT_EMIS_POLSYNCHTH || EMIS == GRT_EMIS_POLSYNCHSYMTH);
       comoving_ortho<WANT_ANG>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
       double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
       else if (FLUID == GRT_FLUID_IHARM) iharm_convert(fl, kela, fd.h3.gam, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       else if (FLUID == GRT_FLUID_HARM3D) harm3d_convert(fl, emk.mbh, emk.mdot, emk.muval, emk.gminval, emk.jetalpha, emk.p1, emk.sigcut, ncgs, ncgsnth, bcgs, tcgs);
       PLPoint plp;
-      if (!WANT_ANG)
+      if (!WANT_ANG && EMIS == GRT_EMIS_POLSYNCHPL)
         polsynchpl_point_sc(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, fsqrt((1.0 - cang) * (1.0 + cang)), cang, plp,
                             IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
       else if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
@@ -555,7 +555,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_tran
             if (IFLAG == GRT_INT_QUAD && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL)
               e11[0] *= (double)1.7320508075688772f / 1.7320508075688772;
           }
+          else if (EMIS == GRT_EMIS_POLSYNCHTH && !WANT_ANG) polsynchth_fast<false, true>(nu, ncgs, bcgs, tcgs, 0.0, e11, fsqrt((1.0 - cang) * (1.0 + cang)), cang);
           else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_POLSYNCHSYMTH && !WANT_ANG) polsynchth_fast<true, true>(nu, ncgs, bcgs, tcgs, 0.0, e11, fsqrt((1.0 - cang) * (1.0 + cang)), cang);
           else if (EMIS == GRT_EMIS_POLSYNCHSYMTH) polsynchth_fast<true>(nu, ncgs, bcgs, tcgs, ang, e11);
           else if (EMIS == GRT_EMIS_MAXJUTT) {
             // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): thermal components w_i n at T delta^i / sum_i w_i delta^i
