@@ -203,66 +203,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gather_ms, gather_via = None, None
-    if dist is not None:
-        # assemble ivals on rank 0 (pgrtrans.f90:221-242): ONE gather of the ranks' fp32 cameras over xGMI, after the timed steps
-        L = capi.lib()
-        nv = 4
-        capi.check(L.grt_stage_reset(C.c_int(args.nfreq), C.c_int(nv), C.c_int64(npix_of_rank[rank])), "grt_stage_reset")
-        one_step(stage=True)                                    # untimed: fills the rank-level image (same bits as the timed steps)
-        torch.cuda.synchronize()
-        full = None
-        try:
-            if cdev != "cuda" or os.environ.get("GRT_BENCH_GATHER") == "torch":
-                raise RuntimeError("torch gather requested")
-            # the library's own RCCL communicator; its ncclUniqueId travels over the process group that exists already
-            idbuf = C.create_string_buffer(128)
-            if rank == 0:
-                capi.check(L.grt_comm_unique_id(idbuf), "grt_comm_unique_id")
-            box = [idbuf.raw]
-            dist.broadcast_object_list(box, src=0)
-            capi.check(L.grt_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(box[0])), "grt_comm_init")
-            cnt = (C.c_int64 * world)(*npix_of_rank)
-            host = np.zeros((args.nfreq, sum(npix_of_rank), nv), dtype=np.float32) if rank == 0 else None
-            dist.barrier(); torch.cuda.synchronize()
-            tg = time.perf_counter()
-            capi.check(L.grt_gather_stage(cnt, C.c_int(0), host.ctypes.data_as(C.c_void_p) if rank == 0 else None), "grt_gather_stage")
-            gather_ms = (time.perf_counter() - tg) * 1e3
-            gather_via = "grt_gather_stage (library RCCL communicator, grouped send/recv per camera, incl. D2H on rank 0)"
-            full = host
-            L.grt_comm_free()
-        except Exception as exc:      # fall back to the process group's own gather (rank-ordered tiles, same layout)
-            from grtrans_amd.tiling import gather_tiles
-            tile = torch.empty((args.nfreq, npix_of_rank[rank], nv), dtype=torch.float32, device="cuda")
-            off = 0
-            L.grt_comm_free()
-            for (i1, i2) in my_ranges:
-                capi.trace_tile(cam, i1, i2, W["fname"], em, freqs, args.iname, resident=True)
-                t1 = torch.empty((args.nfreq, i2 - i1 + 1, nv), dtype=torch.float32, device="cuda")
-                capi.check(L.grt_copy_resident_pixvals(C.c_void_p(t1.data_ptr()), C.c_int64(t1.numel())), "grt_copy_resident_pixvals")
-                tile[:, off:off + i2 - i1 + 1] = t1
-                off += i2 - i1 + 1
-            torch.cuda.synchronize()
-            if cdev == "cpu":
-                tile = tile.cpu()
-            dist.barrier()
-            tg = time.perf_counter()
-            fullt = gather_tiles(tile, dist, 0)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - tg) * 1e3
-            gather_via = "torch.distributed.gather (%s)" % (str(exc)[:80])
-            full = fullt.cpu().numpy() if rank == 0 else None
-        if rank == 0:
-            assert full.shape[1] == sum(npix_of_rank)
-            if os.environ.get("GRT_BENCH_CHECK_IMAGE") == "1":
-                # test hook: the gathered, un-permuted image equals one whole-image trace on this rank, bit for bit
-                img = np.zeros((args.nfreq, nx_total * ny, nv), dtype=np.float32)
-                pre = 0
-                for rr in all_ranges:
-                    for (a, b) in rr:
-                        img[:, a - 1:b] = full[:, pre:pre + b - a + 1]
-                        pre += b - a + 1
-                ref, _, _, _ = capi.trace_tile(cam, 1, nx_total * ny, W["fname"], em, freqs, args.iname)
-                assert np.array_equal(img, ref), "gathered image differs from the single-GPU image"
+    ray_steps_all = ray_steps
+    if dist is not None:       # the timing of the job: max over ranks of the bracketed wall time, sum of the ranks' ray-steps
         tmax = torch.tensor([dt, float(ray_steps), ms_trace], dtype=torch.float64, device=cdev)
         tsum = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -270,10 +212,20 @@ def main():
         dt = float(tmax[0])
         ray_steps_all = int(tsum[1].item())
         ms_trace = float(tmax[2])
-    else:
-        ray_steps_all = ray_steps
+    # The image assembly below (one gather, after the timed steps) has only ever run with more than one rank on the driver's
+    # node: if it does not finish, the line is printed without its timing and the job ends instead of hanging.
+    import threading
+    emitted = threading.Lock()
+    state = {"emit": None}
 
-    if rank == 0:
+    def on_timeout():
+        if emitted.acquire(blocking=False):
+            if rank == 0 and state["emit"] is not None:
+                state["emit"](None, "gather did not finish within %s s (line printed without it)" % os.environ.get("GRT_BENCH_GATHER_TIMEOUT", "240"))
+                sys.stdout.flush()
+            os._exit(0)
+    watchdog = threading.Timer(float(os.environ.get("GRT_BENCH_GATHER_TIMEOUT", "240")), on_timeout) if dist is not None else None
+    def emit(gather_ms, gather_via):
         value = ray_steps_all / dt
         # dominant kernel = grt_geo_kernel (fast class); its launch + the transfer launch process the same
         # ray-steps, so the algorithmic 64 B/step is priced over the sum of the two (HIP events on the library stream)
@@ -331,6 +283,78 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "ffjet":
             out["cpu_baseline"] = cpu_baseline(nx, ny, nup)
         print(json.dumps(out))
+    state["emit"] = emit
+    if watchdog is not None:
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        if dist is not None:
+            # assemble ivals on rank 0 (pgrtrans.f90:221-242): ONE gather of the ranks' fp32 cameras over xGMI, after the timed steps
+            L = capi.lib()
+            nv = 4
+            capi.check(L.grt_stage_reset(C.c_int(args.nfreq), C.c_int(nv), C.c_int64(npix_of_rank[rank])), "grt_stage_reset")
+            one_step(stage=True)                                    # untimed: fills the rank-level image (same bits as the timed steps)
+            torch.cuda.synchronize()
+            full = None
+            try:
+                if cdev != "cuda" or os.environ.get("GRT_BENCH_GATHER") == "torch":
+                    raise RuntimeError("torch gather requested")
+                # the library's own RCCL communicator; its ncclUniqueId travels over the process group that exists already
+                idbuf = C.create_string_buffer(128)
+                if rank == 0:
+                    capi.check(L.grt_comm_unique_id(idbuf), "grt_comm_unique_id")
+                box = [idbuf.raw]
+                dist.broadcast_object_list(box, src=0)
+                capi.check(L.grt_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(box[0])), "grt_comm_init")
+                cnt = (C.c_int64 * world)(*npix_of_rank)
+                host = np.zeros((args.nfreq, sum(npix_of_rank), nv), dtype=np.float32) if rank == 0 else None
+                dist.barrier(); torch.cuda.synchronize()
+                tg = time.perf_counter()
+                capi.check(L.grt_gather_stage(cnt, C.c_int(0), host.ctypes.data_as(C.c_void_p) if rank == 0 else None), "grt_gather_stage")
+                gather_ms = (time.perf_counter() - tg) * 1e3
+                gather_via = "grt_gather_stage (library RCCL communicator, grouped send/recv per camera, incl. D2H on rank 0)"
+                full = host
+                L.grt_comm_free()
+            except Exception as exc:      # fall back to the process group's own gather (rank-ordered tiles, same layout)
+                from grtrans_amd.tiling import gather_tiles
+                tile = torch.empty((args.nfreq, npix_of_rank[rank], nv), dtype=torch.float32, device="cuda")
+                off = 0
+                L.grt_comm_free()
+                for (i1, i2) in my_ranges:
+                    capi.trace_tile(cam, i1, i2, W["fname"], em, freqs, args.iname, resident=True)
+                    t1 = torch.empty((args.nfreq, i2 - i1 + 1, nv), dtype=torch.float32, device="cuda")
+                    capi.check(L.grt_copy_resident_pixvals(C.c_void_p(t1.data_ptr()), C.c_int64(t1.numel())), "grt_copy_resident_pixvals")
+                    tile[:, off:off + i2 - i1 + 1] = t1
+                    off += i2 - i1 + 1
+                torch.cuda.synchronize()
+                if cdev == "cpu":
+                    tile = tile.cpu()
+                dist.barrier()
+                tg = time.perf_counter()
+                fullt = gather_tiles(tile, dist, 0)
+                torch.cuda.synchronize()
+                gather_ms = (time.perf_counter() - tg) * 1e3
+                gather_via = "torch.distributed.gather (%s)" % (str(exc)[:80])
+                full = fullt.cpu().numpy() if rank == 0 else None
+            if rank == 0:
+                assert full.shape[1] == sum(npix_of_rank)
+                if os.environ.get("GRT_BENCH_CHECK_IMAGE") == "1":
+                    # test hook: the gathered, un-permuted image equals one whole-image trace on this rank, bit for bit
+                    img = np.zeros((args.nfreq, nx_total * ny, nv), dtype=np.float32)
+                    pre = 0
+                    for rr in all_ranges:
+                        for (a, b) in rr:
+                            img[:, a - 1:b] = full[:, pre:pre + b - a + 1]
+                            pre += b - a + 1
+                    ref, _, _, _ = capi.trace_tile(cam, 1, nx_total * ny, W["fname"], em, freqs, args.iname)
+                    assert np.array_equal(img, ref), "gathered image differs from the single-GPU image"
+
+    except Exception as exc:      # (both gather paths failed: the job's line is still printed)
+        gather_ms, gather_via = None, "gather failed: %s" % str(exc)[:120]
+    if watchdog is not None:
+        watchdog.cancel()
+    if emitted.acquire(blocking=False) and rank == 0:
+        emit(gather_ms, gather_via)
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
