@@ -16,9 +16,6 @@
 // (tests/test_hostsim_fast.py, tests/test_gpu_parity.py).
 #pragma once
 #include "grt_dev_ray.hpp"
-#ifndef GRT_RJ95
-#define GRT_RJ95 0
-#endif
 
 namespace grtd {
 
@@ -51,25 +48,6 @@ GRT_HD double rc7(double x, double y) {
   return w * (1.0 + s * s * poly) * fsqrt(ia);
 }
 
-// R_C(1, 1+e) in closed form; b = 1+e is passed separately because the caller can form it without
-// cancellation.  |e| shrinks 64x per duplication step, so after the first step or two only the
-// alternating series is evaluated.
-GRT_HD double rc1p(double e, double b) {
-  if (fabs(e) < 0.03) {
-    double s = 1.0 / 25.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int k = 11; k >= 0; --k) s = 1.0 / (2 * k + 1) - e * s;
-    return s;
-  }
-  if (e > 0.0) {
-    double r = fsqrt(e);
-    return fdiv(atan(r), r);
-  }
-  double r = fsqrt(-e);
-  return fdiv(log(fdiv((1.0 + r) * (1.0 + r), b)), 2.0 * r);
-}
 
 // R_F, R_D(x,y,z) and NJ x R_J(x,y,z,p_k) with ONE shared duplication sequence (three square roots
 // and lambda per iteration for all of them), a division-free convergence test and the 7th-order
@@ -131,19 +109,9 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
 #pragma unroll
 #endif
     for (int k = 0; k < NJ; ++k) {
-#if GRT_RJ95
-      // Carlson (1995) form of the R_J step: one square root, one R_C(1,1+e_m) in closed form
-      // (the reference's 1979 form, geokerr_wrapper.f:3735-3746, needs a full R_C duplication here)
-      double sp = fsqrt(pt[k]);
-      double d = (sp + sx) * (sp + sy) * (sp + sz), id = frcp(d);
-      double e = fac * fac * fac * delta[k] * id * id;
-      double b = 2.0 * sp * (pt[k] + alamb) * id;
-      sumj[k] = sumj[k] + fac * id * rc1p(e, b);
-#else
       double t = pt[k] * (sx + sy + sz) + sx * sy * sz;
       double t2 = pt[k] + alamb;
       sumj[k] = sumj[k] + 0.5 * fac * rc7(t * t, pt[k] * (t2 * t2));
-#endif
       pt[k] = .25 * (pt[k] + alamb);
     }
     fac = .25 * fac;
