@@ -1040,6 +1040,30 @@ def test_bench_distributed_path_through_rccl_single_rank():
     assert "torch.distributed.gather" in j["config"]["gather_via"]
 
 
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    # bench.py with TWO ranks launched as the driver launches them, on this 1-GPU box: both ranks trace on device 0
+    # (GRT_BENCH_DEVICE) and the collectives run over gloo (GRT_BENCH_BACKEND; RCCL cannot put two ranks on one GPU).  Covers the
+    # rank-dependent logic of the N > 1 path -- pixel strips of the widened camera (weak), round-robin column tiles of one
+    # camera (strong), max-over-ranks timing, sum of ray-steps, the gather and the un-permutation: with GRT_BENCH_CHECK_IMAGE the
+    # assembled image must equal a whole-image trace bit for bit.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRT_BENCH_BACKEND="gloo", GRT_BENCH_DEVICE="0", GRT_BENCH_CHECK_IMAGE="1")
+    for scaling, npix in (("weak", 96 * 96), ("strong", 96 * 96 // 2)):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                              "--nn", "96", "96", "100", "--scaling", scaling, "--tile-cols", "8", "--no-cpu-baseline"], env=env, cwd=root,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1                      # rank 0 alone prints
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["value"] > 1e7 and j["config"]["pixels_per_gpu"] == npix
+        assert j["config"]["gather_ms"] is not None
+
+
 def test_hosts_gather_path_with_a_one_rank_communicator(tmp_path, monkeypatch):
     # The N-GPU mode of module pgrtrans (one process per GPU; pixel ranges = strips or column tiles; tiles staged device to
     # device into the rank's image; ONE RCCL gather; rank 0 assembles ivals) on this 1-GPU box: GRT_FORCE_COMM=1 runs all of it
