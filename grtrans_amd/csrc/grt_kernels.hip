@@ -36,8 +36,9 @@ using namespace grtd;
 // coefficient code (Bessel functions, tanh, cbrt, a dozen exp/log) needs ~350 live registers: at two waves it spills
 // 340-490 B/lane to scratch, at one wave the spills go to the 256 AGPRs (v_accvgpr moves, no memory): SPHACC
 // 57.5 -> 54.4 ms, HARM 93.9 -> 84.2 ms.
+// (r02, after the emissivities lost their acos + sincos pair: SPHACC is faster at two waves again -- 48.4 -> 42.5 ms -- HARM is not)
 #ifndef GRT_XFER_WPE
-#define GRT_XFER_WPE(EMIS) ((EMIS) == GRT_EMIS_POLSYNCHPL ? 2 : 1)
+#define GRT_XFER_WPE(EMIS, FLUID) (((EMIS) == GRT_EMIS_POLSYNCHPL || (FLUID) == GRT_FLUID_SPHACC) ? 2 : 1)
 #endif
 #define GRT_MAXF 32
 #define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
@@ -346,7 +347,7 @@ template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 
 }
 
 template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
-__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS)) void grt_transfer_kernel(
+__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive_arg, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps,
