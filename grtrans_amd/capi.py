@@ -160,6 +160,32 @@ def trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=4, nextra=0, resident
     return pix, loc, status, st
 
 
+def trace_ranges(cam, ranges, fname, em, freqs, iname, nvals=4, nextra=0, resident=False):
+    """grt_trace_ranges: the pixels of several inclusive 1-based ranges [(lo, hi), ...] in ONE set of launches (a rank's column
+    tiles); rows of the outputs follow the ranges in call order."""
+    f = np.ascontiguousarray(freqs, dtype=np.float64)
+    nf = len(f)
+    fp = f.ctypes.data_as(C.POINTER(C.c_double))
+    nr = len(ranges)
+    lo = (C.c_int64 * nr)(*[int(a) for a, _ in ranges])
+    hi = (C.c_int64 * nr)(*[int(b) for _, b in ranges])
+    n = sum(int(b) - int(a) + 1 for a, b in ranges)
+    st = GrtStats()
+    if resident:
+        check(lib().grt_trace_ranges_resident(C.byref(cam), C.c_int(nr), lo, hi, C.c_int(FLUID[fname]), C.byref(em), C.c_int(nf), fp,
+                                              C.c_int(INTEG[iname]), C.c_int(nvals), C.c_int(nextra), C.byref(st)),
+              "grt_trace_ranges_resident")
+        return None, None, None, st
+    pix = np.zeros((nf, n, nvals + nextra), dtype=np.float32)
+    loc = np.zeros((n, 2), dtype=np.float32)
+    status = np.zeros(n, dtype=np.int32)
+    check(lib().grt_trace_ranges(C.byref(cam), C.c_int(nr), lo, hi, C.c_int(FLUID[fname]), C.byref(em), C.c_int(nf), fp,
+                                 C.c_int(INTEG[iname]), C.c_int(nvals), C.c_int(nextra), pix.ctypes.data_as(C.POINTER(C.c_float)),
+                                 loc.ctypes.data_as(C.POINTER(C.c_float)), status.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st)),
+          "grt_trace_ranges")
+    return pix, loc, status, st
+
+
 def compute_t0(cam, i1, i2):
     """Raw per-ray time origins (nload > 1, geodesics.f90:113-128); normalise with normalise_t0, then set_t0."""
     t0 = np.zeros(i2 - i1 + 1)

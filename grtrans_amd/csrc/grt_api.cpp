@@ -3,6 +3,7 @@
 // stream and the events that time the two kernels.  No CPU compute path exists here: if the HIP
 // device or the code object is missing every entry point returns an error.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +14,8 @@
 #include "grt_pl_pack.hpp"
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin);
+                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin,
+                                       const long long *rng, int nrng);
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
@@ -31,7 +33,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
 
 extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const void *disk, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
-                                      unsigned long long *step_counter, int nvals, int nextra, int bbpol);
+                                      unsigned long long *step_counter, int nvals, int nextra, int bbpol, const long long *rng, int nrng);
 extern "C" size_t grt_sizeof_disk(void);
 
 extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *out6);
@@ -97,7 +99,10 @@ struct Ctx {
     grt_camera cam{};
     long long i1 = 0, i2 = 0, t0_version = 0;
     int nfields = 0, tfield = 0;
+    std::vector<long long> ranges;      // (lo, hi) pairs of a several-range call (grt_trace_ranges); empty for one range
   } geo;
+  long long *d_rng = nullptr;           // device table of a several-range call: (first local index, first pixel) per range
+  size_t cap_rng = 0;
   long long t0_version = 0;
   int geo_reuse = 1;                    // grt_set_geo_reuse
   int class_order = 3;
@@ -180,7 +185,7 @@ int grt_free(void) {
   drain();
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_rng, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -529,11 +534,36 @@ int grt_set_record_steps(int enable) {
   return 0;
 }
 
-static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
+// One call = the pixels of nranges inclusive 1-based ranges (lo[k]..hi[k], in this order: the rows of pixvals / ray_status follow
+// it), traced in ONE set of launches.  nranges == 1 is grt_trace_tile.
+static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, const int64_t *his, int fluid_model, const grt_emis *em, int nfreq,
                         const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
   if (!C.init) return GRT_E_NOTINIT;
-  if (!cam || !em || !freqs || nfreq < 1 || i2 < i1 || i1 < 1) return GRT_E_BADARG;     // any nfreq (pgrtrans.f90:87-91 has no limit)
-  if (i2 > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
+  if (!cam || !em || !freqs || nfreq < 1 || nranges < 1 || !los || !his) return GRT_E_BADARG;     // any nfreq (pgrtrans.f90:87-91 has no limit)
+  long long total = 0;
+  for (int k = 0; k < nranges; ++k) {
+    if (his[k] < los[k] || los[k] < 1 || his[k] > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
+    total += his[k] - los[k] + 1;
+  }
+  if (total > 0x7fffffffLL) return GRT_E_BADARG;
+  const int64_t i1 = los[0], i2 = his[0];       // (the single range when nranges == 1)
+  std::vector<long long> rkey;
+  const long long *d_rng = nullptr;
+  if (nranges > 1) {
+    std::vector<long long> tab((size_t)2 * nranges);
+    long long pre = 0;
+    for (int k = 0; k < nranges; ++k) {
+      tab[2 * k] = pre; tab[2 * k + 1] = los[k];
+      pre += his[k] - los[k] + 1;
+      rkey.push_back(los[k]); rkey.push_back(his[k]);
+    }
+    HIPCHK(hipSetDevice(C.device));
+    int rc0;
+    if ((rc0 = grow(C.d_rng, C.cap_rng, tab.size()))) return rc0;
+    drain();                                      // a previous call's set-up kernel may still read the table
+    HIPCHK(hipMemcpy(C.d_rng, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice));
+    d_rng = C.d_rng;
+  }
   if (cam->standard == 2 && cam->nup == 1) {
     // standard=2 on the device: one point per ray on a thin disk -- BB (Stokes I; BASELINE config 1) or BBPOL (the
     // polarized atmosphere, nvals = 4, with the 7 one-point diagnostics when extra=1; the reference's `thindisk` problem)
@@ -545,7 +575,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
     if (sizeof(C.disk) != grt_sizeof_disk()) return GRT_E_BADARG;
     HIPCHK(hipSetDevice(C.device));
     C.geo.valid = false;
-    const int nrays = (int)(i2 - i1 + 1);
+    const int nrays = (int)total;
     int rc;
     if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
     if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
@@ -556,7 +586,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
     HIPCHK(hipEventRecord(C.ev[1], C.stream));
     C.disk.mbh = (float)em->mbh;
     HIPCHK(grt_launch_disk(C.stream, cam, &C.disk, (long long)i1, nrays, nfreq, C.d_freqs, C.d_pixvals, C.d_npts, C.d_stepcount, nvals, nextra,
-                           bbpol ? 1 : 0));
+                           bbpol ? 1 : 0, d_rng, nranges));
     HIPCHK(hipEventRecord(C.ev[2], C.stream));
     HIPCHK(hipStreamSynchronize(C.stream));
     if (st) {
@@ -615,7 +645,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   if (is_koral) fd.h3.ktype = (fluid_model == GRT_FLUID_KORAL3D_DISK) ? 1 : 0;
   const int kfluid = is_koral ? GRT_FLUID_KORAL3D : fluid_model;      // one instantiation serves both KORAL3D variants
   HIPCHK(hipSetDevice(C.device));
-  const int nrays = (int)(i2 - i1 + 1);
+  const int nrays = (int)total;
   int rc;
   // per-step record in HBM: [field][ray][maxpts] fp64, fields r,theta,lambda always (they carry the
   // geodesic from grt_geo_kernel to grt_transfer_kernel); phi,I,Q,U,V only when recording is on.
@@ -627,7 +657,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1) || (is_koral && C.koral.nt > 1);
   if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;
   const int tfield = need_time ? nfields : -1;
-  if (need_time && C.t0_n != 0 && C.t0_n != (long long)(i2 - i1 + 1)) return GRT_E_BADARG;   // t0 table of another tile
+  if (need_time && C.t0_n != 0 && C.t0_n != total) return GRT_E_BADARG;   // t0 table of another tile
   const double *d_t0 = (need_time && C.t0_n != 0) ? C.d_t0 : nullptr;
   const int nalloc = nfields + (need_time ? 1 : 0);
   // The geodesic hand-over buffers grow with rays x points (12 KB per ray at nup=400): a tile whose buffers would pass the
@@ -643,7 +673,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   }
   // does the resident geodesic record serve this call?  (same camera, pixel range, field layout and time-origin table)
   const bool reuse = C.geo.valid && chunk == nrays && std::memcmp(&C.geo.cam, cam, sizeof(*cam)) == 0 && C.geo.i1 == (long long)i1 &&
-                     C.geo.i2 == (long long)i2 && C.geo.nfields == nfields && C.geo.tfield == tfield && C.geo.t0_version == C.t0_version &&
+                     C.geo.i2 == (long long)i2 && C.geo.ranges == rkey && C.geo.nfields == nfields && C.geo.tfield == tfield && C.geo.t0_version == C.t0_version &&
                      C.geo_reuse && !std::getenv("GRT_NO_GEO_REUSE");
   C.geo.valid = false;
   if ((rc = grow(C.d_rays, C.cap_rays, (size_t)chunk))) return rc;
@@ -682,7 +712,8 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
       C.geo_passes++;
       LAUNCHCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
       LAUNCHCHK(hipEventRecord(C.ev[0], C.stream));
-      LAUNCHCHK(grt_launch_setup(C.stream, cam, (long long)i1 + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays, (need_time ? 1 : 0) | (nfields > 3 ? 2 : 0), nullptr));
+      LAUNCHCHK(grt_launch_setup(C.stream, cam, (nranges > 1 ? 0 : (long long)i1) + off, nch, C.d_rays, C.d_npts + off, C.d_live, C.d_counters, C.d_rrays,
+                                 (need_time ? 1 : 0) | (nfields > 3 ? 2 : 0), nullptr, d_rng, nranges));
     }
     LAUNCHCHK(hipEventRecord(C.ev[1], C.stream));
     // class 0 (fast paths) sits at the front of live[], class 1 (generic) at the back; their sizes stay on the device
@@ -711,7 +742,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
         }
         // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
         LAUNCHCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc,
-                                      nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps,
+                                      nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps,
                                       rstride, fstride, nfields, tfield, C.d_stepcount, C.d_counters + 1, nch));
         LAUNCHCHK(hipEventRecord(C.evj[1], C.stream2));
       } else {
@@ -720,7 +751,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
                                    nfields, tfield, t0c, 0));
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
-                                      C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)i1, C.d_steps, rstride,
+                                      C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
                                       fstride, nfields, tfield, C.d_stepcount, C.d_counters, 0));
       }
     }
@@ -740,7 +771,7 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
 #undef LAUNCHCHK
   if (chunk == nrays) {      // a complete record is resident: the next call with the same key skips set-up and geodesics
     C.geo.valid = true; C.geo.cam = *cam; C.geo.i1 = (long long)i1; C.geo.i2 = (long long)i2; C.geo.nfields = nfields;
-    C.geo.tfield = tfield; C.geo.t0_version = C.t0_version;
+    C.geo.tfield = tfield; C.geo.t0_version = C.t0_version; C.geo.ranges = rkey;
   }
   if (st) {
     unsigned long long steps_done = 0;
@@ -755,14 +786,14 @@ static int trace_common(const grt_camera *cam, int64_t i1, int64_t i2, int fluid
   return 0;
 }
 
-int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
-                            int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
+int grt_trace_ranges_resident(const grt_camera *cam, int nranges, const int64_t *lo, const int64_t *hi, int fluid_model, const grt_emis *em,
+                              int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
   if (!C.init) return GRT_E_NOTINIT;
   EventPair ev;                          // destroyed on every exit path
   HIPCHK(hipEventCreate(&ev.a));
   HIPCHK(hipEventCreate(&ev.b));
   HIPCHK(hipEventRecord(ev.a, C.stream));
-  int rc = trace_common(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
+  int rc = trace_common(cam, nranges, lo, hi, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
   if (rc) return rc;
   HIPCHK(hipEventRecord(ev.b, C.stream));
   HIPCHK(hipEventSynchronize(ev.b));
@@ -770,6 +801,11 @@ int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int f
   HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
   if (st) { st->ms_total = ms; st->ms_setup = ms - st->ms_trace; }
   return 0;
+}
+
+int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
+                            int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st) {
+  return grt_trace_ranges_resident(cam, 1, &i1, &i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
 }
 
 int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status) {
@@ -786,23 +822,32 @@ int grt_copy_resident_pixvals(void *d_dst, int64_t count) {
   return 0;
 }
 
-int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
-                   const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
-                   int32_t *ray_status, grt_stats *st) {
-  int rc = grt_trace_tile_resident(cam, i1, i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
+int grt_trace_ranges(const grt_camera *cam, int nranges, const int64_t *lo, const int64_t *hi, int fluid_model, const grt_emis *em, int nfreq,
+                     const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
+                     int32_t *ray_status, grt_stats *st) {
+  int rc = grt_trace_ranges_resident(cam, nranges, lo, hi, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, st);
   if (rc) return rc;
-  const size_t nrays = (size_t)(i2 - i1 + 1);
+  size_t nrays = 0;
+  for (int k = 0; k < nranges; ++k) nrays += (size_t)(hi[k] - lo[k] + 1);
   if (pixvals) HIPCHK(hipMemcpy(pixvals, C.d_pixvals, nrays * nfreq * (nvals + nextra) * sizeof(float), hipMemcpyDeviceToHost));
   if (ray_status) HIPCHK(hipMemcpy(ray_status, C.d_npts, nrays * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (pixloc) {   // camera.f90:36: pixloc(:,i) = real(alpha), real(beta); pure host arithmetic (geokerr_wrapper.f:258-272)
-    for (size_t t = 0; t < nrays; ++t) {
-      double v[6];
-      grt_host_camera_pixel(cam, (long long)i1 + (long long)t, v);
-      pixloc[2 * t] = (float)v[0];
-      pixloc[2 * t + 1] = (float)v[1];
-    }
+    size_t t = 0;
+    for (int k = 0; k < nranges; ++k)
+      for (int64_t ii = lo[k]; ii <= hi[k]; ++ii, ++t) {
+        double v[6];
+        grt_host_camera_pixel(cam, (long long)ii, v);
+        pixloc[2 * t] = (float)v[0];
+        pixloc[2 * t + 1] = (float)v[1];
+      }
   }
   return 0;
+}
+
+int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em, int nfreq,
+                   const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
+                   int32_t *ray_status, grt_stats *st) {
+  return grt_trace_ranges(cam, 1, &i1, &i2, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, pixvals, pixloc, ray_status, st);
 }
 
 // ---- G-10: class_geokerr's f2py surface (class_geokerr.f90:69-144) --------------------------------------------------
@@ -846,7 +891,10 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   if (!C.init) return GRT_E_NOTINIT;
   if (nrays < 1 || nrays > 0x7fffffff || nup < 1 || kext < 0 || next < 0 || !uf || !l || !q2 || !alpha || !beta || !tpr || !su || !sm)
     return GRT_E_BADARG;
-  if (usegeor != 0 || phit == 0) return GRT_E_UNSUPPORTED;      // the mu-stepping branch (geokerr_wrapper.f:421-461) is not on the device
+  // this entry serves the u-stepping call shape only (USEGEOR false); the mu-stepping branch (geokerr_wrapper.f:421-461) runs on
+  // the device for standard=2 cameras through grt_trace_tile, not through this raw-array surface
+  if (usegeor != 0 || phit == 0) return GRT_E_UNSUPPORTED;
+  if ((long long)nup + next - 2LL * kext < 1) return GRT_E_BADARG;      // the reference's array length (class_geokerr.f90:75) must be positive
   if (!mufill && (kext || next)) return GRT_E_BADARG;
   HIPCHK(hipSetDevice(C.device));
   C.geo.valid = false;                     // the work buffers are about to hold these rays
@@ -884,7 +932,7 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   const long long fstride = (long long)n * rstride;
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
-  hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin);
+  hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin, nullptr, 0);
   if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
   if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
   if (e != hipSuccess) { drain(); return (int)e; }
@@ -931,9 +979,15 @@ int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
                        C.d_steps + ((size_t)src[f] * C.steps_rays + ray0) * C.steps_stride, (size_t)C.steps_stride * sizeof(double),
                        (size_t)maxpts * sizeof(double), (size_t)nrays, hipMemcpyDeviceToHost));
   // on the device r and theta carry the turning-point parities of the point in their sign bits (grt_geo_kernel): not part of the record
-  // (r = 0 marks a standard=2 point GEOR found no solution for: 1/u_f = -1 in the reference's arrays)
-  for (size_t q = 0; q < (size_t)nrays * maxpts; ++q) out[q] = (out[q] == 0.0) ? -1.0 : std::fabs(out[q]);
-  for (size_t q = (size_t)nrays * maxpts; q < (size_t)2 * nrays * maxpts; ++q) out[q] = std::fabs(out[q]);
+  // (r = 0 marks a standard=2 point GEOR found no solution for: 1/u_f = -1 in the reference's arrays).  Only the ray's own
+  // points are touched: slots behind npts stay as the buffer holds them (zero for a fresh record).
+  std::vector<int32_t> np_((size_t)nrays);
+  HIPCHK(hipMemcpy(np_.data(), C.d_npts + ray0, (size_t)nrays * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int64_t ry = 0; ry < nrays; ++ry) {
+    const int n = std::min<int>(std::abs(np_[(size_t)ry]), maxpts);
+    double *r = out + (size_t)ry * maxpts, *th = out + ((size_t)nrays + (size_t)ry) * maxpts;
+    for (int k = 0; k < n; ++k) { r[k] = (r[k] == 0.0) ? -1.0 : std::fabs(r[k]); th[k] = std::fabs(th[k]); }
+  }
   return 0;
 }
 

@@ -6,8 +6,13 @@
 // the data path).  The communicator is owned by the library (grt_comm_init*) or by the caller (grt_gather).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -57,31 +62,82 @@ int grt_comm_free(void) {
   return 0;
 }
 
-// the calling process has selected its device already (grt_init); every rank calls with the same 128 id bytes
-int grt_comm_init(int rank, int nranks, const char *id128) {
+// ncclCommInitRank blocks until every rank has joined and has no timeout of its own: a rank that never arrives (crashed before
+// the rendezvous, stale id) would hang the host silently.  It runs on a helper thread; if it has not returned within timeout_s the
+// call returns GRT_E_IO and the helper is left behind (the caller is expected to stop the process).
+static int comm_init_timed(int rank, int nranks, const ncclUniqueId &id, double timeout_s) {
+  struct Box { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+  auto box = std::make_shared<Box>();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::thread([box, rank, nranks, id, dev]() {
+    (void)hipSetDevice(dev);
+    ncclComm_t c = nullptr;
+    ncclResult_t r = ncclCommInitRank(&c, nranks, id, rank);
+    std::lock_guard<std::mutex> g(box->m);
+    box->r = r; box->comm = c; box->done = true;
+    box->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(box->m);
+  if (timeout_s > 0) {
+    if (!box->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return box->done; })) {
+      fprintf(stderr, "grtrans_amd: ncclCommInitRank (rank %d of %d) did not return within %.0f s: a rank is missing or the id is stale\n", rank, nranks, timeout_s);
+      return GRT_E_IO;
+    }
+  } else {
+    box->cv.wait(lk, [&] { return box->done; });
+  }
+  if (box->r != ncclSuccess) return nccl_rc(box->r);
+  M.comm = box->comm;
+  return 0;
+}
+
+static int comm_init_impl(int rank, int nranks, const char *id128, double timeout_s) {
   if (nranks < 1 || rank < 0 || rank >= nranks || !id128) return GRT_E_BADARG;
-  if (M.comm) grt_comm_free();
+  if (M.comm) { (void)ncclCommDestroy(M.comm); M.comm = nullptr; }       // (the staging buffers and the stream are kept)
   ncclUniqueId id;
   std::memcpy(&id, id128, 128);
-  if (hipStreamCreateWithFlags(&M.stream, hipStreamNonBlocking) != hipSuccess) return GRT_E_NODEVICE;
-  ncclResult_t r = ncclCommInitRank(&M.comm, nranks, id, rank);
-  if (r != ncclSuccess) { M.comm = nullptr; return nccl_rc(r); }
+  if (!M.stream && hipStreamCreateWithFlags(&M.stream, hipStreamNonBlocking) != hipSuccess) return GRT_E_NODEVICE;
+  int rc = comm_init_timed(rank, nranks, id, timeout_s);
+  if (rc) { M.comm = nullptr; return rc; }
   M.rank = rank; M.nranks = nranks;
   return 0;
 }
 
-// Rendezvous through a file for hosts that have no launcher-provided channel (the Fortran executable): rank 0 writes the
-// id to `path`.tmp and renames it, the other ranks poll for `path`.  The launcher chooses a fresh path per run.
+// the calling process has selected its device already (grt_init); every rank calls with the same 128 id bytes
+int grt_comm_init(int rank, int nranks, const char *id128) {
+  const char *e = std::getenv("GRT_COMM_INIT_TIMEOUT");
+  return comm_init_impl(rank, nranks, id128, e ? std::atof(e) : 600.0);
+}
+
+// Rendezvous through a file for hosts that have no launcher-provided channel (the Fortran executable): rank 0 removes whatever
+// sits at `path`, writes [8-byte magic][64-byte run nonce][128-byte id] to `path`.tmp and renames it; the other ranks poll `path`
+// and accept it only when the nonce is THEIR run's (a file left by a crashed run is ignored, not joined).  The nonce is
+// GRT_COMM_NONCE when the launcher sets it, else the parent process id (ranks of one launcher share a parent).  Rank 0 unlinks
+// the file once ncclCommInitRank has returned: every rank has joined, so every rank has read it.
 int grt_comm_init_file(int rank, int nranks, const char *path, double timeout_s) {
-  if (!path || nranks < 1 || rank < 0 || rank >= nranks) return GRT_E_BADARG;
+  if (!path || !*path || nranks < 1 || rank < 0 || rank >= nranks) return GRT_E_BADARG;
+  char rec[8 + 64 + 128];
+  char want[8 + 64];
+  std::memset(want, 0, sizeof want);
+  std::memcpy(want, "GRTCOMM2", 8);
+  {
+    const char *nz = std::getenv("GRT_COMM_NONCE");
+    char buf[64];
+    if (!nz || !*nz) { std::snprintf(buf, sizeof buf, "ppid=%ld", (long)getppid()); nz = buf; }
+    std::strncpy(want + 8, nz, 63);
+  }
   char id[128];
   if (rank == 0) {
     int rc = grt_comm_unique_id(id);
     if (rc) return rc;
+    (void)std::remove(path);                     // never leave a previous run's id where the other ranks could find it
+    std::memcpy(rec, want, sizeof want);
+    std::memcpy(rec + sizeof want, id, 128);
     std::string tmp = std::string(path) + ".tmp";
     FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return GRT_E_IO;
-    const bool ok = std::fwrite(id, 1, 128, f) == 128;
+    const bool ok = std::fwrite(rec, 1, sizeof rec, f) == sizeof rec;
     std::fclose(f);
     if (!ok || std::rename(tmp.c_str(), path) != 0) return GRT_E_IO;
   } else {
@@ -89,15 +145,20 @@ int grt_comm_init_file(int rank, int nranks, const char *path, double timeout_s)
     for (;;) {
       FILE *f = std::fopen(path, "rb");
       if (f) {
-        const size_t n = std::fread(id, 1, 128, f);
+        const size_t n = std::fread(rec, 1, sizeof rec, f);
         std::fclose(f);
-        if (n == 128) break;
+        if (n == sizeof rec && std::memcmp(rec, want, sizeof want) == 0) { std::memcpy(id, rec + sizeof want, 128); break; }
       }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return GRT_E_IO;
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+        fprintf(stderr, "grtrans_amd: rank %d found no rendezvous file of this run at %s within %.0f s\n", rank, path, timeout_s);
+        return GRT_E_IO;
+      }
       std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
   }
-  return grt_comm_init(rank, nranks, id);
+  const int rc = comm_init_impl(rank, nranks, id, timeout_s);
+  if (rank == 0) (void)std::remove(path);
+  return rc;
 }
 
 int grt_comm_rank(int *rank, int *nranks) {

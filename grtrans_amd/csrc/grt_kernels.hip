@@ -44,12 +44,25 @@ using namespace grtd;
 #define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
 #define GRT_INT_QUAD 4    // internal: nvals=1 quadrature (radtrans_integrate.f90:878-882), chosen for either iname
 
+// Pixel of local ray j when a call traces SEVERAL pixel ranges in one launch (grt_trace_ranges: the column tiles of one rank of a
+// multi-GPU run): tab[2k] = local index of the first ray of range k, tab[2k+1] = its first pixel (1-based); ranges in call order.
+__device__ __forceinline__ long long range_pixel(const long long *__restrict__ tab, int nrng, long long j) {
+  int lo = 0, hi = nrng - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[2 * mid] <= j) lo = mid; else hi = mid - 1;
+  }
+  return tab[2 * lo + 1] + (j - tab[2 * lo]);
+}
+
 __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
                                                          int *__restrict__ counters, char *__restrict__ rrays, int need_time /* bit 0: coordinate time wanted (no cubic class), bit 1: azimuth wanted */, double polar_l2,
-                                                         GrtRayIn rin) {
+                                                         GrtRayIn rin, const long long *__restrict__ rng, int nrng) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   bool inr = tid < nrays;
+  // one range: pixel i1 + tid; several (rng): i1 is the local index of this pass's first ray
+  const long long pixel = (nrng > 1 && inr) ? range_pixel(rng, nrng, i1 + tid) : i1 + tid;
   GrtRay R;
   R.npts = 0;
   if (inr) {
@@ -58,9 +71,9 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
       R.pix = tid + 1;
       setup_ray_core(cam, R, rin.uf[tid], rin.tpr[tid]);
     } else if (cam.usegeor) {
-      setup_ray_usegeor(cam, (int)(i1 + tid), R);      // standard=2: mu is the independent variable (generic class)
+      setup_ray_usegeor(cam, (int)pixel, R);      // standard=2: mu is the independent variable (generic class)
     } else {
-      setup_ray(cam, (int)(i1 + tid), R);
+      setup_ray(cam, (int)pixel, R);
     }
     rays[tid] = R;
     ray_npts[tid] = R.npts;
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
     }
   }
   if (!has_ray) return;
-  const int pixslot = R.pix - (int)i1;
+  const int pixslot = (int)i1 + rayidx;      // i1 here: slot of the pass's first ray in the call's pixvals rows (a ray's slot = its local index)
   bool ok0 = true;
 #pragma unroll
   for (int f = 0; f < FB; ++f) {
@@ -752,20 +765,20 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
 __global__ __launch_bounds__(256) void grt_disk_kernel(GrtCam cam, GrtDisk disk, long long i1, int nrays, int nfreq,
                                                        const double *__restrict__ freqs, float *__restrict__ pixvals,
                                                        int *__restrict__ ray_status, unsigned long long *__restrict__ step_counter,
-                                                       int nvals, int nextra, int bbpol) {
+                                                       int nvals, int nextra, int bbpol, const long long *__restrict__ rng, int nrng) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nrays) return;
   const int nv = nvals + nextra;
-  const int st = disk_pixel(cam, disk, (int)(i1 + tid), nfreq, freqs, pixvals + (long long)tid * nv, (long long)nrays * nv, nvals, nextra, bbpol);
+  const int st = disk_pixel(cam, disk, (int)(nrng > 1 ? range_pixel(rng, nrng, tid) : i1 + tid), nfreq, freqs, pixvals + (long long)tid * nv, (long long)nrays * nv, nvals, nextra, bbpol);
   ray_status[tid] = st;
   if (st > 0) atomicAdd(step_counter, 1ull);
 }
 
 extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const void *disk, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
-                                      unsigned long long *step_counter, int nvals, int nextra, int bbpol) {
+                                      unsigned long long *step_counter, int nvals, int nextra, int bbpol, const long long *rng, int nrng) {
   hipLaunchKernelGGL(grt_disk_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, *(const GrtDisk *)disk, i1, nrays, nfreq, freqs, pixvals,
-                     ray_status, step_counter, nvals, nextra, bbpol);
+                     ray_status, step_counter, nvals, nextra, bbpol, rng, nrng);
   return hipGetLastError();
 }
 extern "C" size_t grt_sizeof_disk(void) { return sizeof(GrtDisk); }
@@ -784,13 +797,14 @@ extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *o
 extern "C" size_t grt_sizeof_realray(void) { return GRT_RR_STRIDE; }
 
 extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long long i1, int nrays, GrtRay *rays,
-                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin) {
+                                       int *ray_npts, int *live, int *counters, void *rrays, int need_time, const GrtRayIn *rin,
+                                       const long long *rng, int nrng) {
   int blocks = (nrays + 255) / 256;
   // GRT_POLAR_L2: experiment knob for the near-polar routing threshold (tools/polar_phi.py); the default is the product's
   static const double polar_l2 = std::getenv("GRT_POLAR_L2") ? std::atof(std::getenv("GRT_POLAR_L2")) : GRT_POLAR_L2_DEFAULT;
   GrtRayIn none{};
   hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
-                     (char *)rrays, need_time, polar_l2, rin ? *rin : none);
+                     (char *)rrays, need_time, polar_l2, rin ? *rin : none, rng, nrng);
   return hipGetLastError();
 }
 
@@ -807,11 +821,18 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   // the time field needs the azimuth integrals anyway (Eq. 47 shares them), so NPH = 3 also when phi is not stored
   const int nph = (tfield >= 0) ? 3 : ((nfields > GRT_F_PHI) ? 2 : 0);
   const int kind = !fast ? 0 : (cam->a == 0.0 ? 2 : 1);
+  // a Schwarzschild camera that needs the coordinate time has no fast class (grt_setup_kernel: `cubic` requires !(need_time & 1)):
+  // its fast-class launch has nothing to do
+  if (kind == 2 && nph == 3) return hipSuccess;
+  bool launched = false;
 #define GRT_GEO_CASE(F, P)                                                                                              \
-  if (kind == F && nph == P)                                                                                            \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw);
+  if (kind == F && nph == P) {                                                                                          \
+    launched = true;                                                                                                    \
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw); \
+  }
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE
+  if (!launched) return hipErrorInvalidValue;      // no instantiation for this (class, output) pair: never skip rays silently
   return hipGetLastError();
 }
 

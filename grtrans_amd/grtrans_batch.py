@@ -142,17 +142,55 @@ def read_fits(path):
 
 def _rank_envs(ngpus, tile_cols, base):
     """Environment of rank r = 0..ngpus-1 of a one-process-per-GPU run (read by module pgrtrans, pgrtrans.f90)."""
+    import secrets
     import tempfile
     fd, comm = tempfile.mkstemp(prefix="grtrans_amd_comm_")
     os.close(fd)
-    os.remove(comm)             # rank 0 creates it (grt_comm_init_file)
+    os.remove(comm)             # rank 0 creates it (grt_comm_init_file) and removes it once every rank has joined
+    nonce = secrets.token_hex(16)   # the ranks accept a rendezvous file only with this run's nonce inside
     envs = []
     for r in range(ngpus):
         e = dict(base)
-        e.update(GRT_RANK=str(r), GRT_WORLD_SIZE=str(ngpus), GRT_LOCAL_RANK=str(r), GRT_COMM_FILE=comm, GRT_TILE_COLS=str(int(tile_cols)))
+        e.update(GRT_RANK=str(r), GRT_WORLD_SIZE=str(ngpus), GRT_LOCAL_RANK=str(r), GRT_COMM_FILE=comm, GRT_COMM_NONCE=nonce,
+                 GRT_TILE_COLS=str(int(tile_cols)))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         envs.append(e)
     return envs
+
+
+def _wait_ranks(procs, grace=30.0, poll=0.2):
+    """Wait for the rank processes.  RCCL calls have no timeout: when one rank dies the others would wait for it for ever, so the
+    first non-zero exit starts a bounded grace period (the ranks normally leave together through the error flag their
+    collectives carry) after which what is left is terminated, then killed.  Returns the exit codes."""
+    import time
+    t_fail = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            return rcs
+        if t_fail is None and any(rc not in (None, 0) for rc in rcs):
+            t_fail = time.time()
+        if t_fail is not None and time.time() - t_fail > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t1 = time.time()
+            while time.time() - t1 < 10.0 and any(p.poll() is None for p in procs):
+                time.sleep(poll)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            return [p.wait() for p in procs]
+        time.sleep(poll)
+
+
+def _remove_quietly(*paths):
+    for q in paths:
+        try:
+            if q:
+                os.remove(q)
+        except OSError:
+            pass
 
 
 class grtrans:
@@ -180,9 +218,16 @@ class grtrans:
             subprocess.check_call([exe or HOST_EXE], env=env)
             return
         procs = []
-        for r, e in enumerate(_rank_envs(ngpus, tile_cols, env)):
-            procs.append(subprocess.Popen([exe or HOST_EXE], env=e, stdout=None if r == 0 else subprocess.DEVNULL))
-        rcs = [p.wait() for p in procs]
+        envs = _rank_envs(ngpus, tile_cols, env)
+        try:
+            for r, e in enumerate(envs):
+                procs.append(subprocess.Popen([exe or HOST_EXE], env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+            rcs = _wait_ranks(procs)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            _remove_quietly(envs[0]["GRT_COMM_FILE"], envs[0]["GRT_COMM_FILE"] + ".tmp")
         if any(rcs):
             raise capi.GrtError("grtrans ranks exited with %s" % rcs)
 
@@ -197,30 +242,62 @@ class grtrans:
             print('ERROR in run_pgrtrans: data already exist!')
             return
         self.inputs = grtrans_inputs(**kwargs)
-        procs, saved = [], {}
+        procs, saved, tmpfiles = [], {}, []
+        watchdog_stop = None
         if ngpus > 1:
             import pickle
             import sys
             import tempfile
+            import threading
             envs = _rank_envs(ngpus, tile_cols, dict(os.environ))
             job = tempfile.NamedTemporaryFile(prefix="grt_job_", suffix=".pkl", delete=False)
             pickle.dump(kwargs, job)
             job.close()
+            tmpfiles = [job.name, envs[0]["GRT_COMM_FILE"], envs[0]["GRT_COMM_FILE"] + ".tmp"]
             for r in range(1, ngpus):
                 procs.append(subprocess.Popen([sys.executable, "-m", "grtrans_amd.rank_worker", job.name], env=envs[r],
                                               cwd=os.getcwd(), stdout=subprocess.DEVNULL))
-            for k in ("GRT_RANK", "GRT_WORLD_SIZE", "GRT_LOCAL_RANK", "GRT_COMM_FILE", "GRT_TILE_COLS"):
+            for k in ("GRT_RANK", "GRT_WORLD_SIZE", "GRT_LOCAL_RANK", "GRT_COMM_FILE", "GRT_COMM_NONCE", "GRT_TILE_COLS"):
                 saved[k] = os.environ.get(k)
                 os.environ[k] = envs[0][k]
+            # This process is rank 0 and sits inside the Fortran call: if a child rank dies without reaching the error-flag
+            # exchange (a crash), rank 0 would wait in an RCCL call for ever.  The watchdog gives the orderly path a grace period,
+            # then ends the job instead of hanging the session.
+            watchdog_stop = threading.Event()
+
+            def watchdog(grace=float(os.environ.get("GRT_RANK_GRACE", "60"))):
+                import time
+                t_fail = None
+                while not watchdog_stop.wait(0.5):
+                    if t_fail is None and any(p.poll() not in (None, 0) for p in procs):
+                        t_fail = time.time()
+                    if t_fail is not None and time.time() - t_fail > grace:
+                        sys.stderr.write("grtrans_amd: a rank process died (%s) and rank 0 is still waiting for it after %.0f s: "
+                                         "ending the job\n" % ([p.poll() for p in procs], grace))
+                        for p in procs:
+                            if p.poll() is None:
+                                p.kill()
+                        _remove_quietly(*tmpfiles)
+                        os._exit(70)
+            threading.Thread(target=watchdog, daemon=True).start()
+        failed = True
         try:
             self._call_grtrans_main(pgrtrans)
+            failed = False
         finally:
+            if watchdog_stop is not None:
+                watchdog_stop.set()
             for k, v in saved.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-            rcs = [p.wait() for p in procs]
+            if failed:          # rank 0 raised: the children are of no use any more
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+            rcs = _wait_ranks(procs, grace=10.0) if procs else []
+            _remove_quietly(*tmpfiles)
         if any(rcs):
             raise capi.GrtError("pgrtrans ranks exited with %s" % rcs)
         self.ivals = pgrtrans.ivals.copy()

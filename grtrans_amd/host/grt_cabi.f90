@@ -211,6 +211,21 @@ module grt_cabi
        type(grt_stats), intent(out) :: st
        integer(c_int) :: rc
      end function grt_trace_tile
+     ! the same loop over several pixel ranges in one set of launches (a rank's column tiles); output rows follow the ranges
+     function grt_trace_ranges(cam, nranges, lo, hi, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, pixvals, pixloc, &
+          ray_status, st) bind(C, name='grt_trace_ranges') result(rc)
+       import :: c_int, c_int64_t, c_double, c_float, c_int32_t, grt_camera, grt_emis, grt_stats
+       type(grt_camera), intent(in) :: cam
+       integer(c_int), value :: nranges
+       integer(c_int64_t), intent(in) :: lo(*), hi(*)
+       integer(c_int), value :: fluid_model, nfreq, iflag, nvals, nextra
+       type(grt_emis), intent(in) :: em
+       real(c_double), intent(in) :: freqs(*)
+       real(c_float), intent(out) :: pixvals(*), pixloc(*)
+       integer(c_int32_t), intent(out) :: ray_status(*)
+       type(grt_stats), intent(out) :: st
+       integer(c_int) :: rc
+     end function grt_trace_ranges
   end interface
 
 contains

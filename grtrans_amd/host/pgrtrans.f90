@@ -19,6 +19,10 @@ module pgrtrans
   integer, save :: last_error = 0
   character(len=512), save :: last_error_msg = ' '
   logical, save :: soft_errors = .false.
+  ! multi-rank runs: a rank that fails must not stop on its own (the others would wait for it in the next RCCL call for ever):
+  ! die/die_rc only record the error, every collective of this module carries the error flag (sync_ranks), and all ranks leave
+  ! together; the process then stops with the error code unless soft errors are on
+  logical, save :: defer_stop = .false.
   ! HARM time-stepping state (module variables of fluid_model_harm.f90:12-16)
   integer, save :: cur_fluid = 0, harm_indf = 0, harm_nt = 1
   real, save :: harm_tstep = 20., harm_toffset = 0.
@@ -61,11 +65,12 @@ contains
     ! one process per GPU: rank, world size, the pixel ranges of this rank (and, on the root, of every rank)
     integer :: rank, world, local_rank, tilecols, nrng, g, p, nv, force_comm
     integer, allocatable :: rlo(:), rhi(:), plo(:), phi_(:)
+    integer(c_int64_t), allocatable :: rlo64(:), rhi64(:)
     integer(c_int64_t), allocatable :: npix_of_rank(:)
     integer(c_int64_t) :: npix_rank, off, pre
     real(8) :: red(2)
     real(8), allocatable :: alpha_all(:), beta_all(:)
-    logical :: multi
+    logical :: multi, failed
     type(grt_camera) :: cam
     type(grt_emis) :: em
     type(grt_stats) :: st
@@ -178,11 +183,31 @@ contains
     rc = grt_init(int(dev, c_int)); if (rc /= 0) then
        call die_rc('grt_init', rc); goto 999
     end if
+    if (multi) then
+       ! The communicator comes FIRST: from here on a failure of one rank reaches the others through the error flag every
+       ! collective carries.  Rendezvous file: GRT_COMM_FILE (the Python launchers make a fresh name per run), else a per-user
+       ! name keyed by MASTER_PORT; the run nonce inside it (GRT_COMM_NONCE or the launcher's pid) keeps a file left by a crashed
+       ! run from being joined, and rank 0 removes the file once every rank has joined.
+       call get_environment_variable('GRT_COMM_FILE', path)
+       if (len_trim(path) == 0) then
+          call get_environment_variable('MASTER_PORT', path)
+          if (len_trim(path) == 0 .and. world > 1) then
+             call die('multi-rank run without GRT_COMM_FILE or MASTER_PORT: no rendezvous for the communicator id'); goto 999
+          end if
+          call get_environment_variable('USER', datadir)
+          path = '/tmp/grtrans_amd_comm_'//trim(datadir)//'_'//trim(path)
+       end if
+       rc = grt_comm_init_file(int(rank, c_int), int(world, c_int), cstr(trim(path)), dble(env_int('GRT_COMM_TIMEOUT', 600)))
+       if (rc /= 0) then
+          call die_rc('grt_comm_init_file '//trim(path), rc); goto 999
+       end if
+       defer_stop = .true.
+    end if
     call get_environment_variable('GRTRANS_AMD_DATA', datadir)
     if (len_trim(datadir) == 0) datadir = '.'
     path = trim(datadir)//'/polsynchpl_tables.bin'
     rc = grt_load_polsynchpl_tables_file(cstr(path)); if (rc /= 0) then
-       call die_rc('grt_load_polsynchpl_tables_file '//trim(path), rc); goto 999
+       call die_rc('grt_load_polsynchpl_tables_file '//trim(path), rc); goto 810
     end if
     if (fluid_id == GRT_FLUID_FFJET) then
        path = trim(fdfile)              ! as load_fluid_model does (fluid.f90:226-228)
@@ -192,23 +217,23 @@ contains
           rc = grt_load_ffjet_file(cstr(path))
        end if
        if (rc /= 0) then
-          call die_rc('grt_load_ffjet_file '//trim(fdfile), rc); goto 999
+          call die_rc('grt_load_ffjet_file '//trim(fdfile), rc); goto 810
        end if
     else if (fluid_id == GRT_FLUID_HARM) then
        ! initialize_harm_model(a,ifile,fdfile,fhfile,fnt,findf), fluid.f90:193-194
        ! fnt > 1: that many time slices are loaded and each point reads the one its look-back time selects (slow light)
        if (fnt > 1 .and. extra /= 0) then
-          call die('extra=1 with several HARM slices (fnt > 1) is not supported'); goto 999
+          call die('extra=1 with several HARM slices (fnt > 1) is not supported'); goto 810
        end if
        rc = grt_load_harm_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(fnt, c_int), spin)
        if (rc /= 0) then
-          call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+          call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 810
        end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = fnt
        ! tstep = t(1)-t(2) of the loaded dumps when fnt > 1, the module default 20. otherwise (fluid_model_harm.f90:493-500)
        rc = grt_get_harm_tstep(harm_tstep); if (rc /= 0) then
-          call die_rc('grt_get_harm_tstep', rc); goto 999
+          call die_rc('grt_get_harm_tstep', rc); goto 810
        end if
     else if (fluid_id == GRT_FLUID_HARM3D) then
        harm_tstep = 20.
@@ -216,11 +241,11 @@ contains
        if (fnt /= 1 .or. nload /= 1) then
           ! read_harm3d_data_file never assigns the dump time on its binary branch (fluid_model_harm3d.f90:383, 402-449): the
           ! reference's tstep is whatever the stack held ("WARNING -- Time step changes over dumps!")
-          call die('HARM3D with several loaded slices (fnt, nload > 1): undefined in the reference (dump time never read), refused'); goto 999
+          call die('HARM3D with several loaded slices (fnt, nload > 1): undefined in the reference (dump time never read), refused'); goto 810
        end if
        rc = grt_load_harm3d_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) then
-          call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+          call die_rc('grt_load_harm3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 810
        end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
@@ -228,35 +253,35 @@ contains
        ! initialize_koral3d_model(a,ifile,.false.,fdfile,fhfile,fnt,findf,fscalefac,...), fluid.f90:205-210.  fnt > 1: that many
        ! slices are loaded and each point reads the one its look-back time selects (fluid_model_koral3d.f90:126-128, 212-228)
        if (fnt > 1 .and. extra /= 0) then
-          call die('extra=1 with several KORAL3D slices (fnt > 1) is not supported'); goto 999
+          call die('extra=1 with several KORAL3D slices (fnt > 1) is not supported'); goto 810
        end if
        rc = grt_load_koral3d_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(max(fnt, 1), c_int), spin, fscalefac)
        if (rc /= 0) then
-          call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+          call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 810
        end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = max(fnt, 1); harm_scalefac = fscalefac
        ! tstep = t(1)-t(2) of the loaded dumps when fnt > 1, the module default 20. otherwise (fluid_model_koral3d.f90:23, 617-619)
        rc = grt_get_koral3d_tstep(harm_tstep); if (rc /= 0) then
-          call die_rc('grt_get_koral3d_tstep', rc); goto 999
+          call die_rc('grt_get_koral3d_tstep', rc); goto 810
        end if
     else if (fluid_id == GRT_FLUID_IHARM) then
        harm_tstep = 20.
        ! initialize_iharm_model(a,ifile,fdfile,fhfile,fgfile,fnt,findf), fluid.f90:199-200; one loaded slice, metric 0
        if (fnt /= 1 .or. nload /= 1) then
           ! load_iharm_data stores the HEADER's time for every slice (fluid_model_iharm.f90:745): tstep = t(1)-t(2) = 0 (:778)
-          call die('IHARM with several loaded slices (fnt, nload > 1): undefined in the reference (tstep = 0), refused'); goto 999
+          call die('IHARM with several loaded slices (fnt, nload > 1): undefined in the reference (tstep = 0), refused'); goto 810
        end if
        rc = grt_load_iharm_files(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), spin)
        if (rc /= 0) then
-          call die_rc('grt_load_iharm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 999
+          call die_rc('grt_load_iharm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 810
        end if
        harm_dfile = fdfile; harm_hfile = fhfile; harm_indf = findf; harm_spin = spin; harm_toffset = 0.
        harm_nt = 1
     else if (fluid_id == GRT_FLUID_THINDISK) then
        ! init_thindisk(real(a),ifile,real(fargs%mdot),real(fargs%mbh),real(fargs%rin),real(fargs%rout)), fluid.f90:226-227
        rc = grt_set_thindisk(fmdot, frin, frout); if (rc /= 0) then
-          call die_rc('grt_set_thindisk', rc); goto 999
+          call die_rc('grt_set_thindisk', rc); goto 810
        end if
        if (nup == 1 .and. nvals == 4) then
           ! load_chandra_tab24 (pgrtrans.f90:154): ch24_vals.txt from the working directory, as the reference; else the shipped copy
@@ -266,14 +291,14 @@ contains
              rc = grt_load_chandra_file(cstr(path))
           end if
           if (rc /= 0) then
-             call die_rc('grt_load_chandra_file ch24_vals.txt', rc); goto 999
+             call die_rc('grt_load_chandra_file ch24_vals.txt', rc); goto 810
           end if
        end if
     else if (fluid_id == GRT_FLUID_SPHACC) then
        ! the reference holds these tables as DATA statements (fluid_model_sphacc.f90:40-448)
        path = trim(datadir)//'/sphacc_tables.bin'
        rc = grt_load_sphacc_tables_file(cstr(path)); if (rc /= 0) then
-          call die_rc('grt_load_sphacc_tables_file '//trim(path), rc); goto 999
+          call die_rc('grt_load_sphacc_tables_file '//trim(path), rc); goto 810
        end if
     end if
 
@@ -284,36 +309,37 @@ contains
     ! this rank's pixel ranges (one range = one grt_trace_tile call); with one process it is i1..i2 itself
     call pixel_ranges(rank, world, i1, i2, nphi, tilecols, nrng, rlo, rhi)
     npix_rank = 0
-    ntile = 1
+    allocate(rlo64(max(nrng, 1)), rhi64(max(nrng, 1)))
     do g = 1, nrng
        npix_rank = npix_rank + (rhi(g) - rlo(g) + 1)
-       ntile = max(ntile, rhi(g) - rlo(g) + 1)
+       rlo64(g) = rlo(g); rhi64(g) = rhi(g)
     end do
+    ntile = int(max(npix_rank, 1_c_int64_t))
     if (multi) then
-       call get_environment_variable('GRT_COMM_FILE', path)
-       if (len_trim(path) == 0) then
-          call get_environment_variable('MASTER_PORT', path)
-          path = '/tmp/grtrans_amd_comm_'//trim(path)
-       end if
-       rc = grt_comm_init_file(int(rank, c_int), int(world, c_int), cstr(trim(path)), 600d0)
-       if (rc /= 0) then
-          call die_rc('grt_comm_init_file '//trim(path), rc); goto 999
-       end if
        rc = grt_stage_reset(int(ncams, c_int), int(nv, c_int), npix_rank); if (rc /= 0) then
-          call die_rc('grt_stage_reset', rc); goto 999
+          call die_rc('grt_stage_reset', rc)
        end if
+    end if
+    ! ---- sync point: every rank arrives here whether its loading phase failed or not; all leave together on any failure ----
+810 continue
+    if (multi) then
+       red(1) = 0d0
+       call sync_ranks(red(1), failed)
+       if (failed) goto 999
+    else if (last_error /= 0) then
+       goto 999
     end if
     allocate(pixvals(int(nv,8)*ntile*nfreq), pixloc(2*ntile), status(ntile))
     last_ray_steps = 0d0; last_kernel_ms = 0d0
     do j = 1, nmu
        rc = grt_make_camera(cam, int(standard, c_int), gridvals, int(nn, c_int), spin, mu0(j), uout, phi0)
        if (rc /= 0) then
-          call die_rc('grt_make_camera', rc); goto 999
+          call die_rc('grt_make_camera', rc); goto 820
        end if
        if (nrotype == 1) then
           rc = grt_set_camera_polar(cam, rcut)
           if (rc /= 0) then
-             call die_rc('grt_set_camera_polar', rc); goto 999
+             call die_rc('grt_set_camera_polar', rc); goto 820
           end if
        end if
        if (nload > 1) then
@@ -326,16 +352,15 @@ contains
           do g = 1, nrng
              rc = grt_compute_t0(cam, int(rlo(g), c_int64_t), int(rhi(g), c_int64_t), t0tab(off+1:))
              if (rc /= 0) then
-                call die_rc('grt_compute_t0', rc); goto 999
+                call die_rc('grt_compute_t0', rc); goto 820
              end if
              off = off + (rhi(g) - rlo(g) + 1)
           end do
           red(1) = -huge(1d0)
           if (npix_rank > 0) red(1) = maxval(t0tab(1:npix_rank))
           if (multi) then
-             rc = grt_comm_allreduce(red, 1_c_int, 1_c_int); if (rc /= 0) then
-                call die_rc('grt_comm_allreduce', rc); goto 999
-             end if
+             call sync_ranks(red(1), failed)
+             if (failed) goto 999
           end if
           where (t0tab > 0.)
              t0tab = t0tab - red(1)
@@ -345,9 +370,8 @@ contains
           red(1) = -huge(1d0)
           if (npix_rank > 0) red(1) = -minval(t0tab(1:npix_rank))
           if (multi) then
-             rc = grt_comm_allreduce(red, 1_c_int, 1_c_int); if (rc /= 0) then
-                call die_rc('grt_comm_allreduce', rc); goto 999
-             end if
+             call sync_ranks(red(1), failed)
+             if (failed) goto 999
           end if
           t0tab = t0tab + red(1)
        end if
@@ -355,55 +379,68 @@ contains
        do l = 1, nt
           if (l > 1) then
              call advance_fluid_timestep(dt)             ! pgrtrans.f90:211 (after frame l-1)
-             if (last_error /= 0) goto 999
+             if (last_error /= 0) goto 820
           end if
-          off = 0
-          do g = 1, nrng
-             ntile = rhi(g) - rlo(g) + 1
+          ! every range of this rank in ONE call (grt_trace_ranges): one set of launches fills the GPU where a call per column
+          ! tile would not; the rows of pixvals follow the ranges in order, like the rank-level image the gather sends
+          if (nrng > 0) then
              if (nload > 1) then
-                rc = grt_set_t0(t0tab(off+1:), int(ntile, c_int64_t)); if (rc /= 0) then
-                   call die_rc('grt_set_t0', rc); goto 999
+                rc = grt_set_t0(t0tab, npix_rank); if (rc /= 0) then
+                   call die_rc('grt_set_t0', rc); goto 820
                 end if
              end if
              ! one geodesic serves every m = 1..nmdot (grtrans_driver.f90:134): after the first mdot the library re-uses the
-             ! resident geodesic record of this camera and range and launches only the transfer kernels
+             ! resident geodesic record of this camera and these ranges and launches only the transfer kernels
              do m = 1, nmdot
                 em%mbh = mbh; em%nfac = ftscl; em%bfac = frscl          ! pgrtrans.f90:125-128
                 em%gmin = dble(real(gmin)); em%gmax = dble(real(gmax)); em%p1 = dble(real(p1))  ! emis.f90:32-39
                 em%muval = muval; em%etype = emis_id; em%coefindx = epcoefindx
                 if (nepotherargs < 2 .or. nepotherargs > 8) then
-                   call die('epotherargs = (delta, 1..7 weights)'); goto 999
+                   call die('epotherargs = (delta, 1..7 weights)'); goto 820
                 end if
                 em%nother = nepotherargs; em%otherargs = 0d0; em%otherargs(1:nepotherargs) = epotherargs   ! pgrtrans.f90:119-120
                 em%jetalpha = jetalpha; em%sigcut = sigcut               ! sparams%jetalphaval, %sigcut (pgrtrans.f90:129-136)
                 em%mdot = mdots(m); em%gminval = gmin                   ! sparams%mdot, %gminval (pgrtrans.f90:127-131)
-                rc = grt_trace_tile(cam, int(rlo(g), c_int64_t), int(rhi(g), c_int64_t), fluid_id, em, int(nfreq, c_int), freqs, &
+                rc = grt_trace_ranges(cam, int(nrng, c_int), rlo64, rhi64, fluid_id, em, int(nfreq, c_int), freqs, &
                      int(iflag, c_int), int(nvals, c_int), int(nextra, c_int), pixvals, pixloc, status, st)
                 if (rc /= 0) then
-                   call die_rc('grt_trace_tile', rc); goto 999
+                   call die_rc('grt_trace_ranges', rc); goto 820
                 end if
                 last_ray_steps = last_ray_steps + dble(st%ray_steps); last_kernel_ms = last_kernel_ms + st%ms_total
                 ! camera index (l-1)*nfreq*nparams+(m-1)*nfreq+k with l -> (j-1)*nt+l (grtrans_driver.f90:324)
                 cam_index = ((j-1)*nt + l - 1)*nfreq*nmdot + (m-1)*nfreq
                 if (multi) then
-                   ! the tile stays in HBM: device-to-device into this rank's image, gathered once at the end
-                   rc = grt_stage_resident(int(cam_index, c_int), int(nfreq, c_int), int(ntile, c_int64_t), off)
+                   ! the rank's pixels stay in HBM: device-to-device into this rank's image, gathered once at the end
+                   rc = grt_stage_resident(int(cam_index, c_int), int(nfreq, c_int), npix_rank, 0_c_int64_t)
                    if (rc /= 0) then
-                      call die_rc('grt_stage_resident', rc); goto 999
+                      call die_rc('grt_stage_resident', rc); goto 820
                    end if
                 else
-                   do k = 1, nfreq
-                      ivals(:, rlo(g):rhi(g), cam_index + k) = reshape(dble(pixvals((k-1)*int(nv,8)*ntile+1 : &
-                           k*int(nv,8)*ntile)), (/nv, ntile/))
+                   off = 0
+                   do g = 1, nrng
+                      ntile = rhi(g) - rlo(g) + 1
+                      do k = 1, nfreq
+                         ivals(:, rlo(g):rhi(g), cam_index + k) = reshape(dble(pixvals(((k-1)*npix_rank + off)*nv + 1 : &
+                              ((k-1)*npix_rank + off + ntile)*nv)), (/nv, ntile/))
+                      end do
+                      off = off + ntile
                    end do
                 end if
              end do
-             off = off + ntile
-          end do
+          end if
        end do
        if (allocated(t0tab)) deallocate(t0tab)
        if (rank == 0) write(6,*) 'grtrans wall time elapsed: ', omp_get_wtime() - wtime
     end do
+    ! ---- sync point: end of the trace phase; no rank enters the gather unless every rank has its image ----
+820 continue
+    if (multi) then
+       red(1) = 0d0
+       call sync_ranks(red(1), failed)
+       if (failed) goto 999
+    else if (last_error /= 0) then
+       goto 999
+    end if
     ! ---- assembly of ivals on rank 0 (pgrtrans.f90:221-242): one RCCL gather of the ranks' fp32 images over xGMI ----
     if (multi) then
        allocate(npix_of_rank(world))
@@ -523,7 +560,37 @@ contains
     call del_pgrtrans_data()
     rc = grt_comm_free()
     rc = grt_free()
+    if (defer_stop) then
+       defer_stop = .false.
+       if (.not. soft_errors) then
+          if (last_error == 2) error stop 2
+          error stop 3
+       end if
+    end if
   end subroutine grtrans_main
+
+  ! max over the ranks of x, and of the "this rank has failed" flag: every collective of the host carries the flag, so that a
+  ! rank that failed (its die/die_rc only recorded the error) and the ranks that did not leave grtrans_main together.
+  subroutine sync_ranks(x, failed)
+    use grt_cabi
+    real(8), intent(inout) :: x
+    logical, intent(out) :: failed
+    real(8) :: r2(2)
+    integer :: rc
+    r2(1) = x; r2(2) = merge(1d0, 0d0, last_error /= 0)
+    rc = grt_comm_allreduce(r2, 2_c_int, 1_c_int)
+    if (rc /= 0) then
+       call die_rc('grt_comm_allreduce', rc)
+       failed = .true.
+       return
+    end if
+    x = r2(1)
+    failed = r2(2) > 0d0
+    if (failed .and. last_error == 0) then
+       last_error = 4; last_error_msg = 'another rank failed'
+       write(0,*) 'grtrans_amd: another rank failed, leaving with it'
+    end if
+  end subroutine sync_ranks
 
   ! Binary camera file, one block per camera: the record structure of camera.f90:321-340
   ! (nx,ny,nvals / nkey / nkey x real(4) records / pixloc / pixvals), Fortran sequential unformatted.
@@ -661,7 +728,7 @@ contains
   subroutine die(msg)
     character(len=*), intent(in) :: msg
     write(0,*) 'grtrans_amd: ', trim(msg)
-    if (soft_errors) then
+    if (soft_errors .or. defer_stop) then
        last_error = 2; last_error_msg = msg
        return
     end if
@@ -672,7 +739,7 @@ contains
     character(len=*), intent(in) :: what
     integer, intent(in) :: rc
     write(0,*) 'grtrans_amd: ', trim(what), ' failed, code ', rc
-    if (soft_errors) then
+    if (soft_errors .or. defer_stop) then
        last_error = 3
        write(last_error_msg, '(a,a,i0)') trim(what), ' failed, code ', rc
        return

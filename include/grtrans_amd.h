@@ -226,6 +226,18 @@ int grt_trace_tile(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_mode
                    const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
                    int32_t *ray_status, grt_stats *st);
 
+/* The same loop over SEVERAL pixel ranges in one set of launches: what one rank of a multi-GPU run owns when the image is
+ * shared out in column tiles (the reference has one range, read_inputs.f90:8-9; a rank's share is a list of such ranges).
+ *   lo,hi     nranges inclusive 1-based ranges, reference semantics each; rows of pixvals / pixloc / ray_status follow the
+ *             ranges in call order: [nfreq][sum(hi-lo+1)][nvals+nextra] etc.
+ * One launch fills the GPU where nranges separate grt_trace_tile calls of a few thousand rays each would not (the transfer
+ * kernel maps one ray to a lane: 131072 rays are one resident round of an MI355X).  grt_trace_tile is the nranges = 1 case. */
+int grt_trace_ranges(const grt_camera *cam, int nranges, const int64_t *lo, const int64_t *hi, int fluid_model, const grt_emis *em,
+                     int nfreq, const double *freqs, int iflag, int nvals, int nextra, float *pixvals, float *pixloc,
+                     int32_t *ray_status, grt_stats *st);
+int grt_trace_ranges_resident(const grt_camera *cam, int nranges, const int64_t *lo, const int64_t *hi, int fluid_model,
+                              const grt_emis *em, int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st);
+
 /* Same work, results left in HBM (bench / multi-GPU gather): device pointers valid until the next call. */
 int grt_trace_tile_resident(const grt_camera *cam, int64_t i1, int64_t i2, int fluid_model, const grt_emis *em,
                             int nfreq, const double *freqs, int iflag, int nvals, int nextra, grt_stats *st);

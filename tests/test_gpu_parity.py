@@ -51,14 +51,41 @@ def run(nn, iname, i1=None, i2=None, freqs=(FREQ,)):
     return capi.trace_tile(cam, i1, i2, "FFJET", em, list(freqs), iname)
 
 
-def stokes_err(pix, ref):
+def parity_stats(pix, ref, floor=1e-6):
+    """Sharper statements than "of the image peak" about two fp32 Stokes images: the fraction of values that are the SAME BITS,
+    and over the values above `floor` of their Stokes parameter's peak (a pixel at 1e-4 of the peak must not be 2 % wrong
+    unnoticed) the largest distance in fp32 units in the last place and the largest relative error."""
+    a = np.ascontiguousarray(pix, dtype=np.float32).reshape(-1, pix.shape[-1])
+    b = np.ascontiguousarray(ref, dtype=np.float32).reshape(-1, ref.shape[-1])
+    same = float(((a.view(np.int32) == b.view(np.int32)) | ((a == 0) & (b == 0))).mean())
+
+    def ordered(x):      # fp32 bit patterns as integers that order like the floats
+        i = x.view(np.int32).astype(np.int64)
+        return np.where(i < 0, -(i & 0x7fffffff), i)
+    peak = np.abs(b.astype(float)).max(axis=0)
+    sig = np.abs(b.astype(float)) > floor * peak
+    fin = np.isfinite(a) & np.isfinite(b) & sig
+    ulp = int(np.abs(ordered(a) - ordered(b))[fin].max()) if fin.any() else 0
+    rel = float((np.abs(a.astype(float) - b.astype(float))[fin] / np.abs(b.astype(float))[fin]).max()) if fin.any() else 0.0
+    return dict(bit_identical=same, max_ulp=ulp, max_rel=rel, n_sig=int(fin.sum()))
+
+
+def stokes_err(pix, ref, min_identical=None, max_rel=None):
+    """max |device - reference| per Stokes parameter over its image peak; with min_identical / max_rel also asserts the
+    sharper statements of parity_stats (floors set from the values measured on MI355X, printed in DESIGN.md 6)."""
+    ps = parity_stats(pix, ref)
     ref = ref.astype(float)
     peak = np.abs(ref).reshape(-1, ref.shape[-1]).max(axis=0)
     e = (np.abs(pix.astype(float) - ref).reshape(-1, ref.shape[-1]).max(axis=0) / peak).max()
     if os.environ.get("GRT_TEST_ERRLOG"):      # measured margins, for setting the bars (tools/, DESIGN.md)
         import inspect
         with open(os.environ["GRT_TEST_ERRLOG"], "a") as f:
-            f.write("%d %s %.3e\n" % (inspect.stack()[1].lineno, inspect.stack()[1].function, e))
+            f.write("%d %s %.3e identical=%.5f max_ulp=%d max_rel=%.3e n_sig=%d\n" % (inspect.stack()[1].lineno, inspect.stack()[1].function, e,
+                                                                                  ps["bit_identical"], ps["max_ulp"], ps["max_rel"], ps["n_sig"]))
+    if min_identical is not None:
+        assert ps["bit_identical"] >= min_identical, ps
+    if max_rel is not None:
+        assert ps["max_rel"] <= max_rel, ps
     return e
 
 
@@ -119,6 +146,56 @@ def test_tiles_equal_full_image(dev):
     b, _, sb, _ = run(nn, "formal", 301, 1024)
     assert np.array_equal(np.concatenate([a, b], axis=1), full)
     assert np.array_equal(np.concatenate([sa, sb]), sfull)
+
+
+def test_trace_ranges_one_launch_equals_per_range_calls(dev, monkeypatch):
+    # grt_trace_ranges: several pixel ranges (a rank's column tiles, ragged ends) in ONE set of launches give exactly the rows
+    # that one grt_trace_tile call per range gives, in range order -- image, status, ray-steps, per-step record; also under the
+    # multi-pass memory cap, with two frequencies, and with the resident geodesic record re-used for the next parameter set
+    from grtrans_amd import capi, tiling
+    nn = (40, 24, 100)
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    rng = tiling.ranges(1, 3, 7, nn[0] * nn[1] - 5, nn[1], 3)          # rank 1 of 3, tiles of 3 columns, i1 = 7, i2 = npix - 5
+    assert len(rng) >= 4
+    for iname, freqs in (("formal", [FREQ]), ("delo", [2.3e11, FREQ])):
+        parts = [capi.trace_tile(cam, a, b, "FFJET", em, freqs, iname) for (a, b) in rng]
+        pix, loc, status, st = capi.trace_ranges(cam, rng, "FFJET", em, freqs, iname)
+        assert np.array_equal(pix, np.concatenate([p[0] for p in parts], axis=1))
+        assert np.array_equal(loc, np.concatenate([p[1] for p in parts], axis=0))
+        assert np.array_equal(status, np.concatenate([p[2] for p in parts]))
+        assert st.ray_steps == sum(p[3].ray_steps for p in parts)
+        monkeypatch.setenv("GRT_MAX_WORK_BYTES", str(1024 * 1024))
+        pix2, _, status2, st2 = capi.trace_ranges(cam, rng, "FFJET", em, freqs, iname)
+        monkeypatch.delenv("GRT_MAX_WORK_BYTES")
+        assert np.array_equal(pix2, pix) and np.array_equal(status2, status) and st2.ray_steps == st.ray_steps
+    # per-step record: local ray j of the call is ray j of the record
+    capi.record_steps(True)
+    pix, _, status, _ = capi.trace_ranges(cam, rng, "FFJET", em, [FREQ], "formal")
+    j = int(np.argmax(status > 0)); n = int(status[j])
+    rec = capi.download_steps(j, 1, cam.nup + cam.next)[:, 0, :n]
+    off = 0
+    for (a, b) in rng:
+        if j < off + b - a + 1:
+            pixel = a + j - off
+            break
+        off += b - a + 1
+    capi.trace_tile(cam, pixel, pixel, "FFJET", em, [FREQ], "formal")
+    one = capi.download_steps(0, 1, cam.nup + cam.next)[:, 0, :n]
+    assert np.array_equal(rec, one)
+    capi.record_steps(False)
+    # resident geodesics: same camera + same ranges -> only the transfer kernels run; other ranges -> geodesics again
+    capi.geo_reuse(True)
+    p0 = capi.lib().grt_geo_passes()
+    a1 = capi.trace_ranges(cam, rng, "FFJET", em, [FREQ], "formal")[0]
+    p1 = capi.lib().grt_geo_passes()
+    em2 = capi.make_emis("POLSYNCHPL", 3.4e9, 4.0, 70.0, 100., 1e5, 3.5)
+    a2 = capi.trace_ranges(cam, rng, "FFJET", em2, [FREQ], "formal")[0]
+    p2 = capi.lib().grt_geo_passes()
+    a3 = capi.trace_ranges(cam, rng[:-1], "FFJET", em2, [FREQ], "formal")[0]
+    p3 = capi.lib().grt_geo_passes()
+    assert p1 == p0 + 1 and p2 == p1 and p3 == p2 + 1
+    assert not np.array_equal(a1, a2) and np.array_equal(a3, a2[:, :a3.shape[1]])
 
 
 def test_multi_frequency_matches_single(dev):
@@ -1012,7 +1089,7 @@ def test_bench_distributed_path_through_rccl_single_rank():
     env = dict(os.environ, GRT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
-                          "--nn", "256", "256", "200", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+                          "--nn", "256", "256", "200", "--scaling", "weak", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
@@ -1477,6 +1554,97 @@ def test_config5_full_size_properties(fdev):
     flux_full = full[:, :, 0].astype(float).sum(axis=1) / (1024.0 * 1024.0)
     flux_gold = g["ivals_formal"][:, :, 0].astype(float).sum(axis=1) / (64.0 * 64.0)
     assert np.allclose(flux_full, flux_gold, rtol=0.02), np.abs(flux_full / flux_gold - 1).max()
+
+
+def _full_size_properties(trace, nn, inames, flux_ref, flux_rtol, record_rows=4096):
+    """Size-independent properties of a BASELINE config at its full size (the oracle cannot finish these in seconds):
+    ray-steps = sum of the stored-point counts, finite image, zero pixels exactly where no point was stored, two half-image
+    calls = the whole image bit for bit, the per-step record on or off does not change the image, the image-integrated flux
+    agrees with the small golden camera of the same field of view (flux_ref per Stokes I, rtol flux_rtol).
+    trace(i1, i2, iname) -> pix[1, n, 4], status, stats."""
+    from grtrans_amd import capi
+    npix = nn[0] * nn[1]
+    out = {}
+    for iname in inames:
+        capi.record_steps(False)
+        full, s, st = trace(1, npix, iname)
+        assert st.ray_steps == int(np.abs(s).sum()) and (np.abs(s) <= nn[2] + int(np.ceil(60.0 * nn[2] / 400.0))).all()
+        finite = np.isfinite(full[0]).all(axis=1)
+        assert finite.mean() > 0.999, (iname, 1 - finite.mean())       # (a thermal DELO pixel may overflow in the reference too: counted, not hidden)
+        assert (full[0][s <= 0] == 0).all() and (full[0][finite, 0] >= 0).all()
+        h = npix // 2
+        a, sa, _ = trace(1, h, iname)
+        b, sb, _ = trace(h + 1, npix, iname)
+        assert np.array_equal(np.concatenate([a, b], axis=1), full, equal_nan=True) and np.array_equal(np.concatenate([sa, sb]), s)
+        # the per-step record (azimuth integrals + I,Q,U,V rows) does not change what the image holds: a block of rows in the middle
+        lo = h - record_rows // 2
+        capi.record_steps(True)
+        try:
+            r, sr, _ = trace(lo + 1, lo + record_rows, iname)
+        finally:
+            capi.record_steps(False)
+        assert np.array_equal(r, full[:, lo:lo + record_rows], equal_nan=True) and np.array_equal(sr, s[lo:lo + record_rows])
+        flux = np.nansum(full[0][:, 0].astype(float)) / npix
+        if flux_ref is not None:
+            assert abs(flux / flux_ref[iname] - 1.0) < flux_rtol, (iname, flux, flux_ref[iname])
+        out[iname] = dict(ray_steps=int(st.ray_steps), nonfinite=int((~finite).sum()), flux=flux, ms=st.ms_total)
+    if os.environ.get("GRT_TEST_ERRLOG"):
+        with open(os.environ["GRT_TEST_ERRLOG"], "a") as f:
+            f.write("full_size %s %s\n" % (list(nn), out))
+    return out
+
+
+def test_config2_full_size_properties(fdev):
+    # BASELINE config 2 at its full size: SPHACC POLSYNCHTH nvals=4 spin=0 nn=[256,256,200], formal and DELO
+    from grtrans_amd import capi
+    fdev.load_sphacc()
+    nn = (256, 256, 200)
+    cam = capi.make_camera(1, (-25., 25., -25., 25.), nn, 0.0, 0.5, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+
+    def trace(i1, i2, iname):
+        pix, _, s, st = capi.trace_tile(cam, i1, i2, "SPHACC", em, [FREQ_SPHACC], iname)
+        return pix, s, st
+    g = np.load(os.path.join(G, "sphacc_64x64x200.npz"))
+    ref = {k: g["ivals_" + k][:, 0].astype(float).sum() / 4096.0 for k in ("formal", "delo")}
+    _full_size_properties(trace, nn, ("formal", "delo"), ref, 0.03)
+
+
+def test_config3_full_size_properties(fdev):
+    # BASELINE config 3 at its full size: FFJET POLSYNCHPL nvals=4 spin=0.998 nn=[512,512,400], formal and DELO
+    nn = (512, 512, 400)
+
+    def trace(i1, i2, iname):
+        pix, _, s, st = run(nn, iname, i1, i2)
+        return pix, s, st
+    g = np.load(os.path.join(G, "ffjet_100x100x400.npz"))
+    ref = {k: g["ivals_" + k][:, 0].astype(float).sum() / 10000.0 for k in ("formal", "delo")}
+    _full_size_properties(trace, nn, ("formal", "delo"), ref, 0.03)
+
+
+def test_config4_full_size_properties(fdev, tmp_path):
+    # BASELINE config 4 at its full size: HARM POLSYNCHTH nvals=4 nn=[512,512,400] on the 256 x 256-zone synthetic dump
+    # (dump040 itself does not ship with the reference).  The flux reference is the device's own 64 x 64 x 400 camera of the same
+    # dump: the compiled-reference golden is on the 64-zone dump (test_harm_polsynchth_vs_reference_golden holds that one).
+    import sys
+    from grtrans_amd import capi
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_harm_dump
+    make_harm_dump.write(str(tmp_path), n=256)
+    fdev.load_harm(os.path.join(str(tmp_path), "dump"), os.path.join(str(tmp_path), "dump040"), 40, 0.9375)
+    em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5, muval=0.25, mdot=1.57e15)
+    small = capi.make_camera(1, (-13., 13., -13., 13.), (64, 64, 400), 0.9375, 0.6428, 0.04, -0.5)
+    ref = {}
+    for iname in ("formal", "delo"):
+        p = capi.trace_tile(small, 1, 4096, "HARM", em, [FREQ_HARM], iname)[0]
+        ref[iname] = np.nansum(p[0][:, 0].astype(float)) / 4096.0
+    nn = (512, 512, 400)
+    cam = capi.make_camera(1, (-13., 13., -13., 13.), nn, 0.9375, 0.6428, 0.04, -0.5)
+
+    def trace(i1, i2, iname):
+        pix, _, s, st = capi.trace_tile(cam, i1, i2, "HARM", em, [FREQ_HARM], iname)
+        return pix, s, st
+    _full_size_properties(trace, nn, ("formal", "delo"), ref, 0.05)
 
 
 def test_geokerr_rays_abi_vs_reference_geokerr(fdev):
