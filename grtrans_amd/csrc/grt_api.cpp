@@ -704,7 +704,12 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       drain();                                                                             \
       return (int)e_;                                                                      \
     }                                                                                      \
+    if (dbg_sync) {      /* GRT_TRACE_DEBUG=1: every launch completes before the next (a device fault names its stage) */ \
+      drain();                                                                             \
+      fprintf(stderr, "grtrans_amd: done %.60s\n", #x);                                    \
+    }                                                                                      \
   } while (0)
+  const bool dbg_sync = std::getenv("GRT_TRACE_DEBUG") != nullptr;
   for (int off = 0; off < nrays; off += chunk) {
     const int nch = (nrays - off < chunk) ? (nrays - off) : chunk;
     const double *t0c = d_t0 ? d_t0 + off : nullptr;

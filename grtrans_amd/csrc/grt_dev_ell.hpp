@@ -8,6 +8,14 @@
 #include "grt_dev_special.hpp"
 
 namespace grtd {
+// ---- reference-literal code: NO FMA contraction from here to the matching "contract(fast)" -------------------------------------
+// This code restates GEOKERR statement for statement (generic ray class, per-ray set-up).  Several of its formulas are
+// ill-conditioned by design of the reference (near-polar azimuth integrals, the KMAX schedule for odd NUP, root ordering), so which
+// way a product-sum rounds decides branches: compiled without contraction it rounds like the reference's compiled Fortran and like
+// the oracle (r03: with the whole path inlined and contracted, a ray 1e-5 rad from the axis came out 1.49 rad off in azimuth after
+// its equator crossing; the outlined build had happened to round the other way).  The fast classes (grt_dev_fast.hpp,
+// grt_dev_cubic.hpp) keep contraction: they are new algorithms with their own error analysis.
+#pragma clang fp contract(off)
 
 
 
@@ -446,4 +454,6 @@ GRT_HD double tfnkerr(double u0, double uf, double u1, double u2, double l, doub
           ((1.0 / up - umi) * sup * (u2 / up - 1.0)));
 }
 
+#pragma clang fp contract(fast)
+// ---- end of the reference-literal region ------------------------------------------------------------------------------------------
 }  // namespace grtd

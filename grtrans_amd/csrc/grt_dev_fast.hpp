@@ -563,7 +563,7 @@ GRT_HD void real_mupart(const RealRay &K, double muf, MuPart &o, bool forgeor) {
     bool pastg = past;
     if (forgeor && K.muplusR != K.muplus) {   // GEOR's own (unclamped) muplus: redo the F piece consistently
       double cr = fdiv(muf, K.muplusR), sfr = fsqrt((1.0 - cr) * (1.0 + cr)), qfr = (1.0 - sfr * K.akm) * (1.0 + sfr * K.akm);
-      imuf = sfr * rf(1.0 - sfr * sfr, qfr, 1.0);
+      imuf = sfr * rf_c(1.0 - sfr * sfr, qfr, 1.0);
       pastg = cr < 0.0;
     }
     if (pastg) imuf = K.i3mu * fac - imuf;
@@ -647,7 +647,7 @@ GRT_HD void realray_anchor_z(const GrtCam &cam, const GrtRay &R, RealRay &K, boo
   const double h = sqrt(nchar + k2), sp = sqrt(nchar) / h, cp = k / h, dp = sqrt(1.0 - K.m1m * sp * sp);
   // K' - b = F(psi, k') with tan psi = 1/sqrt(n) (tan am tan psi = 1/k): the small quantity when the ray runs close to the axis
   const double h1 = sqrt(1.0 + nchar), spsi = 1.0 / h1, cpsi = sqrt(nchar) / h1;
-  const double delta = spsi * rf(cpsi * cpsi, 1.0 - K.m1m * spsi * spsi, 1.0);
+  const double delta = spsi * rf_c(cpsi * cpsi, 1.0 - K.m1m * spsi * spsi, 1.0);
   const double eps2 = 2.0 * agp * delta;                               // 2 (z_K' - z_b) = (pi/K)(K' - b)
   // 2 (-1)^j q^(j^2) cosh / sinh (2 j z_b) = (-1)^j [q^(j^2-j) exp(-j eps2) +- q^(j^2+j) exp(j eps2)]
   int np = 0;

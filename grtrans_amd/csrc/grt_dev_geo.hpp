@@ -12,6 +12,14 @@
 #include "grt_dev_ell.hpp"
 
 namespace grtd {
+// ---- reference-literal code: NO FMA contraction from here to the matching "contract(fast)" -------------------------------------
+// This code restates GEOKERR statement for statement (generic ray class, per-ray set-up).  Several of its formulas are
+// ill-conditioned by design of the reference (near-polar azimuth integrals, the KMAX schedule for odd NUP, root ordering), so which
+// way a product-sum rounds decides branches: compiled without contraction it rounds like the reference's compiled Fortran and like
+// the oracle (r03: with the whole path inlined and contracted, a ray 1e-5 rad from the axis came out 1.49 rad off in azimuth after
+// its equator crossing; the outlined build had happened to round the other way).  The fast classes (grt_dev_fast.hpp,
+// grt_dev_cubic.hpp) keep contraction: they are new algorithms with their own error analysis.
+#pragma clang fp contract(off)
 
 struct GKCache {   // the per-geodesic variables GEOKERR threads through its callees
   int ncase = 0;
@@ -370,7 +378,7 @@ GRT_HD void geomu(double &u0, double &uf, double mu0, double &muf, double a, dou
 
 // ---------------------------------------------------------------------------------------------
 // GEOPHITIME  geokerr_wrapper.f:1648-2357
-GRT_HD void geophitime(double u0, double uf, double mu0, double muf, double a, double l, double l2,
+GRT_ALWAYS_INLINE GRT_HD void geophitime(double u0, double uf, double mu0, double muf, double a, double l, double l2,
                        double q2, int tpm, int tpr, double su, double sm, double iu, GKCache &c,
                        double &phimu, double &tmu, double &phiu, double &tu, double &lambda,
                        bool firstpt, int want = 3) {
@@ -704,7 +712,7 @@ GRT_HD void geophitime(double u0, double uf, double mu0, double muf, double a, d
 
 // ---------------------------------------------------------------------------------------------
 // GEOR  geokerr_wrapper.f:2672-3134   (imu is the reference's IMU, returned through GEOKERR's IU)
-GRT_HD void geor(double &u0, double &uf, double mu0, double muf, double a, double l, double l2, double q2,
+GRT_ALWAYS_INLINE GRT_HD void geor(double &u0, double &uf, double mu0, double muf, double a, double l, double l2, double q2,
                  double &imu, int &tpm, int &tpr, double su, double sm, GKCache &c, bool pht, bool firstpt) {
   const double one = 1.0, two = 2.0, half = 0.5, third = 0.3333333333333333, three = 3.0;
   const double pi = acos(-one);
@@ -989,4 +997,6 @@ GRT_HD void geor(double &u0, double &uf, double mu0, double muf, double a, doubl
 }
 
 
+#pragma clang fp contract(fast)
+// ---- end of the reference-literal region ------------------------------------------------------------------------------------------
 }  // namespace grtd

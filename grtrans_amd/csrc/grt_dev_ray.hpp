@@ -11,6 +11,14 @@
 #include "grt_dev_phys.hpp"
 
 namespace grtd {
+// ---- reference-literal code: NO FMA contraction from here to the matching "contract(fast)" -------------------------------------
+// This code restates GEOKERR statement for statement (generic ray class, per-ray set-up).  Several of its formulas are
+// ill-conditioned by design of the reference (near-polar azimuth integrals, the KMAX schedule for odd NUP, root ordering), so which
+// way a product-sum rounds decides branches: compiled without contraction it rounds like the reference's compiled Fortran and like
+// the oracle (r03: with the whole path inlined and contracted, a ray 1e-5 rad from the axis came out 1.49 rad off in azimuth after
+// its equator crossing; the outlined build had happened to round the other way).  The fast classes (grt_dev_fast.hpp,
+// grt_dev_cubic.hpp) keep contraction: they are new algorithms with their own error analysis.
+#pragma clang fp contract(off)
 
 GRT_HD void cache_from_ray(const GrtRay &R, GKCache &c) {
   c.ncase = R.ncase; c.h1 = R.h1; c.u1 = R.u1; c.u2 = R.u2; c.u3 = R.u3; c.u4 = R.u4;
@@ -56,7 +64,7 @@ GRT_HD void camera_pixel(const GrtCam &cam, int ii, GrtRay &R) {
 // Everything after the pixel constants: R.alpha, beta, l, q2, su, sm are set by the caller (camera_pixel for a camera
 // pixel; the caller's own arrays for grt_geokerr_rays = class_geokerr's call_geokerr).  uf_in, tpr_in: GEOKERR's UF and
 // TPR arguments (the camera passes the horizon and 1, geokerr_wrapper.f:255-257).
-GRT_HD void setup_ray_core(const GrtCam &cam, GrtRay &R, double uf_in, int tpr_in) {
+GRT_ALWAYS_INLINE GRT_HD void setup_ray_core(const GrtCam &cam, GrtRay &R, double uf_in, int tpr_in) {
   const double one = 1.0, two = 2.0;
   const double a = cam.a, mu0 = cam.mu0, uout = cam.uout, offset = cam.offset, l = R.l, q2 = R.q2, su = R.su, sm = R.sm;
   const int nup = cam.nup, kext = cam.kext, next = cam.next;
@@ -130,7 +138,7 @@ GRT_HD void setup_ray_core(const GrtCam &cam, GrtRay &R, double uf_in, int tpr_i
   R.npts = npts;
 }
 
-GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
+GRT_ALWAYS_INLINE GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
   camera_pixel(cam, ii, R);
   const double a = cam.a;
   setup_ray_core(cam, R, 1.0 / (1.0 + sqrt(1.0 - a * a)), 1);
@@ -141,7 +149,7 @@ GRT_HD void setup_ray(const GrtCam &cam, int ii, GrtRay &R) {
 // (FIRSTPT) finds the roots and caches; every stored point is then GEOR + GEOPHITIME on that cache.
 GRT_HD double usegeor_mu(const GrtCam &cam, int k) { return cam.mu0 + (k - cam.offset) * (0.0 - cam.mu0) / (double)cam.nup; }
 
-GRT_HD void setup_ray_usegeor(const GrtCam &cam, int ii, GrtRay &R) {
+GRT_ALWAYS_INLINE GRT_HD void setup_ray_usegeor(const GrtCam &cam, int ii, GrtRay &R) {
   camera_pixel(cam, ii, R);
   const double a = cam.a, mu0 = cam.mu0, l = R.l, q2 = R.q2;
   R.sm = (R.beta > 0.0 && mu0 < 1.0) ? 1.0 : -1.0;
@@ -162,7 +170,7 @@ GRT_HD void setup_ray_usegeor(const GrtCam &cam, int ii, GrtRay &R) {
   R.npts = cam.nup;
 }
 
-GRT_HD void ray_point_usegeor(const GrtCam &cam, const GrtRay &R, int idx, double &un, double &mun, double &dt, double &dphi, double &lam,
+GRT_ALWAYS_INLINE GRT_HD void ray_point_usegeor(const GrtCam &cam, const GrtRay &R, int idx, double &un, double &mun, double &dt, double &dphi, double &lam,
                               int &tpm, int &tpr) {
   const double a = cam.a, mu0 = cam.mu0, l = R.l, q2 = R.q2;
   GKCache c;
@@ -185,7 +193,7 @@ struct GeoPoint {
 };
 
 // Stored point idx (1..npts) of ray R.  want: see geophitime (3 = everything).
-GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P, int want = 3) {
+GRT_ALWAYS_INLINE GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P, int want = 3) {
   const double two = 2.0;
   const double a = cam.a, mu0 = cam.mu0, uout = cam.uout, offset = cam.offset, l = R.l, q2 = R.q2, su = R.su, sm = R.sm;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
@@ -226,4 +234,6 @@ GRT_HD void ray_point(const GrtCam &cam, const GrtRay &R, int idx, GeoPoint &P, 
   P.u = un; P.mu = mun; P.dt = tmu + tu; P.dphi = phimu + phiu; P.lam = lambda; P.tpm = tpm; P.tpr = tprp;
 }
 
+#pragma clang fp contract(fast)
+// ---- end of the reference-literal region ------------------------------------------------------------------------------------------
 }  // namespace grtd

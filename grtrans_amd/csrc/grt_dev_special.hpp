@@ -55,6 +55,14 @@ GRT_HD int fint(double x) { return (int)x; }
 GRT_HD double dmax(double a, double b) { return a > b ? a : b; }
 GRT_HD double dmin(double a, double b) { return a < b ? a : b; }
 
+// ---- reference-literal code: NO FMA contraction from here to the matching "contract(fast)" -------------------------------------
+// This code restates GEOKERR statement for statement (generic ray class, per-ray set-up).  Several of its formulas are
+// ill-conditioned by design of the reference (near-polar azimuth integrals, the KMAX schedule for odd NUP, root ordering), so which
+// way a product-sum rounds decides branches: compiled without contraction it rounds like the reference's compiled Fortran and like
+// the oracle (r03: with the whole path inlined and contracted, a ray 1e-5 rad from the axis came out 1.49 rad off in azimuth after
+// its equator crossing; the outlined build had happened to round the other way).  The fast classes (grt_dev_fast.hpp,
+// grt_dev_cubic.hpp) keep contraction: they are new algorithms with their own error analysis.
+#pragma clang fp contract(off)
 // R_F  (geokerr_wrapper.f:3444)
 GRT_HD double rf(double x, double y, double z) {
   const double ERRTOL = 0.0025, THIRD = 1.0 / 3.0, c1 = 1.0 / 24.0, C2 = 0.1, C3 = 3.0 / 44.0, C4 = 1.0 / 14.0;
@@ -226,6 +234,32 @@ GRT_NI void sncndn(double uu, double emmc, double &sn, double &cn, double &dn) {
   }
 }
 
+#pragma clang fp contract(fast)
+// ---- end of the reference-literal region ------------------------------------------------------------------------------------------
+// R_F again, contracted: the copy the fast classes call per point (the literal one above belongs to the reference-literal region)
+GRT_HD double rf_c(double x, double y, double z) {
+  const double ERRTOL = 0.0025, THIRD = 1.0 / 3.0, c1 = 1.0 / 24.0, C2 = 0.1, C3 = 3.0 / 44.0, C4 = 1.0 / 14.0;
+  double xt = x, yt = y, zt = z, ave, delx, dely, delz;
+  do {
+    double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+    double alamb = sx * (sy + sz) + sy * sz;
+    xt = 0.25 * (xt + alamb);
+    yt = 0.25 * (yt + alamb);
+    zt = 0.25 * (zt + alamb);
+    ave = THIRD * (xt + yt + zt);
+    if (ave == 0.0) {
+      delx = dely = delz = 0.0;
+    } else {
+      delx = (ave - xt) / ave;
+      dely = (ave - yt) / ave;
+      delz = (ave - zt) / ave;
+    }
+  } while (dmax(dmax(fabs(delx), fabs(dely)), fabs(delz)) > ERRTOL);
+  double e2 = delx * dely - delz * delz, e3 = delx * dely * delz;
+  return (1.0 + (c1 * e2 - C2 - C3 * e3) * e2 + C4 * e3) / sqrt(ave);
+}
+
+
 // The descending-Landen ladder of sncndn depends only on the complementary parameter emmc, which is a
 // constant of the ray (M(mu) or U(u) modulus): build it once per ray, run only the ascending recurrence
 // (and one sincos) per point.  Same operations in the same order as sncndn above -> identical values.
@@ -395,6 +429,14 @@ GRT_HD void sncndn_ladder_z(const AgmLadder &L, double uu, double emmc, double &
   }
 }
 
+// ---- reference-literal code: NO FMA contraction from here to the matching "contract(fast)" -------------------------------------
+// This code restates GEOKERR statement for statement (generic ray class, per-ray set-up).  Several of its formulas are
+// ill-conditioned by design of the reference (near-polar azimuth integrals, the KMAX schedule for odd NUP, root ordering), so which
+// way a product-sum rounds decides branches: compiled without contraction it rounds like the reference's compiled Fortran and like
+// the oracle (r03: with the whole path inlined and contracted, a ray 1e-5 rad from the axis came out 1.49 rad off in azimuth after
+// its equator crossing; the outlined build had happened to round the other way).  The fast classes (grt_dev_fast.hpp,
+// grt_dev_cubic.hpp) keep contraction: they are new algorithms with their own error analysis.
+#pragma clang fp contract(off)
 GRT_HD double asech(double x) { return (x > 0.0) ? log((1.0 + sqrt(1.0 - x * x)) / x) : 0.0; }
 
 // ---- complex double, only used by the once-per-ray root finder ----
@@ -507,4 +549,6 @@ GRT_HD void zroots(const cd *a, int m, cd *roots) {
   }
 }
 
+#pragma clang fp contract(fast)
+// ---- end of the reference-literal region ------------------------------------------------------------------------------------------
 }  // namespace grtd

@@ -66,15 +66,22 @@ __global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1
   GrtRay R;
   R.npts = 0;
   if (inr) {
-    if (rin.l) {     // caller-given rays (call_geokerr, class_geokerr.f90:69-107): ray tid of the arrays
+    // ONE call site of setup_ray_core, inlined (always_inline): as a real function call from this kernel it faulted on the device
+    // whenever one more value was live across the call (r03: "write access to a read-only page" with the pixel index held in a80
+    // over s_swappc; same sources with the call inlined run clean -- tools notes in DESIGN.md 4)
+    double uf_in = 0.0;
+    int tpr_in = 0;
+    const bool given = rin.l != nullptr;
+    if (given) {     // caller-given rays (call_geokerr, class_geokerr.f90:69-107): ray tid of the arrays
       R.alpha = rin.alpha[tid]; R.beta = rin.beta[tid]; R.l = rin.l[tid]; R.q2 = rin.q2[tid]; R.su = rin.su[tid]; R.sm = rin.sm[tid];
       R.pix = tid + 1;
-      setup_ray_core(cam, R, rin.uf[tid], rin.tpr[tid]);
-    } else if (cam.usegeor) {
-      setup_ray_usegeor(cam, (int)pixel, R);      // standard=2: mu is the independent variable (generic class)
-    } else {
-      setup_ray(cam, (int)pixel, R);
+      uf_in = rin.uf[tid]; tpr_in = rin.tpr[tid];
+    } else if (!cam.usegeor) {
+      camera_pixel(cam, (int)pixel, R);
+      uf_in = 1.0 / (1.0 + sqrt(1.0 - cam.a * cam.a)); tpr_in = 1;      // the camera passes the horizon and TPR = 1 (geokerr_wrapper.f:255-257)
     }
+    if (!given && cam.usegeor) setup_ray_usegeor(cam, (int)pixel, R);      // standard=2: mu is the independent variable (generic class)
+    else setup_ray_core(cam, R, uf_in, tpr_in);
     rays[tid] = R;
     ray_npts[tid] = R.npts;
   }
@@ -882,6 +889,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   }
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
+#ifndef GRT_FAST_BUILD      // experiment builds (tools/build_variant.sh NAME -DGRT_FAST_BUILD): the FFJET kernels only, a sixth of the compile time
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHTH)
@@ -933,6 +941,7 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_SYNCHTHAV)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_SYNCHTHAV)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_KORAL3D, GRT_EMIS_SYNCHTHAV)
+#endif
 #undef GRT_XFER_CASE
   return hipErrorInvalidValue;
 }

@@ -7,9 +7,15 @@
 #define GRT_HD __host__ __device__ inline
 // (real calls for the leaf routines crashed at run time with ROCm 7.2; everything is inlined)
 #define GRT_NI __host__ __device__ inline
+// The inliner's cost model leaves the largest routines (setup_ray_core, geor, geophitime, ray_point: 180-390 KB of code each)
+// as real functions.  Device-side calls are not trustworthy with this toolchain: r03 saw "write access to a read-only page" from
+// grt_setup_kernel as soon as one more value was live across the s_swappc to setup_ray_core (held in an AGPR), and an aperture
+// violation with -enable-ipra=false.  These routines are therefore inlined by attribute: the code object holds no s_swappc.
+#define GRT_ALWAYS_INLINE __attribute__((always_inline))
 #else
 #define GRT_HD inline
 #define GRT_NI inline
+#define GRT_ALWAYS_INLINE
 #endif
 
 #include "../../include/grtrans_amd.h"

@@ -96,7 +96,9 @@ def test_ffjet_vs_reference_golden(dev, nx, nup, iname):
     pix, loc, status, st = run((nx, nx, nup), iname)
     assert np.array_equal(status, g["npts"])                 # bit-exact stored-point counts
     assert st.ray_steps == int(g["npts"].sum())
-    assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL
+    # against the compiled reference: >= 75 % of the fp32 values are the same bits (measured 80-82 %), no value above 1e-6 of its
+    # Stokes peak is off by more than 1e-4 relative (measured <= 2.8e-5 = 333 fp32 ulp, on Q/U/V next to their zero crossings)
+    assert stokes_err(pix[0], g["ivals_" + iname], min_identical=0.75, max_rel=1e-4) < STOKES_TOL
     assert np.array_equal(loc[:, 0], g["cam_alpha"].astype(np.float32))
     assert np.array_equal(loc[:, 1], g["cam_beta"].astype(np.float32))
 
@@ -257,6 +259,8 @@ def test_sphacc_polsynchth_vs_reference_golden(dev, iname):
     dev.load_sphacc()
     g = np.load(os.path.join(G, "sphacc_64x64x200.npz"))
     pix, loc, status, st = run_sphacc((64, 64, 200), iname)
+    assert parity_stats(pix[0], g["ivals_" + iname])["bit_identical"] >= 0.90      # measured 0.936 (formal) / 0.988 (delo)
+    assert parity_stats(pix[0], g["ivals_" + iname])["max_rel"] <= 3e-5             # measured 6.8e-6 over values above 1e-6 of peak
     assert np.array_equal(status, g["npts"])
     assert st.rays_dead == int((g["npts"] == 0).sum())       # image corners outside uout: compacted away
     assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL
@@ -314,7 +318,8 @@ def test_harm_polsynchth_vs_reference_golden(dev, harm_dir, iname):
     g = np.load(os.path.join(G, "harm_48x48x200.npz"))
     pix, loc, status, st = run_harm(dev, harm_dir, (48, 48, 200), iname)
     assert np.array_equal(status, g["npts"])
-    assert stokes_err(pix[0], g["ivals_" + iname]) < STOKES_TOL
+    # measured: 96 % of the fp32 values bit-identical to the compiled reference, <= 1.5e-6 relative (22 ulp) above 1e-6 of peak
+    assert stokes_err(pix[0], g["ivals_" + iname], min_identical=0.93, max_rel=1e-5) < STOKES_TOL
 
 
 def test_harm_per_step_record(dev, harm_dir):
@@ -1168,7 +1173,7 @@ def test_hosts_gather_path_with_a_one_rank_communicator(tmp_path, monkeypatch):
         x.run_grtrans()
         x.read_grtrans_output(bin=1)
         assert np.array_equal(x.ivals, plain), cols
-        os.remove(str(tmp_path / "comm_id"))
+        assert not os.path.exists(str(tmp_path / "comm_id"))       # rank 0 removes the rendezvous file once every rank has joined
         y = gb.grtrans()
         y.run_pgrtrans(**kw)
         assert y.ivals.shape == (4, 1024, 4)
@@ -1504,7 +1509,9 @@ def test_near_polar_ray_azimuth_on_a_3d_dump(tmp_path):
     od = o.ray_dump(90, FREQ_HARM)
     # azimuth along the near-polar ray: the reference's own formulas are ill-conditioned this close to the axis (device and
     # oracle, both literal, differ by up to 2e-5 rad at l^2/(q2+a^2) ~ 1e-11: tools/polar_phi.py); the fast path was off by radians
-    assert np.abs(rec[2] - od["x"][:n, 3]).max() < 1e-4
+    # r03: the reference-literal code is compiled without FMA contraction and rounds like the oracle -- 3e-10 rad over every decade
+    # of l^2/(q2+a^2) (tools/polar_phi.py); contracted, the same code was 2e-5 rad off here and radians off once fully inlined
+    assert np.abs(rec[2] - od["x"][:n, 3]).max() < 1e-8
     assert stokes_err(pix[0], ref[0]) < STOKES_TOL
 
 

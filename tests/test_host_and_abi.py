@@ -348,3 +348,24 @@ def test_usable_cpus_respects_affinity_and_quota(monkeypatch):
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 1, 2})
     assert bench.usable_cpus()[0] <= 3
     assert len(bench.build_id()) == 16 and bench.build_id() == bench.build_id()
+
+
+def test_code_object_holds_no_device_side_calls(tmp_path):
+    # r03: a real function call inside grt_setup_kernel (s_swappc to setup_ray_core, 390 KB the inliner had left outlined) faulted
+    # on the MI355X as soon as one more value was live across it; with -enable-ipra=false the same code raised an aperture
+    # violation.  The large routines are now inlined by attribute (GRT_ALWAYS_INLINE) and the gfx950 code object must stay free
+    # of calls: a new outlined routine shows up here before it shows up as a device fault.
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "grtrans_amd", "csrc", "grt_kernels.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("no object file / llvm tools here")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "k.co")
+    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", co], capture_output=True, text=True, check=True).stdout
+    funcs = [l.split()[-1] for l in syms.splitlines() if " FUNC " in l and not l.rstrip().endswith(".kd")]
+    outlined = [f for f in funcs if "grt_" not in f or "kernel" not in f]
+    assert not outlined, outlined
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+    assert dis.count("s_swappc_b64") == 0      # (s_setpc_b64 alone is the long-branch idiom of these 100-KB kernels, not a call)
