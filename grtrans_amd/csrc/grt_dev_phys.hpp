@@ -31,6 +31,19 @@ GRT_HD float acosf_cr(float x) { return (float)acos((double)x); }
 GRT_HD float logf_cr(float x) { return (float)log((double)x); }
 GRT_HD float powf_cr(float x, float y) { return (float)pow((double)x, (double)y); }
 
+// cos and sin of the REAL(4) polar angle th_f = (float)th, as REAL(4), from the fp64 sin / cos of th the transfer kernel forms anyway:
+// th_f = th + d with |d| <= ulp32(pi)/2 = 1.2e-7, so cos(th_f) = cth - (sth d + cth d^2/2) and sin(th_f) = sth + (cth d - sth d^2/2) to
+// 3e-22 absolute (the d^3 terms), i.e. within 1.5 fp64 ulp -- what (float)cos((double)th_f) of the library gives to 1 ulp.  Saves the
+// two fp64 library evaluations every sampler spent on the single-precision metric and LNRF frame (r03: 90 of 2600 instructions per step).
+struct F32Trig { float c, s; };
+GRT_HD F32Trig f32_trig(double th, double sth, double cth) {
+  const double d = (double)(float)th - th, h = 0.5 * d * d;
+  F32Trig t;
+  t.c = (float)(cth - (sth * d + cth * h));
+  t.s = (float)(sth + (cth * d - sth * h));
+  return t;
+}
+
 struct Metric { double g[10]; };   // slots 1,4,5,8,10 (0-based 0,3,4,7,9) non-zero
 
 // kerr.f90:381 with sin(th), cos(th) supplied (the kernel forms them once per point with one sincos)
@@ -51,11 +64,11 @@ GRT_HD Metric blmetric_cov_sc(double r, double sth, double cth, double a) {
 GRT_HD Metric blmetric_cov(double r, double th, double a) { return blmetric_cov_sc(r, sin(th), cos(th), a); }
 
 // single-precision metric, promoted to double slots (blmetric_cov_real + assign_metric_real)
-GRT_HD Metric blmetric_cov_real(float r, float th, float a) {
+GRT_HD Metric blmetric_cov_real(float r, float th, float a, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
   Metric m;
   for (int i = 0; i < 10; ++i) m.g[i] = 0.0;
-  float cth = cosf_cr(th), sth = sinf_cr(th);
+  float cth = ft ? ft->c : cosf_cr(th), sth = ft ? ft->s : sinf_cr(th);
   float delta = r * r - 2.f * r + a * a;
   float rho2 = r * r + a * a * cth * cth;
   float t = r * r + a * a;
@@ -100,9 +113,9 @@ GRT_HD void calc_nullp(double q2, double l, double a, double r, double mu, doubl
 
 // kerr.f90:476  lnrf_frame_inv_real (single precision)
 GRT_HD void lnrf_frame_inv_real(float vr, float vt, float omega, float r, float a, float th, float &vrl,
-                                float &vtl, float &vpl) {
+                                float &vtl, float &vpl, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
-  float mu = cosf_cr(th);
+  float mu = ft ? ft->c : cosf_cr(th);
   float D = r * r - 2.f * r + a * a;
   float t = r * r + a * a;
   float AR = t * t - a * a * D * (1.f - mu * mu);
@@ -722,11 +735,11 @@ GRT_HD void opacity_matrix(const double *K7, double M[4][4]) {   // :735 ; K7 = 
 // (rho,p,b0,br,bth,bph,u0,vr,vth,vph,0,0): the two r-neighbours of a sample are 96 contiguous
 // bytes, so one sample is two 96-byte segments served from L2 (the 16384-cell table is 768 KB,
 // larger than the 160 KB LDS, smaller than one XCD's 4 MB L2).
-GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, FluidPoint &f) {
+GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, FluidPoint &f, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx1;
   float theta = (float)th_d;
-  float zm = cosf_cr(theta);
+  float zm = ft ? ft->c : cosf_cr(theta);
   float x2 = acosf_cr(fabsf(zm));
   theta = x2;
   float zr = (float)r;
@@ -761,12 +774,12 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
   float vrl0 = inside ? q[7] : 0.f;
   float vtl0 = inside ? q[8] : 1.f;
   float vpl0 = inside ? q[9] : 0.f;
-  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a, ft);
   float bm = (float)dot4(f.b, ms, f.b);
   bm = (bm >= 0.f) ? bm : 0.f;
   f.bmag = sqrtf(bm);
   float vr0, vth0, vph0;
-  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0, ft);
   f.u[1] = f.u[0] * (double)vr0;
   f.u[2] = f.u[0] * (double)vth0;
   f.u[3] = f.u[0] * (double)vph0;
@@ -925,7 +938,7 @@ GRT_HD int harm_theta_index(double h, const float *uniqx2, const float *uniqth, 
   return (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
 }
 
-GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_d, float a, FluidPoint &f, int tindx = 0) {
+GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_d, float a, FluidPoint &f, int tindx = 0, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2;
@@ -975,12 +988,12 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
   const float vrl0 = inside ? q[7] : 0.f;
   const float vtl0 = inside ? q[8] : 1.f;
   const float vpl0 = inside ? q[9] : 0.f;
-  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a, ft);
   float bm = (float)dot4(f.b, ms, f.b);
   bm = (bm >= 0.f) ? bm : 0.f;
   f.bmag = sqrtf(bm);
   float vr0, vth0, vph0;
-  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0, ft);
   f.u[1] = f.u[0] * (double)vr0;
   f.u[2] = f.u[0] * (double)vth0;
   f.u[3] = f.u[0] * (double)vph0;
@@ -1016,7 +1029,7 @@ GRT_HD double bl2ks_phi(double r, double x, double a) {       // kerr.f90:156-16
 // x3l/x3u) of the zone-centred grid, quadlininterp with the zero time weight the reference sets (:262,
 // interpolate.f90:205-232), periodic in phi, nearest zone in r (and 1e-6 scaled rho, p, |b|) inside the innermost zone
 // centre outside the horizon (:205-213).  REAL(4) throughout, as there; crd = the LDS copy of GrtHarm3d::coords.
-GRT_NI void harm3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f) {
+GRT_NI void harm3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2, *uniqx3 = crd + 2 * (nx1 + nx2);
@@ -1087,12 +1100,12 @@ GRT_NI void harm3d_sample(const GrtHarm3d &t, const float *crd, double r, double
   const float vrl0 = inside ? q[7] : 0.f;
   const float vtl0 = inside ? q[8] : 0.f;
   const float vpl0 = inside ? q[9] : 0.f;
-  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a, ft);
   float bm = (float)dot4(f.b, ms, f.b);
   bm = (bm >= 0.f) ? bm : 0.f;
   f.bmag = (float)((double)sqrtf(bm) * fac);
   float vr0, vth0, vph0;
-  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0, ft);
   f.u[1] = f.u[0] * (double)vr0;
   f.u[2] = f.u[0] * (double)vth0;
   f.u[3] = f.u[0] * (double)vph0;
@@ -1193,7 +1206,7 @@ GRT_HD int iharm_theta_index_mmks(const GrtHarm3d &t, const float *uniqx2, const
   return (int)floorf((x2 - uniqx2[0]) / (uniqx2[nx2 - 1] - uniqx2[0]) * (nx2 - 1)) + 1;
 }
 
-GRT_NI void iharm_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &kela) {
+GRT_NI void iharm_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &kela, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqth = crd + 2 * nx1 + nx2, *uniqx3 = crd + 2 * (nx1 + nx2);
@@ -1227,12 +1240,12 @@ GRT_NI void iharm_sample(const GrtHarm3d &t, const float *crd, double r, double 
   f.b[3] = (double)(inside ? c[5] : 1.f);
   f.u[0] = inside ? (double)c[6] : 1.0;
   const float vrl0 = inside ? c[7] : 0.f, vtl0 = inside ? c[8] : 0.f, vpl0 = inside ? c[9] : 0.f;
-  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a, ft);
   float bm = (float)dot4(f.b, ms, f.b);
   bm = (bm >= 0.f) ? bm : 0.f;
   f.bmag = sqrtf(bm);
   float vr0, vth0, vph0;
-  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0, ft);
   f.u[1] = f.u[0] * (double)vr0;
   f.u[2] = f.u[0] * (double)vth0;
   f.u[3] = f.u[0] * (double)vph0;
@@ -1287,7 +1300,7 @@ GRT_HD float koral_theta_of_x2(float x2, float r, float h, float a, float b, flo
 // shift, eight corners (x2 fastest, then x1, then x3), 1e-3 scaling of rho and T_e in the innermost radial zone, the
 // polar trust region (minpolecell = 2 zones; 0.25 rad for the disc variant).  Be (Bernoulli parameter) rides along.
 GRT_NI void koral3d_sample(const GrtHarm3d &t, const float *crd, double r, double th_d, double phi_d, float a, FluidPoint &f, float &Be,
-                           int tindx = 0) {
+                           int tindx = 0, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
   const int nx1 = t.nx1, nx2 = t.nx2, nx3 = t.nx3;
   const float *uniqx1 = crd, *uniqr = crd + nx1, *uniqx2 = crd + 2 * nx1, *uniqx3 = crd + 2 * nx1 + nx2;
@@ -1367,12 +1380,12 @@ GRT_NI void koral3d_sample(const GrtHarm3d &t, const float *crd, double r, doubl
   f.b[3] = (double)(inside ? q[5] : 1.f);
   f.u[0] = inside ? (double)q[6] : 1.0;
   const float vrl0 = inside ? q[7] : 0.f, vtl0 = inside ? q[8] : 1.f, vpl0 = inside ? q[9] : 0.f;
-  Metric ms = blmetric_cov_real(zr, (float)th_d, a);
+  Metric ms = blmetric_cov_real(zr, (float)th_d, a, ft);
   float bm = (float)dot4(f.b, ms, f.b);
   bm = (bm >= 0.f) ? bm : 0.f;
   f.bmag = sqrtf(bm);
   float vr0, vth0, vph0;
-  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0);
+  lnrf_frame_inv_real(vrl0, vtl0, vpl0, zr, a, (float)th_d, vr0, vth0, vph0, ft);
   f.u[1] = f.u[0] * (double)vr0;
   f.u[2] = f.u[0] * (double)vth0;
   f.u[3] = f.u[0] * (double)vph0;

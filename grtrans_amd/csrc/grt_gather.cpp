@@ -63,32 +63,33 @@ int grt_comm_free(void) {
 }
 
 // ncclCommInitRank blocks until every rank has joined and has no timeout of its own: a rank that never arrives (crashed before
-// the rendezvous, stale id) would hang the host silently.  It runs on a helper thread; if it has not returned within timeout_s the
-// call returns GRT_E_IO and the helper is left behind (the caller is expected to stop the process).
+// the rendezvous, stale id) would hang the host silently.  The call stays on the caller's thread (the communicator belongs to
+// it); a watchdog thread ends the PROCESS with exit code 98 and a message if the call has not returned within timeout_s -- a
+// rank stuck in the rendezvous cannot be recovered, and every launcher of this package treats a non-zero exit as the job's failure.
 static int comm_init_timed(int rank, int nranks, const ncclUniqueId &id, double timeout_s) {
-  struct Box { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+  struct Box { std::mutex m; std::condition_variable cv; bool done = false; };
   auto box = std::make_shared<Box>();
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::thread([box, rank, nranks, id, dev]() {
-    (void)hipSetDevice(dev);
-    ncclComm_t c = nullptr;
-    ncclResult_t r = ncclCommInitRank(&c, nranks, id, rank);
+  std::thread dog;
+  if (timeout_s > 0)
+    dog = std::thread([box, rank, nranks, timeout_s]() {
+      std::unique_lock<std::mutex> lk(box->m);
+      if (!box->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return box->done; })) {
+        fprintf(stderr, "grtrans_amd: ncclCommInitRank (rank %d of %d) did not return within %.0f s: a rank is missing or the id is stale; "
+                        "ending this process (exit code 98)\n", rank, nranks, timeout_s);
+        fflush(stderr);
+        _exit(98);
+      }
+    });
+  ncclComm_t c = nullptr;
+  const ncclResult_t r = ncclCommInitRank(&c, nranks, id, rank);
+  {
     std::lock_guard<std::mutex> g(box->m);
-    box->r = r; box->comm = c; box->done = true;
-    box->cv.notify_all();
-  }).detach();
-  std::unique_lock<std::mutex> lk(box->m);
-  if (timeout_s > 0) {
-    if (!box->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return box->done; })) {
-      fprintf(stderr, "grtrans_amd: ncclCommInitRank (rank %d of %d) did not return within %.0f s: a rank is missing or the id is stale\n", rank, nranks, timeout_s);
-      return GRT_E_IO;
-    }
-  } else {
-    box->cv.wait(lk, [&] { return box->done; });
+    box->done = true;
   }
-  if (box->r != ncclSuccess) return nccl_rc(box->r);
-  M.comm = box->comm;
+  box->cv.notify_all();
+  if (dog.joinable()) dog.join();
+  if (r != ncclSuccess) return nccl_rc(r);
+  M.comm = c;
   return 0;
 }
 

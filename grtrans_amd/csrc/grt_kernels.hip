@@ -55,7 +55,11 @@ __device__ __forceinline__ long long range_pixel(const long long *__restrict__ t
   return tab[2 * lo + 1] + (j - tab[2 * lo]);
 }
 
-__global__ __launch_bounds__(256) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
+// two waves per SIMD: 256 registers + 560 B/lane of scratch, 3.4 -> 2.5 ms for 1,048,576 rays against one wave with 316 registers
+#ifndef GRT_WPE_SETUP
+#define GRT_WPE_SETUP 2
+#endif
+__global__ __launch_bounds__(256, GRT_WPE_SETUP) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
                                                          int *__restrict__ counters, char *__restrict__ rrays, int need_time /* bit 0: coordinate time wanted (no cubic class), bit 1: azimuth wanted */, double polar_l2,
                                                          GrtRayIn rin, const long long *__restrict__ rng, int nrng) {
@@ -190,10 +194,21 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // the class size is read on the device (the set-up kernel's counter): the host never waits for it between the launches.
   // The fast-class grid covers the worst case (surplus waves leave at once); the generic-class grid is capped and strides.
+  // The generic class is few rays of very long per-point code (1.4 ms of pure latency for the headline camera when one wave walked
+  // the 8 chunks of a ray in turn, and the fast-class chain waits for it): its work item is (ray, 64-point chunk), so the chunks of
+  // a ray run on different waves.  A chunk needs Lambda of the ray's top stored point (the record holds Lambda(npts) - Lambda): a
+  // wave that does not own the top chunk evaluates that one point first (all lanes, same point).
+  // (Only while the class is small enough to be latency-bound -- at most two resident rounds of (ray, chunk) items: the extra
+  // top-point pass doubles the class's work, which a throughput-bound class of thousands of rays would pay in full.  r03, rank 4 of 8 of the headline
+  // camera: 13.4 -> 12.9 ms per step; one GPU with 2600 generic rays keeps the wave-per-ray walk.)
+  const int nchg = (FAST || *nlive_dev * ((cam.nup + cam.next + 63) / 64) > 4096) ? 1 : (cam.nup + cam.next + 63) / 64;
+  const bool perchunk = !FAST && nchg > 1;
   int slot0 = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
-  if (slot0 >= *nlive_dev) return;   // whole wave leaves together
+  if (slot0 >= *nlive_dev * nchg) return;   // whole wave leaves together
   do {
-  const int slot = __builtin_amdgcn_readfirstlane(slot0);
+  const int item = __builtin_amdgcn_readfirstlane(slot0);
+  const int slot = item / nchg;
+  const int cfix = item - slot * nchg;
   // fast classes fill live[] from the front, the generic class from the back (grt_setup_kernel)
   const int rayidx = FAST ? live[slot] : live[nrays - 1 - slot];
   const GrtRay *Rp = rays + rayidx;
@@ -220,7 +235,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   for (int ph = 0; ph < (leg.nfill > 0 ? 2 : 1); ++ph) {
   const bool fillph = (ph == 1);
   const int cnt = fillph ? leg.nfill : nreg;
-  for (int c = (cnt - 1) >> 6; c >= 0; --c) {
+  const int ctop = (cnt - 1) >> 6;
+  const bool pre = perchunk && cfix < ctop;            // generic class, one chunk per wave: this wave's chunk is not the top one
+  const int c_start = perchunk ? (pre ? cfix + 1 : cfix) : ctop, c_end = perchunk ? cfix : 0;
+  for (int c = c_start; c >= c_end && cfix <= ctop; --c) {
+    const bool toppass = pre && c == cfix + 1;             // the extra pass: every lane evaluates the ray's top point
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
     {
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       asm volatile("" : "+s"(r_), "+s"(k_));
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
     }
-    const int pos = 64 * c + lane + 1;
+    const int pos = toppass ? cnt : 64 * c + lane + 1;
     const bool valid = pos <= cnt;
     const int idx = fillph ? leg.lo + pos : ((pos <= leg.lo) ? pos : pos + leg.nfill);
     GeoPoint P;
@@ -266,7 +285,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
         else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
       }
     }
-    if (ph == 0 && c == ((cnt - 1) >> 6)) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel)
+    if (toppass) { LamN = P.lam; continue; }
+    if (ph == 0 && c == ctop) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel)
     // the turning-point parities ride in the sign bits of r (radial) and theta (polar): both are positive quantities
     if (NPH == 3 && valid && raw) {   // grt_geokerr_rays: GEOKERR's own output arrays UFI, MUFI, LAMBDAI, DPHI, DTI, TPMI, TPRI
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
-  } while (FAST == 0 && slot0 < *nlive_dev);     // only the generic class strides (capped grid); a fast-class wave serves one ray
+  } while (FAST == 0 && slot0 < *nlive_dev * nchg);     // only the generic class strides (capped grid); a fast-class wave serves one ray
 }
 
 // standard=2 with nup > 1 (geodesics.f90:298-347): GEOR returns u_f < 0 where the ray does not reach the requested mu; such
@@ -517,26 +537,45 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       // HARM: the time rides in the fourth tile; KORAL3D needs that tile for phi and reads its time straight from the record
       const double t_i = !(slowlight && valid) ? 0.0 : (FLUID == GRT_FLUID_KORAL3D ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * GRT_TS + e]);
       double kv[4], sth, cth;
-      sincos(th, &sth, &cth);
+      sincos(th, &sth, &cth);      // (the library's: the lean fast_sincos of the geodesic kernels is 5 % slower here, re-measured r03)
       calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
       sumr += valid ? r : 0.0;
       // fluid + frame (grtrans_driver.f90:126-130)
       FluidPoint fl;
-      if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam_a, fl);
+      // cos / sin of the REAL(4) angle the single-precision metric and LNRF frame of every sampler take, from sth, cth (grt_dev_phys.hpp)
+#if !defined(GRT_NO_F32TRIG)
+      const F32Trig ftv = f32_trig(th, sth, cth);
+      const F32Trig *ft = &ftv;
+#else
+      const F32Trig *ft = nullptr;
+#endif
+      if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam_a, fl, ft);
       else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
       else if (FLUID == GRT_FLUID_HARM)
-        harm_sample(fd.hm, s_harm, r, th, (float)cam_a, fl, slowlight ? harm_time_index(fd.hm, r, t_i, r_1, (float)cam_a) : 0);
+        harm_sample(fd.hm, s_harm, r, th, (float)cam_a, fl, slowlight ? harm_time_index(fd.hm, r, t_i, r_1, (float)cam_a) : 0, ft);
       else if (FLUID == GRT_FLUID_HARM3D)
-        harm3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl);
+        harm3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, ft);
       float kela = 0.f;
-      if (FLUID == GRT_FLUID_IHARM) iharm_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela);
+      if (FLUID == GRT_FLUID_IHARM) iharm_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela, ft);
       if (FLUID == GRT_FLUID_KORAL3D)
         koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela,                                  // kela carries Be
-                       slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0);
+                       slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0, ft);
+#if defined(GRT_STAGE_STOP) && GRT_STAGE_STOP == 1      // experiment builds (tools/stage_budget.sh): the step ends after the fluid sample
+      facs[0] += 1.0;
+      I[0][0] += kv[0] + kv[1] + kv[2] + kv[3] + (double)(fl.rho + fl.bmag + fl.u[0] + fl.u[1] + fl.u[2] + fl.u[3] + fl.b[0] + fl.b[1] + fl.b[2] + fl.b[3]);
+      if (valid) lam_prev = lam_i;
+      continue;
+#endif
       double s2xi, c2xi, ang, g, cang;
       // the power-law emissivity takes sin and cos of the field / wave-vector angle, not the angle: no acos + sincos pair per step
       constexpr bool WANT_ANG = EXTRA || !((EMIS == GRT_EMIS_POLSYNCHPL && FLUID == GRT_FLUID_FFJET) || EMIS == GRT_EMIS_POLSYNCHTH || EMIS == GRT_EMIS_POLSYNCHSYMTH);
       comoving_ortho<WANT_ANG>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
+#if defined(GRT_STAGE_STOP) && GRT_STAGE_STOP == 2      // ... after the tetrad / polarization basis
+      facs[0] += 1.0;
+      I[0][0] += s2xi + c2xi + g + cang + (WANT_ANG ? ang : 0.0) + (double)(fl.rho + fl.bmag);
+      if (valid) lam_prev = lam_i;
+      continue;
+#endif
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
       double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
       const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
@@ -613,6 +652,13 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             if (GRT_DEBUG_SEL == 5) { dbg[0] = fl.b[1]; dbg[1] = fl.b[2]; dbg[2] = fl.b[3]; dbg[3] = fl.bmag; }
             if (GRT_DEBUG_SEL == 6) { dbg[0] = fl.u[1]; dbg[1] = fl.u[2]; dbg[2] = fl.u[3]; dbg[3] = fl.rho; }
           }
+#endif
+#if defined(GRT_STAGE_STOP) && GRT_STAGE_STOP == 3      // ... after the emission / absorption / Faraday coefficients
+          { double acc = s2xi + c2xi;
+#pragma unroll
+            for (int c = 0; c < 11; ++c) acc += e11[c];
+            I[f][0] += acc; facs[f] += 1.0; }
+          continue;
 #endif
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
           if constexpr (IFLAG == GRT_INT_QUAD) {
@@ -822,7 +868,12 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
                                      long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
-  if (!fast && nblk > 8192u) nblk = 8192u;     // the generic class is small as a rule: a capped grid that strides over its rays
+  // the generic class is small as a rule: a capped grid that strides over its (ray, chunk) items
+  if (!fast) {
+    const long long items = (long long)nrays * ((cam->nup + cam->next + 63) / 64);
+    const long long nb = (items + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK;
+    nblk = (unsigned)(nb > 8192 ? 8192 : nb);
+  }
   dim3 g(nblk), b(64 * GRT_WAVES_PER_BLOCK);
   const char *rr = (const char *)rrays;
   // the time field needs the azimuth integrals anyway (Eq. 47 shares them), so NPH = 3 also when phi is not stored

@@ -281,8 +281,13 @@ int grt_get_harm_tstep(float *tstep);
  * Communicator owned by the library:
  *   grt_comm_unique_id  128 bytes of an ncclUniqueId, made by one rank and handed to all by the launcher's own channel
  *   grt_comm_init       every rank, same id bytes
- *   grt_comm_init_file  the same with a file rendezvous (rank 0 writes `path`, the others poll it for timeout_s seconds):
- *                       for hosts without a channel of their own (the Fortran executable)
+ *   grt_comm_init_file  the same with a file rendezvous for hosts without a channel of their own (the Fortran executable): rank 0
+ *                       removes whatever sits at `path`, writes [magic][run nonce][id] and renames it into place; the others poll
+ *                       `path` for timeout_s seconds and accept it only with THEIR run's nonce (GRT_COMM_NONCE if the launcher
+ *                       sets it, else the parent process id): a file left by a crashed run is never joined.  Rank 0 removes the
+ *                       file once every rank has joined.  ncclCommInitRank has no timeout of its own: if it has not returned
+ *                       within timeout_s (grt_comm_init: GRT_COMM_INIT_TIMEOUT, default 600 s) a watchdog ends the process with
+ *                       exit code 98 and a message instead of hanging the host silently
  *   grt_comm_allreduce  sum (op 0) / max (op 1) of <= 64 doubles, in place on the host: run statistics only
  * Rank-level image [ncams][npix_rank][nvals] in HBM, zeroed by grt_stage_reset; grt_stage_resident copies the tile of the
  * last grt_trace_tile / grt_trace_tile_resident call (cameras cam0 .. cam0+nfreq-1, npix_tile pixels) into it at pixel
