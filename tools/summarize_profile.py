@@ -11,7 +11,7 @@ import shutil
 import sys
 
 sys.path.insert(0, os.getcwd())
-import bench  # noqa: E402  (build_id: the device sources these counters were collected with; bench.py refuses stale ones)
+import bench as benchmod  # noqa: E402  (build_id: the device sources these counters were collected with; bench.py refuses stale ones)
 
 tag = sys.argv[1]
 args = sys.argv[2:]
@@ -51,7 +51,7 @@ if not args:
     steps = bench["config"]["ray_steps_per_step_per_gpu"] if bench else 474894124
     json.dump({"scope": "trace phase of one record-mode step at 1024x1024x400: grt_geo_kernel<1,2> + grt_geo_kernel<0,2> + the largest "
                         "grt_transfer_kernel dispatch (fast class, record on); the generic-class transfer launch is below 1 % of it",
-               "build_id": bench.build_id(),
+               "build_id": benchmod.build_id(),
                "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
                "hbm_bytes_per_launch_raw_counters": (fetch_kb + write_kb) * 1024.0,
                "algorithmic_bytes_trace_phase": 64.0 * steps,
@@ -70,7 +70,7 @@ if not args:
         pass
     sclk = gui / 8.0 / (dur_ns * 1e-9) if (gui and dur_ns) else 2.4e9
     json.dump({"scope": "trace phase of one record-mode step at 1024x1024x400 (same dispatches as traffic.json)",
-               "build_id": bench.build_id(),
+               "build_id": benchmod.build_id(),
                "fma_f64_wave_insts": rec("SQ_INSTS_VALU_FMA_F64"), "mul_f64_wave_insts": rec("SQ_INSTS_VALU_MUL_F64"),
                "add_f64_wave_insts": rec("SQ_INSTS_VALU_ADD_F64"), "trans_f64_wave_insts": rec("SQ_INSTS_VALU_TRANS_F64"),
                "valu_wave_insts": rec("SQ_INSTS_VALU"), "sclk_hz": sclk,
