@@ -186,6 +186,19 @@ def trace_ranges(cam, ranges, fname, em, freqs, iname, nvals=4, nextra=0, reside
     return pix, loc, status, st
 
 
+def debug_ray(cam, pixel, fname, em, freq, iname, nvals=4):
+    """grt_debug_ray: the arrays of the reference's geodebug.out (debug=1) for one pixel: (npts, header[11], rows[64][npts], fac)."""
+    maxpts = cam.nup + cam.next
+    rows = np.zeros((64, maxpts))
+    header = np.zeros(11)
+    n = C.c_int32(0)
+    fac = C.c_double(0)
+    check(lib().grt_debug_ray(C.byref(cam), C.c_int64(pixel), C.c_int(FLUID[fname]), C.byref(em), C.c_double(freq), C.c_int(INTEG[iname]),
+                              C.c_int(nvals), C.c_int(maxpts), C.byref(n), header.ctypes.data_as(C.POINTER(C.c_double)),
+                              rows.ctypes.data_as(C.POINTER(C.c_double)), C.byref(fac)), "grt_debug_ray")
+    return n.value, header, rows[:, :abs(n.value)], fac.value
+
+
 def compute_t0(cam, i1, i2):
     """Raw per-ray time origins (nload > 1, geodesics.f90:113-128); normalise with normalise_t0, then set_t0."""
     t0 = np.zeros(i2 - i1 + 1)

@@ -37,6 +37,10 @@ extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const vo
 extern "C" size_t grt_sizeof_disk(void);
 
 extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *out6);
+extern "C" int grt_debug_rows(void);
+extern "C" hipError_t grt_launch_debug(hipStream_t s, int fluid, int emis, const GrtCam *cam, const GrtRay *rays, int rayidx, const GrtFluidDev *fd,
+                                       const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, double freq, const double *steps,
+                                       long long ray_stride, long long field_stride, int tfield, double *out, int maxpts, double *scal);
 
 namespace {
 
@@ -104,6 +108,7 @@ struct Ctx {
   long long *d_rng = nullptr;           // device table of a several-range call: (first local index, first pixel) per range
   size_t cap_rng = 0;
   long long t0_version = 0;
+  int force_time = 0;                   // grt_debug_ray: every point carries its coordinate time whatever the fluid model
   int geo_reuse = 1;                    // grt_set_geo_reuse
   int class_order = 3;
   long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
@@ -654,8 +659,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   // extra=1 weights by phi as well; a 3-D fluid model is sampled at the point's azimuth
   const int nfields = C.record_steps ? 8 : ((nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || is_koral) ? 4 : 3);
   // several HARM slices loaded ("slow light"): every point also carries its coordinate time, one more field
-  const bool need_time = (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1) || (is_koral && C.koral.nt > 1);
-  if (need_time && nextra != 0) return GRT_E_UNSUPPORTED;
+  const bool need_time = C.force_time || (fluid_model == GRT_FLUID_HARM && C.harm.nt > 1) || (is_koral && C.koral.nt > 1);
   const int tfield = need_time ? nfields : -1;
   if (need_time && C.t0_n != 0 && C.t0_n != total) return GRT_E_BADARG;   // t0 table of another tile
   const double *d_t0 = (need_time && C.t0_n != 0) ? C.d_t0 : nullptr;
@@ -963,6 +967,82 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
     std::vector<GrtRay> hr((size_t)n);
     HIPCHK(hipMemcpy(hr.data(), C.d_rays, (size_t)n * sizeof(GrtRay), hipMemcpyDeviceToHost));
     for (int k = 0; k < n; ++k) ncase[k] = hr[k].ncase;
+  }
+  return 0;
+}
+
+// debug=1 (grtrans_driver.f90:94-110, 341-421): the arrays of geodebug.out for ONE camera pixel and frequency.
+// rows: HOST out, [64][maxpts] in the file's order -- lam, t, r, th, phi, k(4), tpr, tpm | rho, p, bmag, u(4), b(4) | ncgs, tcgs, bcgs,
+// rshift, incang, j_I, K_1, j_Q, j_V, K_2, K_4, K_5, K_7, I, Q, U, V (integration order), tau, j_U, K_3, K_6, s2xi, c2xi, calc_kb_ang,
+// calcg, s2xi, c2xi | aahat(:,1), aahat(:,2), aahat(:,3) (one block of the file) | aat, aar, aath, aaph, kht, khr, khth, khph, bht, bhr,
+// bhth, bhph; header[11] = npts, nitems, alpha, beta, su, sm, mdot, mbh, fac (0 where the reference writes it), a, mu0; *fac = the last line.
+int grt_debug_ray(const grt_camera *cam, int64_t pixel, int fluid_model, const grt_emis *em, double freq, int iflag, int nvals,
+                  int maxpts, int32_t *npts_out, double *header, double *rows, double *fac_out) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (!cam || !em || !npts_out || !header || !rows || !fac_out || pixel < 1 || pixel > (int64_t)cam->nro * cam->nphi) return GRT_E_BADARG;
+  const bool pair_ok = (fluid_model == GRT_FLUID_FFJET && em->type == GRT_EMIS_POLSYNCHPL) ||
+                       ((fluid_model == GRT_FLUID_SPHACC || fluid_model == GRT_FLUID_HARM) && em->type == GRT_EMIS_POLSYNCHTH);
+  if (!pair_ok || nvals != 4 || cam->standard != 1 || cam->nup < 2) return GRT_E_UNSUPPORTED;
+  if (maxpts < cam->nup + cam->next) return GRT_E_BADARG;
+  // the ray's trace with the per-step record and the coordinate time on: geodesic + running Stokes vector stay in the work buffers
+  const int rec0 = C.record_steps, ft0 = C.force_time, reuse0 = C.geo_reuse;
+  C.record_steps = 1; C.force_time = 1; C.geo_reuse = 0;
+  grt_stats st{};
+  int rc = trace_common(cam, 1, &pixel, &pixel, fluid_model, em, 1, &freq, iflag, nvals, 0, &st);
+  C.record_steps = rec0; C.force_time = ft0; C.geo_reuse = reuse0; C.geo.valid = false;
+  if (rc) return rc;
+  int32_t n = 0;
+  HIPCHK(hipMemcpy(&n, C.d_npts, sizeof n, hipMemcpyDeviceToHost));
+  GrtRay hr;
+  HIPCHK(hipMemcpy(&hr, C.d_rays, sizeof hr, hipMemcpyDeviceToHost));
+  *npts_out = n;
+  header[0] = (double)(n < 0 ? -n : n); header[1] = 18.0; header[2] = hr.alpha; header[3] = hr.beta; header[4] = hr.su; header[5] = hr.sm;
+  header[6] = em->mdot; header[7] = em->mbh; header[8] = 0.0; header[9] = cam->a; header[10] = cam->mu0;
+  *fac_out = 0.0;
+  std::fill(rows, rows + (size_t)64 * maxpts, 0.0);
+  if (n < 2) return 0;              // a ray without a geodesic: the dump has its header only
+  const int nrows = grt_debug_rows();
+  struct Tmp { void *p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } dout, dscal;
+  HIPCHK(hipMalloc(&dout.p, (size_t)nrows * maxpts * sizeof(double)));
+  HIPCHK(hipMalloc(&dscal.p, 4 * sizeof(double)));
+  HIPCHK(hipMemset(dout.p, 0, (size_t)nrows * maxpts * sizeof(double)));
+  GrtFluidDev fd{};
+  fd.fj = C.ffjet; fd.sphacc = C.d_sphacc; fd.hm = C.harm;
+  GrtPLConst plc{};
+  grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
+  const long long rstride = C.steps_stride, fstride = rstride;      // one ray in the buffers
+  HIPCHK(grt_launch_debug(C.stream, fluid_model, em->type, cam, C.d_rays, 0, &fd, &C.tables, em, &plc, freq, C.d_steps, rstride, fstride, 8,
+                          (double *)dout.p, maxpts, (double *)dscal.p));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  std::vector<double> k((size_t)nrows * maxpts), rec((size_t)9 * rstride);
+  double scal[4];
+  HIPCHK(hipMemcpy(k.data(), dout.p, k.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(scal, dscal.p, sizeof scal, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rec.data(), C.d_steps, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+  *fac_out = scal[0];
+  auto row = [&](int r) { return rows + (size_t)r * maxpts; };
+  for (int i = 0; i < n; ++i) {      // geodesic blocks from the record (internal field order r, theta, lambda, phi, I..V, t)
+    row(0)[i] = rec[2 * rstride + i]; row(1)[i] = rec[8 * rstride + i];
+    row(2)[i] = std::fabs(rec[0 * rstride + i]); row(3)[i] = std::fabs(rec[1 * rstride + i]); row(4)[i] = rec[3 * rstride + i];
+  }
+  for (int r = 0; r < 4; ++r) std::copy(k.begin() + (size_t)r * maxpts, k.begin() + (size_t)r * maxpts + n, row(5 + r));           // k^mu
+  for (int r = 4; r <= 41; ++r) std::copy(k.begin() + (size_t)r * maxpts, k.begin() + (size_t)r * maxpts + n, row(11 + (r - 4)));  // rho .. c2xi
+  for (int r = 42; r <= 56; ++r) std::copy(k.begin() + (size_t)r * maxpts, k.begin() + (size_t)r * maxpts + n, row(49 + (r - 42))); // aahat .. bhat
+  // g%tprarr, g%tpmarr: GEOKERR's turning-point COUNTS of every stored point (the record carries their parities only): the raw-array
+  // surface (grt_geokerr_rays) on this pixel's constants; it re-uses the work buffers, which nothing below needs any more
+  {
+    double al, be, q2, l, su, sm, uf;
+    int32_t tpr0 = 0;
+    rc = grt_camera_pixels(cam, pixel, pixel, &al, &be, &q2, &l, &su, &sm, &uf, nullptr, nullptr, &tpr0);
+    if (rc) return rc;
+    const int m = cam->nup + cam->next - 2 * cam->kext;
+    std::vector<int32_t> tpm((size_t)m), tpr((size_t)m);
+    int32_t np2 = 0;
+    rc = grt_geokerr_rays(1, cam->u0, cam->uout, cam->mu0, cam->a, cam->offset, cam->nup, cam->phit, cam->usegeor, cam->mufill, cam->kext, cam->next,
+                          &uf, &l, &q2, &al, &be, &tpr0, &su, &sm, nullptr, nullptr, nullptr, nullptr, nullptr, tpm.data(), tpr.data(), nullptr, &np2);
+    if (rc) return rc;
+    if (np2 != n) return GRT_E_BADARG;
+    for (int i = 0; i < n && i < m; ++i) { row(9)[i] = (double)tpr[i]; row(10)[i] = (double)tpm[i]; }
   }
   return 0;
 }

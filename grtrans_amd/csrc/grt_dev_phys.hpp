@@ -155,7 +155,8 @@ GRT_HD void transport_perpk(const double *k, double r, double sth, double cth, d
 // sin and cos alone: sin = sqrt(1 - cos^2) exactly where acos followed by sincos gave it to rounding)
 template <bool WANT_ANG = true>
 GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double alpha, double beta, double mus, const double *u,
-                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang, double &g, double *cang = nullptr) {
+                           const double *b, const double *k, double &s2xi, double &c2xi, double &ang, double &g, double *cang = nullptr,
+                           double *dbg15 = nullptr /* debug=1: aahat(3), aa(4), khat(4), bhat(4) of comoving_ortho_debug, kerr.f90:564-584 */) {
   Metric m = blmetric_cov_sc(r, sth, cth, a);
   double gtt = m.g[0], gtp = m.g[3], grr = m.g[4], gmm = m.g[7], gpp = m.g[9];
   double ut = u[0], ur = u[1], um = u[2], up = u[3];
@@ -210,6 +211,49 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
   ang = WANT_ANG ? acos(t) : 0.0;
   if (cang) *cang = t;
   g = ikt;
+  if (dbg15) {
+    dbg15[0] = aahat1; dbg15[1] = aahat2; dbg15[2] = aahat3;
+    dbg15[3] = aa[0]; dbg15[4] = aa[1]; dbg15[5] = aa[2]; dbg15[6] = aa[3];
+    dbg15[7] = khatt; dbg15[8] = khatr; dbg15[9] = khatm; dbg15[10] = khatp;
+    dbg15[11] = dot4(ekt, m, b); dbg15[12] = bhatr; dbg15[13] = bhatm; dbg15[14] = bhatp;
+  }
+}
+
+// ---- debug=1 (geodebug.out) only: the two cross-checks grtrans_driver.f90:383-393 prints next to the path's own values ----
+// calc_kb_ang, kerr.f90:220-252: angle between wave vector and field from covariant dot products (Broderick 2004)
+GRT_HD double calc_kb_ang(const double *k, const double *b, const double *u, double r, double sth, double cth, double a) {
+  const Metric m = blmetric_cov_sc(r, sth, cth, a);
+  const double bdotk = dot4(b, m, k), bdotb = dot4(b, m, b), kdotk = dot4(k, m, k), om = -dot4(k, m, u);
+  double cdot2 = bdotk * bdotk / bdotb / (kdotk + om * om);
+  cdot2 = (cdot2 <= 1.0) ? ((cdot2 >= 0.0) ? cdot2 : 0.0) : 1.0;
+  return acos(fsign(1.0, bdotk) * sqrt(cdot2));
+}
+// lnrf_frame (double precision), kerr.f90:402-425, then CALCG, kerr.f90:181-218: the redshift from the LNRF velocities
+GRT_HD double calcg_dbg(double u, double mu, double q2, double l, double a, int tpm, int tpr, double su, double sm, const double *uf /* u^mu */,
+                        double r, double th) {
+  const double vr = uf[1] / uf[0], vt = uf[2] / uf[0], omg = uf[3] / uf[0];
+  const double muc = cos(th);
+  double D = r * r - 2.0 * r + a * a;
+  double AR = (r * r + a * a) * (r * r + a * a) - a * a * D * (1.0 - muc * muc);
+  double RHO = r * r + a * a * muc * muc;
+  double ENU = sqrt(D * RHO / AR), EMU1 = sqrt(RHO / D), EMU2 = sqrt(RHO), EPSI = sqrt(1.0 - muc * muc) * sqrt(AR / RHO), OM = 2.0 * a * r / AR;
+  double vrl = EMU1 / ENU * vr, vtl = EMU2 / ENU * vt, vpl = EPSI / ENU * (omg - OM);
+  if (!(D > 0.0)) { vrl = 0.0; vtl = 0.0; vpl = 0.0; }
+  // CALCG(U=1/r, MU=cos(th), ...)
+  const double R = 1.0 / u;
+  D = R * R - 2.0 * R + a * a;
+  AR = (R * R + a * a) * (R * R + a * a) - a * a * D * (1.0 - mu * mu);
+  RHO = R * R + a * a * mu * mu;
+  ENU = sqrt(D * RHO / AR); EMU1 = sqrt(RHO / D); EMU2 = sqrt(RHO); EPSI = sqrt(1.0 - mu * mu) * sqrt(AR / RHO); OM = 2.0 * a * R / AR;
+  const double SR = powm1(tpr) * su, ST = -powm1(tpm) * sm;
+  double OMEGA = ENU / EPSI * vpl + OM;
+  if (!(EPSI != 0.0)) OMEGA = 0.0;
+  const double GAM = 1.0 / sqrt(1.0 - (vrl * vrl + vtl * vtl + vpl * vpl));
+  double RR = -a * a * q2 * u * u * u * u + 2.0 * u * u * u * (q2 + (a - l) * (a - l)) + u * u * (a * a - q2 - l * l) + 1.0;
+  double TT = (q2 + mu * mu * (a * a - l * l - q2) - a * a * mu * mu * mu * mu) / (1.0 - mu * mu);
+  TT = (TT >= 0.0) ? sqrt(TT) : 0.0;
+  RR = (RR >= 0.0) ? sqrt(RR) * R * R : 0.0;
+  return ENU / GAM / (1.0 - l * OMEGA - EMU1 * ENU * vrl / RHO * SR * RR - EMU2 * ENU * vtl / RHO * ST * TT);
 }
 
 // phys_constants.f90

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
   const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
   const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
   const double lam_1 = has_ray ? steps[GRT_F_LAM * field_stride + base] : 0.0;   // g%lambda(1)
-  const bool slowlight = (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_KORAL3D) && !EXTRA && tfield >= 0;    // several slices: the point's time picks one
+  const bool slowlight = (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_KORAL3D) && tfield >= 0;    // several slices: the point's time picks one
   const double r_1 = (slowlight && has_ray) ? fabs(steps[GRT_F_R * field_stride + base]) : 10.0;
   double I[FB][4], facs[FB];
   double jn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][4], Kn[(IFLAG == GRT_INT_FORMAL) ? 1 : FB][7];
@@ -535,7 +535,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       const int fl8 = (int)(__double2hiint(ths_) < 0) | ((int)(__double2hiint(rs_) < 0) << 1);
       const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? tl3[lane * GRT_TS + e] : 0.0;
       // HARM: the time rides in the fourth tile; KORAL3D needs that tile for phi and reads its time straight from the record
-      const double t_i = !(slowlight && valid) ? 0.0 : (FLUID == GRT_FLUID_KORAL3D ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * GRT_TS + e]);
+      // (extra=1 needs the fourth tile for phi as well: the time then comes straight from the record, as for KORAL3D)
+      const double t_i = !(slowlight && valid) ? 0.0 : ((FLUID == GRT_FLUID_KORAL3D || EXTRA) ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * GRT_TS + e]);
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);      // (the library's: the lean fast_sincos of the geodesic kernels is 5 % slower here, re-measured r03)
       calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
@@ -812,6 +813,132 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
     if (sumr < 0.0) ray_status[rayidx] = -n;
     atomicAdd(step_counter, (unsigned long long)n);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// debug=1 (grtrans_driver.f90:94-110, 341-421: geodebug.out): the per-point arrays of ONE ray that the dump prints between the
+// geodesic itself and `fac`.  One wave, lanes = stored points; the ray's geodesic and running Stokes vector are read from the
+// per-step record of the trace that has just run (record + coordinate time on), everything else is recomputed per point with the
+// transfer kernel's own device functions.  Rows of `out` ([GRT_DBG_ROWS][maxpts], point order = g%... arrays: 1 = camera end):
+//   0-3 k^mu | 4 rho 5 p 6 bmag 7-10 u^mu 11-14 b^mu | 15 ncgs 16 tcgs 17 bcgs 18 rshift 19 incang | 20 j_I 21 K_1 22 j_Q 23 j_V 24 K_2
+//   25 K_4 26 K_5 27 K_7 | 28-31 I,Q,U,V (integration order: 1 = far end) | 32 tau | 33 j_U 34 K_3 35 K_6 | 36 s2xi 37 c2xi |
+//   38 calc_kb_ang 39 calcg | 40 s2xi 41 c2xi | 42-44 aahat(:,1:3) | 45-48 aa | 49-52 khat | 53-56 bhat
+// (j, K after rotate_emis / invariant_emis, j / fac and K L_BH as the driver holds them when it writes); scal[0] = fac, scal[1] = L_BH.
+#define GRT_DBG_ROWS 57
+template <int FLUID, int EMIS>
+__global__ __launch_bounds__(64) void grt_debug_kernel(GrtCam cam, const GrtRay *__restrict__ rays, int rayidx, GrtFluidDev fd, GrtTables tb,
+                                                       GrtEmis em, GrtPLConst plc, double freq, const double *__restrict__ steps,
+                                                       long long ray_stride, long long field_stride, int tfield, double *__restrict__ out,
+                                                       int maxpts, double *__restrict__ scal) {
+  __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
+  __shared__ float s_harm[FLUID == GRT_FLUID_HARM ? 2 * GRT_HARM_MAXCOORD : 1];
+  __shared__ double s_fac;
+  const int lane = threadIdx.x;
+  if (FLUID == GRT_FLUID_HARM) { const int nc = 2 * (fd.hm.nx1 + fd.hm.nx2); for (int i = lane; i < nc; i += 64) s_harm[i] = fd.hm.coords[i]; }
+  if (FLUID == GRT_FLUID_SPHACC) for (int i = lane; i < GRT_SPHACC_NTAB; i += 64) s_sphacc[i] = fd.sphacc[i];
+  if (lane == 0) s_fac = 0.0;
+  __syncthreads();
+  const GrtRay &R = rays[rayidx];
+  const int n = R.npts;
+  const long long base = (long long)rayidx * ray_stride;
+  const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
+  const double lam_1 = steps[GRT_F_LAM * field_stride + base];
+  const bool slow = (FLUID == GRT_FLUID_HARM) && tfield >= 0 && fd.hm.nt > 1;
+  const double r_1 = fabs(steps[GRT_F_R * field_stride + base]);
+  double facl = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    const double rs_ = steps[GRT_F_R * field_stride + base + i], ths_ = steps[GRT_F_TH * field_stride + base + i];
+    const double r = fabs(rs_), th = fabs(ths_), lam_i = steps[GRT_F_LAM * field_stride + base + i];
+    const int ptm = (int)(__double2hiint(ths_) < 0), ptr = (int)(__double2hiint(rs_) < 0);
+    const double t_i = (tfield >= 0) ? steps[(long long)tfield * field_stride + base + i] : 0.0;
+    double kv[4], sth, cth;
+    sincos(th, &sth, &cth);
+    calc_nullp(R.q2, R.l, cam.a, r, cth, R.su * powm1(ptr), R.sm * powm1(ptm), kv);
+    FluidPoint fl;
+    if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam.a, fl);
+    else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
+    else if (FLUID == GRT_FLUID_HARM) harm_sample(fd.hm, s_harm, r, th, (float)cam.a, fl, slow ? harm_time_index(fd.hm, r, t_i, r_1, (float)cam.a) : 0);
+    double s2xi, c2xi, ang, g, cang, d15[15];
+    comoving_ortho<true>(r, sth, cth, cam.a, R.alpha, R.beta, cam.mu0, fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang, d15);
+    double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
+    if (FLUID == GRT_FLUID_FFJET) { ncgsnth = (double)fl.rho * em.nfac; bcgs = (double)fl.bmag * em.bfac; }
+    else if (FLUID == GRT_FLUID_SPHACC) { ncgs = (double)fl.rho; bcgs = (double)fl.bmag; tcgs = (double)fl.p; }
+    else if (FLUID == GRT_FLUID_HARM) { harm_convert(fl, em.mbh, em.mdot, em.muval, em.gminval, ncgs, bcgs, tcgs); ncgsnth = ncgs; }
+    const double nu = freq / g;
+    double e11[11];
+    if (EMIS == GRT_EMIS_POLSYNCHPL) {
+      PLPoint plp;
+      polsynchpl_point(plc, ncgsnth, bcgs, ang, plp);
+      polsynchpl_freq(tb, plc, plp, nu, log(freq) - log(g), e11);
+    } else {
+      polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
+    }
+    facl += e11[0] * (lam_1 - lam_i);
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+      if (!em.coefindx[c]) e11[4 + c] = 0.0;
+    double jj4[4] = {e11[0], c2xi * e11[1] - s2xi * e11[2], s2xi * e11[1] + c2xi * e11[2], e11[3]};
+    double KK[7] = {e11[4], c2xi * e11[5] - s2xi * e11[6], s2xi * e11[5] + c2xi * e11[6], e11[7],
+                    c2xi * e11[8] - s2xi * e11[9], s2xi * e11[8] + c2xi * e11[9], e11[10]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) KK[c] = KK[c] / g * LBH;
+    double *o = out + i;
+    const long long m_ = maxpts;
+    o[0 * m_] = kv[0]; o[1 * m_] = kv[1]; o[2 * m_] = kv[2]; o[3 * m_] = kv[3];
+    o[4 * m_] = (double)fl.rho; o[5 * m_] = (double)fl.p; o[6 * m_] = (double)fl.bmag;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { o[(7 + c) * m_] = fl.u[c]; o[(11 + c) * m_] = fl.b[c]; }
+    o[15 * m_] = ncgs; o[16 * m_] = tcgs; o[17 * m_] = bcgs; o[18 * m_] = g; o[19 * m_] = ang;
+    o[20 * m_] = jj4[0]; o[21 * m_] = KK[0]; o[22 * m_] = jj4[1]; o[23 * m_] = jj4[3]; o[24 * m_] = KK[1]; o[25 * m_] = KK[3]; o[26 * m_] = KK[4];
+    o[27 * m_] = KK[6];
+    // r%I(c,:)/fac/LBH in INTEGRATION order (1 = the far end = stored point n): the record holds the running Stokes vector times L_BH
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[(28 + c) * m_ + (n - 1 - i)] = steps[(GRT_F_I + c) * field_stride + base + i] / LBH;
+    o[33 * m_] = jj4[2]; o[34 * m_] = KK[2]; o[35 * m_] = KK[5];
+    o[36 * m_] = s2xi; o[37 * m_] = c2xi;
+    o[38 * m_] = calc_kb_ang(kv, fl.b, fl.u, r, sth, cth, cam.a);
+    o[39 * m_] = calcg_dbg(1.0 / r, cos(th), R.q2, R.l, cam.a, ptm, ptr, R.su, R.sm, fl.u, r, th);
+    o[40 * m_] = s2xi; o[41 * m_] = c2xi;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) o[(42 + c) * m_] = d15[c];
+  }
+  for (int d = 32; d >= 1; d >>= 1) facl += __shfl_xor(facl, d);
+  if (lane == 0) s_fac = facl;
+  __syncthreads();
+  const double fac = s_fac;
+  for (int i = lane; i < n; i += 64) {       // e%j = e%j / fac (grtrans_driver.f90:216)
+    out[20LL * maxpts + i] /= fac; out[22LL * maxpts + i] /= fac; out[23LL * maxpts + i] /= fac; out[33LL * maxpts + i] /= fac;
+  }
+  __syncthreads();
+  if (lane == 0) {       // tau = -tsum(lambda, |K_1|): the running trapezoid sum (math.f90:30-44 with sum = cum_sum)
+    double acc = 0.0;
+    out[32LL * maxpts] = -0.0;
+    for (int i = 1; i < n; ++i) {
+      const double xd = steps[GRT_F_LAM * field_stride + base + i] - steps[GRT_F_LAM * field_stride + base + i - 1];
+      acc += xd * ((fabs(out[21LL * maxpts + i - 1]) + fabs(out[21LL * maxpts + i])) / 2.0);
+      out[32LL * maxpts + i] = -acc;
+    }
+    scal[0] = fac; scal[1] = LBH; scal[2] = (double)n;
+  }
+}
+
+extern "C" int grt_debug_rows(void) { return GRT_DBG_ROWS; }
+extern "C" hipError_t grt_launch_debug(hipStream_t s, int fluid, int emis, const GrtCam *cam, const GrtRay *rays, int rayidx, const GrtFluidDev *fd,
+                                       const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, double freq, const double *steps,
+                                       long long ray_stride, long long field_stride, int tfield, double *out, int maxpts, double *scal) {
+#define GRT_DBG_CASE(F, E)                                                                                                               \
+  if (fluid == F && emis == E) {                                                                                                         \
+    hipLaunchKernelGGL((grt_debug_kernel<F, E>), dim3(1), dim3(64), 0, s, *cam, rays, rayidx, *fd, *tb, *em, *plc, freq, steps, ray_stride, \
+                       field_stride, tfield, out, maxpts, scal);                                                                          \
+    return hipGetLastError();                                                                                                            \
+  }
+  GRT_DBG_CASE(GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
+  GRT_DBG_CASE(GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
+  GRT_DBG_CASE(GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+#undef GRT_DBG_CASE
+  return hipErrorInvalidValue;
 }
 
 // standard=2 / nup=1 / THINDISK / BB or BBPOL: one lane per pixel, one point per ray (grt_dev_disk.hpp)

@@ -211,6 +211,19 @@ module grt_cabi
        type(grt_stats), intent(out) :: st
        integer(c_int) :: rc
      end function grt_trace_tile
+     ! debug=1: the arrays of geodebug.out for one pixel and frequency (grtrans_driver.f90:94-110, 341-421)
+     function grt_debug_ray(cam, pixel, fluid_model, em, freq, iflag, nvals, maxpts, npts, header, rows, fac) &
+          bind(C, name='grt_debug_ray') result(rc)
+       import :: c_int, c_int64_t, c_double, c_int32_t, grt_camera, grt_emis
+       type(grt_camera), intent(in) :: cam
+       integer(c_int64_t), value :: pixel
+       integer(c_int), value :: fluid_model, iflag, nvals, maxpts
+       type(grt_emis), intent(in) :: em
+       real(c_double), value :: freq
+       integer(c_int32_t), intent(out) :: npts
+       real(c_double), intent(out) :: header(11), rows(*), fac
+       integer(c_int) :: rc
+     end function grt_debug_ray
      ! the same loop over several pixel ranges in one set of launches (a rank's column tiles); output rows follow the ranges
      function grt_trace_ranges(cam, nranges, lo, hi, fluid_model, em, nfreq, freqs, iflag, nvals, nextra, pixvals, pixloc, &
           ray_status, st) bind(C, name='grt_trace_ranges') result(rc)

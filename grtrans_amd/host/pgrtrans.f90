@@ -114,9 +114,8 @@ contains
     end if
     ! uin never reaches GEOKERR in the reference either (geodesics.f90:71-75); rcut is the outer radius of the polar pixel grid
     ! of nrotype=1 (geokerr_wrapper.f:138-149), gridvals(1) its inner radius
-    if (debug /= 0) then
-       call die('debug=1 (geodebug.out) is not supported; use grt_set_record_steps / grt_download_steps'); goto 999
-    end if
+    ! debug=1: geodebug.out of the LAST pixel, mdot, frequency of the run (the reference re-opens the file for every ray, so that is
+    ! what a serial run leaves behind); one process only (written after the trace phase, see write_geodebug)
     ! extra=1 with one point per ray: the 7 diagnostics of grtrans_driver.f90:298-311 go through transpol, which reads the
     ! Chandrasekhar table -- loaded only for nvals = 4 (pgrtrans.f90:154), so the reference itself needs BBPOL here
     if (extra == 1 .and. nup <= 1 .and. .not. (trim(ename) == 'BBPOL' .and. nvals == 4)) then
@@ -222,9 +221,6 @@ contains
     else if (fluid_id == GRT_FLUID_HARM) then
        ! initialize_harm_model(a,ifile,fdfile,fhfile,fnt,findf), fluid.f90:193-194
        ! fnt > 1: that many time slices are loaded and each point reads the one its look-back time selects (slow light)
-       if (fnt > 1 .and. extra /= 0) then
-          call die('extra=1 with several HARM slices (fnt > 1) is not supported'); goto 810
-       end if
        rc = grt_load_harm_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(fnt, c_int), spin)
        if (rc /= 0) then
           call die_rc('grt_load_harm_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 810
@@ -252,9 +248,6 @@ contains
     else if (fluid_id == GRT_FLUID_KORAL3D .or. fluid_id == GRT_FLUID_KORAL3D_DISK) then
        ! initialize_koral3d_model(a,ifile,.false.,fdfile,fhfile,fnt,findf,fscalefac,...), fluid.f90:205-210.  fnt > 1: that many
        ! slices are loaded and each point reads the one its look-back time selects (fluid_model_koral3d.f90:126-128, 212-228)
-       if (fnt > 1 .and. extra /= 0) then
-          call die('extra=1 with several KORAL3D slices (fnt > 1) is not supported'); goto 810
-       end if
        rc = grt_load_koral3d_files_nt(cstr(trim(fdfile)), cstr(trim(fhfile)), int(findf, c_int), int(max(fnt, 1), c_int), spin, fscalefac)
        if (rc /= 0) then
           call die_rc('grt_load_koral3d_files '//trim(fdfile)//' '//trim(fhfile), rc); goto 810
@@ -432,6 +425,14 @@ contains
        if (allocated(t0tab)) deallocate(t0tab)
        if (rank == 0) write(6,*) 'grtrans wall time elapsed: ', omp_get_wtime() - wtime
     end do
+    if (debug /= 0) then
+       if (world > 1) then
+          call die('debug=1 (geodebug.out) with more than one rank: run the pixel of interest with one process'); goto 820
+       end if
+       em%mdot = mdots(nmdot)
+       call write_geodebug(cam, int(i2, c_int64_t), fluid_id, em, freqs(nfreq), iflag, nvals)
+       if (last_error /= 0) goto 820
+    end if
     ! ---- sync point: end of the trace phase; no rank enters the gather unless every rank has its image ----
 820 continue
     if (multi) then
@@ -615,6 +616,44 @@ contains
     write(12) real(iv)
     close(12)
   end subroutine write_camera
+
+  ! geodebug.out in the reference's block order (grtrans_driver.f90:94-110, 341-421; read_geodebug_file.py reads one block per
+  ! line, which is how it is written here -- the reference's list-directed WRITE wraps long records, compiler permitting)
+  subroutine write_geodebug(cam, pixel, fluid_id, em, freq, iflag, nvals)
+    use grt_cabi
+    type(grt_camera), intent(in) :: cam
+    integer(c_int64_t), intent(in) :: pixel
+    integer, intent(in) :: fluid_id, iflag, nvals
+    type(grt_emis), intent(in) :: em
+    real(8), intent(in) :: freq
+    real(c_double), allocatable :: rows(:)
+    real(c_double) :: header(11), fac
+    integer(c_int32_t) :: n
+    integer :: maxpts, rc, b, np
+    maxpts = cam%nup + cam%next
+    allocate(rows(64*maxpts))
+    rc = grt_debug_ray(cam, pixel, int(fluid_id, c_int), em, freq, int(iflag, c_int), int(nvals, c_int), int(maxpts, c_int), n, header, rows, fac)
+    if (rc /= 0) then
+       call die_rc('grt_debug_ray (debug=1 serves FFJET+POLSYNCHPL, SPHACC+POLSYNCHTH, HARM+POLSYNCHTH with nvals=4)', rc)
+       return
+    end if
+    np = abs(n)
+    open(unit=9, file='geodebug.out', form='formatted', status='replace')
+    write(9, '(i0,1x,i0,9(1x,es24.16e3))') np, 18, header(3:11)
+    if (np >= 2) then
+       do b = 1, 49
+          write(9, '(*(es24.16e3,1x))') rows((b-1)*maxpts+1 : (b-1)*maxpts+np)
+       end do
+       ! aahat(npts,3): one block, column after column
+       write(9, '(*(es24.16e3,1x))') rows(49*maxpts+1 : 49*maxpts+np), rows(50*maxpts+1 : 50*maxpts+np), rows(51*maxpts+1 : 51*maxpts+np)
+       do b = 53, 64
+          write(9, '(*(es24.16e3,1x))') rows((b-1)*maxpts+1 : (b-1)*maxpts+np)
+       end do
+       write(9, '(es24.16e3)') fac
+    end if
+    close(9)
+    deallocate(rows)
+  end subroutine write_geodebug
 
   subroutine del_pgrtrans_data()
     if (allocated(ivals)) deallocate(ivals)

@@ -251,6 +251,16 @@ int grt_copy_resident_pixvals(void *d_dst, int64_t count);
 int grt_set_record_steps(int enable);
 int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out);
 
+/* replaces the debug=1 dump of grtrans_driver (grtrans_driver.f90:94-110, 341-421; parser read_geodebug_file.py): the arrays of
+ * `geodebug.out` for ONE camera pixel and frequency, computed on the device (the ray is traced with the per-step record and the
+ * coordinate time on; a one-wave kernel recomputes the per-point fluid, frame and coefficient arrays with the transfer kernel's own
+ * device functions; the turning-point counts come from grt_geokerr_rays).  rows: HOST out, [64][maxpts] doubles in the file's block
+ * order with aahat(npts,3) as three rows (49..51); header[11] and *fac are the file's first and last line; *npts = the ray's stored
+ * points (< 2: the dump has no arrays).  maxpts >= nup + next.  FFJET+POLSYNCHPL, SPHACC+POLSYNCHTH, HARM+POLSYNCHTH, nvals = 4,
+ * standard = 1; everything else GRT_E_UNSUPPORTED. */
+int grt_debug_ray(const grt_camera *cam, int64_t pixel, int fluid_model, const grt_emis *em, double freq, int iflag, int nvals,
+                  int maxpts, int32_t *npts, double *header, double *rows, double *fac);
+
 /* replaces class_geokerr's f2py surface (class_geokerr.f90:69-144; consumer geokerr_interface.py:36-86).
  * grt_camera_pixels = `pixel` -> get_pixel_locations (INITIALIZE_CAMERA_GEOKERR, geokerr_wrapper.f:1-354) for a standard=1
  * camera: the module arrays aarr, barr, q2arr, larr, suarr, smarr, ufarr, mufarr, tpmarr, tprarr of pixels i1..i2 (u0 and

@@ -128,6 +128,10 @@ def run(kw, nthreads=None, writer=None, links=(), keep=False, timeout=3600):
         raise RuntimeError("reference run failed (rc=%d), log: %s" % (rc, open(os.path.join(wd, "stdout.log")).read()[-2000:]))
     res = read_camera_file(outs[0])
     res["log"] = open(os.path.join(wd, "stdout.log")).read()
+    gd = os.path.join(wd, "geodebug.out")
+    if os.path.exists(gd):      # debug=1: the reference's own dump of the last ray (list-directed, wrapped lines): the number stream
+        import numpy as _np
+        res["geodebug"] = _np.array(open(gd).read().split(), dtype=float)
     if not keep:
         import shutil
         shutil.rmtree(wd, ignore_errors=True)

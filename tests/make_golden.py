@@ -608,6 +608,55 @@ KORAL_SLOW_DUMPS = {41: (20261103, 2040.0, 0.12), 40: (20261102, 2020.0, 0.2), 3
                     44: (20261104, 2100.0, 0.16), 43: (20261105, 2080.0, 0.26), 42: (20261106, 2060.0, 0.09)}
 
 
+def harm_slowlight_extra():
+    # extra=1 (the 19 ray diagnostics of grtrans_driver.f90:230-292) on a SLOW-LIGHT HARM run: three loaded slices 20 M apart
+    # (hnt=3, hindf=41; fluid_model_harm.f90:175-186 picks the slice per point), through the reference's own grtrans_main
+    import hashlib
+    import tempfile
+    from oracle import refmain
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_slow_dumps(td)
+        out["dump_sha256"] = np.array([hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)])
+        kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=1,
+                  nn=[32, 32, 100], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428, mumax=.6428,
+                  gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', hdfile='dump', hhfile='dump041', hindf=41, hnt=3,
+                  extra=1)
+        r = refmain.run(kw, nthreads=8, links=[paths[k] for k in sorted(paths)])
+        assert r["nvals"] == 23
+        out["vals"] = r["ivals"][0]
+        g = np.load(os.path.join(G, "harm_slowlight_32x32x100.npz"))
+        # the Stokes columns are the slow-light image of harm_slowlight() (the reference's own driver against ref_driver.f90)
+        print("extra slow light: Stokes vs harm_slowlight golden", np.abs(out["vals"][:, :4].astype(float) - g["ivals_formal"].astype(float)).max())
+    np.savez_compressed(os.path.join(G, "harm_slowlight_extra_32x32x100.npz"), freq=FREQ_HARM, **out)
+
+
+def geodebug():
+    # debug=1 through the reference's own grtrans_driver (grtrans_driver.f90:94-110, 341-421): geodebug.out of one pixel of the
+    # FFJET, SPHACC and HARM problems (the file is re-opened per ray: i1 = i2 = the pixel).  Stored as the file's number stream.
+    import tempfile
+    import make_harm_dump
+    from oracle import refmain
+    out = {}
+    r = refmain.run(dict(FFJET_KW, nn=[32, 32, 100], i1=500, i2=500, debug=1, iname="formal"), nthreads=1)
+    out["ffjet_500"] = r["geodebug"]
+    r = refmain.run(dict(FFJET_KW, nn=[32, 32, 100], i1=611, i2=611, debug=1, iname="delo"), nthreads=1)
+    out["ffjet_611_delo"] = r["geodebug"]
+    r = refmain.run(dict(SPHACC_KW, nn=[32, 32, 100], i1=400, i2=400, debug=1, iname="formal"), nthreads=1)
+    out["sphacc_400"] = r["geodebug"]
+    with tempfile.TemporaryDirectory() as td:
+        path = make_harm_dump.write(td, n=64)
+        kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=1,
+                  nn=[32, 32, 100], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428, mumax=.6428,
+                  gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', hdfile='dump', hhfile='dump040', hindf=40, hnt=1,
+                  i1=530, i2=530, debug=1)
+        r = refmain.run(kw, nthreads=1, links=[path])
+        out["harm_530"] = r["geodebug"]
+    for k, v in out.items():
+        print(k, len(v), v[:3])
+    np.savez_compressed(os.path.join(G, "geodebug_32x32x100.npz"), **out)
+
+
 def write_koral_slow_dumps(outdir, zones=None):
     import make_koral3d_dump
     zones = zones or dict(n1=32, n2=32, n3=16)
@@ -744,6 +793,8 @@ if __name__ == "__main__":
     thindisk()
     harm_movie()
     harm_slowlight()
+    harm_slowlight_extra()
+    geodebug()
     harm3d()
     hybrid()
     maxjutt()

@@ -683,6 +683,138 @@ def test_harm_slow_light_three_slices_device_and_fortran_host(tmp_path, monkeypa
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0].astype(np.float32))
 
 
+def test_extra_diagnostics_on_a_slow_light_run_device_and_fortran_host(tmp_path, monkeypatch):
+    # extra=1 with several loaded HARM slices (VERDICT r02 missing #5): the 19 ray diagnostics of grtrans_driver.f90:230-292 while
+    # every point reads the slice its look-back time selects (fluid_model_harm.f90:175-186).  The EXTRA instantiation keeps phi in the
+    # fourth LDS tile, so the time is read straight from the record.  Golden = the reference's own grtrans_main (hnt=3, extra=1).
+    import hashlib
+    import sys
+    from grtrans_amd import capi, grtrans_batch as gb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    g = np.load(os.path.join(G, "harm_slowlight_extra_32x32x100.npz"))
+    gs = np.load(os.path.join(G, "harm_slowlight_32x32x100.npz"))
+    monkeypatch.chdir(tmp_path)
+    paths = make_golden.write_slow_dumps(str(tmp_path))
+    assert [hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)] == list(g["dump_sha256"])
+    tolc = np.array([1e-5] * 4 + [1e-5] * 6 + [5e-5] * 8 + [1e-4] * 5)      # as test_extra_ray_diagnostics_vs_reference
+
+    def check(vals, ref):
+        a = np.asarray(vals, float); b = np.asarray(ref, float)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        a = np.nan_to_num(a); b = np.nan_to_num(b)
+        err = np.abs(a - b).max(axis=0) / (np.abs(b).max(axis=0) + 1e-300)
+        assert np.all(err < tolc), err
+    dev = capi.Device(0)
+    dev.load_tables()
+    dev.load_harm("dump", "dump041", 41, 0.9375, nt=3)
+    cam = capi.make_camera(1, (-13., 13., -13., 13.), (32, 32, 100), 0.9375, 0.6428, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5, muval=0.25, mdot=1.57e15)
+    pix, _, status, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], "formal", nvals=4, nextra=19)
+    assert pix.shape == (1, 1024, 23) and np.array_equal(status, gs["npts"])
+    check(pix[0], g["vals"])
+    assert stokes_err(pix[0][:, :4], gs["ivals_formal"]) < STOKES_TOL
+    # and the slices matter: one loaded slice gives other diagnostics
+    dev.load_harm("dump", "dump041", 41, 0.9375, nt=1)
+    fast, _, _, _ = capi.trace_tile(cam, 1, 1024, "HARM", em, [FREQ_HARM], "formal", nvals=4, nextra=19)
+    assert np.abs(np.nan_to_num(fast[0][:, 4:10]) - np.nan_to_num(pix[0][:, 4:10])).max() > 0
+    dev.close()
+    kw = dict(fname='HARM', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375,
+              standard=1, nn=[32, 32, 100], uout=0.04, mbh=4e6, mdotmin=1.57e15, mdotmax=1.57e15, nmdot=1, mumin=.6428,
+              mumax=.6428, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', cflag=0, hdfile='dump',
+              hhfile='dump041', hindf=41, hnt=3, extra=1)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    x.read_grtrans_output(bin=1)
+    assert x.ivals.shape == (1024, 23, 1)
+    check(x.ivals[:, :, 0], g["vals"])
+
+
+def _geodebug_blocks(tokens):
+    """split the number stream of a geodebug.out (header 11, 49 blocks of npts, aahat 3 npts, 12 blocks of npts, fac)"""
+    t = np.asarray(tokens, dtype=float)
+    n = int(t[0])
+    sizes = [n] * 49 + [3 * n] + [n] * 12 + [1]
+    assert len(t) == 11 + sum(sizes)
+    out, off = [], 11
+    for sz in sizes:
+        out.append(t[off:off + sz]); off += sz
+    return n, t[:11], out
+
+
+# per block of geodebug.out: tolerance as a fraction of the block's largest magnitude.  Geodesic and frame quantities 1e-9 (phi 1e-8);
+# REAL(4) fluid variables bit-equal; coefficients and Stokes 2e-6 (the Stokes bar); aahat / aa / khat / bhat 1e-9
+_GD_TOL = ([1e-9] * 4 + [1e-8] + [1e-9] * 4 + [0, 0] + [0] * 3 + [1e-12] * 8 + [1e-9] * 5 + [2e-6] * 8 + [2e-6] * 4 + [2e-6] + [2e-6] * 3 + [1e-8] * 2 +
+           [1e-8, 1e-8] + [1e-8] * 2 + [1e-8] + [1e-8] * 12 + [2e-6])
+
+
+def test_debug_dump_geodebug_out_vs_the_reference(tmp_path, monkeypatch, harm_dir):
+    # debug=1 (VERDICT r02 missing #3): geodebug.out in the reference's 64-block layout (grtrans_driver.f90:94-110, 341-421; parser
+    # read_geodebug_file.py), computed on the device, against the file the reference's own driver writes for the same pixel
+    # (tests/make_golden.py:geodebug): FFJET formal and DELO, SPHACC, HARM; through the C ABI and through ./grtrans.
+    from grtrans_amd import capi, grtrans_batch as gb
+    g = np.load(os.path.join(G, "geodebug_32x32x100.npz"))
+    nn = (32, 32, 100)
+
+    def compare(blocks, hdr, fac, key):
+        n, h0, ref = _geodebug_blocks(g[key])
+        assert int(hdr[0]) == n and np.allclose(hdr[1:8], h0[1:8], rtol=1e-15) and np.allclose(hdr[9:], h0[9:], rtol=1e-15)
+        worst = {}
+        for b, (mine, want, tol) in enumerate(zip(blocks, ref, _GD_TOL)):
+            assert mine.shape == want.shape, (key, b)
+            assert np.array_equal(np.isnan(mine), np.isnan(want)), (key, b)
+            if b in (11, 12, 13):      # rho, p, bmag are REAL(4): the reference prints their shortest decimal form -- same REAL(4) bits
+                assert np.array_equal(mine.astype(np.float32), want.astype(np.float32)), (key, "block", b + 1)
+                continue
+            scale = np.nanmax(np.abs(want)) + 1e-300
+            err = np.nanmax(np.abs(mine - want)) / scale if want.size else 0.0
+            worst[b] = err
+            assert err <= max(tol, 1e-15), (key, "block", b + 1, err)
+        if os.environ.get("GRT_TEST_ERRLOG"):
+            with open(os.environ["GRT_TEST_ERRLOG"], "a") as f:
+                f.write("geodebug %s %s\n" % (key, " ".join("%d:%.1e" % (b + 1, e) for b, e in worst.items())))
+        return worst
+
+    def from_rows(rows, fac):
+        return [rows[b] for b in range(49)] + [np.concatenate([rows[49], rows[50], rows[51]])] + [rows[b] for b in range(52, 64)] + [np.array([fac])]
+
+    dev = capi.Device(0)
+    dev.load_ffjet(); dev.load_tables(); dev.load_sphacc()
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5, mdot=1.57e15)
+    for pixel, iname, key in ((500, "formal", "ffjet_500"), (611, "delo", "ffjet_611_delo")):
+        n, hdr, rows, fac = capi.debug_ray(cam, pixel, "FFJET", em, FREQ, iname)
+        compare(from_rows(rows, fac), hdr, fac, key)
+    cam = capi.make_camera(1, (-25., 25., -25., 25.), nn, 0.0, 0.5, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 10.0, 1.0, 6.0, 100., 1e5, 3.5)
+    n, hdr, rows, fac = capi.debug_ray(cam, 400, "SPHACC", em, FREQ_SPHACC, "formal")
+    compare(from_rows(rows, fac), hdr, fac, "sphacc_400")
+    dev.load_harm(os.path.join(harm_dir, "dump"), os.path.join(harm_dir, "dump040"), 40, 0.9375)
+    cam = capi.make_camera(1, (-13., 13., -13., 13.), nn, 0.9375, 0.6428, 0.04, -0.5)
+    em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5, muval=0.25, mdot=1.57e15)
+    n, hdr, rows, fac = capi.debug_ray(cam, 530, "HARM", em, FREQ_HARM, "formal")
+    compare(from_rows(rows, fac), hdr, fac, "harm_530")
+    with pytest.raises(capi.GrtError):
+        capi.debug_ray(cam, 530, "HARM", capi.make_emis("POLSYNCHSYMTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5), FREQ_HARM, "formal")
+    dev.close()
+    # the Fortran host: inputs.in with debug=1, i1 = i2 = the pixel -> geodebug.out, one block per line as read_geodebug_file.py reads it
+    monkeypatch.chdir(tmp_path)
+    kw = dict(fname='FFJET', jdfile='m87bl09rfp10xi5a998fluidvars.bin', nfreq=1, nmu=1, fmin=FREQ, fmax=FREQ, ename='POLSYNCHPL', nvals=4,
+              spin=0.998, standard=1, nn=[32, 32, 100], uout=0.01, mbh=3.4e9, mdotmin=1.57e15, mdotmax=1.57e15, mumin=.906, mumax=.906,
+              gridvals=[-40, 20, -20, 40], ntscl=2., nrscl=70., iname='formal', cflag=0, i1=500, i2=500, debug=1)
+    x = gb.grtrans()
+    x.write_grtrans_inputs('inputs.in', oname='grtrans.out', **kw)
+    x.run_grtrans()
+    lines = open('geodebug.out').read().splitlines()
+    assert len(lines) == 64                                     # header + 62 arrays + fac: data[0..63] of read_geodebug_file.py
+    toks = np.array(" ".join(lines).split(), dtype=float)
+    n, hdr, blocks = _geodebug_blocks(toks)
+    compare(blocks, hdr, blocks[-1][0], "ffjet_500")
+    assert len(lines[1].split()) == n and len(lines[50].split()) == 3 * n and len(lines[63].split()) == 1
+
+
 def test_koral3d_several_slices_slow_light_nload_and_movie(tmp_path, monkeypatch):
     # KORAL3D with fnt = 3 loaded slices (each point reads the dump its Kerr-Schild look-back time selects,
     # fluid_model_koral3d.f90:126-128, 212-228), nload = 2 (per-ray time origin) and two movie frames of a two-slice run
