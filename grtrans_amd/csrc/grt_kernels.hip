@@ -824,7 +824,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
 //   25 K_4 26 K_5 27 K_7 | 28-31 I,Q,U,V (integration order: 1 = far end) | 32 tau | 33 j_U 34 K_3 35 K_6 | 36 s2xi 37 c2xi |
 //   38 calc_kb_ang 39 calcg | 40 s2xi 41 c2xi | 42-44 aahat(:,1:3) | 45-48 aa | 49-52 khat | 53-56 bhat
 // (j, K after rotate_emis / invariant_emis, j / fac and K L_BH as the driver holds them when it writes); scal[0] = fac, scal[1] = L_BH.
-#define GRT_DBG_ROWS 57
+#define GRT_DBG_ROWS 68      // 57 printed rows + 11 scratch rows (the raw coefficients, for a ray the driver does not integrate)
 template <int FLUID, int EMIS>
 __global__ __launch_bounds__(64) void grt_debug_kernel(GrtCam cam, const GrtRay *__restrict__ rays, int rayidx, GrtFluidDev fd, GrtTables tb,
                                                        GrtEmis em, GrtPLConst plc, double freq, const double *__restrict__ steps,
@@ -897,6 +897,8 @@ __global__ __launch_bounds__(64) void grt_debug_kernel(GrtCam cam, const GrtRay 
 #pragma unroll
     for (int c = 0; c < 4; ++c) out[(28 + c) * m_ + (n - 1 - i)] = steps[(GRT_F_I + c) * field_stride + base + i] / LBH;
     o[33 * m_] = jj4[2]; o[34 * m_] = KK[2]; o[35 * m_] = KK[5];
+#pragma unroll
+    for (int c = 0; c < 11; ++c) o[(57 + c) * m_] = e11[c];
     o[36 * m_] = s2xi; o[37 * m_] = c2xi;
     o[38 * m_] = calc_kb_ang(kv, fl.b, fl.u, r, sth, cth, cam.a);
     o[39 * m_] = calcg_dbg(1.0 / r, cos(th), R.q2, R.l, cam.a, ptm, ptr, R.su, R.sm, fl.u, r, th);
@@ -908,8 +910,24 @@ __global__ __launch_bounds__(64) void grt_debug_kernel(GrtCam cam, const GrtRay 
   if (lane == 0) s_fac = facl;
   __syncthreads();
   const double fac = s_fac;
+  if (!(fac / 1e16 > 0.0)) {
+    // no emission along the ray, or a NaN coefficient (fac <= 0 or NaN): the driver skips rotate / invariant / scaling and the integration
+    // (grtrans_driver.f90:183, 314-317), so the dump holds the RAW coefficients and r%I = 0 (printed as 0 / fac / L_BH); tau is not set
+    static const int jrow[4] = {20, 22, 33, 23}, krow[7] = {21, 24, 34, 25, 26, 35, 27};
+    for (int i = lane; i < n; i += 64) {
+      for (int c = 0; c < 4; ++c) out[(long long)jrow[c] * maxpts + i] = out[(57LL + c) * maxpts + i];
+      for (int c = 0; c < 7; ++c) out[(long long)krow[c] * maxpts + i] = out[(61LL + c) * maxpts + i];
+      for (int c = 0; c < 4; ++c) out[(28LL + c) * maxpts + i] = 0.0 / fac / LBH;
+      out[32LL * maxpts + i] = 0.0;
+    }
+    if (lane == 0) { scal[0] = fac; scal[1] = LBH; scal[2] = (double)n; }
+    return;
+  }
   for (int i = lane; i < n; i += 64) {       // e%j = e%j / fac (grtrans_driver.f90:216)
     out[20LL * maxpts + i] /= fac; out[22LL * maxpts + i] /= fac; out[23LL * maxpts + i] /= fac; out[33LL * maxpts + i] /= fac;
+    // (the transfer kernel integrates the unscaled j: its running vector is the driver's r%I / L_BH; the dump prints r%I / fac / L_BH)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[(28LL + c) * maxpts + i] /= fac;
   }
   __syncthreads();
   if (lane == 0) {       // tau = -tsum(lambda, |K_1|): the running trapezoid sum (math.f90:30-44 with sum = cum_sum)

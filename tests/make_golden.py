@@ -651,7 +651,9 @@ def geodebug():
                   gridvals=[-13, 13, -13, 13], muval=0.25, gmin=1., iname='formal', hdfile='dump', hhfile='dump040', hindf=40, hnt=1,
                   i1=530, i2=530, debug=1)
         r = refmain.run(kw, nthreads=1, links=[path])
-        out["harm_530"] = r["geodebug"]
+        out["harm_530"] = r["geodebug"]          # a ray that ends behind the horizon: NaN coefficient at its last point -> fac = NaN, not integrated
+        r = refmain.run(dict(kw, i1=200, i2=200), nthreads=1, links=[path])
+        out["harm_200"] = r["geodebug"]
     for k, v in out.items():
         print(k, len(v), v[:3])
     np.savez_compressed(os.path.join(G, "geodebug_32x32x100.npz"), **out)
