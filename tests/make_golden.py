@@ -693,6 +693,27 @@ def koral3d_slowlight():
     np.savez_compressed(os.path.join(G, "koral3d_slowlight_24x24x100.npz"), freq=FREQ_HARM, **out)
 
 
+def koral3d_slowlight_extra():
+    # extra=1 on the KORAL3D slow-light run of koral3d_slowlight() (fnt = 3), through the reference's own grtrans_main
+    import hashlib
+    import tempfile
+    from oracle import refmain
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_koral_slow_dumps(td)
+        out["dump_sha256"] = np.array([hashlib.sha256(open(paths[k], "rb").read()).hexdigest() for k in sorted(paths)])
+        links = [paths[k] for k in sorted(paths)] + [os.path.join(td, "koral_header")]
+        kw = dict(fname='KORAL3D', nfreq=1, nmu=1, fmin=FREQ_HARM, fmax=FREQ_HARM, ename='POLSYNCHTH', nvals=4, spin=0.9375, standard=1,
+                  nn=[24, 24, 100], uout=0.04, mbh=4e6, nmdot=1, mumin=.5, mumax=.5, gridvals=[-13, 13, -13, 13], muval=0.25, gmin=-1.,
+                  iname='formal', hdfile='koral', hhfile='koral_header', hindf=41, hnt=3, ntscl=1.5, extra=1)
+        r = refmain.run(kw, nthreads=8, links=links)
+        assert r["nvals"] == 23
+        out["vals"] = r["ivals"][0]
+        g = np.load(os.path.join(G, "koral3d_slowlight_24x24x100.npz"))
+        print("koral extra slow: Stokes vs slow golden", np.nanmax(np.abs(out["vals"][:, :4].astype(float) - g["ivals_slow"][0].astype(float))))
+    np.savez_compressed(os.path.join(G, "koral3d_slowlight_extra_24x24x100.npz"), freq=FREQ_HARM, **out)
+
+
 def standard2():
     # standard=2 with nup > 1 (GEOKERR's USEGEOR branch, geokerr_wrapper.f:421-461: mu steps from mu0 to the equatorial plane;
     # ends with u_f < 0 trimmed, geodesics.f90:298-323) on the FFJET problem: images through the reference's own main, trimmed
@@ -807,6 +828,7 @@ if __name__ == "__main__":
     config5()
     thindisk_pol()
     harm_slowmovie()
+    koral3d_slowlight_extra()
     standard2()
     polar_camera()
     crosscheck_main()
