@@ -37,6 +37,9 @@ using namespace grtd;
 // 340-490 B/lane to scratch, at one wave the spills go to the 256 AGPRs (v_accvgpr moves, no memory): SPHACC
 // 57.5 -> 54.4 ms, HARM 93.9 -> 84.2 ms.
 // (r02, after the emissivities lost their acos + sincos pair: SPHACC is faster at two waves again -- 48.4 -> 42.5 ms -- HARM is not)
+#ifdef GRT_XFER_WPE_ALL      // experiment builds: one occupancy for every instantiation
+#define GRT_XFER_WPE(EMIS, FLUID) GRT_XFER_WPE_ALL
+#endif
 #ifndef GRT_XFER_WPE
 #define GRT_XFER_WPE(EMIS, FLUID) (((EMIS) == GRT_EMIS_POLSYNCHPL || (FLUID) == GRT_FLUID_SPHACC) ? 2 : 1)
 #endif
@@ -214,6 +217,24 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const GrtRay *Rp = rays + rayidx;
   const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)(FAST ? rayidx : 0) * GRT_RR_STRIDE);
   const CubRay *Cp = reinterpret_cast<const CubRay *>(Kp);
+#if !defined(GRT_NO_GEO_LDS_RR)
+  // Image-only four-real-root kernel (NPH = 0): the wave copies its ray's RealRay (2 KB) into LDS once and every per-ray constant is a
+  // broadcast ds_read where it is used, instead of ~90 scalar loads per 64-point pass whose latency two waves per SIMD could not hide
+  // (r03: 29.1 -> 23.9 ms at 1024x1024x400; images bit-equal to the scalar-load build and to the record-mode kernel's).  NOT used for
+  // NPH = 2 / 3: the record-mode kernel is 9 % slower with it (192 B/lane of scratch: the constants then live in VGPRs), and the
+  // NPH = 3 build returned garbage turning-point counts in the mu-fill segment (test_geokerr_rays_abi...; not understood).
+  const RealRay *Kg = Kp;
+  constexpr int RRW = (sizeof(RealRay) + 7) / 8;
+  __shared__ double s_rr[(FAST == 1 && NPH == 0) ? GRT_WAVES_PER_BLOCK : 1][(FAST == 1 && NPH == 0) ? RRW : 1];
+  if (FAST == 1 && NPH == 0) {
+    typedef double __attribute__((may_alias)) grt_word;      // (the record is read back through its own field types)
+    const grt_word *src = reinterpret_cast<const grt_word *>(Kp);
+    grt_word *dst = reinterpret_cast<grt_word *>(&s_rr[wave][0]);
+    for (int w = lane; w < RRW; w += 64) dst[w] = src[w];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+#endif
   const int n = Rp->npts;
   double LamN = 0.0;                              // (ray_stride is a multiple of 64 points: every full chunk row is a 512-byte aligned run of four 128-byte lines)
   constexpr int NQ = (NPH == 3) ? 4 : (NPH == 2 ? 3 : 2);   // u-side quantities of the segment scheme: iu1, tu11[, phiu1[, tu1]]
@@ -245,9 +266,17 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     {
       // (constant address space: the loads below become scalar loads of the wave's ray; see grt_fresh)
       const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rp;
+#if !defined(GRT_NO_GEO_LDS_RR)
+      const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kg;
+#else
       const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kp;
+#endif
       asm volatile("" : "+s"(r_), "+s"(k_));
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
+#if !defined(GRT_NO_GEO_LDS_RR)
+      Kg = Kp;
+      if (FAST == 1 && NPH == 0) { int o_ = 0; asm volatile("" : "+v"(o_)); Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][o_]); }
+#endif
     }
     const int pos = toppass ? cnt : 64 * c + lane + 1;
     const bool valid = pos <= cnt;
@@ -1085,6 +1114,10 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   }
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
+#ifdef GRT_FAST_BUILD_THERMAL      // ... plus the two thermal BASELINE kernels (formal)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+#endif
 #ifndef GRT_FAST_BUILD      // experiment builds (tools/build_variant.sh NAME -DGRT_FAST_BUILD): the FFJET kernels only, a sixth of the compile time
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
