@@ -224,9 +224,12 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   // NPH = 2 / 3: the record-mode kernel is 9 % slower with it (192 B/lane of scratch: the constants then live in VGPRs), and the
   // NPH = 3 build returned garbage turning-point counts in the mu-fill segment (test_geokerr_rays_abi...; not understood).
   const RealRay *Kg = Kp;
-  constexpr int RRW = (sizeof(RealRay) + 7) / 8;
-  __shared__ double s_rr[(FAST == 1 && NPH == 0) ? GRT_WAVES_PER_BLOCK : 1][(FAST == 1 && NPH == 0) ? RRW : 1];
-  if (FAST == 1 && NPH == 0) {
+  // ... and the Schwarzschild-cubic class (CubRay, 648 B) in both of its forms: SPHACC 1024^2 x 400 geodesics 24.3 -> 20.8 ms image only,
+  // 29.0 -> 24.7 ms with the record
+  constexpr bool LDSRR = (FAST == 1 && NPH == 0) || FAST == 2;
+  constexpr int RRW = ((FAST == 2 ? sizeof(CubRay) : sizeof(RealRay)) + 7) / 8;
+  __shared__ double s_rr[LDSRR ? GRT_WAVES_PER_BLOCK : 1][LDSRR ? RRW : 1];
+  if (LDSRR) {
     typedef double __attribute__((may_alias)) grt_word;      // (the record is read back through its own field types)
     const grt_word *src = reinterpret_cast<const grt_word *>(Kp);
     grt_word *dst = reinterpret_cast<grt_word *>(&s_rr[wave][0]);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
 #if !defined(GRT_NO_GEO_LDS_RR)
       Kg = Kp;
-      if (FAST == 1 && NPH == 0) { int o_ = 0; asm volatile("" : "+v"(o_)); Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][o_]); }
+      if (LDSRR) { int o_ = 0; asm volatile("" : "+v"(o_)); Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][o_]); Cp = reinterpret_cast<const CubRay *>(Kp); }
 #endif
     }
     const int pos = toppass ? cnt : 64 * c + lane + 1;
