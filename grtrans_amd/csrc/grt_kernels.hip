@@ -37,11 +37,17 @@ using namespace grtd;
 // 340-490 B/lane to scratch, at one wave the spills go to the 256 AGPRs (v_accvgpr moves, no memory): SPHACC
 // 57.5 -> 54.4 ms, HARM 93.9 -> 84.2 ms.
 // (r02, after the emissivities lost their acos + sincos pair: SPHACC is faster at two waves again -- 48.4 -> 42.5 ms -- HARM is not)
+// KORAL3D is compiled for two waves (r03): its one-wave DELO batch instantiation <1, 25, 2, 8, false> (256 VGPR + 230 AGPR, 1,008 B/lane
+// of scratch) returned garbage -- r read back as 0 for most rays: status -n, zero pixels; the r02 build of the same kernel raised a
+// memory aperture violation -- found by tools/fuzz_cameras.py.  Not the register count as such: the extra=1 instantiations of
+// HARM / HARM3D / IHARM use up to 512 registers and are bit-equal to their plain runs.  The same source at two waves (scratch instead
+// of AGPR spills) is bit-equal to single-frequency runs; tests/test_gpu_parity.py::test_frequency_batches_on_every_fluid_model holds
+// every fluid's batch kernels to their single-frequency results and every extra=1 kernel's Stokes columns to the plain run.
 #ifdef GRT_XFER_WPE_ALL      // experiment builds: one occupancy for every instantiation
 #define GRT_XFER_WPE(EMIS, FLUID) GRT_XFER_WPE_ALL
 #endif
 #ifndef GRT_XFER_WPE
-#define GRT_XFER_WPE(EMIS, FLUID) (((EMIS) == GRT_EMIS_POLSYNCHPL || (FLUID) == GRT_FLUID_SPHACC) ? 2 : 1)
+#define GRT_XFER_WPE(EMIS, FLUID) (((EMIS) == GRT_EMIS_POLSYNCHPL || (FLUID) == GRT_FLUID_SPHACC || (FLUID) == GRT_FLUID_KORAL3D) ? 2 : 1)
 #endif
 #define GRT_MAXF 32
 #define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
@@ -222,7 +228,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   // broadcast ds_read where it is used, instead of ~90 scalar loads per 64-point pass whose latency two waves per SIMD could not hide
   // (r03: 29.1 -> 23.9 ms at 1024x1024x400; images bit-equal to the scalar-load build and to the record-mode kernel's).  NOT used for
   // NPH = 2 / 3: the record-mode kernel is 9 % slower with it (192 B/lane of scratch: the constants then live in VGPRs), and the
-  // NPH = 3 build returned garbage turning-point counts in the mu-fill segment (test_geokerr_rays_abi...; not understood).
+  // NPH = 3 build returned garbage turning-point counts in the mu-fill segment (test_geokerr_rays_abi...; not understood).  The
+  // branch-per-segment form of ray_point_real for NPH = 2, with or without the LDS copy: 68-71 ms (0.7-0.9 KB/lane of scratch).
   const RealRay *Kg = Kp;
   // ... and the Schwarzschild-cubic class (CubRay, 648 B) in both of its forms: SPHACC 1024^2 x 400 geodesics 24.3 -> 20.8 ms image only,
   // 29.0 -> 24.7 ms with the record
@@ -842,7 +849,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       for (int c = 0; c < 4; ++c) steps[(GRT_F_I + c) * field_stride + base + i] = 0.0;
   }
   if (first_batch) {
-    if (sumr < 0.0) ray_status[rayidx] = -n;
+    ray_status[rayidx] = (sumr < 0.0) ? -n : n;      // (written either way: a resident geodesic record is re-used by later calls, whose status must not inherit this one's)
     atomicAdd(step_counter, (unsigned long long)n);
   }
 }

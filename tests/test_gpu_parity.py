@@ -829,6 +829,56 @@ def test_debug_dump_geodebug_out_vs_the_reference(tmp_path, monkeypatch, harm_di
     assert len(lines[1].split()) == n and len(lines[50].split()) == 3 * n and len(lines[63].split()) == 1
 
 
+def test_frequency_batches_on_every_fluid_model(tmp_path):
+    # r03: the DELO frequency-batch kernel of KORAL3D (FB = 8) returned zero pixels / negative status for most rays when compiled for one
+    # wave per SIMD (486 registers; a memory aperture violation with the r02 build) -- no test ran a thermal GRMHD model with more than
+    # one frequency through DELO on KORAL3D.  Every fluid model, both integrators, 2 and 9 frequencies: each camera of the batch run is
+    # the bits of its single-frequency run, statuses equal.
+    import sys
+    from grtrans_amd import capi
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_harm_dump, make_harm3d_dump, make_iharm_dump, make_koral3d_dump
+    td = str(tmp_path)
+    dk, hk = make_koral3d_dump.write(td, n1=32, n2=32, n3=16)
+    make_harm_dump.write(td, n=64)
+    d3, h3 = make_harm3d_dump.write(td, n1=32, n2=32, n3=16)
+    di, hi = make_iharm_dump.write(td, n1=32, n2=32, n3=16, metric=1)
+    dev = capi.Device(0)
+    try:
+        dev.load_tables(); dev.load_ffjet(); dev.load_sphacc(); dev.load_koral3d(dk, hk, 40, 0.9375)
+        dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
+        dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375)
+        capi.geo_reuse(False)
+        nn = (12, 12, 100)
+        grid = [2.3e11 * x for x in (1.0, 0.3, 0.45, 0.9, 1.3, 1.8, 2.2, 2.6, 3.0)]
+        cases = (("KORAL3D", "POLSYNCHTH", dict(mbh=4e6, nfac=1.5, gmin=-1.), 0.9375), ("HARM", "POLSYNCHTH", dict(mbh=4e6, gmin=1., mdot=1.57e15), 0.9375),
+                 ("HARM3D", "POLSYNCHTH", dict(mbh=4e6, gmin=2., mdot=1e20), 0.9375), ("IHARM", "POLSYNCHTH", dict(mbh=4e6, gmin=3., mdot=1e20), 0.9375),
+                 ("HARM3D", "HYBRIDTHPL", dict(mbh=4e6, gmin=2., mdot=1e20), 0.9375), ("IHARM", "MAXJUTT", dict(mbh=4e6, gmin=3., mdot=1e20), 0.9375),
+                 ("SPHACC", "POLSYNCHTH", dict(mbh=10., gmin=100.), 0.0), ("FFJET", "POLSYNCHPL", dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 0.998))
+        for fname, ename, emk, a in cases:
+            gv = (-25., 25., -25., 25.) if fname in ("SPHACC", "FFJET") else (-13., 13., -13., 13.)
+            cam = capi.make_camera(1, gv, nn, a, 0.5, 0.04, -0.5)
+            em = capi.make_emis(ename, emk["mbh"], emk.get("nfac", 1.0), emk.get("bfac", 6.0), emk["gmin"], 1e5, 3.5, muval=0.25, mdot=emk.get("mdot", 0.0),
+                                otherargs=(1.5, 1.0, 0.5) if ename == "MAXJUTT" else (1.0, 1.0))
+            for iname in ("delo", "formal"):
+                singles = [capi.trace_tile(cam, 1, 144, fname, em, [x], iname) for x in grid]
+                if True:
+                    # the extra=1 instantiation (up to 512 registers at one wave per SIMD) integrates the same Stokes vector
+                    ex, _, stx, _ = capi.trace_tile(cam, 1, 144, fname, em, grid[:1], iname, nvals=4, nextra=19)
+                    assert np.array_equal(stx, singles[0][2]), (fname, ename, iname, "extra")
+                    a_, b_ = ex[0][:, :4].astype(float), singles[0][0][0].astype(float)
+                    assert np.array_equal(np.isnan(a_), np.isnan(b_))
+                    assert np.nanmax(np.abs(a_ - b_)) <= 1e-7 * np.nanmax(np.abs(b_)), (fname, ename, iname, "extra")
+                for nf in (2, 9):
+                    pix, _, st, _ = capi.trace_tile(cam, 1, 144, fname, em, grid[:nf], iname)
+                    assert np.array_equal(st, singles[0][2]), (fname, ename, iname, nf)
+                    for k in range(nf):
+                        assert np.array_equal(pix[k], singles[k][0][0], equal_nan=True), (fname, ename, iname, nf, k)
+    finally:
+        capi.geo_reuse(True)
+        dev.close()
+
+
 def test_koral3d_several_slices_slow_light_nload_and_movie(tmp_path, monkeypatch):
     # KORAL3D with fnt = 3 loaded slices (each point reads the dump its Kerr-Schild look-back time selects,
     # fluid_model_koral3d.f90:126-128, 212-228), nload = 2 (per-ray time origin) and two movie frames of a two-slice run

@@ -369,3 +369,4 @@ def test_code_object_holds_no_device_side_calls(tmp_path):
     assert not outlined, outlined
     dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
     assert dis.count("s_swappc_b64") == 0      # (s_setpc_b64 alone is the long-branch idiom of these 100-KB kernels, not a call)
+

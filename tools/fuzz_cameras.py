@@ -64,6 +64,8 @@ for c in range(ncams):
     capi.record_steps(rec)
     cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
     em = capi.make_emis(ename, ekw["mbh"], ekw.get("nfac", 1.0), ekw.get("bfac", 6.0), ekw["gmin"], 1e5, p1, muval=0.25, mdot=ekw.get("mdot", 0.0))
+    if os.environ.get("GRT_FUZZ_VERBOSE"):
+        print("next: cam %d %s %s a=%r mu0=%r gv=%r uout=%r nn=%r %s rec=%d p=%r freqs=%r i=%d..%d" % (c, fname, ename, a, mu0, gv, uout, nn, iname, rec, p1, freqs, i1, i2), flush=True)
     pix, _, status, _ = capi.trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=okw.get("nvals", 4))
     ok_n = np.array_equal(status, rn)
     # pixels where the integrator overflowed (NaN or inf, as in the reference) must be the same pixels; the rest is compared
