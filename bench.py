@@ -42,7 +42,7 @@ WORKLOADS = {
 BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lambda,I,Q,U,V) per ray-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
-TILE_COLS_DEFAULT = 32         # strong scaling share-out; chosen from the predicted balance table of DESIGN.md 7
+TILE_COLS_DEFAULT = 1          # strong scaling share-out: single image columns round-robin (the generic ray class sits in a few columns)
 
 
 def build_id():

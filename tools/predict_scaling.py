@@ -37,7 +37,7 @@ t1, steps1 = timed([(1, npix)])
 out = {"nn": nn, "per_step_record": record, "one_gpu_ms": t1, "ray_steps": int(steps1), "rows": []}
 print("1 GPU: %.2f ms, %d ray-steps" % (t1, steps1))
 for n in (2, 4, 8):
-    for tc in (0, 8, 32, 128):
+    for tc in [int(x) for x in os.environ.get("GRT_TILE_COLS_LIST", "0,8,32,128").split(",")]:
         if tc and nn[0] // tc < n:
             continue
         ms, work = [], []
