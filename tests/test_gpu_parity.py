@@ -171,6 +171,13 @@ def test_trace_ranges_one_launch_equals_per_range_calls(dev, monkeypatch):
         pix2, _, status2, st2 = capi.trace_ranges(cam, rng, "FFJET", em, freqs, iname)
         monkeypatch.delenv("GRT_MAX_WORK_BYTES")
         assert np.array_equal(pix2, pix) and np.array_equal(status2, status) and st2.ray_steps == st.ray_steps
+    # many narrow ranges (bench.py's default share-out: single image columns round-robin; 128 ranges per rank at 8 GPUs)
+    cam2 = capi.make_camera(1, (-40., 20., -20., 40.), (96, 16, 60), 0.998, 0.906, 0.01, -0.5)
+    rng2 = tiling.ranges(2, 4, 1, 96 * 16, 16, 1)
+    assert len(rng2) == 24
+    parts = [capi.trace_tile(cam2, a, b, "FFJET", em, [FREQ], "delo") for (a, b) in rng2]
+    pix, _, status, st = capi.trace_ranges(cam2, rng2, "FFJET", em, [FREQ], "delo")
+    assert np.array_equal(pix, np.concatenate([p[0] for p in parts], axis=1)) and np.array_equal(status, np.concatenate([p[2] for p in parts]))
     # per-step record: local ray j of the call is ray j of the record
     capi.record_steps(True)
     pix, _, status, _ = capi.trace_ranges(cam, rng, "FFJET", em, [FREQ], "formal")

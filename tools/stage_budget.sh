@@ -9,7 +9,7 @@ mkdir -p $R/build/variants
 for n in ${STAGES:-1 2 3 4}; do
   T=/tmp/stage_$n; rm -rf $T; mkdir -p $T/grtrans_amd $T/build/variants $T/tools
   cp -r $R/grtrans_amd/csrc $T/grtrans_amd/; cp -r $R/include $T/; cp $R/tools/build_variant.sh $T/tools/
-  F="-DGRT_FAST_BUILD"; [ $n -lt 4 ] && F="$F -DGRT_STAGE_STOP=$n"
+  F="-DGRT_FAST_BUILD -DGRT_FAST_BUILD_THERMAL"; [ $n -lt 4 ] && F="$F -DGRT_STAGE_STOP=$n"
   (cd $T && bash tools/build_variant.sh stage$n "$F" > $T/log 2>&1 && cp $T/build/variants/lib_stage$n.so $R/build/variants/) &
 done
 wait

@@ -1,8 +1,8 @@
 """Summarise gpurun_out/stage_budget (tools/stage_budget_run.sh): per stage build the transfer kernel's time and its wave-level
 instruction counts per ray-step (largest grt_transfer_kernel dispatch of the run); stage cost = difference of consecutive builds."""
-import collections, csv, glob, json, os
-O = "gpurun_out/stage_budget"
-names = {1: "read + sincos + calc_nullp + FFJET sample", 2: "+ comoving_ortho (tetrad, basis)", 3: "+ polsynchpl coefficients",
+import collections, csv, glob, json, os, sys
+O = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/stage_budget"
+names = {1: "read + sincos + calc_nullp + fluid sample", 2: "+ comoving_ortho (tetrad, basis)", 3: "+ emission / absorption / Faraday coefficients",
          4: "+ rotate / invariant / calc_O propagator (product)"}
 rows = {}
 for n in (1, 2, 3, 4):
