@@ -1028,8 +1028,13 @@ extern "C" void grt_host_camera_pixel(const GrtCam *cam, long long ii, double *o
   out6[0] = R.alpha; out6[1] = R.beta; out6[2] = R.l; out6[3] = R.q2; out6[4] = R.su; out6[5] = R.sm;
 }
 
+// Near-polar rays (l^2 < polar_l2 (q2 + a^2)) were routed to the generic class in r01/r02 (threshold 1e-6): the fast path's azimuth was
+// radians off for them.  r03 found the cause upstream of the fast path -- FMA contraction in the once-per-ray GEOKERR set-up the
+// fast-class constants are built from; with that code uncontracted (grt_dev_geo/ell/ray.hpp) the fast path agrees with the oracle to
+// 1.6e-9 rad in every decade of l^2/(q2+a^2) down to 1e-12 (tools/polar_phi.py 0), so nothing is routed any more: 1,402 fewer
+// generic rays on the headline camera (three whole image columns at alpha = 0).  The knob stays for experiments (GRT_POLAR_L2).
 #ifndef GRT_POLAR_L2_DEFAULT
-#define GRT_POLAR_L2_DEFAULT 1.e-6
+#define GRT_POLAR_L2_DEFAULT 0.0
 #endif
 extern "C" size_t grt_sizeof_realray(void) { return GRT_RR_STRIDE; }
 
