@@ -690,8 +690,10 @@ GRT_HD RealLeg real_leg(const GrtCam &cam, const GrtRay &R) {
 // allocator spilled inside the duplication loops).
 // pre: the u-side quantities of a non-fill point, summed from segments by the caller (grt_geo_kernel); NULL = evaluate here
 template <int NPH>
-GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr) {
+GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr,
+                           const RealRay *KLp = nullptr /* the same record in LDS: the Jacobi ladders and the Zeta / theta-series constants are read there */) {
   constexpr bool PHI = NPH > 0;
+  const RealRay &KL = KLp ? *KLp : K;
   const double one = 1.0, two = 2.0;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
   const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
@@ -751,14 +753,14 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 #endif
       for (int w = 0; w < 2; ++w) {
         const bool mine = (w == 0) ? !isfill : isfill;
-        const AgmLadder &L = (w == 0) ? K.agm_mu : K.agm_u;
+        const AgmLadder &L = (w == 0) ? KL.agm_mu : KL.agm_u;
         const double emmc = (w == 0) ? K.m1m : K.m1u;
         if (mine) sncndn_ladder_z(L, jarg, emmc, sn, cn, dn, zz, s0, c0);
       }
       if (!isfill) {
         mun = K.sym ? K.muminus * cn : fdiv(K.muminus, dn);
-        Tz = zeta_T(K, zz, tpm, iu);
-        if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);
+        Tz = zeta_T(KL, zz, tpm, iu);
+        if (PHI && K.pok) Pz = theta_P(KL, s0, c0, tpm, iu);
       } else {
         if (c7) {
           un = fdiv((K.u2 - K.u1) * K.u3 * sn * sn - K.u2 * (K.u3 - K.u1), (K.u2 - K.u1) * sn * sn - (K.u3 - K.u1));

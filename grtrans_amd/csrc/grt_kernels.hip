@@ -226,21 +226,39 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 #if !defined(GRT_NO_GEO_LDS_RR)
   // Image-only four-real-root kernel (NPH = 0): the wave copies its ray's RealRay (2 KB) into LDS once and every per-ray constant is a
   // broadcast ds_read where it is used, instead of ~90 scalar loads per 64-point pass whose latency two waves per SIMD could not hide
-  // (r03: 29.1 -> 23.9 ms at 1024x1024x400; images bit-equal to the scalar-load build and to the record-mode kernel's).  NOT used for
-  // NPH = 2 / 3: the record-mode kernel is 9 % slower with it (192 B/lane of scratch: the constants then live in VGPRs), and the
-  // NPH = 3 build returned garbage turning-point counts in the mu-fill segment (test_geokerr_rays_abi...; not understood).  The
-  // branch-per-segment form of ray_point_real for NPH = 2, with or without the LDS copy: 68-71 ms (0.7-0.9 KB/lane of scratch).
+  // (r03: 29.1 -> 23.9 ms at 1024x1024x400; images bit-equal to the scalar-load build and to the record-mode kernel's).  The whole
+  // record through LDS is NOT used for NPH = 2 / 3: the record-mode kernel is 9 % slower with it (192 B/lane of scratch: the
+  // constants then live in VGPRs), and the NPH = 3 build returned garbage turning-point counts in the mu-fill segment
+  // (test_geokerr_rays_abi...; not understood).  The branch-per-segment form of ray_point_real for NPH = 2, with or without the
+  // LDS copy: 68-71 ms (0.7-0.9 KB/lane of scratch).
+  // Record mode (NPH = 2) takes the middle road (LDSHYB): the same LDS copy is made, but only the two Jacobi ladders and the
+  // Zeta / theta-series constants (the long runs of back-to-back loads in ray_point_real) are read from it; everything else
+  // stays on scalar loads.  With the ray's GrtRay (320 B) also in LDS (LDSR): 49.0 -> 44.2 ms at 1024x1024x400 (GrtRay alone
+  // 47.4, ladders alone 44.8; 56 B/lane of scratch instead of 40).
   const RealRay *Kg = Kp;
+  const GrtRay *Rg = Rp;
+  constexpr int RW = (sizeof(GrtRay) + 7) / 8;
+  constexpr bool LDSR = (FAST == 1 && NPH == 2);
+  __shared__ double s_r[LDSR ? GRT_WAVES_PER_BLOCK : 1][LDSR ? RW : 1];
+  if (LDSR) {
+    typedef double __attribute__((may_alias)) grt_word2;
+    const grt_word2 *src2 = reinterpret_cast<const grt_word2 *>(Rp);
+    grt_word2 *dst2 = reinterpret_cast<grt_word2 *>(&s_r[wave][0]);
+    for (int w = lane; w < RW; w += 64) dst2[w] = src2[w];
+  }
   // ... and the Schwarzschild-cubic class (CubRay, 648 B) in both of its forms: SPHACC 1024^2 x 400 geodesics 24.3 -> 20.8 ms image only,
   // 29.0 -> 24.7 ms with the record
+  constexpr bool LDSHYB = (FAST == 1 && NPH == 2);
   constexpr bool LDSRR = (FAST == 1 && NPH == 0) || FAST == 2;
   constexpr int RRW = ((FAST == 2 ? sizeof(CubRay) : sizeof(RealRay)) + 7) / 8;
-  __shared__ double s_rr[LDSRR ? GRT_WAVES_PER_BLOCK : 1][LDSRR ? RRW : 1];
-  if (LDSRR) {
+  __shared__ double s_rr[(LDSRR || LDSHYB) ? GRT_WAVES_PER_BLOCK : 1][(LDSRR || LDSHYB) ? RRW : 1];
+  if (LDSRR || LDSHYB) {
     typedef double __attribute__((may_alias)) grt_word;      // (the record is read back through its own field types)
     const grt_word *src = reinterpret_cast<const grt_word *>(Kp);
     grt_word *dst = reinterpret_cast<grt_word *>(&s_rr[wave][0]);
     for (int w = lane; w < RRW; w += 64) dst[w] = src[w];
+  }
+  if (LDSR || LDSRR || LDSHYB) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
   }
@@ -275,7 +293,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
     {
       // (constant address space: the loads below become scalar loads of the wave's ray; see grt_fresh)
+#if !defined(GRT_NO_GEO_LDS_RR)
+      const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rg;
+#else
       const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rp;
+#endif
 #if !defined(GRT_NO_GEO_LDS_RR)
       const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kg;
 #else
@@ -285,6 +307,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
 #if !defined(GRT_NO_GEO_LDS_RR)
       Kg = Kp;
+      Rg = Rp;
+      if (LDSR) { int o2_ = 0; asm volatile("" : "+v"(o2_)); Rp = reinterpret_cast<const GrtRay *>(&s_r[wave][o2_]); }
       if (LDSRR) { int o_ = 0; asm volatile("" : "+v"(o_)); Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][o_]); Cp = reinterpret_cast<const CubRay *>(Kp); }
 #endif
     }
@@ -320,6 +344,9 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
         const UPart *pre = usable ? &S : nullptr;
         if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
         else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
+#if !defined(GRT_NO_GEO_LDS_RR)
+        else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_])); }
+#endif
         else if (FAST == 1) ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre);
         else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
       }
