@@ -43,11 +43,18 @@ using namespace grtd;
 // HARM / HARM3D / IHARM use up to 512 registers and are bit-equal to their plain runs.  The same source at two waves (scratch instead
 // of AGPR spills) is bit-equal to single-frequency runs; tests/test_gpu_parity.py::test_frequency_batches_on_every_fluid_model holds
 // every fluid's batch kernels to their single-frequency results and every extra=1 kernel's Stokes columns to the plain run.
+// r03, later: EVERY instantiation is compiled for two waves, and no kernel of this file may hold a value in an AGPR
+// (tests/test_host_and_abi.py reads kernel_resource_usage.txt).  The one-wave IHARM hybrid kernel <2, 29, 20, 1, false> (256 VGPR +
+// 148 AGPR, no scratch) returned 300-350 zero pixels of 1,296, different ones on every run, once the formal step was applied
+// without forming O (grt_dev_phys.hpp:formal_apply); the same source through calc_O, and the same source at two waves, are
+// correct and bit-equal run to run.  Two kernels out of ~150 whose results depend on how the allocator parks values in AGPRs are
+// two too many for a code whose tests cannot visit every (kernel, input) pair: the thermal kernels pay 1-2 % for it
+// (HARM 512x512x400 transfer 18.5 -> 18.7 ms image only, 19.1 -> 19.5 ms with the record).
 #ifdef GRT_XFER_WPE_ALL      // experiment builds: one occupancy for every instantiation
 #define GRT_XFER_WPE(EMIS, FLUID) GRT_XFER_WPE_ALL
 #endif
 #ifndef GRT_XFER_WPE
-#define GRT_XFER_WPE(EMIS, FLUID) (((EMIS) == GRT_EMIS_POLSYNCHPL || (FLUID) == GRT_FLUID_SPHACC || (FLUID) == GRT_FLUID_KORAL3D) ? 2 : 1)
+#define GRT_XFER_WPE(EMIS, FLUID) 2
 #endif
 #define GRT_MAXF 32
 #define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256, GRT_WPE_SETUP) void grt_setup_kernel(GrtCam ca
 
 // nload > 1 (pgrtrans.f90:172-189 -> initialize_geo_tabs, geodesics.f90:113-128): the time origin of a ray is the
 // coordinate time of the single point of its nup=1, no-mu-fill geodesic = the first-point dt the set-up caches.
-__global__ __launch_bounds__(256) void grt_t0_kernel(GrtCam cam, long long i1, int nrays, double *__restrict__ t0) {
+__global__ __launch_bounds__(256, 2) void grt_t0_kernel(GrtCam cam, long long i1, int nrays, double *__restrict__ t0) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nrays) return;
   GrtCam c1 = cam;
@@ -762,11 +769,19 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             if constexpr (IFLAG == GRT_INT_FORMAL) {
               // I <- O_k (j_k dx_k + I)   (radtrans_integrate.f90:863-871)
               if (step) {
+#if defined(GRT_FORMAL_VIA_O)      // experiment switch: the step through the 16 entries of O
                 double O[4][4];
                 calc_O(KK, KK + 4, dx, O);
                 const double v0 = jj4[0] * dx + I[f][0], v1 = jj4[1] * dx + I[f][1], v2 = jj4[2] * dx + I[f][2], v3 = jj4[3] * dx + I[f][3];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) I[f][c] = O[c][0] * v0 + O[c][1] * v1 + O[c][2] * v2 + O[c][3] * v3;
+#else
+                const double V[4] = {jj4[0] * dx + I[f][0], jj4[1] * dx + I[f][1], jj4[2] * dx + I[f][2], jj4[3] * dx + I[f][3]};
+                double In[4];
+                formal_apply(KK, KK + 4, dx, V, In);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) I[f][c] = In[c];
+#endif
               }
             } else {
               // DELO couples point k with k+1 = the previous trip (radtrans_integrate.f90:811-837);
@@ -892,7 +907,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
 // (j, K after rotate_emis / invariant_emis, j / fac and K L_BH as the driver holds them when it writes); scal[0] = fac, scal[1] = L_BH.
 #define GRT_DBG_ROWS 68      // 57 printed rows + 11 scratch rows (the raw coefficients, for a ray the driver does not integrate)
 template <int FLUID, int EMIS>
-__global__ __launch_bounds__(64) void grt_debug_kernel(GrtCam cam, const GrtRay *__restrict__ rays, int rayidx, GrtFluidDev fd, GrtTables tb,
+__global__ __launch_bounds__(64, 2) void grt_debug_kernel(GrtCam cam, const GrtRay *__restrict__ rays, int rayidx, GrtFluidDev fd, GrtTables tb,
                                                        GrtEmis em, GrtPLConst plc, double freq, const double *__restrict__ steps,
                                                        long long ray_stride, long long field_stride, int tfield, double *__restrict__ out,
                                                        int maxpts, double *__restrict__ scal) {
@@ -1159,6 +1174,9 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
 #ifdef GRT_FAST_BUILD_THERMAL      // ... plus the two thermal BASELINE kernels (formal)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHTH)
+#endif
+#ifdef GRT_FAST_BUILD_HYBRID       // ... plus the IHARM hybrid kernel (formal)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_HYBRIDTHPL)
 #endif
 #ifndef GRT_FAST_BUILD      // experiment builds (tools/build_variant.sh NAME -DGRT_FAST_BUILD): the FFJET kernels only, a sixth of the compile time
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHTH)

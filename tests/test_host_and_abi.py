@@ -370,3 +370,19 @@ def test_code_object_holds_no_device_side_calls(tmp_path):
     dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
     assert dis.count("s_swappc_b64") == 0      # (s_setpc_b64 alone is the long-branch idiom of these 100-KB kernels, not a call)
 
+
+
+def test_no_kernel_parks_values_in_agprs():
+    # r03: two transfer-kernel instantiations compiled for one wave per SIMD (256 VGPRs + values parked in AGPRs) returned garbage on
+    # the MI355X -- KORAL3D DELO batches, and the IHARM hybrid kernel with 300-350 zero pixels that moved from run to run -- while the
+    # same sources at two waves (256 registers, scratch instead of AGPRs) were correct.  Every kernel is now compiled for two waves;
+    # the compiler's own resource remarks of the shipped object must show no AGPR anywhere.
+    usage = os.path.join(ROOT, "grtrans_amd", "csrc", "kernel_resource_usage.txt")
+    if not os.path.exists(usage):
+        pytest.skip("no resource-usage remarks here (the library was not built in this tree)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_usage
+    k = kernel_usage.parse(open(usage).read())
+    assert len(k) > 100
+    bad = {n: v for n, v in k.items() if int(v.get("AGPRs", "0")) != 0 or int(v.get("Occupancy", "2")) < 2}
+    assert not bad, sorted(bad)[:5]
