@@ -36,7 +36,7 @@ MODELS = [
 ]
 EXT = len(sys.argv) > 3 and sys.argv[3] in ("ext", "allext")      # also vary the power-law index, frequency count and tile
 only = set(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else None      # examine these camera indices in detail
-bad = 0; cond = 0
+bad = 0; cond = 0; ampl = 0
 for c in range(ncams):
     fname, ename, okw, ekw, freq, tol = MODELS[int(rng.integers(0, len(MODELS)))] if (len(sys.argv) > 3 and sys.argv[3] in ("all", "allext")) else MODELS[0]
     a = float(rng.choice([rng.uniform(0.01, 0.998), -rng.uniform(0.05, 0.99), 0.998, 0.5])) if fname == "FFJET" else 0.9375
@@ -119,6 +119,20 @@ for c in range(ncams):
         o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)   # the library holds one problem
         if err < 10 * floor and same_nan:
             flag = "  (ill-conditioned in the reference: it moves by %.1e itself when the frequency changes by 1e-13 or the camera by one ulp)" % floor; cond += 1
+        elif same_nan:
+            # amplification of a perturbation at the level the device's coefficient functions agree with the reference's (1e-7):
+            # the reference against itself with every frequency moved by 1e-8.  A well-conditioned pixel moves by a few 1e-8
+            # (d ln I / d ln nu of order one); DELO in its alternating-growth regime (negative intensities; SPHACC at 24 GHz)
+            # multiplies whatever difference reaches the last steps by 10-100 per step.
+            amp = 0.0
+            for rel in (1e-8, -1e-8):
+                rp, _, _ = o.trace(i1, i2, [float(f * (1 + rel)) for f in freqs], nthreads=0)
+                for k in range(len(freqs)):
+                    okm = np.isfinite(ref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
+                    if okm.any():
+                        amp = max(amp, (np.abs(rp[k][okm] - ref[k][okm]).max(axis=0) / (np.abs(ref[k][okm]).max(axis=0) + 1e-300)).max() / 1e-8)
+            if amp > 30.0 and err < amp * 1e-7:
+                flag = "  (amplified by the reference's own integrator: a 1e-8 change of the frequency moves its answer by %.0f x 1e-8)" % amp; ampl += 1
     bad += ("MISMATCH" in flag)
     print("cam %2d %-8s %s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
           (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag, (" IQUV per frequency " + str(perf)) if flag else ""))
@@ -159,4 +173,4 @@ for c in range(ncams):
             print("      worst theta point %d of %d: dev th %.12g ref th %.12g | r dev %.12g ref %.12g" % (k, n, recd[1][k], x[k, 2], recd[0][k], x[k, 1]))
 capi.record_steps(False)
 dev.close()
-print("MISMATCHES:", bad, " ill-conditioned in the reference itself:", cond)
+print("MISMATCHES:", bad, " ill-conditioned in the reference itself:", cond, " amplified (kappa > 30):", ampl)
