@@ -788,11 +788,19 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
               // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 is local: dx * mean |alpha_I|
               if (step) {
                 const double delta = dx * ((fabs(KK[0]) + fabs(Kn[f][0])) / 2.0);
+#if defined(GRT_DELO_VIA_MAP)      // experiment switch: the step as the affine map P + Q I through the 4x4 cofactor inverse
                 Affine M;
                 delo_map(jj4, KK, jn[f], Kn[f], dx, delta, M);
                 const double v0 = I[f][0], v1 = I[f][1], v2 = I[f][2], v3 = I[f][3];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) I[f][c] = M.A[c][0] * v0 + M.A[c][1] * v1 + M.A[c][2] * v2 + M.A[c][3] * v3 + M.b[c];
+#else
+                const double Iv[4] = {I[f][0], I[f][1], I[f][2], I[f][3]};
+                double In[4];
+                delo_apply(jj4, KK, jn[f], Kn[f], dx, delta, Iv, In);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) I[f][c] = In[c];
+#endif
               }
               if (valid) {
 #pragma unroll

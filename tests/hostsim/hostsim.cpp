@@ -435,6 +435,9 @@ void hs_frame_and_coeffs(double r, double th, double a, double alpha, double bet
   polsynchpl_fast(g_T, g_plc, nu_obs / out[7], nnth, B, out[6], out + 8);
 }
 void hs_delo_step(const double *j0, const double *K0, const double *j1, const double *K1, double dx, double delta, const double *Iin, double *Iout) {
+  delo_apply(j0, K0, j1, K1, dx, delta, Iin, Iout);      // the form the transfer kernel runs
+}
+void hs_delo_step_via_map(const double *j0, const double *K0, const double *j1, const double *K1, double dx, double delta, const double *Iin, double *Iout) {
   Affine M;
   delo_map(j0, K0, j1, K1, dx, delta, M);
   for (int i = 0; i < 4; ++i) Iout[i] = M.A[i][0] * Iin[0] + M.A[i][1] * Iin[1] + M.A[i][2] * Iin[2] + M.A[i][3] * Iin[3] + M.b[i];

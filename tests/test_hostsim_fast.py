@@ -672,3 +672,39 @@ def test_standard2_mu_stepping_points_vs_reference_geokerr(L, key):
         for k, name in enumerate(("u", "mu", "dt", "dphi", "lam")):
             if ok.any():
                 assert np.max(np.abs(d[k][:n][ok] - ref[name][ok])) <= 1e-10 * (np.max(np.abs(ref[name][ok])) + 1e-300), (i, name)
+
+
+def test_delo_step_without_the_inverse_matches_oracle_and_the_map_form(L):
+    # the closed-form DELO step of the transfer kernel (grt_dev_phys.hpp:delo_apply) against (1) the affine-map form with the 4x4
+    # cofactor inverse it replaced and (2) the oracle's integrate_delo along random rays, optically thin and thick steps mixed
+    sig = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.hs_delo_step.argtypes = sig
+    L.hs_delo_step_via_map.argtypes = sig
+    rng = np.random.default_rng(11)
+    worst_map, worst_ora = 0.0, 0.0
+    for trial in range(40):
+        n = 24
+        x = np.sort(rng.uniform(0.0, 5.0, n))[::-1].copy()                # affine parameter, decreasing with k as the driver hands it over
+        scale = 10.0 ** rng.uniform(-3, 1.2)                               # steps from 1e-3 to 30 optical depths
+        aI = scale * rng.uniform(0.2, 1.0, n)
+        pol = rng.uniform(-0.6, 0.6, (n, 3)) * aI[:, None] / np.sqrt(3)  # |a_QUV| < a_I
+        rho = rng.uniform(-3.0, 3.0, (n, 3)) * aI[:, None]
+        K = np.ascontiguousarray(np.concatenate([aI[:, None], pol, rho], axis=1))
+        j = np.ascontiguousarray(rng.uniform(0.1, 1.0, (n, 1)) * np.concatenate([np.ones((n, 1)), rng.uniform(-0.5, 0.5, (n, 3))], axis=1))
+        tau = np.zeros(n)
+        for k in range(n - 2, -1, -1):                                    # grtrans_driver.f90:219-220: tau grows towards the camera (k = 0)
+            tau[k] = tau[k + 1] - (x[k] - x[k + 1]) * 0.5 * (aI[k] + aI[k + 1])
+        tau = -tau
+        want = O.integrate(1, x, j, K, tau)                               # out[n-k]: intensity after the step k -> k-1 (integration order)
+        I = np.zeros(4); Im = np.zeros(4)
+        for k in range(n - 1, 0, -1):
+            delta, dx = float(tau[k] - tau[k - 1]), float(x[k - 1] - x[k])
+            nxt, nxm = np.zeros(4), np.zeros(4)
+            a0, a1 = np.ascontiguousarray(j[k - 1]), np.ascontiguousarray(j[k])
+            k0, k1 = np.ascontiguousarray(K[k - 1]), np.ascontiguousarray(K[k])
+            L.hs_delo_step(a0.ctypes.data, k0.ctypes.data, a1.ctypes.data, k1.ctypes.data, dx, delta, I.ctypes.data, nxt.ctypes.data)
+            L.hs_delo_step_via_map(a0.ctypes.data, k0.ctypes.data, a1.ctypes.data, k1.ctypes.data, dx, delta, Im.ctypes.data, nxm.ctypes.data)
+            I, Im = nxt, nxm
+            worst_map = max(worst_map, np.abs(I - Im).max() / np.abs(Im).max())
+            worst_ora = max(worst_ora, np.abs(I - want[n - k]).max() / np.abs(want[n - k]).max())
+    assert worst_map < 1e-11 and worst_ora < 1e-11, (worst_map, worst_ora)
