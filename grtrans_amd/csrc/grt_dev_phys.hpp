@@ -359,7 +359,7 @@ GRT_HD void polsynchpl_point_sc(const GrtPLConst &C, double nnth, double B, doub
   double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe;
   P.itanth = frcp(tanth);
   double sinth = s0 + (plain ? 0.0 : thsafe);
-  P.nubperp = ec * B / m / c / 2.0 / pi * sinth + nufloor;
+  P.nubperp = B * (ec / m / c / 2.0 / pi) * sinth + nufloor;      // (the constant is folded: no IEEE division per step)
   P.lnub = log(P.nubperp);
   P.A = C.A0 * nnth;
   P.kperp = P.A * (ec * ec / m / c) * frcp(P.nubperp);
@@ -430,17 +430,17 @@ GRT_HD double besseli0(double x) {
   const double q[9] = {0.398942280, 0.1328592e-10, 0.225319e-20, -0.157565e-20, 0.916281e-20,
                               -0.2057706e-10, 0.2635537e-10, -0.1647633e-10, 0.392377e-20};
   double ax = fabs(x);
-  if (ax < 3.75) return poly(sq(x / 3.750), p, 7);
-  double y = 3.750 / ax;
-  return (exp(ax) / sqrt(ax)) * poly(y, q, 9);
+  if (ax < 3.75) return poly(sq(x * (1.0 / 3.750)), p, 7);
+  const double iax = frcp(ax), y = 3.750 * iax;
+  return (exp(ax) * fsqrt(iax)) * poly(y, q, 9);
 }
 GRT_HD double besseli1(double x) {
   const double p[7] = {0.50, 0.878905940, 0.514988690, 0.150849340, 0.2658733e-10, 0.301532e-20, 0.32411e-30};
   const double q[9] = {0.398942280, -0.3988024e-10, -0.362018e-20, 0.163801e-20, -0.1031555e-10,
                               0.2282967e-10, -0.2895312e-10, 0.1787654e-10, -0.420059e-20};
   double ax = fabs(x), r;
-  if (ax < 3.75) r = ax * poly(sq(x / 3.750), p, 7);
-  else { double y = 3.750 / ax; r = (exp(ax) / sqrt(ax)) * poly(y, q, 9); }
+  if (ax < 3.75) r = ax * poly(sq(x * (1.0 / 3.750)), p, 7);
+  else { const double iax = frcp(ax), y = 3.750 * iax; r = (exp(ax) * fsqrt(iax)) * poly(y, q, 9); }
   if (x < 0.0) r = -r;
   return r;
 }
@@ -448,15 +448,15 @@ GRT_HD double besselk0(double x) {
   const double p[7] = {-0.57721566, 0.42278420, 0.23069756, 0.3488590e-1, 0.262698e-2, 0.10750e-3, 0.74e-5};
   const double q[7] = {1.25331414, -0.7832358e-1, 0.2189568e-1, -0.1062446e-1, 0.587872e-2, -0.251540e-2, 0.53208e-3};
   if (x <= 2.0) { double y = x * x / 4.0; return (-log(x / 2.0) * besseli0(x)) + poly(y, p, 7); }
-  double y = 2.0 / x;
-  return (exp(-x) / sqrt(x)) * poly(y, q, 7);
+  const double ix = frcp(x), y = 2.0 * ix;
+  return (exp(-x) * fsqrt(ix)) * poly(y, q, 7);
 }
 GRT_HD double besselk1(double x) {
   const double p[7] = {1.0, 0.15443144, -0.67278579, -0.18156897, -0.1919402e-1, -0.110404e-2, -0.4686e-4};
   const double q[7] = {1.25331414, 0.23498619, -0.3655620e-1, 0.1504268e-1, -0.780353e-2, 0.325614e-2, -0.68245e-3};
-  if (x <= 2.0) { double y = x * x / 4.0; return (log(x / 2.0) * besseli1(x)) + (1.0 / x) * poly(y, p, 7); }
-  double y = 2.0 / x;
-  return (exp(-x) / sqrt(x)) * poly(y, q, 7);
+  if (x <= 2.0) { double y = x * x / 4.0; return (log(x / 2.0) * besseli1(x)) + frcp(x) * poly(y, p, 7); }
+  const double ix = frcp(x), y = 2.0 * ix;
+  return (exp(-x) * fsqrt(ix)) * poly(y, q, 7);
 }
 GRT_HD double besselk(int n, double x) {
   double tox = 2.0 / x, bkm = besselk0(x), bk = besselk1(x);
@@ -466,8 +466,9 @@ GRT_HD double besselk(int n, double x) {
 
 GRT_HD double bnu(double T, double nu) {   // polsynchemis.f90:1014
   double b;
-  if (PH_h * nu / PH_k / T < 1e-6) b = 2.0 * nu * nu * PH_k * T / PH_c2;
-  else b = 2.0 * PH_h * nu / PH_c2 * nu * nu / (exp(PH_h * nu / PH_k / T) - 1.0);
+  const double xh = nu * (PH_h / PH_k) * frcp_s(T);      // h nu / k T (constants folded: reciprocals, no IEEE division; T = 0 -> inf as before)
+  if (xh < 1e-6) b = nu * nu * (2.0 * PH_k / PH_c2) * T;
+  else b = nu * nu * nu * (2.0 * PH_h / PH_c2) * frcp_s(exp(xh) - 1.0);
   if (b == 0) b = 2.220446049250313e-16;   // epsilon(T)
   return b;
 }
@@ -591,8 +592,10 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
     sth = sin(theta); cth = cos(theta);
 #endif
   }
-  const double thetae = k * T / m / c / c + thetaemin, th2 = thetae * thetae;
-  const double nuc = 3.0 * ec * B * sth / 4.0 / pi / m / c * th2 + nucminval;
+  // (every quotient of constants below is folded at compile time: the per-step code keeps no IEEE division by a constant,
+  //  which the compiler may not turn into a multiplication by itself -- 12 instructions each, ~20 of them per step before r03)
+  const double thetae = T * (k / m / c / c) + thetaemin, th2 = thetae * thetae;
+  const double nuc = B * sth * (3.0 * ec / 4.0 / pi / m / c) * th2 + nucminval;
   const double xm = fdiv(nu, nuc);
   const double x13 = cbrt(xm), x23 = x13 * x13;
   const double i13 = frcp(x13), i23 = i13 * i13, ixm = i23 * i13;
@@ -602,48 +605,56 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   const double ivx = (1.81384 * ixm + 3.42319 * i23 + 0.0292545 * frcp(fsqrt(xm)) + 2.03773 * i13) * ex;
   const double jfac = (ec * ec / c / s3 / 2.0) * n * frcp(th2) * nu;
   double ji = jfac * iix, jq = jfac * iqx;
-  double jv = (4.0 * (ec * ec) / c / 3.0 / s3) * fdiv(cth, sth) * n / 2.0 * frcp(th2 * thetae) * nu * ivx;
+  double jv = (4.0 * (ec * ec) / c / 3.0 / s3 / 2.0) * fdiv(cth, sth) * n * frcp(th2 * thetae) * nu * ivx;
   if (SYM) {
-    const double nucs = ec * B / m / c / 2.0 / pi + nucminval;
-    const double lxs = log(nu / (2.0 / 9.0 * nucs * th2 * sth));          // log x
-    const double x16 = exp(lxs / 6.0), x13s = x16 * x16, sqx = x13s * x16;  // x^(1/6), x^(1/3), sqrt(x)
+    const double nucs = B * (ec / m / c / 2.0 / pi) + nucminval;
+    const double lxs = log(nu * frcp_s(2.0 / 9.0 * nucs * th2 * sth));          // log x
+    const double x16 = exp(lxs * (1.0 / 6.0)), x13s = x16 * x16, sqx = x13s * x16;  // x^(1/6), x^(1/3), sqrt(x)
     const double lte = log(thetae), t2425 = exp(0.96 * lte);
     const double c1112 = 1.8877486253633870;                                // 2^(11/12)
     const double pf = 1.4142135623730951 * pi / 27.0 * sth;
     const double jis = pf * sq(sqx + c1112 * x16);
-    const double jqs = -pf * sq(sqx + (7.0 * t2425 + 35.0) / (10.0 * t2425 + 75.0) * c1112 * x16);
+    const double jqs = -pf * sq(sqx + (7.0 * t2425 + 35.0) * frcp(10.0 * t2425 + 75.0) * c1112 * x16);
     // sin(theta - 28/25) from sin and cos of theta when the caller handed those over
     const double sshift = HAVE_SC ? (sth * 0.4356824462767121 - cth * 0.9001004421765051) : sin(theta - 28.0 / 25.0);
-    const double jvs = -(37.0 - 87.0 * sshift) / 100.0 / (thetae + 1.0) *
-                       exp(5.0 / 3.0 * log(1.0 + (exp(0.6 * lte) / 25.0 + 7.0 / 10.0) * exp(0.36 * lxs)));
-    const double fac = n * (ec * ec) / c * nucs * exp(-x13s);
+    const double jvs = -(37.0 - 87.0 * sshift) * 0.01 * frcp(thetae + 1.0) *
+                       exp(5.0 / 3.0 * log(1.0 + (exp(0.6 * lte) * 0.04 + 7.0 / 10.0) * exp(0.36 * lxs)));
+    const double fac = n * ((ec * ec) / c) * nucs * exp(-x13s);
     ji = fac * jis; jq = -fac * jqs; jv = -fac * jvs;
   }
   const double ibn = frcp(bnu(T, nu));
   const double ai = ji * ibn, aq = jq * ibn, av = jv * ibn;
-  const double wp2 = 4.0 * pi * n * (ec * ec) / m;
-  const double omega0 = ec * B / m / c;
-  const double x = thetae * fsqrt(1.4142135623730951 * sth * (1e3 * omega0 / 2.0 / pi) * frcp(nu));
+  const double wp2 = n * (4.0 * pi * (ec * ec) / m);
+  const double omega0 = B * (ec / m / c);
+  const double x = thetae * fsqrt(1.4142135623730951 * sth * (omega0 * (1e3 / 2.0 / pi)) * frcp(nu));
   // jffunc, shgmfunc (polsynchemis.f90:799-822)
   const double lx = log(x), lxe = log(x + 1e-16);
-  const double e472 = exp(-x / 47.2);
-  const double extraterm = (.011 * e472 - 369.69342869090826 * exp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh((lx - 4.787491742782046) / 0.1));
-  const double jff = 2.011 * exp(-exp(1.035 * lx) / 4.7) - cos(x / 2.0) * exp(-exp(1.2 * lx) / 2.73) - .011 * e472 + extraterm;
+  const double e472 = exp(x * (-1.0 / 47.2));
+  const double extraterm = (.011 * e472 - 369.69342869090826 * exp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh((lx - 4.787491742782046) * 10.0));
+  const double jff = 2.011 * exp(exp(1.035 * lx) * (-1.0 / 4.7)) - cos(x / 2.0) * exp(exp(1.2 * lx) * (-1.0 / 2.73)) - .011 * e472 + extraterm;
   const double w = 2.0 * pi * nu, iw = frcp(w), iw3 = iw * iw * iw;
-  double eps11m22, eps12;
-  if (thetae > 1e-2) {
-    const double it = frcp(thetae);
+  // No DIVERGENT branch on thetae (r03).  The if-else that stood here was where hipcc's register allocator saved two loop-carried
+  // accumulators of a transfer kernel under the `then` side's exec mask (tools/check_flow_copies.py).  The branch is now
+  // wave-uniform -- taken when ANY lane is warm (a scalar branch: no exec-mask flow block) -- and the lanes select their form; cold
+  // lanes (thetae <= 0.01) of a mixed wave evaluate the Bessel functions at 1 and discard them.  Same arithmetic per lane as before.
+  const bool warm = thetae > 1e-2;
+  const double e11c = jff * wp2 * (omega0 * omega0) * (iw3 * iw), e12c = wp2 * omega0 * iw3;
+  double eps11m22 = e11c * (1.0 + 6.0 * thetae) * (sth * sth), eps12 = e12c * cth;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__builtin_amdgcn_ballot_w64(warm) != 0ull) {
+#else
+  if (warm) {
+#endif
+    const double it = frcp(warm ? thetae : 1.0);
     const double k0 = besselk0(it), k1 = besselk1(it), k2 = k0 + 2.0 * thetae * k1, ik2 = frcp(k2);     // besselk(2, 1/thetae)
     const double shgm = (double)0.43793091f * log(1.0 + (double)0.00185777f * exp((double)1.50316886f * lx));
-    eps11m22 = jff * wp2 * (omega0 * omega0) * (iw3 * iw) * (k1 * ik2 + 6.0 * thetae) * (sth * sth);
-    const double step = 0.5 + 0.5 * tanh((thetae - 1.0) / 0.05);
-    eps12 = wp2 * omega0 * iw3 * (k0 - step * shgm) * ik2 * cth;
-  } else {
-    eps11m22 = jff * wp2 * (omega0 * omega0) * (iw3 * iw) * (1.0 + 6.0 * thetae) * (sth * sth);
-    eps12 = wp2 * omega0 * iw3 * cth;
+    const double step = 0.5 + 0.5 * tanh((thetae - 1.0) * 20.0);
+    const double w11 = e11c * (k1 * ik2 + 6.0 * thetae) * (sth * sth), w12 = e12c * (k0 - step * shgm) * ik2 * cth;
+    eps11m22 = warm ? w11 : eps11m22;
+    eps12 = warm ? w12 : eps12;
   }
   e[0] = ji; e[1] = jq; e[2] = 0.0; e[3] = jv; e[4] = ai; e[5] = aq; e[6] = 0.0 * ibn; e[7] = av;
-  e[8] = w / 2.0 / c * eps11m22; e[9] = 0.0 * ibn; e[10] = w / c * eps12;
+  e[8] = w * (0.5 / c) * eps11m22; e[9] = 0.0 * ibn; e[10] = w * (1.0 / c) * eps12;
 }
 
 // MAXJUTT: calc_maxjutt_subroutine (calc_maxjutt.f90:8-63).  otherargs = (delta, w_1..w_N): N thermal components with
@@ -711,7 +722,7 @@ GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]
   M4[0][3] = au * rhoq - aq * rhou; M4[1][3] = av * aq + rhov * rhoq; M4[2][3] = au * av + rhou * rhov; M4[3][3] = av * av + rhov * rhov - (a2 + p2) / 2.0;
   double ep = exp(lam1 * dx), em = frcp(ep);
   double ch = 0.5 * (ep + em), zz = lam1 * dx;
-  double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz / 6.0 * (1.0 + zz * zz / 20.0)) : 0.5 * (ep - em);
+  double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz * (1.0 / 6.0) * (1.0 + zz * zz * 0.05)) : 0.5 * (ep - em);
   if (zz > 709.0) {
     // e^zz overflows at 709.78 but cosh/sinh stay finite up to 710.4758, and the reference's COSH/SINH intrinsics return
     // them there (the step then gives O = exp(-a_I dx) * finite, usually 0, instead of NaN): (e^{zz/2}/2) e^{zz/2}
@@ -762,7 +773,7 @@ GRT_NI void formal_apply(const double *a, const double *rho, double dx, const do
   const double sig = fsign(1.0, ap), s1 = sig * lam1, s2 = sig * lam2;
   const double ep = exp(lam1 * dx), em = frcp(ep), zz = lam1 * dx;
   double ch = 0.5 * (ep + em);
-  double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz / 6.0 * (1.0 + zz * zz / 20.0)) : 0.5 * (ep - em);
+  double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz * (1.0 / 6.0) * (1.0 + zz * zz * 0.05)) : 0.5 * (ep - em);
   if (zz > 709.0) {      // (see calc_O: cosh / sinh stay finite where e^zz overflows)
     const double w = exp(0.5 * zz);
     ch = (0.5 * w) * w; sh = ch;
@@ -1109,22 +1120,30 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
 }
 
 // convert_fluidvars_harm fluid.f90:957-973 (scale_sim_units :765-790, monika_e :870-892)
+// scale_sim_units (fluid.f90:765-790) in the form the kernels run: rhocgs = mdotcgs / mdot / lcgs^3 * tc * rho with tc = lcgs / c,
+// n = rhocgs / mp, pcgs = p rhocgs / rho c^2, T = pcgs / n / k, B = bmag sqrt(rhocgs / rho) c sqrt(4 pi).  The reference's twelve
+// divisions are three reciprocals here (the quotients of constants are folded); rhocgs / rho is kept as a product with 1/rho so that
+// an empty zone (rho = 0) gives the same NaN.  Values agree with the literal forms to 2-3 ulp (tests/test_hostsim_fast.py, 1e-12).
+GRT_HD void sim_units(double rho, double p, double bmag, double mbh, double mdotcgs, double mdot_code, double &rhocgs, double &ncgs,
+                      double &bcgs, double &tcgs) {
+  const double mp = 1.67262158e-24;
+  const double lcgs = mbh * (PH_G * PH_msun / (PH_c * PH_c));
+  rhocgs = mdotcgs * frcp(mdot_code * (lcgs * lcgs) * PH_c) * rho;
+  const double rr = rhocgs * frcp_s(rho);
+  ncgs = rhocgs * (1.0 / mp);
+  tcgs = p * rr * (PH_c * PH_c * mp / PH_k) * frcp_s(rhocgs);
+  bcgs = bmag * fsqrt(rr) * (PH_c * 3.5449077018110318);      // sqrt(4 pi)
+}
+
 GRT_HD void harm_convert(const FluidPoint &f, double mbh, double mdotcgs, double muval, double gminval, double &ncgs,
                          double &bcgs, double &tcgs) {
   GRT_NO_CONTRACT
-  const double mdot = (double).003f, mp = 1.67262158e-24;     // REAL(4) literal held in a REAL(8)
-  const double lcgs = PH_G * mbh * PH_msun / (PH_c * PH_c), tc = lcgs / PH_c;
-  const double rho = (double)f.rho, p = (double)f.p, bmag = (double)f.bmag;
-  const double rhocgs = mdotcgs / mdot / (lcgs * lcgs * lcgs) * tc * rho;
-  ncgs = rhocgs / mp;
-  const double pcgs = p * rhocgs / rho * (PH_c * PH_c);
-  tcgs = pcgs / ncgs / PH_k;
-  bcgs = bmag * sqrt(rhocgs / rho) * PH_c;
-  bcgs = bcgs * sqrt(4.0 * PH_pi);
-  const double rlow = muval, rhigh = muval / gminval;
+  double rhocgs;
+  sim_units((double)f.rho, (double)f.p, (double)f.bmag, mbh, mdotcgs, (double).003f /* REAL(4) literal held in a REAL(8) */, rhocgs, ncgs, bcgs, tcgs);
+  const double rlow = muval, rhigh = muval * frcp_s(gminval);
   const double beta = (double)(f.p / (f.bmag * f.bmag)) / 0.5;
   const double b2 = beta * beta;
-  const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
+  const double trat = (f.bmag > 0.f) ? (rhigh * b2 + rlow) * frcp_s(1.0 + b2) : rhigh;
   tcgs = tcgs * trat;
 }
 
@@ -1226,23 +1245,17 @@ GRT_HD void harm3d_convert(const FluidPoint &f, double mbh, double mdotcgs, doub
                            double p1, double sigcut, double &ncgs, double &ncgsnth, double &bcgs, double &tcgs) {
   GRT_NO_CONTRACT
   const double mp = 1.67262158e-24;
-  const double mdot = PH_G * mbh * PH_msun / (PH_c * PH_c * PH_c);
-  const double lcgs = PH_G * mbh * PH_msun / (PH_c * PH_c), tc = lcgs / PH_c;
-  const double rho = (double)f.rho, p = (double)f.p, bmag = (double)f.bmag;
-  const double rhocgs = mdotcgs / mdot / (lcgs * lcgs * lcgs) * tc * rho;
-  ncgs = rhocgs / mp;
-  const double pcgs = p * rhocgs / rho * (PH_c * PH_c);
-  tcgs = pcgs / ncgs / PH_k;
-  bcgs = bmag * sqrt(rhocgs / rho) * PH_c;
-  bcgs = bcgs * sqrt(4.0 * PH_pi);
-  const double rlow = 1.0 / muval - 1.0, rhigh = gminval * (1.0 / muval - 1.0);
+  const double rho = (double)f.rho, bmag = (double)f.bmag;
+  double rhocgs;
+  sim_units(rho, (double)f.p, bmag, mbh, mdotcgs, mbh * (PH_G * PH_msun / (PH_c * PH_c * PH_c)), rhocgs, ncgs, bcgs, tcgs);
+  const double rlow = frcp_s(muval) - 1.0, rhigh = gminval * rlow;
   const double beta = (double)(f.p / (f.bmag * f.bmag)) / 0.5;
   const double b2 = beta * beta;
-  const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
-  tcgs = tcgs / (1.0 + trat);
-  const double bmagrho = (bmag * bmag) / rho;
-  ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) / 8.0 / PH_pi / gminval * (p1 - 2.0) / (p1 - 1.0) / 8.2e-7 : 0.0;
-  const double sigmacgs = (bcgs * bcgs) / ((ncgs * mp) * 8.988e20 * 4.0 * PH_pi);
+  const double trat = (f.bmag > 0.f) ? (rhigh * b2 + rlow) * frcp_s(1.0 + b2) : rhigh;
+  tcgs = tcgs * frcp_s(1.0 + trat);
+  const double bmagrho = (bmag * bmag) * frcp_s(rho);
+  ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) * (1.0 / 8.0 / PH_pi / 8.2e-7) * (p1 - 2.0) * frcp_s(gminval * (p1 - 1.0)) : 0.0;
+  const double sigmacgs = (bcgs * bcgs) * frcp_s(ncgs * (mp * 8.988e20 * 4.0 * PH_pi));
   if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
 }
 
@@ -1366,28 +1379,22 @@ GRT_HD void iharm_convert(const FluidPoint &f, float kela, float gam, double mbh
                           double jetalpha, double p1, double sigcut, double &ncgs, double &ncgsnth, double &bcgs, double &tcgs) {
   GRT_NO_CONTRACT
   const double mp = 1.67262158e-24;
-  const double mdot = PH_G * mbh * PH_msun / (PH_c * PH_c * PH_c);
-  const double lcgs = PH_G * mbh * PH_msun / (PH_c * PH_c), tc = lcgs / PH_c;
-  const double rho = (double)f.rho, p = (double)f.p, bmag = (double)f.bmag;
-  const double rhocgs = mdotcgs / mdot / (lcgs * lcgs * lcgs) * tc * rho;
-  ncgs = rhocgs / mp;
-  const double pcgs = p * rhocgs / rho * (PH_c * PH_c);
-  tcgs = pcgs / ncgs / PH_k;
-  bcgs = bmag * sqrt(rhocgs / rho) * PH_c;
-  bcgs = bcgs * sqrt(4.0 * PH_pi);
+  const double rho = (double)f.rho, bmag = (double)f.bmag;
+  double rhocgs;
+  sim_units(rho, (double)f.p, bmag, mbh, mdotcgs, mbh * (PH_G * PH_msun / (PH_c * PH_c * PH_c)), rhocgs, ncgs, bcgs, tcgs);
   if (gminval >= 1.0) {
     const float pp = f.p * (gam - 1.f);
-    const double rlow = 1.0 / muval - 1.0, rhigh = gminval * (1.0 / muval - 1.0);
+    const double rlow = frcp_s(muval) - 1.0, rhigh = gminval * rlow;
     const double beta = (double)(pp / (f.bmag * f.bmag)) / 0.5, b2 = beta * beta;
-    const double trat = (f.bmag > 0.f) ? rhigh * b2 / (1.0 + b2) + rlow / (1.0 + b2) : rhigh;
-    tcgs = 2.0 * tcgs / 3.0 / (2.0 + trat);
+    const double trat = (f.bmag > 0.f) ? (rhigh * b2 + rlow) * frcp_s(1.0 + b2) : rhigh;
+    tcgs = tcgs * (2.0 / 3.0) * frcp_s(2.0 + trat);
   } else if (gminval == -1.0) {
-    const double thetae = mp / PH_m * (double)kela * pow((double)f.rho, 4.0 / 3.0 - (double)1.f);
-    tcgs = thetae * PH_m * PH_c2 / PH_k;
+    const double thetae = (mp / PH_m) * (double)kela * pow((double)f.rho, 4.0 / 3.0 - (double)1.f);
+    tcgs = thetae * (PH_m * PH_c2 / PH_k);
   }
-  const double bmagrho = (bmag * bmag) / rho;
-  ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) / 8.0 / PH_pi / gminval * (p1 - 2.0) / (p1 - 1.0) / 8.2e-7 : 0.0;
-  const double sigmacgs = (bcgs * bcgs) / ((ncgs * mp) * 8.988e20 * 4.0 * PH_pi);
+  const double bmagrho = (bmag * bmag) * frcp_s(rho);
+  ncgsnth = (bmagrho > 1.0) ? jetalpha * (bcgs * bcgs) * (1.0 / 8.0 / PH_pi / 8.2e-7) * (p1 - 2.0) * frcp_s(gminval * (p1 - 1.0)) : 0.0;
+  const double sigmacgs = (bcgs * bcgs) * frcp_s(ncgs * (mp * 8.988e20 * 4.0 * PH_pi));
   if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
 }
 
@@ -1507,20 +1514,20 @@ GRT_HD void koral3d_convert(const FluidPoint &f, float Be, int type, double nfac
   GRT_NO_CONTRACT
   const double mp = 1.67262158e-24;
   double rhocgs = (double)f.rho;
-  ncgs = rhocgs / mp;
-  bcgs = (double)f.bmag * sqrt(4 * PH_pi);
-  bcgs = bcgs * sqrt(nfac);
+  ncgs = rhocgs * (1.0 / mp);
+  bcgs = (double)f.bmag * 3.5449077018110318;      // sqrt(4 pi)
+  bcgs = bcgs * fsqrt(nfac);
   ncgs = ncgs * nfac; rhocgs = rhocgs * nfac;
   tcgs = 0.0;
   if (gminval >= 1.0) {
     const float pe = f.p + Be, ue = 2.f * f.p + Be;
-    const double beta = 2.0 * (double)f.rho * PH_k * (double)pe / mp / (double)(f.bmag * f.bmag), b2 = beta * beta;
-    const double trat = (f.bmag > 0.f) ? gminval * b2 / (1.0 + b2) + 1.0 / (1.0 + b2) : gminval;
-    tcgs = (double)ue / (2.0 + trat);
+    const double beta = (double)f.rho * (2.0 * PH_k / mp) * (double)pe * frcp_s((double)(f.bmag * f.bmag)), b2 = beta * beta;
+    const double trat = (f.bmag > 0.f) ? (gminval * b2 + 1.0) * frcp_s(1.0 + b2) : gminval;
+    tcgs = (double)ue * frcp_s(2.0 + trat);
   } else if (gminval < 0.0) {
     tcgs = (double)f.p;
   }
-  const double sigmacgs = (bcgs * bcgs) / (rhocgs * 8.988e20 * 4.0 * PH_pi);
+  const double sigmacgs = (bcgs * bcgs) * frcp_s(rhocgs * (8.988e20 * 4.0 * PH_pi));
   if (sigmacgs >= sigcut) { ncgs = 0.0; tcgs = 1e9; }
   if (type == 1 && Be >= 0.05f) { tcgs = 10.0; bcgs = 0.0; }
   ncgsnth = 0.0;

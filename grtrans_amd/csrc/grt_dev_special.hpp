@@ -29,6 +29,14 @@ GRT_HD double frcp(double b) {
 #endif
   return r;
 }
+// frcp for arguments that may be 0 or infinite: the Newton steps turn the hardware's correct 1/0 = inf, 1/inf = 0 into NaN
+// (0 x inf inside the residual), so the seed is kept when the residual is not a number
+GRT_HD double frcp_s(double b) {
+  const double r = __builtin_amdgcn_rcp(b);
+  const double r1 = fma(fma(-b, r, 1.0), r, r);
+  const double e = fma(-b, r1, 1.0);
+  return (fabs(e) <= 1.0) ? fma(e, r1, r1) : r;
+}
 GRT_HD double fdiv(double a, double b) {
   double r = frcp(b), q = a * r;
   return fma(fma(-b, q, a), r, q);
@@ -46,6 +54,7 @@ GRT_HD double fsqrt(double x) {
 }
 #else
 GRT_HD double frcp(double b) { return 1.0 / b; }
+GRT_HD double frcp_s(double b) { return 1.0 / b; }
 GRT_HD double fdiv(double a, double b) { return a / b; }
 GRT_HD double fsqrt(double x) { return sqrt(x); }
 #endif

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       else if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
         polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp,
                          IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
-      const double lg = log(g);
+      const double lg = log(g), igs = frcp(g);      // (1/g once per step: the frequency loop divides by g twice per frequency)
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
       double xJK[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // EXTRA: j_I and K(1:7) of the first frequency after rotate/invariant/cgs
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
 #pragma clang loop unroll(disable)
       for (int f = 0; f < FB; ++f) {
         if (f < nf) {
-          const double nu = freqs[f0 + f] / g;
+          const double nu = freqs[f0 + f] * igs;
           double e11[11];
           if (EMIS == GRT_EMIS_POLSYNCHPL) {
             GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
@@ -734,12 +734,18 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             I[f][0] += acc; facs[f] += 1.0; }
           continue;
 #endif
+#ifdef GRT_DEBUG_SEL
+          if (f == 0 && GRT_DEBUG_SEL == 7) { dbg[0] = facs[0]; dbg[1] = valid ? e11[0] * (lam_1 - lam_i) : 0.0; }
+#endif
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
+#ifdef GRT_DEBUG_SEL
+          if (f == 0 && GRT_DEBUG_SEL == 7) { dbg[2] = facs[0]; dbg[3] = (double)k; }
+#endif
           if constexpr (IFLAG == GRT_INT_QUAD) {
             // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
             // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end, is the scalar recurrence
             // I <- e^{-dtau} I + dx/2 (j_k + j_k+1 e^{-dtau}).
-            const double j0 = e11[0] * g * g, K0 = e11[4] / g * LBH;
+            const double j0 = e11[0] * g * g, K0 = e11[4] * igs * LBH;
             if (EXTRA && f == 0) { xJK[0] = j0; xJK[1] = K0; }
             const double delta = dx * ((fabs(K0) + fabs(Kn[f][0])) / 2.0);
             if (step) {
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             double jj4[4] = {e11[0], c2xi * e11[1] - s2xi * e11[2], s2xi * e11[1] + c2xi * e11[2], e11[3]};
             double KK[7] = {e11[4], c2xi * e11[5] - s2xi * e11[6], s2xi * e11[5] + c2xi * e11[6], e11[7],
                             c2xi * e11[8] - s2xi * e11[9], s2xi * e11[8] + c2xi * e11[9], e11[10]};
-            const double ig = frcp(g);
+            const double ig = igs;
 #pragma unroll
             for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g;
 #pragma unroll

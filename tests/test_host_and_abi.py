@@ -386,3 +386,20 @@ def test_no_kernel_parks_values_in_agprs():
     assert len(k) > 100
     bad = {n: v for n, v in k.items() if int(v.get("AGPRs", "0")) != 0 or int(v.get("Occupancy", "2")) < 2}
     assert not bad, sorted(bad)[:5]
+
+
+def test_no_live_range_copy_under_a_partial_exec_mask():
+    # r03: in grt_transfer_kernel<FORMAL, IHARM, HYBRIDTHPL, 1, false> hipcc's register allocator saved two loop-carried accumulators
+    # (v_mov v[124:125], v[220:221]) in the FLOW block of a divergent if-else BEFORE the instruction that flips the exec mask, i.e.
+    # for the lanes of the `then` side only; the restore ran for every lane, so the lanes of the `else` side got another variable's
+    # value.  Pixels that must be zeroed by the fac gate came out NaN (or, one build earlier, zero pixels moved from run to run).
+    # The divergent branch is gone from the source; this scans the assembly of the shipped object for the signature (a register-to-
+    # register copy before the exec flip whose source lives through the if-else, whose destination the else side never writes and
+    # which is undone later) so that the next occurrence is a failing CPU test, not a wrong image.
+    asm = os.path.join(ROOT, "grtrans_amd", "csrc", "grt_kernels.gfx950.s")
+    if not os.path.exists(asm):
+        pytest.skip("no device assembly here (the library was not built in this tree)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_flow_copies
+    sites = check_flow_copies.scan(asm)
+    assert not sites, sites[:3]
