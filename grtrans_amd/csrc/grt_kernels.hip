@@ -748,9 +748,30 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             const double j0 = e11[0] * g * g, K0 = e11[4] * igs * LBH;
             if (EXTRA && f == 0) { xJK[0] = j0; xJK[1] = K0; }
             const double delta = dx * ((fabs(K0) + fabs(Kn[f][0])) / 2.0);
+            // A ray whose affine parameter is not monotonic (a = 0.985 camera on the Schwarzschild SPHACC flow, r03 fuzz: lambda jumps
+            // back by 2.3 where the ray dives under r = 2.6) has a step of NEGATIVE optical depth, -1200 there: e^{+1200} overflows in
+            // this recurrence although the ray's later steps attenuate it by e^{-6000} -- the reference sums j exp(-tau) with tau
+            // measured from the camera and never forms the large number.  The running value is therefore I e^{-P} with an exponent P <= 0
+            // (jn[f][1], unused by the quadrature otherwise) that banks the negative depth until positive steps have paid it back.
+            // P = 0 and delta >= 0 -- every ordinary ray -- takes the recurrence above unchanged (a wave-uniform branch selects).
             if (step) {
               const double E = exp(-delta);
-              I[f][0] = E * I[f][0] + 0.5 * dx * (j0 + jn[f][0] * E);
+              const double Inorm = E * I[f][0] + 0.5 * dx * (j0 + jn[f][0] * E);
+              const bool banked = (jn[f][1] != 0.0) || (delta < 0.0);
+              double Inew = Inorm, Pnew = 0.0;
+              if (__builtin_amdgcn_ballot_w64(banked) != 0ull) {
+                const double P = jn[f][1];
+                double M = I[f][0] + 0.5 * dx * jn[f][0] * exp(P);      // point k+1's half of the trapezoid at the running scale
+                double Pn = P + delta;
+                const double att = exp(-dmax(Pn, 0.0));                 // a positive balance is paid out at once
+                M = M * att;
+                Pn = dmin(Pn, 0.0);
+                M = M + 0.5 * dx * j0 * exp(Pn);
+                Inew = banked ? M : Inorm;
+                Pnew = banked ? Pn : 0.0;
+              }
+              I[f][0] = Inew;
+              jn[f][1] = Pnew;
             }
             if (valid) { jn[f][0] = j0; Kn[f][0] = K0; }
           } else {
@@ -843,7 +864,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
         for (int c = 0; c < 9; ++c) xWp[c] = jI * qv[c];
       }
       if (record) {   // running intensity of the first frequency into the consumed tile slot
-        tl0[lane * GRT_TS + e] = I[0][0] * LBH;
+        tl0[lane * GRT_TS + e] = I[0][0] * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
         tl1[lane * GRT_TS + e] = I[0][1] * LBH;
         tl2[lane * GRT_TS + e] = I[0][2] * LBH;
         tl3[lane * GRT_TS + e] = I[0][3] * LBH;
@@ -880,7 +901,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       if (f == 0) ok0 = ok;
       if (!EXTRA)
         for (int c = 0; c < nvals && c < 4; ++c)
-          pixvals[((long long)(f0 + f) * npix_tile + pixslot) * nvals + c] = (float)(ok ? I[f][c] * LBH : 0.0);
+          pixvals[((long long)(f0 + f) * npix_tile + pixslot) * nvals + c] =
+              (float)(ok ? I[f][c] * LBH * ((IFLAG == GRT_INT_QUAD && jn[(IFLAG == GRT_INT_FORMAL) ? 0 : f][1] != 0.0) ? exp(-jn[(IFLAG == GRT_INT_FORMAL) ? 0 : f][1]) : 1.0) : 0.0);
     }
   }
   if (EXTRA) {

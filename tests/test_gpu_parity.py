@@ -2056,3 +2056,30 @@ def test_polar_camera_grid_nrotype1(fdev, tmp_path, monkeypatch):
     y = gb.grtrans()
     y.run_pgrtrans(**kw)
     assert np.array_equal(y.ivals[:, :, 0].T.astype(np.float32), x.ivals[:, :, 0])
+
+
+def test_quadrature_survives_a_step_of_negative_optical_depth(fdev):
+    # tools/fuzz_cameras.py 700 5151 allext, camera 290: a spin-0.985 camera on the Schwarzschild SPHACC flow has a ray (pixel 91) whose affine
+    # parameter jumps back by 2.3 where it dives under r = 2.6, a step of optical depth -1200 at 24 GHz.  The reference's nvals = 1
+    # quadrature sums j exp(-tau) with tau measured from the camera and never forms e^{+1200}; the device recurrence
+    # I <- e^{-dtau} I + ... did (inf - inf = NaN in that pixel, every library up to r03_e) and now banks the negative depth in an exponent
+    # until the later steps have paid it back (grt_kernels.hip, IFLAG == GRT_INT_QUAD).
+    from grtrans_amd import capi
+    from oracle import orabind
+    fdev.load_sphacc()
+    gv = (-29.623082372504165, 17.25895576416562, -21.347376884693908, 25.534661251975876)
+    spin, mu0, nn, freqs = 0.9845592285987614, -0.6534576984273296, (12, 12, 40), [7.23e11, 2.41e11, 2.41e10]
+    cam = capi.make_camera(1, gv, nn, spin, mu0, 0.02, -0.5)
+    em = capi.make_emis("SYNCHTHAV", 10.0, 1.0, 6.0, 100., 1e5, 5.5)
+    o = orabind.Oracle(nn=nn, iname="formal", spin=spin, mu0=mu0, gridvals=gv, uout=0.02, fname="SPHACC", ename="SYNCHTHAV", mbh=10., gmin=100., nvals=1)
+    ref, rn, _ = o.trace(1, 144, freqs, nthreads=0)
+    for rec in (False, True):
+        capi.record_steps(rec)
+        pix, _, status, _ = capi.trace_tile(cam, 1, 144, "SPHACC", em, freqs, "formal", nvals=1)
+        assert np.array_equal(status, rn)
+        assert np.isfinite(ref[2][90]).all() and ref[2][90][0] > 0         # the pixel the device used to lose
+        for k in range(3):
+            assert np.array_equal(np.isfinite(pix[k]), np.isfinite(ref[k])), k
+            ok = np.isfinite(ref[k]).all(axis=1)
+            assert np.abs(pix[k][ok] - ref[k][ok]).max() <= STOKES_TOL * np.abs(ref[k][ok]).max(), k
+    capi.record_steps(False)

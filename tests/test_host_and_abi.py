@@ -384,7 +384,8 @@ def test_no_kernel_parks_values_in_agprs():
     import kernel_usage
     k = kernel_usage.parse(open(usage).read())
     assert len(k) > 100
-    bad = {n: v for n, v in k.items() if int(v.get("AGPRs", "0")) != 0 or int(v.get("Occupancy", "2")) < 2}
+    assert all("AGPRs" in v and "Occupancy" in v and "VGPRs" in v for v in k.values()), "resource remarks not understood"
+    bad = {n: v for n, v in k.items() if int(v["AGPRs"]) != 0 or int(v["Occupancy"]) < 2}
     assert not bad, sorted(bad)[:5]
 
 

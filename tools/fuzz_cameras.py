@@ -137,13 +137,29 @@ for c in range(ncams):
     print("cam %2d %-8s %s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
           (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag, (" IQUV per frequency " + str(perf)) if flag else ""))
     if only is not None:
+        print("   exact: spin %r mu0 %r gridvals %r uout %r freqs %r" % (a, mu0, gv, uout, freqs))
+    if only is not None:
         kb = max(perf, key=lambda k: perf[k].max()); freq = freqs[kb]      # detail: the worst frequency, traced alone
         pix, ref = [pix[kb]], [ref[kb]]
         pk = np.nanmax(np.abs(np.where(np.isfinite(ref[0]), ref[0], np.nan)), axis=0)
         d = np.abs(pix[0] - ref[0]) / (pk + 1e-300)
         worst = np.argsort(-d.max(axis=1))[:1]
+        nanpix = np.where(~np.isfinite(pix[0]).all(axis=1) & np.isfinite(ref[0]).all(axis=1))[0]
+        if len(nanpix):                                                # a pixel that is NaN on the device only goes first
+            worst = nanpix[:1]
         capi.record_steps(True)
-        capi.trace_tile(cam, 1, nn[0] * nn[1], fname, em, [freq], iname)
+        capi.trace_tile(cam, 1, nn[0] * nn[1], fname, em, [freq], iname, nvals=nst)
+        if nst == 1:
+            for w in worst:
+                w = int(w + i1 - 1)
+                od = o.ray_dump(w + 1, freq)
+                n = od["npts"]
+                recd = capi.download_steps(w, 1, cam.nup + cam.next)[:, 0, :n]
+                print("   nvals=1 pixel %d npts %d: device running I (record field 4), oracle j_I, alpha_I, T, n, B per point" % (w + 1, n))
+                for kk in range(n):
+                    print("     %3d r %.5f th %.5f lam %.8e  I_dev %.6e | j %.6e K %.6e  T %.4e n %.4e B %.4e g %.5f" % (
+                        kk, recd[0][kk], recd[1][kk], recd[3][kk], recd[4][kk], od["j"][kk][0], od["K"][kk][0], od["tcgs"][kk], od["ncgs"][kk], od["bcgs"][kk], od["rshift"][kk]))
+            continue
         for w in worst:
             w = w + i1 - 1                                            # pixel index in the whole image
             od = o.ray_dump(int(w) + 1, freq)

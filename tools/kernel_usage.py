@@ -13,7 +13,8 @@ def parse(txt):
             cur = m.group(1)
             out[cur] = {}
             continue
-        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)", ln)
+        # "file:l:c: remark:     VGPRs: 256 [-Rpass...]" (plain compile) or "remark: file:l:c:     VGPRs: 256 [-Rpass...]" (-save-temps)
+        m = re.search(r"[:\s]\s+([A-Za-z][A-Za-z ]*?)(?: \[[^\]]*\])?: (\S+) \[-Rpass-analysis", ln)
         if m and cur:
             out[cur][m.group(1).strip()] = m.group(2)
     return out
