@@ -379,7 +379,10 @@ GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double 
 // lnu = log(nu): log x = log(nub/nu) = lnub - lnu, so a frequency costs exponentials only
 GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoint &P, double nu, double lnu, double *e) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
-  double lx = P.lnub - lnu, x = exp(lx);
+  const double l15 = 0.4054651081081644;                   // log(1.5)
+  const double lx = P.lnub - lnu;
+  const double sq15 = exp(0.5 * (lx + l15));               // sqrt(1.5 x)
+  const double x = sq15 * sq15 * (2.0 / 3.0);              // x = nub / nu from the same exponential (one exp less per frequency)
   double lxmin = -lx - C.lmin, lxmax = -lx - C.lmax;      // log(nu/nucmin), log(nu/nucmax)
   int ix1, ix2;
   ix2 = (int)((lxmax - C.gx0) * C.gxs); ix2 = (ix2 < 180) ? ((ix2 > 1) ? ix2 : 1) : 180;
@@ -392,8 +395,6 @@ GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoi
   double gapfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yap, T.syap) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yap, T.syap);
   double gvfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yv, T.syv) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yv, T.syv);
   double gavfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yav, T.syav) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yav, T.syav);
-  const double l15 = 0.4054651081081644;                   // log(1.5)
-  double sq15 = exp(0.5 * (lx + l15));                     // sqrt(1.5 x)
   double pw = exp(C.alpha * (lx + l15));                   // (3 nub/2 nu)^((p-1)/2)
   double jfac = P.A * (ec * ec / c * 1.7320508075688772 / 4.0) * pw * P.nubperp;
   double ji = jfac * gxfac;
