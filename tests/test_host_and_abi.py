@@ -404,3 +404,13 @@ def test_no_live_range_copy_under_a_partial_exec_mask():
     import check_flow_copies
     sites = check_flow_copies.scan(asm)
     assert not sites, sites[:3]
+
+
+def test_the_flow_copy_scanner_sees_the_defect_and_not_the_ordinary_merge():
+    # positive and negative control of tools/check_flow_copies.py on two hand-reduced shapes of compiler output (tests/golden/flow_copy_*.s):
+    # the save / restore pair around a divergent if-else that cost r03 an image, and the then side's ordinary copy into a merge register
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_flow_copies
+    bad = check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_copy_bad.s"))
+    assert len(bad) == 1 and bad[0][0] == "kernel_with_the_defect" and len(bad[0][2]) == 2
+    assert check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_copy_ok.s")) == []
