@@ -8,11 +8,11 @@ the metric "ray-steps/sec + HBM GB/s" is quoted on.  Inputs (fluid table, coeffi
 resident in HBM before the timed region; outputs stay in HBM (16 B/ray D2H is outside).
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL).
-  --scaling weak (default): the camera is nn=[1024*N,1024,400] over the same field of view and rank r traces the
-      contiguous pixel strip i1..i2 of 1024*1024 rays (the reference's own i1,i2 partition key).
-  --scaling strong: BASELINE config 5's shape -- the SAME nn=[1024,1024,400] camera shared out over the N ranks in
+  --scaling strong (default): BASELINE's metric -- the SAME nn=[1024,1024,400] camera shared out over the N ranks in
       tiles of --tile-cols image columns dealt round-robin (grtrans_amd/tiling.py:ranges, the share-out
       module pgrtrans uses); `value` = ray-steps of the whole image / max-over-ranks time.
+  --scaling weak: the camera is nn=[1024*N,1024,400] over the same field of view and rank r traces the
+      contiguous pixel strip i1..i2 of 1024*1024 rays (the reference's own i1,i2 partition key).
 Either way the only exchange is one gather of the ranks' fp32 cameras to rank 0 over xGMI after the timed steps,
 through the library's own RCCL communicator (grt_stage_* / grt_gather_stage, include/grtrans_amd.h; the ncclUniqueId
 travels over torch.distributed) with torch.distributed.gather as the fall-back; `gather_ms` is reported.
@@ -312,6 +312,9 @@ def main():
                 sys.stdout.flush()
             os._exit(3)
     watchdog = threading.Timer(gather_timeout, on_timeout) if dist is not None else None
+    # the library's ncclCommInitRank watchdog (exit code 98) fires first: a rank whose peer never joins then fails inside
+    # grt_comm_init and takes the agreed fall-back instead of sitting in it until the gather watchdog above ends the job
+    os.environ.setdefault("GRT_COMM_INIT_TIMEOUT", "%g" % max(10.0, 0.5 * gather_timeout))
 
     def emit(gather_ms, gather_via):
         value = ray_steps_all / dt
@@ -377,6 +380,12 @@ def main():
                          "note": "algorithmic 64 B per ray-step (SURVEY 8d) over the trace kernels' HIP-event time (rank 0's launches; "
                                  "N > 1: max over ranks); the path is fp64-VALU issue bound, not HBM bound: see roofline.valu and DESIGN.md 5"},
         }
+        if valu is not None:
+            # The bound that matters is named first: the dominant kernels are fp64-VALU bound, so the roofline's
+            # own achieved / peak / frac are the fp64 vector figures; the HBM reading (64 B per ray-step against 8 TB/s) stays beside it.
+            hbm = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "traffic_ratio")}
+            out["roofline"].update({"bound": "fp64_valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": "TFLOP/s",
+                                    "frac": valu["frac"], "hbm": hbm})
         if stale is not None:
             out["roofline"].update(stale)
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "ffjet":
@@ -408,15 +417,24 @@ def main():
             if use_lib:
                 # the library's own RCCL communicator; its ncclUniqueId travels over the process group that exists already
                 ok = True
-                try:
-                    idbuf = C.create_string_buffer(128)
-                    if rank == 0:
+                # Rank 0 ALWAYS broadcasts -- the id, or None when it could not make one -- so that every rank issues the same
+                # collectives in the same order (a rank 0 that skipped the broadcast left the others waiting in it until the watchdog)
+                box = [None]
+                if rank == 0:
+                    try:
+                        idbuf = C.create_string_buffer(128)
                         capi.check(L.grt_comm_unique_id(idbuf), "grt_comm_unique_id")
-                    box = [idbuf.raw]
-                    dist.broadcast_object_list(box, src=0)
-                    capi.check(L.grt_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(box[0])), "grt_comm_init")
-                except Exception as exc:
-                    ok, why = False, str(exc)[:80]
+                        box = [idbuf.raw]
+                    except Exception as exc:
+                        ok, why = False, str(exc)[:80]
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is None:
+                    ok, why = False, (why if rank == 0 else "rank 0 has no communicator id")
+                else:
+                    try:
+                        capi.check(L.grt_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(box[0])), "grt_comm_init")
+                    except Exception as exc:
+                        ok, why = False, str(exc)[:80]
                 use_lib = agree(ok)           # one rank without a communicator: ALL ranks fall back together
             if use_lib:
                 cnt = (C.c_int64 * world)(*npix_of_rank)

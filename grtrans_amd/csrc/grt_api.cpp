@@ -19,7 +19,8 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw,
+                                     double *tailc);
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
                                       double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield);
@@ -88,6 +89,8 @@ struct Ctx {
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
+  double *d_tailc = nullptr;            // [ray][4]: what grt_geo_tail_kernel hands to grt_geo_kernel (sums at the top chunk's lowest point, Lambda(npts))
+  size_t cap_tailc = 0;
   long long steps_stride = 0;
   int steps_fields = 0;
   hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -113,6 +116,7 @@ struct Ctx {
   int class_order = 3;
   long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
   int n_class[2] = {0, 0};              // class sizes of the resident record
+  std::vector<long long> last_tile;     // (lo, hi) pairs of the last trace call: the rows a time-origin table (grt_set_t0) refers to
 };
 Ctx C;
 
@@ -190,7 +194,7 @@ int grt_free(void) {
   drain();
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_rng, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_rng, C.d_tailc, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -552,6 +556,8 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   }
   if (total > 0x7fffffffLL) return GRT_E_BADARG;
   const int64_t i1 = los[0], i2 = his[0];       // (the single range when nranges == 1)
+  C.last_tile.clear();                          // (grt_debug_ray looks a pixel's row of the time-origin table up in it)
+  for (int k = 0; k < nranges; ++k) { C.last_tile.push_back(los[k]); C.last_tile.push_back(his[k]); }
   std::vector<long long> rkey;
   const long long *d_rng = nullptr;
   if (nranges > 1) {
@@ -684,6 +690,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
+  if ((rc = grow(C.d_tailc, C.cap_tailc, (size_t)chunk * 4))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * chunk * rstride))) return rc;
@@ -737,7 +744,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       if (generic) {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps,
-                                   rstride, fstride, nfields, tfield, t0c, 0));
+                                   rstride, fstride, nfields, tfield, t0c, 0, nullptr));
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
@@ -757,7 +764,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       } else {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
-                                   nfields, tfield, t0c, 0));
+                                   nfields, tfield, t0c, 0, C.d_tailc));
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                                       C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
@@ -942,8 +949,8 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
   hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin, nullptr, 0);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, nullptr);
   if (e != hipSuccess) { drain(); return (int)e; }
   HIPCHK(hipStreamSynchronize(C.stream));
   // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them
@@ -986,6 +993,23 @@ int grt_debug_ray(const grt_camera *cam, int64_t pixel, int fluid_model, const g
   if (maxpts < cam->nup + cam->next) return GRT_E_BADARG;
   // the ray's trace with the per-step record and the coordinate time on: geodesic + running Stokes vector stay in the work buffers
   const int rec0 = C.record_steps, ft0 = C.force_time, reuse0 = C.geo_reuse;
+  // nload > 1: the run's time-origin table (grt_set_t0 / grt_compute_t0) has one row per ray of the tile the run traced; the
+  // one-pixel trace below takes this pixel's row as a one-row table, and the run's table is put back afterwards (r04: the
+  // trace used to be refused -- "t0 table of another tile" -- so debug=1 with nload>1 always died after the full run)
+  struct T0Swap {
+    double *d = nullptr, *one = nullptr; size_t cap = 0; long long n = 0; bool on = false;
+    ~T0Swap() { if (on) { C.d_t0 = d; C.cap_t0 = cap; C.t0_n = n; C.t0_version++; } if (one) (void)hipFree(one); }
+  } swap;
+  if (C.t0_n != 0) {
+    long long row = -1, pre = 0;
+    for (size_t k = 0; k + 1 < C.last_tile.size(); pre += C.last_tile[k + 1] - C.last_tile[k] + 1, k += 2)
+      if (pixel >= C.last_tile[k] && pixel <= C.last_tile[k + 1]) { row = pre + (pixel - C.last_tile[k]); break; }
+    if (row < 0 || row >= C.t0_n) return GRT_E_BADARG;          // the table belongs to a tile that does not hold this pixel
+    HIPCHK(hipMalloc(&swap.one, sizeof(double)));
+    HIPCHK(hipMemcpy(swap.one, C.d_t0 + row, sizeof(double), hipMemcpyDeviceToDevice));
+    swap.d = C.d_t0; swap.cap = C.cap_t0; swap.n = C.t0_n; swap.on = true;
+    C.d_t0 = swap.one; C.cap_t0 = 1; C.t0_n = 1; C.t0_version++;
+  }
   C.record_steps = 1; C.force_time = 1; C.geo_reuse = 0;
   grt_stats st{};
   int rc = trace_common(cam, 1, &pixel, &pixel, fluid_model, em, 1, &freq, iflag, nvals, 0, &st);
@@ -993,6 +1017,7 @@ int grt_debug_ray(const grt_camera *cam, int64_t pixel, int fluid_model, const g
   if (rc) return rc;
   int32_t n = 0;
   HIPCHK(hipMemcpy(&n, C.d_npts, sizeof n, hipMemcpyDeviceToHost));
+  if (n < 0) n = -n;                  // a ray flagged by sum(r) < 0 keeps its points in the dump (the host prints abs(npts) of them)
   GrtRay hr;
   HIPCHK(hipMemcpy(&hr, C.d_rays, sizeof hr, hipMemcpyDeviceToHost));
   *npts_out = n;

@@ -45,7 +45,7 @@ GRT_HD double rc7(double x, double y) {
   s = s * ia;
   const double poly = 0.3 + s * (1.0 / 7.0 + s * (0.375 + s * (9.0 / 22.0 + s * (159.0 / 208.0 + s * (9.0 / 8.0 + s * (4275.0 / 2176.0 +
                       s * (985.0 / 304.0 + s * (1449.0 / 256.0 + s * (28875.0 / 2944.0 + s * (445039.0 / 25600.0))))))))));
-  return w * (1.0 + s * s * poly) * fsqrt(ia);
+  return w * (1.0 + s * s * poly) * fsqrt_nz(ia);
 }
 
 
@@ -123,7 +123,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     double inv = frcp(avef), X = (avef - xt) * inv, Y = (avef - yt) * inv, Z = -X - Y;
     double E2 = X * Y - Z * Z, E3 = X * Y * Z;
     orf = (1.0 - E2 * (1.0 / 10.0) + E3 * (1.0 / 14.0) + E2 * E2 * (1.0 / 24.0) - (3.0 / 44.0) * E2 * E3 - 5.0 / 208.0 * E2 * E2 * E2 +
-           3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 * (1.0 / 16.0)) * fsqrt(inv);
+           3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 * (1.0 / 16.0)) * fsqrt_nz(inv);
   }
   ord = 0.0;
   if (WD) {  // R_D (DLMF 19.36.2 with the elementary symmetric functions of X,Y,Z,Z,Z)
@@ -132,7 +132,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
                  E2 * E2 * E2 * (1.0 / 16.0) + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
                  9.0 / 68.0 * (E3 * E4 + E2 * E5);
-    ord = 3.0 * sumd + fac * ser * inv * fsqrt(inv);
+    ord = 3.0 * sumd + fac * ser * inv * fsqrt_nz(inv);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -144,7 +144,7 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
                  E2 * E2 * E2 * (1.0 / 16.0) + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
                  9.0 / 68.0 * (E3 * E4 + E2 * E5);
-    double r = 6.0 * sumj[k] + fac * ser * inv * fsqrt(inv);
+    double r = 6.0 * sumj[k] + fac * ser * inv * fsqrt_nz(inv);
     if (neg[k]) r = aa[k] * (bb[k] * r + 3.0 * (rcx[k] - orf));
     orj[k] = r;
   }
@@ -184,6 +184,7 @@ struct RealRay {
   double mneg, mpos, muplus, muminus, mposR, muplusR;
   double facm, facmR, m1m, akm, nn, fac2, i1mu, i3mu, rfc, rdc, rjc, tmu1, tmu3, phimu1, phimu3;
   double sgna_pi;
+  double jscale;                   // sqrt(mpos - mneg) (symmetric M) or |muplus|: the Jacobi argument's scale, formed once per ray (r04)
   AgmLadder agm_mu, agm_u;         // Landen ladders of the two Jacobi inversions (moduli m1m, m1u are per-ray constants)
   // ncase 5 (two real roots u1, u4 and a complex pair, or u2, u3 behind the horizon): the u integrals are Carlson
   // (1991) "one quadratic factor" forms with f + g u + u^2 the pair's factor (geokerr_wrapper.f ELLQUARTICCOMPLEX);
@@ -304,6 +305,7 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   K.i1mu = R.i1mu; K.i3mu = R.i3mu; K.rfc = R.rffmu3; K.rdc = R.rdc; K.rjc = R.rjc;
   K.tmu1 = R.tmu1; K.tmu3 = R.tmu3; K.phimu1 = R.phimu1; K.phimu3 = R.phimu3;
   K.sgna_pi = fsign(1.0, a) * 3.141592653589793;
+  K.jscale = K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus);
   K.siu0m = K.su * K.iu0 / K.sqmee; K.siu0e = K.su * K.iu0 / K.sqee;
   K.isqee = 1.0 / K.sqee; K.ii3mu = 1.0 / K.i3mu; K.imuplus = 1.0 / K.muplus; K.imposneg = 1.0 / (K.mpos - K.mneg);
   K.ifac2facm = 1.0 / K.fac2 / K.facm;
@@ -530,12 +532,21 @@ GRT_HD void useg_lane(const GrtCam &cam, const GrtRay &R, const RealRay &K, int 
     return;
   }
   if (!K.cplx && ua == root) return;    // clamped onto the turning point: S = 0
+#if !defined(GRT_NO_USEG_MERGE)
+  // ONE copy of the pair integrals (r04): the last inbound point's upper neighbour is the turning point itself -- a select on the
+  // upper limit, not a second inlined evaluation that the chunk holding that point ran in addition to everybody else's
+  const bool lastinb = inb && R.tpr != 0 && idx == lo;
+  const double un = leg_u(cam, R, K, lastinb ? idx : idx + 1, inb);
+  reset = lastinb;
+  upair_diff<NPH>(K, ua, lastinb ? root : un, o);
+#else
   if (inb && R.tpr != 0 && idx == lo) { // last inbound point: its upper neighbour is the turning point itself
     upair_diff<NPH>(K, ua, root, o);
     return;
   }
   reset = false;
   upair_diff<NPH>(K, ua, leg_u(cam, R, K, idx + 1, inb), o);
+#endif
 }
 
 // mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)
@@ -740,7 +751,11 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
         double a2 = K.sm * powm1(tpm);
         double a3 = two * fint((two * (double)tpm + 3.0 - K.sm) / 4.0) - one;
         double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);   // a2 = +-1: 1/a2 == a2
+#if !defined(GRT_NO_JSCALE)
+        jarg = K.jscale * iarg;
+#else
         jarg = (K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus)) * iarg;
+#endif
       } else {
         double b1 = K.sm, b2 = K.sm * powm1(tpm + 1), b3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
         iu = b1 * K.i1mu + b2 * M.i2mu + b3 * K.i3mu;                      // I_mu
@@ -831,7 +846,11 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
     double sn, cn, dn;
     if (K.sym) {
       double zz, s0, c0;
+#if !defined(GRT_NO_JSCALE)
+      sncndn_ladder_z(K.agm_mu, K.jscale * iarg, K.m1m, sn, cn, dn, zz, s0, c0);
+#else
       sncndn_ladder_z(K.agm_mu, fsqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn, zz, s0, c0);
+#endif
       mun = K.muminus * cn;
       Tz = zeta_T(K, zz, tpm, iu);
       if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);

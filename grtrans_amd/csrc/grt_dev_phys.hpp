@@ -1623,8 +1623,8 @@ GRT_HD void delo_solve(double eps, const double *a, const double *p, const doubl
   x[0] = x0; x[1] = u0 - ex * w0; x[2] = u1 - ex * w1; x[3] = u2 - ex * w2;
 }
 
-GRT_HD void delo_apply(const double *j0, const double *K0p, const double *j1, const double *K1p, double dx, double delta, const double *I,
-                       double *out) {
+GRT_HD void delo_apply_core(const double *j0, const double *K0p, const double *j1, const double *K1p, double dx, double delta, const double *I,
+                            double *out) {
   const double thin = 1e-2;
   const double ki = K0p[0], ki1 = K1p[0];
   // N1 I
@@ -1652,6 +1652,38 @@ GRT_HD void delo_apply(const double *j0, const double *K0p, const double *j1, co
     y[2] = (c1 * j0[2] + cb1 * j1[2] + cA * I[2] - cK * n2) * is;
     y[3] = (c1 * j0[3] + cb1 * j1[3] + cA * I[3] - cK * n3) * is;
     delo_solve(c1 * is, K0p + 1, K0p + 4, y, out);
+  }
+}
+
+// The step for very small coefficients (r04).  Rays that start in near-vacuum zones of a GRMHD dump carry j, alpha ~ 1e-306 ... 1e-310
+// -- at and below the smallest normal number -- into their first emitting step, and DELO's thick branch works with the SOURCE FUNCTION
+// S = j / alpha_I and K / alpha_I (radtrans_integrate.f90:811-824): O(1) ratios of numbers with a handful of significant bits.  The
+// reference forms those ratios FIRST, with IEEE divisions.  delo_apply_core multiplies by 1 / alpha_I -- a Newton reciprocal that is only
+// valid for normal operands (1 / 1e-310 overflows its seed: NaN where the reference has a finite pixel) --, forms N1 I = alpha x I in the
+// subnormal range, where the products lose the bits the ratios still had, and squares eps = (F - G) / alpha_I (overflow below
+// alpha_I ~ 1e-154, with a.A^-1 a ~ alpha_I^2 underflowing beside it).  An end of a thick step whose alpha_I is below 1e-140 is therefore
+// rescaled by a power of two that brings alpha_I into [0.5, 1) -- exact, and the step is homogeneous of degree zero in (j, K) of either
+// end -- before anything is multiplied or inverted: the closed form then sees the same O(1) ratios the reference does.  Lanes whose
+// alpha_I is an ordinary number keep scale 1 (bit-identical to the core); the branch is wave-uniform and almost never taken.
+GRT_HD void delo_apply(const double *j0, const double *K0p, const double *j1, const double *K1p, double dx, double delta, const double *I,
+                       double *out) {
+  const double tiny = 1e-140, up = 0x1p+300;
+  const bool thick = delta > 1e-2;
+  const bool t0 = thick && fabs(K0p[0]) < tiny && K0p[0] != 0.0, t1 = thick && fabs(K1p[0]) < tiny && K1p[0] != 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__builtin_amdgcn_ballot_w64(t0 || t1) != 0ull) {
+#else
+  if (t0 || t1) {
+#endif
+    int e0 = 0, e1 = 0;
+    (void)frexp(K0p[0] * up, &e0); (void)frexp(K1p[0] * up, &e1);       // (2^300 first: the argument is a normal number even for 4.9e-324)
+    const double u0 = t0 ? up : 1.0, u1 = t1 ? up : 1.0, s0 = t0 ? ldexp(1.0, -e0) : 1.0, s1 = t1 ? ldexp(1.0, -e1) : 1.0;
+    double j0s[4], j1s[4], K0s[7], K1s[7];
+    for (int c = 0; c < 4; ++c) { j0s[c] = (j0[c] * u0) * s0; j1s[c] = (j1[c] * u1) * s1; }
+    for (int c = 0; c < 7; ++c) { K0s[c] = (K0p[c] * u0) * s0; K1s[c] = (K1p[c] * u1) * s1; }
+    delo_apply_core(j0s, K0s, j1s, K1s, dx, delta, I, out);
+  } else {
+    delo_apply_core(j0, K0p, j1, K1p, dx, delta, I, out);
   }
 }
 

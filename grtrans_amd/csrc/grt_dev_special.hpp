@@ -52,7 +52,23 @@ GRT_HD double fsqrt(double x) {
 #endif
   return (x == 0.0) ? 0.0 : g;
 }
+// fsqrt for arguments that are never zero (sums of squares plus one, reciprocals of positive means, the radicands of a segment
+// between two DIFFERENT stored points): without the x == 0 guard -- a compare and two selects per call, ~12 calls per stored point
+GRT_HD double fsqrt_nz(double x) {
+#if defined(GRT_NO_SQRT_NZ)
+  return fsqrt(x);
 #else
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  g = fma(fma(-g, g, x), h, g);
+  return g;
+#endif
+}
+#else
+GRT_HD double fsqrt_nz(double x) { return sqrt(x); }
 GRT_HD double frcp(double b) { return 1.0 / b; }
 GRT_HD double frcp_s(double b) { return 1.0 / b; }
 GRT_HD double fdiv(double a, double b) { return a / b; }
@@ -328,13 +344,14 @@ struct AgmLadder {
   double d, c;          // sqrt(1-emmc) for emmc<0 ; final mean (scale of u)
   double em[13], en[13];
   double opk[13];       // 1 + en/em = 1 + k'_n of level n (sncndn_ladder_z)
+  double iem[13];       // 1 / em: the level's division c / b of sncndn_ladder_z as a multiplication (r04)
 };
 
 GRT_HD void agm_ladder(double emmc, AgmLadder &L) {
   const double CA = 3.e-8;
   double emc = emmc, a = 1.0, c = 0.0;
   L.l = 0; L.bo = 0; L.d = 1.0; L.c = 0.0;
-  for (int i = 0; i < 13; ++i) { L.em[i] = 0.0; L.en[i] = 0.0; L.opk[i] = 2.0; }
+  for (int i = 0; i < 13; ++i) { L.em[i] = 0.0; L.en[i] = 0.0; L.opk[i] = 2.0; L.iem[i] = 0.0; }
   if (emc == 0.0) return;
   L.bo = (emc < 0.0);
   if (L.bo) {
@@ -349,6 +366,7 @@ GRT_HD void agm_ladder(double emmc, AgmLadder &L) {
     emc = sqrt(emc);
     L.en[i - 1] = emc;
     L.opk[i - 1] = 1.0 + emc / a;
+    L.iem[i - 1] = 1.0 / a;
     c = 0.5 * (a + emc);
     if (fabs(a - emc) <= CA * a) break;
     emc = a * emc;
@@ -422,11 +440,15 @@ GRT_HD void sncndn_ladder_z(const AgmLadder &L, double uu, double emmc, double &
       c = dn * c;
       const double r = frcp(b + a);
       dn = (L.en[ii - 1] + a) * r;
+#if !defined(GRT_NO_LADDER_RCP)
+      a = c * L.iem[ii - 1];          // (b is a constant of the ray: its reciprocal comes with the ladder; 1.5 ulp instead of 1)
+#else
       a = fdiv(c, b);
+#endif
       z = L.opk[ii - 1] * z + (b - L.en[ii - 1]) * r * a;
     }
     zeta = z;
-    a = frcp(fsqrt(c * c + 1.0));
+    a = frcp(fsqrt_nz(c * c + 1.0));
     sn = (sn < 0.0) ? -a : a;
     cn = c * sn;
   }

@@ -59,6 +59,16 @@ using namespace grtd;
 #define GRT_MAXF 32
 #define GRT_RR_STRIDE ((sizeof(RealRay) > sizeof(CubRay) ? sizeof(RealRay) : sizeof(CubRay)))   // per-ray constants record
 #define GRT_INT_QUAD 4    // internal: nvals=1 quadrature (radtrans_integrate.f90:878-882), chosen for either iname
+// The transfer equation is linear in j, and the kernel integrates with j -- hence I -- scaled UP by 2^128 (exact; taken off again
+// where a Stokes value leaves the walk).  The reference integrates j / fac (grtrans_driver.f90:183-228; fac = sum j_I dlambda ~ 1e-13 on a
+// faint ray), which lifts the emissivities of near-vacuum zones -- a few units of 4.9e-324 after j g g -- back among numbers with 53
+// significant bits BEFORE anything is multiplied by a step length; the device does not know fac until the walk ends, and without the
+// scale a product like (dx / 2) j of such a zone rounds to a whole number of those units.  That matters because DELO divides the
+// Faraday terms of the NEXT point by its alpha_I (radtrans_integrate.f90:815: Kp1 = K1 / ki1 - 1): rho_V / alpha_I ~ 1e303 at a vacuum
+// point beside an emitting one turns the 1e-308-sized intensity accumulated in the vacuum into 1e-6 of the pixel (r03 fuzz, KORAL3D
+// DELO at 69 GHz: 2e-4 of the V peak; r04: found by following the per-step record, tests/test_gpu_parity.py open cases).
+#define GRT_JSCALE 0x1p+128
+#define GRT_IUNSCALE 0x1p-128
 
 // Pixel of local ray j when a call traces SEVERAL pixel ranges in one launch (grt_trace_ranges: the column tiles of one rank of a
 // multi-GPU run): tab[2k] = local index of the first ray of range k, tab[2k+1] = its first pixel (1-based); ranges in call order.
@@ -205,7 +215,8 @@ template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
-    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
+    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw,
+    const double *__restrict__ tailc, int tailw) {
   constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // the class size is read on the device (the set-up kernel's counter): the host never waits for it between the launches.
@@ -288,12 +299,26 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   leg.lo = n; leg.nfill = 0; leg.fill = false;
   if (FAST == 1) leg = real_leg(cam, *Rp);
   const int nreg = n - leg.nfill;
+  // The partial TOP chunk of the regular points (394 = 6 x 64 + 10 for the escaping rays of the headline camera: a pass that used
+  // 10 of its 64 lanes, 1 pass in 8.2) is served by grt_geo_tail_kernel, four rays to a wave (r04): it leaves Lambda of the ray's top
+  // point and the segment scheme's running sums at the chunk's lowest point in tailc, and this wave starts one chunk lower.
+  bool served = false;
+  if (FAST == 1 && NPH != 3 && tailw > 0) {
+    const int rtop = nreg - 64 * ((nreg - 1) >> 6);
+    served = nreg > 0 && rtop <= tailw;
+    if (served) {
+      const double *tc = tailc + (size_t)rayidx * 4;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) carry[q] = tc[q];
+      LamN = tc[3];
+    }
+  }
   for (int ph = 0; ph < (leg.nfill > 0 ? 2 : 1); ++ph) {
   const bool fillph = (ph == 1);
   const int cnt = fillph ? leg.nfill : nreg;
   const int ctop = (cnt - 1) >> 6;
   const bool pre = perchunk && cfix < ctop;            // generic class, one chunk per wave: this wave's chunk is not the top one
-  const int c_start = perchunk ? (pre ? cfix + 1 : cfix) : ctop, c_end = perchunk ? cfix : 0;
+  const int c_start = perchunk ? (pre ? cfix + 1 : cfix) : ((served && !fillph) ? ctop - 1 : ctop), c_end = perchunk ? cfix : 0;
   for (int c = c_start; c >= c_end && cfix <= ctop; --c) {
     const bool toppass = pre && c == cfix + 1;             // the extra pass: every lane evaluates the ray's top point
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       }
     }
     if (toppass) { LamN = P.lam; continue; }
-    if (ph == 0 && c == ctop) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel)
+    if (ph == 0 && c == ctop) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel); a served ray never gets here
     // the turning-point parities ride in the sign bits of r (radial) and theta (polar): both are positive quantities
     if (NPH == 3 && valid && raw) {   // grt_geokerr_rays: GEOKERR's own output arrays UFI, MUFI, LAMBDAI, DPHI, DTI, TPMI, TPRI
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
@@ -379,6 +404,94 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
   } while (FAST == 0 && slot0 < *nlive_dev * nchg);     // only the generic class strides (capped grid); a fast-class wave serves one ray
+}
+
+// The partial top chunk of the regular points of a four-real-root / complex-pair ray, served for 64 / W rays by one wave: lanes
+// [slot W, slot W + r) hold the r <= W topmost regular points of the wave's ray number `slot`.  The per-ray constants cannot be
+// wave-uniform here, so every ray's GrtRay and RealRay are copied into LDS and read through per-lane addresses (the LDSRR form of
+// grt_geo_kernel with a lane-dependent base).  The chunk is the ray's first in the segment scheme: its chain starts at the anchor
+// (useg_lane: idx == npts) and the sums at its lowest lane are handed to grt_geo_kernel, with Lambda of the top point, through
+// tailc[ray][4] = {iu1, tu11, phiu1, Lambda(npts)}.  Same device functions, same arithmetic per lane as the chunk it replaces.
+#define GRT_TAIL_MAXS 4
+template <int NPH>
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_tail_kernel(
+    GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
+    const int *__restrict__ nlive_dev, double *__restrict__ steps, long long ray_stride, long long field_stride, int nfields,
+    double *__restrict__ tailc, int W) {
+  constexpr bool PHI = NPH > 0;
+  constexpr int NQ = (NPH == 2) ? 3 : 2;
+  constexpr int RW = (sizeof(GrtRay) + 7) / 8, RRW = (sizeof(RealRay) + 7) / 8;
+  __shared__ double s_r[GRT_WAVES_PER_BLOCK][GRT_TAIL_MAXS][RW];
+  __shared__ double s_rr[GRT_WAVES_PER_BLOCK][GRT_TAIL_MAXS][RRW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int S = 64 / W;                                   // rays per wave (host: W = 16 or 32)
+  const int nlive = *nlive_dev;
+  const int ray0 = (blockIdx.x * GRT_WAVES_PER_BLOCK + wave) * S;
+  if (ray0 >= nlive) return;                              // whole wave leaves together
+  typedef double __attribute__((may_alias)) grt_word;
+  // the records of all S rays in ONE sweep of independent loads (r04: a loop over the rays -- index, then record, four times in a
+  // row -- left the wave waiting for eight dependent memory round trips before its single pass: 3.7 ms for 262,144 waves)
+  const int slot = lane / W, j = lane - slot * W;
+  const bool haveray = ray0 + slot < nlive;
+  const int rayidx = haveray ? live[ray0 + slot] : 0;
+  {
+    const int myri = (lane < S && ray0 + lane < nlive) ? live[ray0 + lane] : -1;     // lane sl holds the ray of slot sl
+    constexpr int TW = RW + RRW;
+#pragma unroll 8
+    for (int t = lane; t < S * TW; t += 64) {
+      const int sl = t / TW, w = t - sl * TW;
+      const int ri = __shfl(myri, sl);
+      if (ri >= 0) {
+        if (w < RW) reinterpret_cast<grt_word *>(&s_r[wave][sl][0])[w] = reinterpret_cast<const grt_word *>(rays + ri)[w];
+        else reinterpret_cast<grt_word *>(&s_rr[wave][sl][0])[w - RW] = reinterpret_cast<const grt_word *>(rrays + (size_t)ri * GRT_RR_STRIDE)[w - RW];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  const GrtRay *Rp = reinterpret_cast<const GrtRay *>(&s_r[wave][haveray ? slot : 0][0]);
+  const RealRay *Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][haveray ? slot : 0][0]);
+  const int n = Rp->npts;
+  const RealLeg leg = real_leg(cam, *Rp);
+  const int nreg = n - leg.nfill;
+  const int ctop = (nreg - 1) >> 6;
+  const int rtop = nreg - 64 * ctop;
+  const bool served = haveray && nreg > 0 && rtop <= W;   // (the same test as grt_geo_kernel's)
+  const int pos = 64 * ctop + j + 1;
+  const bool valid = served && j < rtop;
+  const int idx = (pos <= leg.lo) ? pos : pos + leg.nfill;
+  double phi_ref = cam.phi0;
+  if (PHI && fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
+  GeoPoint P;
+  P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
+  UPart Sg;
+  bool usable = false, reset = true;
+  useg_lane<NPH>(cam, *Rp, *Kp, valid ? idx : 0, Sg, reset, usable);
+  double v[NQ];
+  v[0] = Sg.iu1; v[1] = Sg.tu11;
+  if (NQ > 2) v[2] = Sg.phiu1;
+  seg_suffix_scan<NQ>(v, reset, lane);                    // every chain of this chunk ends at its ray's top point (a reset lane)
+  Sg.iu1 = v[0]; Sg.tu11 = v[1];
+  if (NQ > 2) Sg.phiu1 = v[2];
+  if (valid) {
+    const UPart *pre = usable ? &Sg : nullptr;
+    if (NPH == 0) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
+    else ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre);
+  }
+  const double LamN = __shfl(P.lam, slot * W + (served ? rtop - 1 : 0));
+  if (valid) {
+    double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
+    const double rr = (P.u > 0.0) ? frcp(P.u) : 0.0;
+    const double th = fast_acos(P.mu);
+    sp[GRT_F_R * field_stride] = (P.tpr & 1) ? -rr : rr;
+    sp[GRT_F_TH * field_stride] = (P.tpm & 1) ? -th : th;
+    sp[GRT_F_LAM * field_stride] = LamN - P.lam;
+    if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
+    if (j == 0) {
+      double *tc = tailc + (size_t)rayidx * 4;
+      tc[0] = v[0]; tc[1] = v[1]; tc[2] = (NQ > 2) ? v[2] : 0.0; tc[3] = LamN;
+    }
+  }
 }
 
 // standard=2 with nup > 1 (geodesics.f90:298-347): GEOR returns u_f < 0 where the ray does not reach the requested mu; such
@@ -745,7 +858,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
             // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end, is the scalar recurrence
             // I <- e^{-dtau} I + dx/2 (j_k + j_k+1 e^{-dtau}).
-            const double j0 = e11[0] * g * g, K0 = e11[4] * igs * LBH;
+            const double j0 = e11[0] * g * g * GRT_JSCALE, K0 = e11[4] * igs * LBH;
             if (EXTRA && f == 0) { xJK[0] = j0; xJK[1] = K0; }
             const double delta = dx * ((fabs(K0) + fabs(Kn[f][0])) / 2.0);
             // A ray whose affine parameter is not monotonic (a = 0.985 camera on the Schwarzschild SPHACC flow, r03 fuzz: lambda jumps
@@ -785,7 +898,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
                             c2xi * e11[8] - s2xi * e11[9], s2xi * e11[8] + c2xi * e11[9], e11[10]};
             const double ig = igs;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g;
+            for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g * GRT_JSCALE;      // ((j g) g) as invariant_emis rounds it (emis.f90:836), then the exact scale
 #pragma unroll
             for (int c = 0; c < 7; ++c) KK[c] = KK[c] * ig * LBH;
             if (EXTRA && f == 0) {
@@ -864,10 +977,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
         for (int c = 0; c < 9; ++c) xWp[c] = jI * qv[c];
       }
       if (record) {   // running intensity of the first frequency into the consumed tile slot
-        tl0[lane * GRT_TS + e] = I[0][0] * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
-        tl1[lane * GRT_TS + e] = I[0][1] * LBH;
-        tl2[lane * GRT_TS + e] = I[0][2] * LBH;
-        tl3[lane * GRT_TS + e] = I[0][3] * LBH;
+        tl0[lane * GRT_TS + e] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
+        tl1[lane * GRT_TS + e] = I[0][1] * GRT_IUNSCALE * LBH;
+        tl2[lane * GRT_TS + e] = I[0][2] * GRT_IUNSCALE * LBH;
+        tl3[lane * GRT_TS + e] = I[0][3] * GRT_IUNSCALE * LBH;
 #ifdef GRT_DEBUG_SEL
         tl0[lane * GRT_TS + e] = dbg[0]; tl1[lane * GRT_TS + e] = dbg[1]; tl2[lane * GRT_TS + e] = dbg[2]; tl3[lane * GRT_TS + e] = dbg[3];
 #endif
@@ -902,13 +1015,15 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       if (!EXTRA)
         for (int c = 0; c < nvals && c < 4; ++c)
           pixvals[((long long)(f0 + f) * npix_tile + pixslot) * nvals + c] =
-              (float)(ok ? I[f][c] * LBH * ((IFLAG == GRT_INT_QUAD && jn[(IFLAG == GRT_INT_FORMAL) ? 0 : f][1] != 0.0) ? exp(-jn[(IFLAG == GRT_INT_FORMAL) ? 0 : f][1]) : 1.0) : 0.0);
+              (float)(ok ? I[f][c] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[(IFLAG == GRT_INT_FORMAL) ? 0 : f][1] != 0.0) ? exp(-jn[(IFLAG == GRT_INT_FORMAL) ? 0 : f][1]) : 1.0) : 0.0);
     }
   }
   if (EXTRA) {
     const int nx = nvals, ns = nvals - 19;      // the launcher passes the full row width nvals+nextra as `nvals`
     float *o = pixvals + ((long long)f0 * npix_tile + pixslot) * nx;
-    for (int c = 0; c < ns && c < 4; ++c) o[c] = (float)(ok0 ? I[0][c] * LBH : 0.0);
+    // (the quadrature's banked exponent, as in the plain write above: the running value is I e^{-P})
+    const double unbank = (IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0;
+    for (int c = 0; c < ns && c < 4; ++c) o[c] = (float)(ok0 ? I[0][c] * GRT_IUNSCALE * LBH * unbank : 0.0);
     double xt[19];
 #pragma unroll
     for (int c = 0; c < 6; ++c) xt[c] = xT[c];
@@ -1132,7 +1247,8 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 // the grid is sized for, and the length of live[] (the generic class is read from its back)
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw) {
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw,
+                                     double *tailc) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
   // the generic class is small as a rule: a capped grid that strides over its (ray, chunk) items
@@ -1149,11 +1265,27 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   // a Schwarzschild camera that needs the coordinate time has no fast class (grt_setup_kernel: `cubic` requires !(need_time & 1)):
   // its fast-class launch has nothing to do
   if (kind == 2 && nph == 3) return hipSuccess;
+  // partial top chunks to grt_geo_tail_kernel: a slot width that holds the top chunk of the camera's rays (captured rays have nup
+  // regular points, rays with a radial turning point nup - 2 kext when the mu-fill segment is on)
+  int tailw = 0;
+  if (kind == 1 && nph != 3 && !raw && tailc && !std::getenv("GRT_NO_GEO_TAIL")) {
+    const int r1 = (cam->nup - 1) % 64 + 1, n2 = cam->nup - 2 * cam->kext, r2 = (n2 > 0) ? (n2 - 1) % 64 + 1 : 64;
+    const int rmin = r1 < r2 ? r1 : r2;
+    tailw = rmin <= 16 ? 16 : (rmin <= 32 ? 32 : 0);
+    if (const char *e = std::getenv("GRT_GEO_TAILW")) tailw = std::atoi(e);
+    if (tailw != 16 && tailw != 32) tailw = 0;
+  }
+  if (tailw) {
+    const int S = 64 / tailw;
+    dim3 gt((unsigned)((nrays + S * GRT_WAVES_PER_BLOCK - 1) / (S * GRT_WAVES_PER_BLOCK)));
+    if (nph == 2) hipLaunchKernelGGL((grt_geo_tail_kernel<2>), gt, b, 0, s, *cam, rays, rr, live, nlive_dev, steps, ray_stride, field_stride, nfields, tailc, tailw);
+    else hipLaunchKernelGGL((grt_geo_tail_kernel<0>), gt, b, 0, s, *cam, rays, rr, live, nlive_dev, steps, ray_stride, field_stride, nfields, tailc, tailw);
+  }
   bool launched = false;
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P) {                                                                                          \
     launched = true;                                                                                                    \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw); \
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw, tailc, (F == 1) ? tailw : 0); \
   }
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE

@@ -368,11 +368,22 @@ class grtrans:
         self.nx, self.ny, self.nvals = nx, ny, nvals
         self.calc_spec(len(nus))
 
+    def calc_freqs(self, n):
+        # the run's frequency grid (grtrans_batch.py:490-497 = pgrtrans.f90:87-91)
+        fmin, fmax = self.inputs.fmin, self.inputs.fmax
+        self.freqs = fmin * np.exp(np.arange(n) * np.log(fmax / fmin) / (n - 1)) if n > 1 else np.array([fmin])
+
     def calc_spec(self, n):
         if self.ny != 1:
             da = self.ab[self.ny, 0] - self.ab[0, 0]
             db = self.ab[1, 1] - self.ab[0, 1]
             spec = np.sum(self.ivals, 0) * da * db
+            if self.nvals >= 4:      # image-integrated and pixel-summed polarization fractions (grtrans_batch.py:505-509)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    self.lp = np.sqrt(spec[1, :] ** 2. + spec[2, :] ** 2.) / spec[0, :]
+                    self.cp = spec[3, :] / spec[0, :]
+                    self.lpf = np.sum(np.sqrt(self.ivals[:, 1, :] ** 2. + self.ivals[:, 2, :] ** 2.), 0) * da * db / spec[0, :]
+                    self.cpf = np.sum(np.abs(self.ivals[:, 3, :]), 0) * da * db / spec[0, :]
         else:
             da = self.ab[1, 0] - self.ab[0, 0]
             db = 0.
@@ -385,9 +396,36 @@ class grtrans:
             da = self.ab[0, self.ny] - self.ab[0, 0]
             db = self.ab[1, 1] - self.ab[1, 0]
             spec = np.sum(self.ivals, 1) * da * db
+            if self.nvals >= 4:      # (grtrans_batch.py:529-533)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    self.lp = np.sqrt(spec[1, :] ** 2. + spec[2, :] ** 2.) / spec[0, :]
+                    self.cp = spec[3, :] / spec[0, :]
+                    self.lpf = np.sum(np.sqrt(self.ivals[1] ** 2. + self.ivals[2] ** 2.), 0) * da * db / spec[0, :]
+                    self.cpf = np.sum(np.abs(self.ivals[3]), 0) * da * db / spec[0, :]
         else:
             da = self.ab[0, 1] - self.ab[0, 0]
             db = 0.
             spec = np.array([[np.sum(self.ivals[j, :, i] * self.ab[0, :], 0) * da * 2. * np.arccos(-1.)
                               for j in range(self.nvals)] for i in range(n)])
         self.spec, self.da, self.db = spec, da, db
+
+    # unit conversions of the file-reader layout (ivals[pixel, stokes, camera], ab[pixel, 2]); constants as the reference's harness
+    # defines them (grtrans_batch.py:12-14)
+    def _lbh(self):
+        return 6.67259e-8 * 1.99e33 * self.inputs.mbh / 8.98755179e20
+
+    def convert_to_lum(self):
+        """spectrum and intensities to L_iso in cgs units (grtrans_batch.py:545-552)"""
+        fac = 4 * np.pi * self._lbh() ** 2
+        da = self.ab[self.ny, 0] - self.ab[0, 0]
+        db = self.ab[1, 1] - self.ab[0, 1]
+        self.spec = self.spec * fac
+        self.ivals = self.ivals * (fac * da * db)
+
+    def convert_to_Jy(self, D):
+        """spectrum and intensities to Jy for a source at distance D in cm (grtrans_batch.py:555-562)"""
+        fac = (self._lbh() ** 2 / D ** 2.) * 1e23
+        da = self.ab[self.ny, 0] - self.ab[0, 0]
+        db = self.ab[1, 1] - self.ab[0, 1]
+        self.ivals = self.ivals * (fac * da * db)
+        self.spec = self.spec * fac

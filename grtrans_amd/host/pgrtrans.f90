@@ -79,6 +79,7 @@ contains
     integer :: tempi
 
     last_error = 0; last_error_msg = ' '
+    defer_stop = .false.          ! set once this call owns a communicator; never inherited from an earlier call of the process
     nro = nn(1); nphi = nn(2); nup = nn(3); npix = nro*nphi
     if (allocated(ivals) .or. allocated(ab) .or. allocated(freqs)) call del_pgrtrans_data()
     allocate(freqs(nfreq), mu0(nmu), mdots(nmdot))
@@ -505,6 +506,7 @@ contains
     if (rank /= 0) then          ! only the root holds the assembled image and writes the file
        deallocate(pixvals, pixloc, status, mu0, mdots)
        rc = grt_free()
+       defer_stop = .false.      ! (a later single-process call in the same host process must stop where it fails again)
        return
     end if
     if (len_trim(outfile) > 0 .and. cflag /= 1) then
@@ -546,6 +548,7 @@ contains
     end if
     deallocate(pixvals, pixloc, status, mu0, mdots)
     rc = grt_free()
+    defer_stop = .false.
     return
     ! soft-error exit (pgrtrans_set_soft_errors: callers that must survive a refusal, e.g. the Python harness): everything
     ! this call allocated is released, last_error / last_error_msg say why

@@ -800,6 +800,81 @@ def crosscheck_main():
     assert all(rec.values()), rec
 
 
+# ---- the open parity cases of the r03 fuzz sweeps, pinned against the COMPILED reference ------------------------
+# Each case = the exact camera of a sweep log (tools/fuzz_cameras.py in GRT_FUZZ_DRY mode prints it), the compiled reference's image,
+# and the compiled reference's OWN response to perturbations no user can specify: every frequency moved by one ulp either way and by
+# 1e-13, the camera by one ulp in inclination, spin, uout ("cond": largest change per frequency and Stokes parameter, as a fraction of
+# that Stokes peak), and every frequency moved by 1e-8 ("amp": the change divided by 1e-8).  The GPU tests state their bars from these.
+OPEN_CASES = {
+    # profiles/r03_h_fuzz_700.log (seed 31337) camera 524: rays that start in near-vacuum zones of the KORAL3D dump
+    "koral3d_delo_69ghz": dict(fname="KORAL3D", ename="POLSYNCHTH", iname="delo", spin=0.9375, mu0=0.0, uout=0.04, nn=(12, 12, 60),
+                               gridvals=(-9.572477643577713, 5.75296751663922, -11.596725842453694, 3.7287193177632396),
+                               dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5, p1=5.5,
+                               freqs=[2.3e11, 6.9e10], i1=43, i2=132, dump="koral3d"),
+    # profiles/r03_g_fuzz_700.log (seed 777) camera 240: equatorial Schwarzschild camera, lambda carries a constant of 9e8
+    "sphacc_formal_equatorial": dict(fname="SPHACC", ename="POLSYNCHTH", iname="formal", spin=0.0, mu0=0.0, uout=0.04, nn=(12, 12, 60),
+                                     gridvals=(-36.402300212602, 48.39734536577427, -41.53000646055861, 43.26963911781766),
+                                     mbh=10., gmin=100., p1=3.0, freqs=[7.23e11, 2.41e11, 2.41e10], i1=71, i2=110, dump=None),
+    # profiles/r03_f_fuzz_700.log (seed 5151) camera 303: DELO at optical depths of tens per step, alternating-sign growth
+    "sphacc_delo_24ghz": dict(fname="SPHACC", ename="POLSYNCHTH", iname="delo", spin=0.0, mu0=0.0, uout=0.01, nn=(12, 12, 100),
+                              gridvals=(-6.46579504122852, 4.212597494570896, -9.68891574108579, 0.9894767947136254),
+                              mbh=10., gmin=100., p1=3.5, freqs=[7.23e11, 2.41e11, 2.41e10], i1=1, i2=144, dump=None),
+}
+
+
+def open_cases():
+    import tempfile
+    import make_koral3d_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        make_koral3d_dump.write(td, n1=32, n2=32, n3=16)          # the sweep's dump (tools/fuzz_cameras.py)
+        for name, case in OPEN_CASES.items():
+            kw = {k: v for k, v in case.items() if k not in ("freqs", "i1", "i2", "dump")}
+            if case["dump"]:
+                kw["datadir"] = td
+            freqs, i1, i2 = case["freqs"], case["i1"], case["i2"]
+
+            def run(fr=freqs, **chg):
+                r = R.Ref(**dict(kw, **chg))
+                pix, npts, _ = r.trace(i1, i2, list(fr), nthreads=1)
+                return np.asarray(pix, dtype=np.float64), np.asarray(npts)
+            ref, npts = run()
+            nf = len(freqs)
+            pk = np.zeros((nf, 4))
+            for k in range(nf):
+                okm = np.isfinite(ref[k]).all(axis=1)
+                pk[k] = np.abs(ref[k][okm]).max(axis=0)
+                pk[k] = np.maximum(pk[k], 1e-2 * pk[k][0])      # a Stokes parameter that vanishes by symmetry (as the sweep prices it)
+
+            def resp(other, onp):
+                d = np.zeros((nf, 4))
+                if not np.array_equal(onp, npts):
+                    return d
+                for k in range(nf):
+                    okm = np.isfinite(ref[k]).all(axis=1) & np.isfinite(other[k]).all(axis=1)
+                    if okm.any():
+                        d[k] = np.abs(other[k][okm] - ref[k][okm]).max(axis=0) / pk[k]
+                return d
+            cond = np.zeros((nf, 4))
+            for fr in ([float(np.nextafter(f, np.inf)) for f in freqs], [float(np.nextafter(f, 0.0)) for f in freqs],
+                       [f * (1 + 1e-13) for f in freqs], [f * (1 - 1e-13) for f in freqs]):
+                cond = np.maximum(cond, resp(*run(fr=fr)))
+            # (an equatorial camera has mu0 = 0, where "one ulp" is a denormal: the inclination moves by 1e-15 rad as well)
+            gvp = tuple(float(np.nextafter(v, np.inf)) for v in kw["gridvals"])
+            for chg in (dict(mu0=float(np.nextafter(kw["mu0"], 2.0))), dict(mu0=float(np.nextafter(kw["mu0"], -2.0))),
+                        dict(mu0=kw["mu0"] + 1e-15), dict(mu0=kw["mu0"] - 1e-15), dict(gridvals=gvp),
+                        dict(uout=float(np.nextafter(kw["uout"], 1.0))), dict(uout=float(np.nextafter(kw["uout"], -1.0)))) + \
+                       ((dict(spin=float(np.nextafter(kw["spin"], 2.0))),) if kw["spin"] != 0.0 else ()):
+                cond = np.maximum(cond, resp(*run(**chg)))
+            amp = np.zeros((nf, 4))
+            for rel in (1e-8, -1e-8):
+                amp = np.maximum(amp, resp(*run(fr=[f * (1 + rel) for f in freqs])) / 1e-8)
+            out[name + "_ivals"] = ref.astype(np.float32); out[name + "_npts"] = npts
+            out[name + "_peak"] = pk; out[name + "_cond"] = cond; out[name + "_amp"] = amp
+            print(name, "cond", cond.max(axis=1), "amp", amp.max(axis=1))
+    np.savez_compressed(os.path.join(G, "open_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:            # e.g. `python tests/make_golden.py config5 extra_main crosscheck_main`
         for name in sys.argv[1:]:
@@ -831,5 +906,6 @@ if __name__ == "__main__":
     koral3d_slowlight_extra()
     standard2()
     polar_camera()
+    open_cases()
     crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

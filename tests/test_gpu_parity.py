@@ -2083,3 +2083,112 @@ def test_quadrature_survives_a_step_of_negative_optical_depth(fdev):
             ok = np.isfinite(ref[k]).all(axis=1)
             assert np.abs(pix[k][ok] - ref[k][ok]).max() <= STOKES_TOL * np.abs(ref[k][ok]).max(), k
     capi.record_steps(False)
+
+
+def test_delo_step_on_the_device_with_subnormal_absorption():
+    # ADVICE r03 (medium) / VERDICT r03 item 3: tests/delo_tiny_check.hip runs grt_dev_phys.hpp:delo_apply ON THE DEVICE for 16,384 steps
+    # between a near-vacuum zone (alpha_I 1e-305 ... 1e-312, at and below the smallest normal number) and an emitting one, in both
+    # orders and mixed with ordinary steps in the same waves, and compares with the reference-literal affine map (IEEE divisions by
+    # alpha_I first, cofactor inverse: radtrans_integrate.f90:746-837) evaluated on the host.  Before r04 the device returned NaN
+    # there (the Newton reciprocal of 1e-310 overflows) where the reference has finite Stokes values.
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "delo_tiny_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "grtrans_amd", "csrc"), "../../tests/delo_tiny_check"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"ordinary (\S+) far_vacuum (\S+) near_vacuum (\S+) both (\S+) nonfinite (\d+) ref_nonfinite (\d+)", r.stdout)
+    assert m, r.stdout
+    worst = [float(m.group(k)) for k in range(1, 5)]
+    assert int(m.group(5)) == 0 and int(m.group(6)) == 0, r.stdout
+    assert max(worst) < 1e-10, r.stdout            # (1e-13 ... 1e-12 measured: the two forms differ by rounding only)
+
+
+# The open cases of the r03 sweeps, each against the COMPILED reference's image of the exact camera
+# (tests/golden/open_cases.npz <- tests/make_golden.py:open_cases) with a bar stated from the compiled reference's own behaviour:
+# `cond` = how far the reference's own pixels move when the frequencies move by one ulp / 1e-13 or the camera by one ulp / 1e-15 rad.
+OPEN_CASE_SETUP = {
+    # name: (fluid, emissivity arguments of the sweep, camera, frequencies, pixel range, integrator)
+    "koral3d_delo_69ghz": ("KORAL3D", dict(mbh=4e6, nfac=1.5, bfac=6.0, gmin=-1., p1=5.5), 0.9375, 0.0, 0.04, (12, 12, 60),
+                           (-9.572477643577713, 5.75296751663922, -11.596725842453694, 3.7287193177632396), [2.3e11, 6.9e10], 43, 132, "delo"),
+    "sphacc_formal_equatorial": ("SPHACC", dict(mbh=10., nfac=1.0, bfac=6.0, gmin=100., p1=3.0), 0.0, 0.0, 0.04, (12, 12, 60),
+                                 (-36.402300212602, 48.39734536577427, -41.53000646055861, 43.26963911781766), [7.23e11, 2.41e11, 2.41e10], 71, 110, "formal"),
+    "sphacc_delo_24ghz": ("SPHACC", dict(mbh=10., nfac=1.0, bfac=6.0, gmin=100., p1=3.5), 0.0, 0.0, 0.01, (12, 12, 100),
+                          (-6.46579504122852, 4.212597494570896, -9.68891574108579, 0.9894767947136254), [7.23e11, 2.41e11, 2.41e10], 1, 144, "delo"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPEN_CASE_SETUP))
+def test_open_cases_of_the_r03_sweeps_vs_compiled_reference(fdev, tmp_path, name):
+    # koral3d_delo_69ghz (seed 31337 camera 524): rays that start in near-vacuum zones, j and alpha_I ~ 1e-306 ... 1e-310; DELO's first
+    #   emitting step works with S = j / alpha_I of those.  The reference is STABLE here (cond ~ 4e-11): the bar is an absolute one,
+    #   1e-5 of each Stokes peak (r03: 2.0e-4 with the plain closed-form step, 7.8e-6 with the reference-literal map; r04 rescales such
+    #   an end of the step by a power of two before anything is multiplied -- grt_dev_phys.hpp:delo_apply).
+    # sphacc_formal_equatorial (seed 777 camera 240): GEOKERR's lambda carries a constant of 9e8 on the equatorial Schwarzschild
+    #   camera, so d(lambda) of the topmost steps is quantised at 7e-6 of its value IN THE REFERENCE: its own 24 GHz image moves by
+    #   6.2e-6 of the U peak when the inclination moves by 1e-15 rad (cond).  Bar: 3 x cond per frequency and Stokes parameter, and
+    #   never below the suite's 2e-6.
+    # sphacc_delo_24ghz (seed 5151 camera 303): DELO at tens of optical depths per step (alternating-sign growth, intensities of
+    #   +-860 against 1e-3 at the higher frequencies): the reference moves by 1.2e-6 under the same perturbations and by 6,900 x any
+    #   relative change of the frequency.  Same bar.
+    from grtrans_amd import capi
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    g = np.load(os.path.join(G, "open_cases.npz"))
+    fname, ekw, spin, mu0, uout, nn, gv, freqs, i1, i2, iname = OPEN_CASE_SETUP[name]
+    if fname == "KORAL3D":
+        import make_koral3d_dump
+        dk, hk = make_koral3d_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+        fdev.load_koral3d(dk, hk, 40, 0.9375)
+    else:
+        fdev.load_sphacc()
+    cam = capi.make_camera(1, gv, nn, spin, mu0, uout, -0.5)
+    em = capi.make_emis("POLSYNCHTH", ekw["mbh"], ekw["nfac"], ekw["bfac"], ekw["gmin"], 1e5, ekw["p1"], muval=0.25, mdot=0.0)
+    ref, pk, cond = g[name + "_ivals"].astype(np.float64), g[name + "_peak"], g[name + "_cond"]
+    bar = np.full_like(cond, 1e-5) if name == "koral3d_delo_69ghz" else np.maximum(2e-6, 3.0 * cond)
+    for rec in (False, True):
+        capi.record_steps(rec)
+        pix, _, status, _ = capi.trace_tile(cam, i1, i2, fname, em, freqs, iname)
+        assert np.array_equal(status, g[name + "_npts"])
+        for k in range(len(freqs)):
+            assert np.array_equal(np.isfinite(pix[k]), np.isfinite(ref[k])), (name, k)
+            okm = np.isfinite(ref[k]).all(axis=1)
+            err = np.abs(pix[k][okm].astype(np.float64) - ref[k][okm]).max(axis=0) / pk[k]
+            assert np.all(err <= bar[k]), (name, rec, k, err, bar[k])
+    capi.record_steps(False)
+
+
+def test_top_chunks_served_by_the_tail_kernel_equal_the_one_ray_per_wave_walk(fdev, monkeypatch):
+    # r04: the partial top chunk of a ray's regular points (394 = 6 x 64 + 10 on the headline camera) is evaluated by
+    # grt_geo_tail_kernel, 64 / W rays to a wave with the per-ray constants read through per-lane LDS addresses, and grt_geo_kernel
+    # starts one chunk lower with the segment sums and Lambda(npts) it left in tailc.  Same device functions per lane: the geodesic
+    # record, the status and the image must have the bits of the plain walk (GRT_NO_GEO_TAIL=1), for both slot widths, with and
+    # without the azimuth, on cameras whose top chunks hold 16 / 10 (nup 400), 32 / 26 (nup 160), 8 / 2 (nup 200) and 64 (nup 128:
+    # full top chunk for the captured rays, 58 for the others -> nothing served) points.
+    from grtrans_amd import capi
+    fdev.load_ffjet()
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    for nup, spin, mu0, gv in ((400, 0.998, 0.906, (-40., 20., -20., 40.)), (160, 0.9375, 0.3, (-15., 15., -15., 15.)),
+                               (200, 0.5, -0.6, (-20., 20., -20., 20.)), (128, 0.998, 0.906, (-40., 20., -20., 40.))):
+        nn = (40, 40, nup)
+        cam = capi.make_camera(1, gv, nn, spin, mu0, 0.01, -0.5)
+        for rec in (True, False):
+            capi.record_steps(rec)
+            out = {}
+            for mode, env in (("plain", {"GRT_NO_GEO_TAIL": "1"}), ("auto", {}), ("w16", {"GRT_GEO_TAILW": "16"}), ("w32", {"GRT_GEO_TAILW": "32"})):
+                monkeypatch.delenv("GRT_NO_GEO_TAIL", raising=False); monkeypatch.delenv("GRT_GEO_TAILW", raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                capi.geo_reuse(False)
+                pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [FREQ], "formal")
+                steps = capi.download_steps(0, nn[0] * nn[1], cam.nup + cam.next) if rec else None
+                out[mode] = (pix, status, steps)
+            for mode in ("auto", "w16", "w32"):
+                assert np.array_equal(out[mode][1], out["plain"][1]), (nup, rec, mode)
+                assert np.array_equal(out[mode][0], out["plain"][0], equal_nan=True), (nup, rec, mode)
+                if rec:
+                    assert np.array_equal(out[mode][2], out["plain"][2], equal_nan=True), (nup, rec, mode)
+    monkeypatch.delenv("GRT_NO_GEO_TAIL", raising=False); monkeypatch.delenv("GRT_GEO_TAILW", raising=False)
+    capi.record_steps(False); capi.geo_reuse(True)

@@ -414,3 +414,43 @@ def test_the_flow_copy_scanner_sees_the_defect_and_not_the_ordinary_merge():
     bad = check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_copy_bad.s"))
     assert len(bad) == 1 and bad[0][0] == "kernel_with_the_defect" and len(bad[0][2]) == 2
     assert check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_copy_ok.s")) == []
+
+
+def test_harness_unit_conversions_and_polarization_fractions():
+    # calc_freqs / convert_to_lum / convert_to_Jy and the lp, cp, lpf, cpf of calc_spec (grtrans_batch.py:490-564): the formulas of the
+    # reference's harness on a small synthetic image in the file reader's layout
+    from grtrans_amd import grtrans_batch as gb
+    x = gb.grtrans()
+    x.inputs = gb.grtrans_inputs(fmin=1e10, fmax=1e12, nfreq=5, mbh=4e6)
+    x.calc_freqs(5)
+    assert np.allclose(x.freqs, 1e10 * 100.0 ** (np.arange(5) / 4.0), rtol=1e-14) and x.freqs[-1] == pytest.approx(1e12, rel=1e-14)
+    x.calc_freqs(1)
+    assert np.array_equal(x.freqs, [1e10])
+    nx = ny = 6
+    rng = np.random.default_rng(3)
+    a, b = np.meshgrid(np.linspace(-5, 5, nx), np.linspace(-4, 4, ny), indexing="ij")
+    x.ab = np.stack([a.ravel(), b.ravel()], axis=1)
+    x.ivals = rng.uniform(0.1, 1.0, (nx * ny, 4, 2)) * np.array([1.0, 0.3, -0.2, 0.05])[None, :, None]
+    x.nx, x.ny, x.nvals = nx, ny, 4
+    x.calc_spec(2)
+    da, db = 10.0 / (nx - 1), 8.0 / (ny - 1)
+    assert x.da == pytest.approx(da) and x.db == pytest.approx(db)
+    spec = x.ivals.sum(axis=0) * da * db
+    assert np.allclose(x.spec, spec)
+    assert np.allclose(x.lp, np.hypot(spec[1], spec[2]) / spec[0]) and np.allclose(x.cp, spec[3] / spec[0])
+    assert np.allclose(x.lpf, np.hypot(x.ivals[:, 1], x.ivals[:, 2]).sum(axis=0) * da * db / spec[0])
+    assert np.allclose(x.cpf, np.abs(x.ivals[:, 3]).sum(axis=0) * da * db / spec[0])
+    lbh = 6.67259e-8 * 1.99e33 * 4e6 / 8.98755179e20
+    iv0, sp0 = x.ivals.copy(), x.spec.copy()
+    x.convert_to_lum()
+    assert np.allclose(x.spec, sp0 * 4 * np.pi * lbh ** 2) and np.allclose(x.ivals, iv0 * 4 * np.pi * lbh ** 2 * da * db)
+    x.ivals, x.spec = iv0.copy(), sp0.copy()
+    D = 8.1 * 3.086e21
+    x.convert_to_Jy(D)
+    assert np.allclose(x.spec, sp0 * lbh ** 2 / D ** 2 * 1e23) and np.allclose(x.ivals, iv0 * lbh ** 2 / D ** 2 * 1e23 * da * db)
+    # the pgrtrans layout (ivals[stokes, pixel, camera], ab[2, pixel]) gives the same fractions
+    y = gb.grtrans()
+    y.inputs = x.inputs
+    y.ab, y.ivals, y.nx, y.ny, y.nvals = x.ab.T.copy(), np.transpose(iv0, (1, 0, 2)).copy(), nx, ny, 4
+    y.calc_spec_pgrtrans(2)
+    assert np.allclose(y.spec, sp0) and np.allclose(y.lp, np.hypot(sp0[1], sp0[2]) / sp0[0]) and np.allclose(y.cpf, np.abs(iv0[:, 3]).sum(axis=0) * da * db / sp0[0])

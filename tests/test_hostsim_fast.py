@@ -708,3 +708,55 @@ def test_delo_step_without_the_inverse_matches_oracle_and_the_map_form(L):
             worst_map = max(worst_map, np.abs(I - Im).max() / np.abs(Im).max())
             worst_ora = max(worst_ora, np.abs(I - want[n - k]).max() / np.abs(want[n - k]).max())
     assert worst_map < 1e-11 and worst_ora < 1e-11, (worst_map, worst_ora)
+
+
+def test_delo_step_between_a_vacuum_zone_and_an_emitting_one(L):
+    # ADVICE r03 / VERDICT r03 item 3: alpha_I at and below the smallest normal number (1e-305 ... 1e-312: the near-vacuum zones of
+    # a GRMHD dump) on one end of an optically thick step.  The reference divides j and K by alpha_I with IEEE divisions FIRST
+    # (radtrans_integrate.f90:811-824); delo_apply rescales such an end by 2^300 before its reciprocals (the plain closed form
+    # returned inf / NaN here: 1 / 1e-310 overflows).  Against the reference-literal map form, and against the oracle's
+    # integrate_delo for a whole ray that starts in vacuum.
+    sig = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.hs_delo_step.argtypes = sig
+    L.hs_delo_step_via_map.argtypes = sig
+    rng = np.random.default_rng(5)
+
+    def coef(aI, S):
+        K = np.concatenate([[aI], aI * rng.uniform(-0.45, 0.45, 3), aI * rng.uniform(-30, 30, 3)])
+        j = aI * S * np.concatenate([[1.0], rng.uniform(-0.45, 0.45, 3)])
+        return np.ascontiguousarray(j), np.ascontiguousarray(K)
+
+    worst = 0.0
+    for trial in range(600):
+        tiny = float(rng.choice([1e-305, 3e-308, 1e-308, 4e-309, 1e-310, 1e-312])) * rng.uniform(0.5, 1.5)
+        big = 10.0 ** rng.uniform(-2, 1)
+        a0, a1 = (tiny, big) if trial % 2 else (big, tiny)
+        j0, K0 = coef(a0, 1e4 * rng.uniform(0.5, 1.5)); j1, K1 = coef(a1, 1e4 * rng.uniform(0.5, 1.5))
+        delta = 10.0 ** rng.uniform(-1.5, 1.0)
+        dx = 2.0 * delta / (a0 + a1)
+        I = np.array([1e3, 100., -50., 20.]); got, want = np.zeros(4), np.zeros(4)
+        L.hs_delo_step(j0.ctypes.data, K0.ctypes.data, j1.ctypes.data, K1.ctypes.data, dx, delta, I.ctypes.data, got.ctypes.data)
+        L.hs_delo_step_via_map(j0.ctypes.data, K0.ctypes.data, j1.ctypes.data, K1.ctypes.data, dx, delta, I.ctypes.data, want.ctypes.data)
+        assert np.isfinite(want).all() and np.isfinite(got).all(), (trial, a0, a1, got, want)
+        worst = max(worst, np.abs(got - want).max() / np.abs(want).max())
+    assert worst < 1e-11, worst
+    # a ray whose far half lies in vacuum (K = 1e-310 ... 1e-307, S = j / K of order 1e4) and whose near half emits
+    n = 16
+    x = np.linspace(5.0, 0.0, n)
+    aI = np.where(np.arange(n) >= n // 2, 10.0 ** rng.uniform(-310, -307, n), rng.uniform(0.5, 2.0, n))
+    jj, KK = zip(*[coef(a, 1e4) for a in aI])
+    j, K = np.ascontiguousarray(np.array(jj)), np.ascontiguousarray(np.array(KK))
+    tau = np.zeros(n)
+    for k in range(n - 2, -1, -1):
+        tau[k] = tau[k + 1] - (x[k] - x[k + 1]) * 0.5 * (aI[k] + aI[k + 1])
+    tau = -tau
+    want = O.integrate(1, x, j, K, tau)
+    I = np.zeros(4)
+    for k in range(n - 1, 0, -1):
+        nxt = np.zeros(4)
+        a0, a1 = np.ascontiguousarray(j[k - 1]), np.ascontiguousarray(j[k])
+        k0, k1 = np.ascontiguousarray(K[k - 1]), np.ascontiguousarray(K[k])
+        L.hs_delo_step(a0.ctypes.data, k0.ctypes.data, a1.ctypes.data, k1.ctypes.data, float(x[k - 1] - x[k]), float(tau[k] - tau[k - 1]), I.ctypes.data, nxt.ctypes.data)
+        I = nxt
+    assert np.isfinite(I).all() and np.isfinite(want[n - 1]).all()
+    assert np.abs(I - want[n - 1]).max() < 1e-11 * np.abs(want[n - 1]).max()

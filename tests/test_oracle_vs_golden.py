@@ -552,3 +552,42 @@ def test_config5_frequency_grid():
         err = np.abs(pix.astype(float) - ref[:, i1 - 1:i2]).max(axis=1) / peak
         bar = np.maximum(1e-6, 10.0 * g["cond_" + iname])
         assert (err < bar).all(), (iname, err.max(axis=1))
+
+
+OPEN_CASES = {      # the cameras of tests/make_golden.py:OPEN_CASES (the open parity cases of the r03 fuzz sweeps)
+    "koral3d_delo_69ghz": dict(fname="KORAL3D", ename="POLSYNCHTH", iname="delo", spin=0.9375, mu0=0.0, uout=0.04, nn=(12, 12, 60),
+                               gridvals=(-9.572477643577713, 5.75296751663922, -11.596725842453694, 3.7287193177632396),
+                               dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5, p1=5.5,
+                               freqs=[2.3e11, 6.9e10], i1=43, i2=132, dump=True),
+    "sphacc_formal_equatorial": dict(fname="SPHACC", ename="POLSYNCHTH", iname="formal", spin=0.0, mu0=0.0, uout=0.04, nn=(12, 12, 60),
+                                     gridvals=(-36.402300212602, 48.39734536577427, -41.53000646055861, 43.26963911781766),
+                                     mbh=10., gmin=100., p1=3.0, freqs=[7.23e11, 2.41e11, 2.41e10], i1=71, i2=110, dump=False),
+    "sphacc_delo_24ghz": dict(fname="SPHACC", ename="POLSYNCHTH", iname="delo", spin=0.0, mu0=0.0, uout=0.01, nn=(12, 12, 100),
+                              gridvals=(-6.46579504122852, 4.212597494570896, -9.68891574108579, 0.9894767947136254),
+                              mbh=10., gmin=100., p1=3.5, freqs=[7.23e11, 2.41e11, 2.41e10], i1=1, i2=144, dump=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPEN_CASES))
+def test_open_cases_of_the_r03_sweeps(tmp_path, name):
+    # the restatement against the COMPILED reference on the three cameras the r03 sweeps left open (open_cases.npz): the oracle
+    # follows the reference through the subnormal coefficients of the KORAL3D vacuum zones (j of ONE or TWO units of 4.9e-324 after
+    # j g g, grtrans_driver's j / fac, DELO's S = j / alpha_I), the 9e8-sized lambda of the equatorial camera and DELO's
+    # alternating-sign growth at 24 GHz to 1e-9 of each Stokes peak or better -- so device-vs-oracle sweeps mean device-vs-reference here
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    g = load("open_cases.npz")
+    case = OPEN_CASES[name]
+    kw = {k: v for k, v in case.items() if k not in ("freqs", "i1", "i2", "dump")}
+    if case["dump"]:
+        import make_koral3d_dump
+        make_koral3d_dump.write(str(tmp_path), n1=32, n2=32, n3=16)
+        kw["datadir"] = str(tmp_path)
+    o = O.Oracle(**kw)
+    pix, npts, _ = o.trace(case["i1"], case["i2"], case["freqs"], nthreads=0)
+    ref, pk = g[name + "_ivals"].astype(np.float64), g[name + "_peak"]
+    assert np.array_equal(npts, g[name + "_npts"])
+    for k in range(len(case["freqs"])):
+        assert np.array_equal(np.isfinite(pix[k]), np.isfinite(ref[k]))
+        okm = np.isfinite(ref[k]).all(axis=1)
+        assert np.all(np.abs(pix[k][okm] - ref[k][okm]).max(axis=0) / pk[k] < 2e-9), (name, k)

@@ -13,14 +13,18 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 import tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import make_harm_dump, make_harm3d_dump, make_iharm_dump, make_koral3d_dump
+DRY = bool(os.environ.get("GRT_FUZZ_DRY"))      # replay the draws only: print the exact parameters of the listed cameras (no device, no oracle)
 td = tempfile.mkdtemp(prefix="grt_fuzz_")
+if DRY:
+    capi = None
 make_harm_dump.write(td, n=64)
 d3, h3 = make_harm3d_dump.write(td, n1=32, n2=32, n3=16)
 di, hi = make_iharm_dump.write(td, n1=32, n2=32, n3=16, metric=1)
 dk, hk = make_koral3d_dump.write(td, n1=32, n2=32, n3=16)
-dev = capi.Device(0); dev.load_ffjet(); dev.load_tables(); dev.load_sphacc()
-dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
-dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375); dev.load_koral3d(dk, hk, 40, 0.9375)
+if not DRY:
+    dev = capi.Device(0); dev.load_ffjet(); dev.load_tables(); dev.load_sphacc()
+    dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
+    dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375); dev.load_koral3d(dk, hk, 40, 0.9375)
 # (fluid model, emissivity, oracle keywords, make_emis arguments, frequency, tolerance); GRMHD dumps fix the spin
 MODELS = [
     ("FFJET", "POLSYNCHPL", {}, dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 3.45e11, 2e-6),
@@ -59,6 +63,9 @@ for c in range(ncams):
     if only is not None and c not in only:
         continue
     okw = dict(okw, p1=p1)
+    if DRY:
+        print("cam %d: %r" % (c, dict(fname=fname, ename=ename, okw=okw, ekw=ekw, spin=a, mu0=mu0, gridvals=gv, uout=uout, nn=nn, iname=iname, rec=rec, p1=p1, freqs=freqs, i1=i1, i2=i2, tol=tol)))
+        continue
     o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)
     ref, rn, _ = o.trace(i1, i2, freqs, nthreads=0)
     capi.record_steps(rec)
@@ -187,6 +194,8 @@ for c in range(ncams):
                 print("        point %d r %.6f th dev %.12f ref %.12f  phi dev %.9f ref %.9f  tpm %d tpr %d  mu %.3e" % (kk, x[kk, 1], recd[1][kk], x[kk, 2], recd[2][kk], x[kk, 3], od["tpm"][kk], od["tpr"][kk], np.cos(x[kk, 2])))
             k = int(np.argmax(np.abs(recd[1] - x[:, 2])))
             print("      worst theta point %d of %d: dev th %.12g ref th %.12g | r dev %.12g ref %.12g" % (k, n, recd[1][k], x[k, 2], recd[0][k], x[k, 1]))
+if DRY:
+    sys.exit(0)
 capi.record_steps(False)
 dev.close()
 print("MISMATCHES:", bad, " ill-conditioned in the reference itself:", cond, " amplified (kappa > 30):", ampl)
