@@ -89,7 +89,7 @@ struct Ctx {
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
-  double *d_tailc = nullptr;            // [ray][4]: what grt_geo_tail_kernel hands to grt_geo_kernel (sums at the top chunk's lowest point, Lambda(npts))
+  double *d_tailc = nullptr;            // [ray][8]: what grt_geo_tail_kernel hands to grt_geo_kernel (sums at the top chunk's lowest point, Lambda(npts))
   size_t cap_tailc = 0;
   long long steps_stride = 0;
   int steps_fields = 0;
@@ -690,7 +690,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
-  if ((rc = grow(C.d_tailc, C.cap_tailc, (size_t)chunk * 4))) return rc;
+  if ((rc = grow(C.d_tailc, C.cap_tailc, (size_t)chunk * 8))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * chunk * rstride))) return rc;

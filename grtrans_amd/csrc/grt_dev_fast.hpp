@@ -185,6 +185,7 @@ struct RealRay {
   double facm, facmR, m1m, akm, nn, fac2, i1mu, i3mu, rfc, rdc, rjc, tmu1, tmu3, phimu1, phimu3;
   double sgna_pi;
   double jscale;                   // sqrt(mpos - mneg) (symmetric M) or |muplus|: the Jacobi argument's scale, formed once per ray (r04)
+  double froot[4];                 // real_froots at the radial turning point (the upper neighbour of the last inbound point)
   AgmLadder agm_mu, agm_u;         // Landen ladders of the two Jacobi inversions (moduli m1m, m1u are per-ray constants)
   // ncase 5 (two real roots u1, u4 and a complex pair, or u2, u3 behind the horizon): the u integrals are Carlson
   // (1991) "one quadratic factor" forms with f + g u + u^2 the pair's factor (geokerr_wrapper.f ELLQUARTICCOMPLEX);
@@ -194,6 +195,15 @@ struct RealRay {
   double cwp[3], cws[3], cpa[3], ci3a[3], ci3b[3];   // per (a5,b5): Wp2 - M2, U2 - W2, P2 - Q2, 2 a11/(3 c55), 4 d14 (a152 + a11 c55)/d15
   double ci2a, ci2b, ci2c, ct1, ct2, ct3;            // the [-4] integral with (a5,b5) = (0,1)
 };
+
+// The square roots of the four linear factors at u: X_i (or Y_i) of Carlson (1988) 2.1 for a limit u.  Neighbouring stored points of
+// a leg share a limit, so grt_geo_kernel evaluates them once per POINT and hands the upper neighbour's over by a lane shift
+// (real_upair_pre) instead of eight square roots per segment (r04).  A radicand that vanishes (the turning point itself) is held at
+// 1e-300: its root then multiplies into sums of O(1) terms, where 1e-150 and 0 round alike.
+GRT_HD void real_froots(const RealRay &K, double u, double *f) {
+  f[0] = fsqrt_nz(dmax(K.a1 + K.b1 * u, 1e-300)); f[1] = fsqrt_nz(dmax(K.a2 + K.b2 * u, 1e-300));
+  f[2] = fsqrt_nz(dmax(K.a3 + K.b3 * u, 1e-300)); f[3] = fsqrt_nz(dmax(K.a4 + K.b4 * u, 1e-300));
+}
 
 GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   const double one = 1.0, two = 2.0;
@@ -312,6 +322,7 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   for (int k = 0; k < 3; ++k) K.id15[k] = 1.0 / K.d15[k];
   agm_ladder(K.m1m, K.agm_mu);
   agm_ladder(K.m1u, K.agm_u);
+  real_froots(K, (R.ncase == 7) ? R.u2 : R.u3, K.froot);
   K.anc[0] = K.anc[1] = K.anc[2] = K.anc[3] = 0.0;
   K.tbeta = K.tmu3 * K.ii3mu; K.tC = 0.0; K.zok = 0; K.zpad = 0;
   K.pbeta = K.phimu3 * K.ii3mu; K.pC = 0.0; K.pG = 0.0; K.pok = 0; K.pn = 0; K.pomt1 = 1.0;
@@ -379,6 +390,61 @@ GRT_HD void real_upair(const RealRay &K, double x, double y, UPart &o, bool endt
     }
     o.phiu1 = -K.cP * v[0] + K.cQ * v[1];
     if (NPH == 3) o.tu1 = K.cA * o.tu11 + K.cB * v[2] - K.cC * v[0] + K.cD * v[1];   // :2215-2219
+  }
+}
+
+// S(ua) - S(ub) (upair_diff) for a real-quartic ray from the square roots at the two limits: fa = real_froots(ua), fb = real_froots(ub).
+// Carlson's formulas are symmetric in the two limits apart from the end-point term A(1,1,1,-1,-2), which is antisymmetric: the
+// orientation sign of upair_diff multiplies everything else.
+template <int NPH>
+GRT_HD void real_upair_pre(const RealRay &K, double ua, double ub, const double *fa, const double *fb, UPart &o) {
+  const double two = 2.0;
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
+  if (ua == ub) return;
+  const double sg = (ub >= ua) ? 1.0 : -1.0;
+  const double X1 = fa[0], X2 = fa[1], X3 = fa[2], X4 = fa[3], Y1 = fb[0], Y2 = fb[1], Y3 = fb[2], Y4 = fb[3];
+  const double idxy = frcp(fabs(ua - ub));
+  const double U122 = sq((X1 * X2 * Y3 * Y4 + Y1 * Y2 * X3 * X4) * idxy);
+  const double U132 = sq((X1 * X3 * Y2 * Y4 + Y1 * Y3 * X2 * X4) * idxy);
+  const double U14 = (X1 * X4 * Y2 * Y3 + Y1 * Y4 * X2 * X3) * idxy;
+  const double U142 = sq(U14);
+  constexpr int NJ = NPH;
+  constexpr int NA = NPH > 0 ? NPH : 1;
+  double W22[NA], rj2[NA], rff, rdd;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < NPH; ++k) W22[k] = U122 - K.wk[k];
+  const double tI2 = two * X1 * Y1 * frcp(X4 * Y4 * fabs(U14));
+  const double Adiff = Y1 * Y2 * Y3 * frcp(Y4 * ub) - X1 * X2 * X3 * frcp(X4 * ua);      // A at ub minus A at ua
+  double P22[NA], Q22[NA];
+  if (NPH > 0) {
+    const double ixy1 = frcp(sq(X1 * Y1));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NPH; ++k) {
+      const double X52 = K.a5[k] + K.b5[k] * ua, Y52 = K.a5[k] + K.b5[k] * ub;
+      Q22[k] = X52 * Y52 * ixy1 * W22[k];
+      P22[k] = Q22[k] + K.pk[k];
+    }
+  }
+  carlson_bundle<NJ>(U122, U132, U142, W22, rff, rdd, rj2);
+  const double I1 = two * rff;
+  o.iu1 = sg * I1;
+  const double I2 = K.cRD * rdd + tI2;
+  o.tu11 = sg * (K.cI2 * I2 + K.cI1 * I1) - K.cA4 * Adiff;
+  if (NPH > 0) {
+    double v[NA];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NPH; ++k) {
+      const double I3 = K.jk[k] * rj2[k] + two * rc7(P22[k], Q22[k]);
+      v[k] = (K.b5[k] * I3 - K.b1 * I1) * K.id15[k];
+    }
+    o.phiu1 = sg * (-K.cP * v[0] + K.cQ * v[1]);
+    if (NPH == 3) o.tu1 = K.cA * o.tu11 + sg * (K.cB * v[2] - K.cC * v[0] + K.cD * v[1]);
   }
 }
 
@@ -547,6 +613,36 @@ GRT_HD void useg_lane(const GrtCam &cam, const GrtRay &R, const RealRay &K, int 
   reset = false;
   upair_diff<NPH>(K, ua, leg_u(cam, R, K, idx + 1, inb), o);
 #endif
+}
+
+// useg_lane in two halves for the shared-square-root form: the classification (which limits, which special case) here, the pair
+// integrals from the caller's roots afterwards.  pair: the lane needs S(ua) - S(ub); lastinb: ub is the turning point itself (its
+// roots are RealRay.froot, not the upper lane's); o is final for lanes without a pair (anchor, clamped, invalid, mu-fill).
+struct USegClass { double ua, ub; bool pair, lastinb; };
+GRT_HD void useg_classify(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, USegClass &cl, UPart &o, bool &reset, bool &usable) {
+  const int next = cam.next, kmax = R.kmax, n = R.npts;
+  const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
+  const int lo = fill ? (kmax - cam.kext) : kmax;
+  const bool c7 = (K.ncase == 7);
+  const double root = K.cplx ? K.u0 : (c7 ? K.u2 : K.u3);
+  o.iu1 = 0.0; o.phiu1 = 0.0; o.tu11 = 0.0; o.tu1 = 0.0;
+  reset = true; usable = false;
+  cl.ua = root; cl.ub = root; cl.pair = false; cl.lastinb = false;
+  if (idx < 1 || idx > n) return;
+  const bool isfill = fill && idx > lo && idx <= lo + next && R.tpr != 0;
+  if (isfill) return;
+  usable = true;
+  const bool inb = (idx <= lo || R.tpr == 0);
+  cl.ua = leg_u(cam, R, K, idx, inb);
+  if (idx == n) {                       // top of the ray: the per-ray anchor
+    o.iu1 = K.anc[0]; o.tu11 = K.anc[1]; o.phiu1 = K.anc[2]; o.tu1 = K.anc[3];
+    return;
+  }
+  if (!K.cplx && cl.ua == root) return; // clamped onto the turning point: S = 0
+  cl.lastinb = inb && R.tpr != 0 && idx == lo;
+  cl.ub = cl.lastinb ? root : leg_u(cam, R, K, idx + 1, inb);
+  reset = cl.lastinb;
+  cl.pair = true;
 }
 
 // mu end-point: F, E, Pi pieces for mu_f (calcimu*f + ellphitmu muf part)

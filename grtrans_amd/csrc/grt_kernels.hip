@@ -194,6 +194,11 @@ extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long 
 // (v,f)_k o (v,f)_k+d = (v_k + (f_k ? 0 : v_k+d), f_k | f_k+d).
 template <int NQ>
 __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int lane) {
+#if !defined(GRT_NO_SCAN_LAUNDER)
+  // the six lane-index compares stay HERE (r04): hoisted out of the chunk loop they were twelve SGPRs parked in VGPR lanes, and every
+  // use a v_readlane on the vector pipe; re-formed per pass they are six v_cmp with a result that dies at once
+  asm volatile("" : "+v"(lane));
+#endif
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const bool have = lane + d < 64;
@@ -256,7 +261,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const RealRay *Kg = Kp;
   const GrtRay *Rg = Rp;
   constexpr int RW = (sizeof(GrtRay) + 7) / 8;
+#if defined(GRT_LDS_NPH3)      // experiment: the slow-light kernel <1,3> with the LDS copies of <1,2> (r03: garbage turning-point counts in the mu-fill segment)
+  constexpr bool LDSR = (FAST == 1 && (NPH == 2 || NPH == 3));
+#else
   constexpr bool LDSR = (FAST == 1 && NPH == 2);
+#endif
   __shared__ double s_r[LDSR ? GRT_WAVES_PER_BLOCK : 1][LDSR ? RW : 1];
   if (LDSR) {
     typedef double __attribute__((may_alias)) grt_word2;
@@ -266,7 +275,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
   // ... and the Schwarzschild-cubic class (CubRay, 648 B) in both of its forms: SPHACC 1024^2 x 400 geodesics 24.3 -> 20.8 ms image only,
   // 29.0 -> 24.7 ms with the record
+#if defined(GRT_LDS_NPH3)
+  constexpr bool LDSHYB = (FAST == 1 && (NPH == 2 || NPH == 3));
+#else
   constexpr bool LDSHYB = (FAST == 1 && NPH == 2);
+#endif
   constexpr bool LDSRR = (FAST == 1 && NPH == 0) || FAST == 2;
   constexpr int RRW = ((FAST == 2 ? sizeof(CubRay) : sizeof(RealRay)) + 7) / 8;
   __shared__ double s_rr[(LDSRR || LDSHYB) ? GRT_WAVES_PER_BLOCK : 1][(LDSRR || LDSHYB) ? RRW : 1];
@@ -280,6 +293,12 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
   }
+#endif
+#if defined(GRT_GEO_CAMK)
+  const GrtCam *camp = nullptr;
+#define GRT_CAMREF (*camp)
+#else
+#define GRT_CAMREF cam
 #endif
   const int n = Rp->npts;
   double LamN = 0.0;                              // (ray_stride is a multiple of 64 points: every full chunk row is a 512-byte aligned run of four 128-byte lines)
@@ -299,6 +318,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   leg.lo = n; leg.nfill = 0; leg.fill = false;
   if (FAST == 1) leg = real_leg(cam, *Rp);
   const int nreg = n - leg.nfill;
+  double cF[4] = {1.0, 1.0, 1.0, 1.0};      // real_froots of the lowest point of the chunk above (the upper neighbour of this chunk's lane 63)
   // The partial TOP chunk of the regular points (394 = 6 x 64 + 10 for the escaping rays of the headline camera: a pass that used
   // 10 of its 64 lanes, 1 pass in 8.2) is served by grt_geo_tail_kernel, four rays to a wave (r04): it leaves Lambda of the ray's top
   // point and the segment scheme's running sums at the chunk's lowest point in tailc, and this wave starts one chunk lower.
@@ -307,10 +327,12 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     const int rtop = nreg - 64 * ((nreg - 1) >> 6);
     served = nreg > 0 && rtop <= tailw;
     if (served) {
-      const double *tc = tailc + (size_t)rayidx * 4;
+      const double *tc = tailc + (size_t)rayidx * 8;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) carry[q] = tc[q];
       LamN = tc[3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cF[q] = tc[4 + q];
     }
   }
   for (int ph = 0; ph < (leg.nfill > 0 ? 2 : 1); ++ph) {
@@ -337,6 +359,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 #endif
       asm volatile("" : "+s"(r_), "+s"(k_));
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
+#if defined(GRT_GEO_CAMK)
+      // the camera struct re-read from the kernarg segment per chunk (as the transfer kernel does): its ~60 SGPRs are not held, and
+      // spilled to VGPR lanes, across the whole pass
+      const GrtCam GRT_AS4 *c_ = (const GrtCam GRT_AS4 *)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(c_));
+      camp = (const GrtCam *)c_;
+#endif
 #if !defined(GRT_NO_GEO_LDS_RR)
       Kg = Kp;
       Rg = Rp;
@@ -356,7 +385,28 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       if (FAST == 1 && !fillph) {
         // u-side integrals from segments between neighbouring points, summed down the wave (grt_dev_fast.hpp:useg_lane)
         bool reset;
-        useg_lane<NPH>(cam, *Rp, *Kp, valid ? idx : 0, S, reset, usable);
+#if defined(GRT_USEG_SHARE)
+        // the square roots of the four linear factors once per POINT: a segment takes its upper limit's from the lane above
+        // (lane 63: from the chunk above; the last inbound point: the turning point's, a constant of the ray)
+        USegClass cl;
+        useg_classify(GRT_CAMREF, *Rp, *Kp, valid ? idx : 0, cl, S, reset, usable);
+        if (Kp->cplx) {
+          if (cl.pair) upair_diff<NPH>(*Kp, cl.ua, cl.ub, S);
+        } else {
+          double fo[4], fn[4];
+          real_froots(*Kp, cl.ua, fo);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double up = __shfl_down(fo[q], 1);
+            fn[q] = cl.lastinb ? Kp->froot[q] : ((lane == 63) ? cF[q] : up);
+          }
+          if (cl.pair) real_upair_pre<NPH>(*Kp, cl.ua, cl.ub, fo, fn, S);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cF[q] = __shfl(fo[q], 0);
+        }
+#else
+        useg_lane<NPH>(GRT_CAMREF, *Rp, *Kp, valid ? idx : 0, S, reset, usable);
+#endif
         double v[NQ];
         v[0] = S.iu1; v[1] = S.tu11;
         if (NQ > 2) v[2] = S.phiu1;
@@ -374,13 +424,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 #endif
       if (valid) {
         const UPart *pre = usable ? &S : nullptr;
-        if (FAST == 2) ray_point_cubic<PHI>(cam, *Rp, *Cp, idx, P);
-        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
+        if (FAST == 2) ray_point_cubic<PHI>(GRT_CAMREF, *Rp, *Cp, idx, P);
+        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(GRT_CAMREF, *Rp, *Kp, idx, P, pre);
 #if !defined(GRT_NO_GEO_LDS_RR)
-        else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_])); }
+        else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_])); }
 #endif
-        else if (FAST == 1) ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre);
-        else ray_point(cam, *Rp, idx, P, NPH == 3 ? 3 : NPH);
+        else if (FAST == 1) ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre);
+        else ray_point(GRT_CAMREF, *Rp, idx, P, NPH == 3 ? 3 : NPH);
       }
     }
     if (toppass) { LamN = P.lam; continue; }
@@ -411,7 +461,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 // wave-uniform here, so every ray's GrtRay and RealRay are copied into LDS and read through per-lane addresses (the LDSRR form of
 // grt_geo_kernel with a lane-dependent base).  The chunk is the ray's first in the segment scheme: its chain starts at the anchor
 // (useg_lane: idx == npts) and the sums at its lowest lane are handed to grt_geo_kernel, with Lambda of the top point, through
-// tailc[ray][4] = {iu1, tu11, phiu1, Lambda(npts)}.  Same device functions, same arithmetic per lane as the chunk it replaces.
+// tailc[ray][8] = {iu1, tu11, phiu1, Lambda(npts), real_froots of the lowest point}.  Same device functions, same arithmetic per lane as the chunk it replaces.
 #define GRT_TAIL_MAXS 4
 template <int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_tail_kernel(
@@ -426,9 +476,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int S = 64 / W;                                   // rays per wave (host: W = 16 or 32)
   const int nlive = *nlive_dev;
-  const int ray0 = (blockIdx.x * GRT_WAVES_PER_BLOCK + wave) * S;
-  if (ray0 >= nlive) return;                              // whole wave leaves together
   typedef double __attribute__((may_alias)) grt_word;
+  // A wave serves one group of S rays after the other (grid-stride; the launcher sizes the grid to the chip): with one group per wave
+  // -- 262,144 waves of a single pass each at 1024^2 -- the kernel ran at a quarter of its instruction rate, waves leaving faster
+  // than the dispatcher replaced them (r04: 3.7-4.0 ms against 0.9 ms of issue).
+  for (int ray0 = (blockIdx.x * GRT_WAVES_PER_BLOCK + wave) * S; ray0 < nlive; ray0 += gridDim.x * GRT_WAVES_PER_BLOCK * S) {
+  __builtin_amdgcn_wave_barrier();                        // the previous group's reads of the LDS copies are done (in-order per wave)
+  asm volatile("" ::: "memory");
   // the records of all S rays in ONE sweep of independent loads (r04: a loop over the rays -- index, then record, four times in a
   // row -- left the wave waiting for eight dependent memory round trips before its single pass: 3.7 ms for 262,144 waves)
   const int slot = lane / W, j = lane - slot * W;
@@ -466,7 +520,26 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
   UPart Sg;
   bool usable = false, reset = true;
+  double fo[4] = {1.0, 1.0, 1.0, 1.0};
+#if defined(GRT_USEG_SHARE)
+  {
+    USegClass cl;
+    useg_classify(cam, *Rp, *Kp, valid ? idx : 0, cl, Sg, reset, usable);
+    double fn[4];
+    real_froots(*Kp, cl.ua, fo);                   // (complex-pair rays: unused)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double up = __shfl_down(fo[q], 1);     // (the top lane of a slot holds the anchor: no pair reaches into the next slot)
+      fn[q] = cl.lastinb ? Kp->froot[q] : up;
+    }
+    if (cl.pair) {
+      if (Kp->cplx) upair_diff<NPH>(*Kp, cl.ua, cl.ub, Sg);
+      else real_upair_pre<NPH>(*Kp, cl.ua, cl.ub, fo, fn, Sg);
+    }
+  }
+#else
   useg_lane<NPH>(cam, *Rp, *Kp, valid ? idx : 0, Sg, reset, usable);
+#endif
   double v[NQ];
   v[0] = Sg.iu1; v[1] = Sg.tu11;
   if (NQ > 2) v[2] = Sg.phiu1;
@@ -488,9 +561,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
     sp[GRT_F_LAM * field_stride] = LamN - P.lam;
     if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
     if (j == 0) {
-      double *tc = tailc + (size_t)rayidx * 4;
+      double *tc = tailc + (size_t)rayidx * 8;
       tc[0] = v[0]; tc[1] = v[1]; tc[2] = (NQ > 2) ? v[2] : 0.0; tc[3] = LamN;
+      tc[4] = fo[0]; tc[5] = fo[1]; tc[6] = fo[2]; tc[7] = fo[3];
     }
+  }
   }
 }
 
@@ -1277,7 +1352,9 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   }
   if (tailw) {
     const int S = 64 / tailw;
-    dim3 gt((unsigned)((nrays + S * GRT_WAVES_PER_BLOCK - 1) / (S * GRT_WAVES_PER_BLOCK)));
+    unsigned nbt = (unsigned)((nrays + S * GRT_WAVES_PER_BLOCK - 1) / (S * GRT_WAVES_PER_BLOCK));
+    if (nbt > 2048) nbt = 2048;                    // 8 blocks per CU: every wave serves several groups in turn
+    dim3 gt(nbt);
     if (nph == 2) hipLaunchKernelGGL((grt_geo_tail_kernel<2>), gt, b, 0, s, *cam, rays, rr, live, nlive_dev, steps, ray_stride, field_stride, nfields, tailc, tailw);
     else hipLaunchKernelGGL((grt_geo_tail_kernel<0>), gt, b, 0, s, *cam, rays, rr, live, nlive_dev, steps, ray_stride, field_stride, nfields, tailc, tailw);
   }

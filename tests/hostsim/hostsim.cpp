@@ -66,6 +66,7 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
   realray_anchor(*cam, R, K);
   realray_anchor_z(*cam, R, K);
   UPart carry; carry.iu1 = carry.tu11 = carry.phiu1 = carry.tu1 = 0.0;
+  double cF[4] = {1.0, 1.0, 1.0, 1.0};
   // as grt_geo_kernel walks a ray: the regular points compacted into 64-point chunks (segment sums down each chunk, carry from
   // the chunk above), then the mu-fill segment on its own
   const RealLeg leg = real_leg(*cam, R);
@@ -76,10 +77,35 @@ int hs_ray_points_seg(const GrtCam *cam, int ii, int maxn, int nph, double *u, d
       const int pos = 64 * c + lane + 1;
       const int idx = (pos > nreg) ? 0 : (pos <= leg.lo ? pos : pos + leg.nfill);
       idxs[lane] = idx;
-      if (nph == 3) useg_lane<3>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
-      else if (nph == 2) useg_lane<2>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
-      else useg_lane<0>(*cam, R, K, idx, S[lane], reset[lane], usable[lane]);
     }
+#if !defined(GRT_USEG_SHARE)      // the form the kernel ships with
+    for (int lane = 0; lane < 64; ++lane) {
+      if (nph == 3) useg_lane<3>(*cam, R, K, idxs[lane], S[lane], reset[lane], usable[lane]);
+      else if (nph == 2) useg_lane<2>(*cam, R, K, idxs[lane], S[lane], reset[lane], usable[lane]);
+      else useg_lane<0>(*cam, R, K, idxs[lane], S[lane], reset[lane], usable[lane]);
+    }
+#else
+    // the shared-square-root form (experiment switch GRT_USEG_SHARE of grt_kernels.hip): roots once per point, the upper neighbour's by a lane shift
+    USegClass cl[64]; double fo[64][4];
+    for (int lane = 0; lane < 64; ++lane) {
+      useg_classify(*cam, R, K, idxs[lane], cl[lane], S[lane], reset[lane], usable[lane]);
+      real_froots(K, cl[lane].ua, fo[lane]);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+      if (!cl[lane].pair) continue;
+      if (K.cplx) {
+        if (nph == 3) upair_diff<3>(K, cl[lane].ua, cl[lane].ub, S[lane]);
+        else if (nph == 2) upair_diff<2>(K, cl[lane].ua, cl[lane].ub, S[lane]);
+        else upair_diff<0>(K, cl[lane].ua, cl[lane].ub, S[lane]);
+        continue;
+      }
+      const double *fn = cl[lane].lastinb ? K.froot : ((lane == 63) ? cF : fo[lane + 1]);
+      if (nph == 3) real_upair_pre<3>(K, cl[lane].ua, cl[lane].ub, fo[lane], fn, S[lane]);
+      else if (nph == 2) real_upair_pre<2>(K, cl[lane].ua, cl[lane].ub, fo[lane], fn, S[lane]);
+      else real_upair_pre<0>(K, cl[lane].ua, cl[lane].ub, fo[lane], fn, S[lane]);
+    }
+    for (int q = 0; q < 4; ++q) cF[q] = fo[0][q];
+#endif
     for (int lane = 63; lane >= 0; --lane) {
       if (reset[lane]) continue;
       const UPart &up = (lane < 63) ? S[lane + 1] : carry;

@@ -414,6 +414,11 @@ def test_the_flow_copy_scanner_sees_the_defect_and_not_the_ordinary_merge():
     bad = check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_copy_bad.s"))
     assert len(bad) == 1 and bad[0][0] == "kernel_with_the_defect" and len(bad[0][2]) == 2
     assert check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_copy_ok.s")) == []
+    # r04: the same placement of a SPILL (scratch_store of a value that lives through the if-else, reloaded from the slot under the full
+    # mask) is seen; the then side's own spill into a merge slot and an SGPR spill (v_writelane ignores the exec mask) are not flagged
+    bad = check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_spill_bad.s"))
+    assert len(bad) == 1 and bad[0][0] == "kernel_with_the_spill_defect" and bad[0][2][0].startswith("scratch_store_dwordx2")
+    assert check_flow_copies.scan(os.path.join(ROOT, "tests", "golden", "flow_spill_ok.s")) == []
 
 
 def test_harness_unit_conversions_and_polarization_fractions():
@@ -454,3 +459,51 @@ def test_harness_unit_conversions_and_polarization_fractions():
     y.ab, y.ivals, y.nx, y.ny, y.nvals = x.ab.T.copy(), np.transpose(iv0, (1, 0, 2)).copy(), nx, ny, 4
     y.calc_spec_pgrtrans(2)
     assert np.allclose(y.spec, sp0) and np.allclose(y.lp, np.hypot(sp0[1], sp0[2]) / sp0[0]) and np.allclose(y.cpf, np.abs(iv0[:, 3]).sum(axis=0) * da * db / sp0[0])
+
+
+def test_bench_self_launch_builds_the_exact_launcher_command(monkeypatch):
+    # `python bench.py --gpus 8` without a launcher starts its ranks through exactly the command line the driver
+    # uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <its own
+    # arguments>), with dmabuf IPC selected, and ends with the launcher's exit code
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+
+    class A:
+        gpus = 8
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert bench.self_launch(A, argv) == 7
+    cmd = seen["cmd"]
+    port = cmd[cmd.index("--master-port") + 1]
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", port, os.path.join(ROOT, "bench.py")] + argv
+    assert 1024 <= int(port) <= 65535 and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_a_rank_that_exits_98_or_3_ends_the_launched_job_nonzero_in_bounded_time(tmp_path):
+    # the library's communicator watchdog ends a rank with exit code 98, bench.py's gather watchdog with 3: the launcher bench.py relies
+    # on must then end the WHOLE job non-zero promptly -- not leave the other ranks waiting in a collective.  Two ranks on CPU: rank 1
+    # exits with the code after a second, rank 0 would sleep for two minutes.
+    import subprocess
+    import time
+    helper = tmp_path / "rank.py"
+    helper.write_text("import os, sys, time\n"
+                      "code = int(sys.argv[1])\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    time.sleep(1.0); os._exit(code)\n"
+                      "time.sleep(120)\n")
+    for code in (98, 3):
+        port = _free_port()
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), str(helper), str(code)], capture_output=True, text=True, timeout=100)
+        assert r.returncode != 0, r.stdout + r.stderr
+        assert time.time() - t0 < 60.0

@@ -10,8 +10,12 @@ cp $ROOT/grtrans_amd/csrc/*.h $ROOT/grtrans_amd/csrc/*.hpp $ROOT/grtrans_amd/csr
 cp $ROOT/include/*.h $ROOT/build/variants/src_$1/include/
 cd $ROOT/build/variants/src_$1/grtrans_amd/csrc
 O=$ROOT/build/variants/obj_$1
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast-honor-pragmas -I. -Wno-unused-result $2"
-/opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage -c grt_kernels.hip -o $O/k.o 2> $O/usage.txt
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast-honor-pragmas ${GRT_VARIANT_LICM--mllvm -disable-machine-licm} -I. -Wno-unused-result $2"
+if [ -n "$GRT_VARIANT_ASM" ]; then      # keep the device assembly (tools/check_flow_copies.py)
+  (cd $O && /opt/rocm/bin/hipcc $F -I$ROOT/build/variants/src_$1/grtrans_amd/csrc -save-temps=obj -Rpass-analysis=kernel-resource-usage -c $ROOT/build/variants/src_$1/grtrans_amd/csrc/grt_kernels.hip -o $O/k.o 2> $O/usage.txt && mv $O/grt_kernels-hip-amdgcn-amd-amdhsa-gfx950.s $O/k.gfx950.s && rm -f $O/grt_kernels-hip-* $O/grt_kernels-host-* $O/grt_kernels.hip-hip-*)
+else
+  /opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage -c grt_kernels.hip -o $O/k.o 2> $O/usage.txt
+fi
 /opt/rocm/bin/hipcc $F -x hip -c grt_api.cpp -o $O/a.o
 /opt/rocm/bin/hipcc $F -x hip -c grt_gather.cpp -o $O/g.o
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -c grt_harm_loader.cpp -o $O/h.o

@@ -2,7 +2,11 @@
 the FLOW block of a divergent if-else BEFORE the instruction that flips the exec mask (s_andn2_saveexec / s_or_saveexec ... s_xor exec):
 such a copy runs for the lanes of the `then` side only, and the lanes of the `else` side later read a stale register.  r03 found
 `facs` of grt_transfer_kernel<FORMAL, IHARM, HYBRIDTHPL, 1, false> restored from another variable's register that way
-(DESIGN.md 6).  Usage: python tools/check_flow_copies.py file.s [more.s]  -> one line per suspicious site, exit 1 if any."""
+(DESIGN.md 6).  r04: the same placement of a SPILL -- scratch_store of a register that lives through the if-else, before the flip,
+reloaded from the same slot later -- and of v_accvgpr_write / v_accvgpr_read parks is flagged too.  SGPR spills are NOT a hazard of this
+kind: v_writelane_b32 / v_readlane_b32 ignore the exec mask (they address one lane by number), so a lane written under a partial mask is
+written all the same; the scanner counts them per flow block only to report that they were looked at.
+Usage: python tools/check_flow_copies.py file.s [more.s]  -> one line per suspicious site, exit 1 if any."""
 import re
 import sys
 
@@ -98,6 +102,31 @@ def scan(path):
                             restored = True
                             break
                     if not written and not computed and restored and target:
+                        keep.append(h)
+                # spill stores before the flip: scratch_store_dword* off, v[a:b], <base> offset:N of a register the then side did
+                # not compute, into a slot the else side does not store to, reloaded from that slot later
+                for h in hits:
+                    ms = re.match(r"^(?:scratch|buffer)_store_dword(?:x[234])?\s+(?:off,\s*)?(v\[?\d+(?::\d+)?\]?),\s*(.*)$", h)
+                    if not ms:
+                        continue
+                    src = regset(ms.group(1))
+                    slot = re.sub(r"\s+", " ", ms.group(2)).strip()
+                    computed = False
+                    for tl in lines[then_start:i]:
+                        m2 = re.match(r"^\s*(\S+)\s+([av]\[?\d+(?::\d+)?\]?)", tl)
+                        if m2 and not m2.group(1).startswith(("scratch_store", "buffer_store")) and regset(m2.group(2)) & src:
+                            computed = True
+                            break
+                    stored_else = any(re.match(r"^\s*(?:scratch|buffer)_store_dword", el) and re.sub(r"\s+", " ", el).strip().endswith(slot) for el in else_txt)
+                    reloaded = False
+                    for rl in lines[i:min(n, i + 6000)]:
+                        if rl.startswith(".Lfunc_end"):
+                            break
+                        m3 = re.match(r"^\s*(?:scratch|buffer)_load_dword(?:x[234])?\s+(v\[?\d+(?::\d+)?\]?),\s*(?:off,\s*)?(.*)$", rl)
+                        if m3 and re.sub(r"\s+", " ", m3.group(2)).strip() == slot:
+                            reloaded = True
+                            break
+                    if not computed and not stored_else and reloaded and target:
                         keep.append(h)
                 if keep:
                     out.append((func, i + 1, keep))
