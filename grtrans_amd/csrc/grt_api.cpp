@@ -19,8 +19,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw,
-                                     double *tailc);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw);
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
                                       double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield);
@@ -89,8 +88,6 @@ struct Ctx {
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
-  double *d_tailc = nullptr;            // [ray][8]: what grt_geo_tail_kernel hands to grt_geo_kernel (sums at the top chunk's lowest point, Lambda(npts))
-  size_t cap_tailc = 0;
   long long steps_stride = 0;
   int steps_fields = 0;
   hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -194,7 +191,7 @@ int grt_free(void) {
   drain();
   void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_sphacc,
-                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_rng, C.d_tailc, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
+                  C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_rng, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 3; ++i)
@@ -637,6 +634,10 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   // standard=2 with nup > 1: GEOKERR's USEGEOR branch (mu as the independent variable, geokerr_wrapper.f:421-461) on the
   // generic class, ends trimmed as geodesics.f90:298-323 does
   if ((cam->standard != 1 && cam->standard != 2) || cam->nup < 2 || (nvals != 4 && nvals != 1) || (nextra != 0 && nextra != 19)) return GRT_E_UNSUPPORTED;
+  // extra=1 needs nvals=4: with nvals=1 the reference's diagnostics take optical depths of opacity columns 2..7 that a one-column
+  // emissivity does not have (grtrans_driver.f90:236-240 with calc_opt_depth on e%K(:,inds)) -- no defined answer, so no kernel (r04:
+  // the quadrature kernels had extra=1 instantiations that no test could check against anything)
+  if (nextra != 0 && nvals != 4) return GRT_E_UNSUPPORTED;
   if (cam->standard == 2 && (!cam->usegeor || cam->mufill || cam->kext || cam->next)) return GRT_E_BADARG;
   // nvals=1: both iname=delo and iname=formal fall through to the quadrature (radtrans_integrate.f90:176-189)
   const int kflag = (nvals == 1) ? 4 /* GRT_INT_QUAD */ : iflag;
@@ -690,7 +691,6 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
-  if ((rc = grow(C.d_tailc, C.cap_tailc, (size_t)chunk * 8))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * chunk * rstride))) return rc;
@@ -744,7 +744,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       if (generic) {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps,
-                                   rstride, fstride, nfields, tfield, t0c, 0, nullptr));
+                                   rstride, fstride, nfields, tfield, t0c, 0));
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
@@ -764,7 +764,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       } else {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
-                                   nfields, tfield, t0c, 0, C.d_tailc));
+                                   nfields, tfield, t0c, 0));
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                                       C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
@@ -949,8 +949,8 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
   hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin, nullptr, 0);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, nullptr);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
   if (e != hipSuccess) { drain(); return (int)e; }
   HIPCHK(hipStreamSynchronize(C.stream));
   // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them

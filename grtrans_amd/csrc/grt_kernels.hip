@@ -26,6 +26,24 @@
 
 using namespace grtd;
 
+// GRT_LOG_LAUNCHES=path (test tooling, tests/test_gpu_parity.py instantiation coverage): every launch below appends the mangled-name
+// stem of the kernel it starts, e.g. grt_transfer_kernelILi2ELi13ELi4ELi1ELb0EE, so that the ~180 instantiations of this file can be
+// checked against what the GPU suite actually runs.  One getenv per process; nothing is written without the variable.
+#include <cstdio>
+#include <cstdarg>
+static void note_launch(const char *fmt, ...) {
+  static const char *path = std::getenv("GRT_LOG_LAUNCHES");
+  if (!path || !*path) return;
+  if (FILE *f = std::fopen(path, "a")) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vfprintf(f, fmt, ap);
+    va_end(ap);
+    std::fputc('\n', f);
+    std::fclose(f);
+  }
+}
+
 #define GRT_WAVES_PER_BLOCK 4
 #ifndef GRT_WPE_GEO
 #define GRT_WPE_GEO 2     // waves per SIMD the register allocator must make room for
@@ -184,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void grt_t0_kernel(GrtCam cam, long long i1
 }
 
 extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long i1, int nrays, double *t0) {
+  note_launch("grt_t0_kernel");
   hipLaunchKernelGGL(grt_t0_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, i1, nrays, t0);
   return hipGetLastError();
 }
@@ -220,8 +239,7 @@ template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
-    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw,
-    const double *__restrict__ tailc, int tailw) {
+    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
   constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // the class size is read on the device (the set-up kernel's counter): the host never waits for it between the launches.
@@ -280,7 +298,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
 #else
   constexpr bool LDSHYB = (FAST == 1 && NPH == 2);
 #endif
+#if defined(GRT_LDSRR_NPH3)    // experiment: the r03 failure (whole RealRay through LDS in the slow-light kernel)
+  constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 3)) || FAST == 2;
+#else
   constexpr bool LDSRR = (FAST == 1 && NPH == 0) || FAST == 2;
+#endif
   constexpr int RRW = ((FAST == 2 ? sizeof(CubRay) : sizeof(RealRay)) + 7) / 8;
   __shared__ double s_rr[(LDSRR || LDSHYB) ? GRT_WAVES_PER_BLOCK : 1][(LDSRR || LDSHYB) ? RRW : 1];
   if (LDSRR || LDSHYB) {
@@ -318,29 +340,17 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   leg.lo = n; leg.nfill = 0; leg.fill = false;
   if (FAST == 1) leg = real_leg(cam, *Rp);
   const int nreg = n - leg.nfill;
-  double cF[4] = {1.0, 1.0, 1.0, 1.0};      // real_froots of the lowest point of the chunk above (the upper neighbour of this chunk's lane 63)
-  // The partial TOP chunk of the regular points (394 = 6 x 64 + 10 for the escaping rays of the headline camera: a pass that used
-  // 10 of its 64 lanes, 1 pass in 8.2) is served by grt_geo_tail_kernel, four rays to a wave (r04): it leaves Lambda of the ray's top
-  // point and the segment scheme's running sums at the chunk's lowest point in tailc, and this wave starts one chunk lower.
-  bool served = false;
-  if (FAST == 1 && NPH != 3 && tailw > 0) {
-    const int rtop = nreg - 64 * ((nreg - 1) >> 6);
-    served = nreg > 0 && rtop <= tailw;
-    if (served) {
-      const double *tc = tailc + (size_t)rayidx * 8;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) carry[q] = tc[q];
-      LamN = tc[3];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cF[q] = tc[4 + q];
-    }
-  }
+  double cF[4] = {1.0, 1.0, 1.0, 1.0};      // (GRT_USEG_SHARE) real_froots of the lowest point of the chunk above
+  // The partial TOP chunk of the regular points (394 = 6 x 64 + 10 for the escaping rays of the headline camera) costs a full pass: a
+  // masked-off 16-lane group is not skipped by the hardware (tools/exec_skip_bench.hip).  r04 gave those chunks to a separate kernel,
+  // four rays to a wave with per-lane LDS addresses for the per-ray constants: this kernel lost 4.1 ms, that one took 3.5-4.0 ms
+  // (1.7 ms of it waiting for its 12 KB of records per pass, the rest at half this kernel's instruction rate) -- removed again.
   for (int ph = 0; ph < (leg.nfill > 0 ? 2 : 1); ++ph) {
   const bool fillph = (ph == 1);
   const int cnt = fillph ? leg.nfill : nreg;
   const int ctop = (cnt - 1) >> 6;
   const bool pre = perchunk && cfix < ctop;            // generic class, one chunk per wave: this wave's chunk is not the top one
-  const int c_start = perchunk ? (pre ? cfix + 1 : cfix) : ((served && !fillph) ? ctop - 1 : ctop), c_end = perchunk ? cfix : 0;
+  const int c_start = perchunk ? (pre ? cfix + 1 : cfix) : ctop, c_end = perchunk ? cfix : 0;
   for (int c = c_start; c >= c_end && cfix <= ctop; --c) {
     const bool toppass = pre && c == cfix + 1;             // the extra pass: every lane evaluates the ray's top point
     // launder the wave-uniform record pointers once per chunk so that the per-ray constants are
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
       }
     }
     if (toppass) { LamN = P.lam; continue; }
-    if (ph == 0 && c == ctop) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel); a served ray never gets here
+    if (ph == 0 && c == ctop) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel)
     // the turning-point parities ride in the sign bits of r (radial) and theta (polar): both are positive quantities
     if (NPH == 3 && valid && raw) {   // grt_geokerr_rays: GEOKERR's own output arrays UFI, MUFI, LAMBDAI, DPHI, DTI, TPMI, TPRI
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
@@ -454,119 +464,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
   } while (FAST == 0 && slot0 < *nlive_dev * nchg);     // only the generic class strides (capped grid); a fast-class wave serves one ray
-}
-
-// The partial top chunk of the regular points of a four-real-root / complex-pair ray, served for 64 / W rays by one wave: lanes
-// [slot W, slot W + r) hold the r <= W topmost regular points of the wave's ray number `slot`.  The per-ray constants cannot be
-// wave-uniform here, so every ray's GrtRay and RealRay are copied into LDS and read through per-lane addresses (the LDSRR form of
-// grt_geo_kernel with a lane-dependent base).  The chunk is the ray's first in the segment scheme: its chain starts at the anchor
-// (useg_lane: idx == npts) and the sums at its lowest lane are handed to grt_geo_kernel, with Lambda of the top point, through
-// tailc[ray][8] = {iu1, tu11, phiu1, Lambda(npts), real_froots of the lowest point}.  Same device functions, same arithmetic per lane as the chunk it replaces.
-#define GRT_TAIL_MAXS 4
-template <int NPH>
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_tail_kernel(
-    GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
-    const int *__restrict__ nlive_dev, double *__restrict__ steps, long long ray_stride, long long field_stride, int nfields,
-    double *__restrict__ tailc, int W) {
-  constexpr bool PHI = NPH > 0;
-  constexpr int NQ = (NPH == 2) ? 3 : 2;
-  constexpr int RW = (sizeof(GrtRay) + 7) / 8, RRW = (sizeof(RealRay) + 7) / 8;
-  __shared__ double s_r[GRT_WAVES_PER_BLOCK][GRT_TAIL_MAXS][RW];
-  __shared__ double s_rr[GRT_WAVES_PER_BLOCK][GRT_TAIL_MAXS][RRW];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int S = 64 / W;                                   // rays per wave (host: W = 16 or 32)
-  const int nlive = *nlive_dev;
-  typedef double __attribute__((may_alias)) grt_word;
-  // A wave serves one group of S rays after the other (grid-stride; the launcher sizes the grid to the chip): with one group per wave
-  // -- 262,144 waves of a single pass each at 1024^2 -- the kernel ran at a quarter of its instruction rate, waves leaving faster
-  // than the dispatcher replaced them (r04: 3.7-4.0 ms against 0.9 ms of issue).
-  for (int ray0 = (blockIdx.x * GRT_WAVES_PER_BLOCK + wave) * S; ray0 < nlive; ray0 += gridDim.x * GRT_WAVES_PER_BLOCK * S) {
-  __builtin_amdgcn_wave_barrier();                        // the previous group's reads of the LDS copies are done (in-order per wave)
-  asm volatile("" ::: "memory");
-  // the records of all S rays in ONE sweep of independent loads (r04: a loop over the rays -- index, then record, four times in a
-  // row -- left the wave waiting for eight dependent memory round trips before its single pass: 3.7 ms for 262,144 waves)
-  const int slot = lane / W, j = lane - slot * W;
-  const bool haveray = ray0 + slot < nlive;
-  const int rayidx = haveray ? live[ray0 + slot] : 0;
-  {
-    const int myri = (lane < S && ray0 + lane < nlive) ? live[ray0 + lane] : -1;     // lane sl holds the ray of slot sl
-    constexpr int TW = RW + RRW;
-#pragma unroll 8
-    for (int t = lane; t < S * TW; t += 64) {
-      const int sl = t / TW, w = t - sl * TW;
-      const int ri = __shfl(myri, sl);
-      if (ri >= 0) {
-        if (w < RW) reinterpret_cast<grt_word *>(&s_r[wave][sl][0])[w] = reinterpret_cast<const grt_word *>(rays + ri)[w];
-        else reinterpret_cast<grt_word *>(&s_rr[wave][sl][0])[w - RW] = reinterpret_cast<const grt_word *>(rrays + (size_t)ri * GRT_RR_STRIDE)[w - RW];
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("" ::: "memory");
-  const GrtRay *Rp = reinterpret_cast<const GrtRay *>(&s_r[wave][haveray ? slot : 0][0]);
-  const RealRay *Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][haveray ? slot : 0][0]);
-  const int n = Rp->npts;
-  const RealLeg leg = real_leg(cam, *Rp);
-  const int nreg = n - leg.nfill;
-  const int ctop = (nreg - 1) >> 6;
-  const int rtop = nreg - 64 * ctop;
-  const bool served = haveray && nreg > 0 && rtop <= W;   // (the same test as grt_geo_kernel's)
-  const int pos = 64 * ctop + j + 1;
-  const bool valid = served && j < rtop;
-  const int idx = (pos <= leg.lo) ? pos : pos + leg.nfill;
-  double phi_ref = cam.phi0;
-  if (PHI && fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);
-  GeoPoint P;
-  P.u = 1.0; P.mu = 0.0; P.dt = 0.0; P.dphi = 0.0; P.lam = 0.0; P.tpm = 0; P.tpr = 0;
-  UPart Sg;
-  bool usable = false, reset = true;
-  double fo[4] = {1.0, 1.0, 1.0, 1.0};
-#if defined(GRT_USEG_SHARE)
-  {
-    USegClass cl;
-    useg_classify(cam, *Rp, *Kp, valid ? idx : 0, cl, Sg, reset, usable);
-    double fn[4];
-    real_froots(*Kp, cl.ua, fo);                   // (complex-pair rays: unused)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double up = __shfl_down(fo[q], 1);     // (the top lane of a slot holds the anchor: no pair reaches into the next slot)
-      fn[q] = cl.lastinb ? Kp->froot[q] : up;
-    }
-    if (cl.pair) {
-      if (Kp->cplx) upair_diff<NPH>(*Kp, cl.ua, cl.ub, Sg);
-      else real_upair_pre<NPH>(*Kp, cl.ua, cl.ub, fo, fn, Sg);
-    }
-  }
-#else
-  useg_lane<NPH>(cam, *Rp, *Kp, valid ? idx : 0, Sg, reset, usable);
-#endif
-  double v[NQ];
-  v[0] = Sg.iu1; v[1] = Sg.tu11;
-  if (NQ > 2) v[2] = Sg.phiu1;
-  seg_suffix_scan<NQ>(v, reset, lane);                    // every chain of this chunk ends at its ray's top point (a reset lane)
-  Sg.iu1 = v[0]; Sg.tu11 = v[1];
-  if (NQ > 2) Sg.phiu1 = v[2];
-  if (valid) {
-    const UPart *pre = usable ? &Sg : nullptr;
-    if (NPH == 0) ray_point_real_branchy<false>(cam, *Rp, *Kp, idx, P, pre);
-    else ray_point_real<NPH>(cam, *Rp, *Kp, idx, P, pre);
-  }
-  const double LamN = __shfl(P.lam, slot * W + (served ? rtop - 1 : 0));
-  if (valid) {
-    double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
-    const double rr = (P.u > 0.0) ? frcp(P.u) : 0.0;
-    const double th = fast_acos(P.mu);
-    sp[GRT_F_R * field_stride] = (P.tpr & 1) ? -rr : rr;
-    sp[GRT_F_TH * field_stride] = (P.tpm & 1) ? -th : th;
-    sp[GRT_F_LAM * field_stride] = LamN - P.lam;
-    if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
-    if (j == 0) {
-      double *tc = tailc + (size_t)rayidx * 8;
-      tc[0] = v[0]; tc[1] = v[1]; tc[2] = (NQ > 2) ? v[2] : 0.0; tc[3] = LamN;
-      tc[4] = fo[0]; tc[5] = fo[1]; tc[6] = fo[2]; tc[7] = fo[3];
-    }
-  }
-  }
 }
 
 // standard=2 with nup > 1 (geodesics.f90:298-347): GEOR returns u_f < 0 where the ray does not reach the requested mu; such
@@ -611,6 +508,7 @@ extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *li
                                       double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield) {
   if (nrays <= 0) return hipSuccess;
+  note_launch("grt_trim_kernel");
   hipLaunchKernelGGL(grt_trim_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, rays, live, nlive_dev, nrays, ray_npts, steps, ray_stride,
                      field_stride, nfields, tfield);
   return hipGetLastError();
@@ -1255,6 +1153,7 @@ extern "C" hipError_t grt_launch_debug(hipStream_t s, int fluid, int emis, const
                                        long long ray_stride, long long field_stride, int tfield, double *out, int maxpts, double *scal) {
 #define GRT_DBG_CASE(F, E)                                                                                                               \
   if (fluid == F && emis == E) {                                                                                                         \
+    note_launch("grt_debug_kernelILi%dELi%dEE", F, E);                                                               \
     hipLaunchKernelGGL((grt_debug_kernel<F, E>), dim3(1), dim3(64), 0, s, *cam, rays, rayidx, *fd, *tb, *em, *plc, freq, steps, ray_stride, \
                        field_stride, tfield, out, maxpts, scal);                                                                          \
     return hipGetLastError();                                                                                                            \
@@ -1282,6 +1181,7 @@ __global__ __launch_bounds__(256) void grt_disk_kernel(GrtCam cam, GrtDisk disk,
 extern "C" hipError_t grt_launch_disk(hipStream_t s, const GrtCam *cam, const void *disk, long long i1,
                                       int nrays, int nfreq, const double *freqs, float *pixvals, int *ray_status,
                                       unsigned long long *step_counter, int nvals, int nextra, int bbpol, const long long *rng, int nrng) {
+  note_launch("grt_disk_kernel");
   hipLaunchKernelGGL(grt_disk_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, *cam, *(const GrtDisk *)disk, i1, nrays, nfreq, freqs, pixvals,
                      ray_status, step_counter, nvals, nextra, bbpol, rng, nrng);
   return hipGetLastError();
@@ -1313,6 +1213,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
   // GRT_POLAR_L2: experiment knob for the near-polar routing threshold (tools/polar_phi.py); the default is the product's
   static const double polar_l2 = std::getenv("GRT_POLAR_L2") ? std::atof(std::getenv("GRT_POLAR_L2")) : GRT_POLAR_L2_DEFAULT;
   GrtRayIn none{};
+  note_launch("grt_setup_kernel");
   hipLaunchKernelGGL(grt_setup_kernel, dim3(blocks), dim3(256), 0, s, *cam, i1, nrays, rays, ray_npts, live, counters,
                      (char *)rrays, need_time, polar_l2, rin ? *rin : none, rng, nrng);
   return hipGetLastError();
@@ -1322,8 +1223,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 // the grid is sized for, and the length of live[] (the generic class is read from its back)
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw,
-                                     double *tailc) {
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
   // the generic class is small as a rule: a capped grid that strides over its (ray, chunk) items
@@ -1340,29 +1240,12 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   // a Schwarzschild camera that needs the coordinate time has no fast class (grt_setup_kernel: `cubic` requires !(need_time & 1)):
   // its fast-class launch has nothing to do
   if (kind == 2 && nph == 3) return hipSuccess;
-  // partial top chunks to grt_geo_tail_kernel: a slot width that holds the top chunk of the camera's rays (captured rays have nup
-  // regular points, rays with a radial turning point nup - 2 kext when the mu-fill segment is on)
-  int tailw = 0;
-  if (kind == 1 && nph != 3 && !raw && tailc && !std::getenv("GRT_NO_GEO_TAIL")) {
-    const int r1 = (cam->nup - 1) % 64 + 1, n2 = cam->nup - 2 * cam->kext, r2 = (n2 > 0) ? (n2 - 1) % 64 + 1 : 64;
-    const int rmin = r1 < r2 ? r1 : r2;
-    tailw = rmin <= 16 ? 16 : (rmin <= 32 ? 32 : 0);
-    if (const char *e = std::getenv("GRT_GEO_TAILW")) tailw = std::atoi(e);
-    if (tailw != 16 && tailw != 32) tailw = 0;
-  }
-  if (tailw) {
-    const int S = 64 / tailw;
-    unsigned nbt = (unsigned)((nrays + S * GRT_WAVES_PER_BLOCK - 1) / (S * GRT_WAVES_PER_BLOCK));
-    if (nbt > 2048) nbt = 2048;                    // 8 blocks per CU: every wave serves several groups in turn
-    dim3 gt(nbt);
-    if (nph == 2) hipLaunchKernelGGL((grt_geo_tail_kernel<2>), gt, b, 0, s, *cam, rays, rr, live, nlive_dev, steps, ray_stride, field_stride, nfields, tailc, tailw);
-    else hipLaunchKernelGGL((grt_geo_tail_kernel<0>), gt, b, 0, s, *cam, rays, rr, live, nlive_dev, steps, ray_stride, field_stride, nfields, tailc, tailw);
-  }
   bool launched = false;
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P) {                                                                                          \
     launched = true;                                                                                                    \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw, tailc, (F == 1) ? tailw : 0); \
+    note_launch("grt_geo_kernelILi%dELi%dEE", F, P);                                                                    \
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw); \
   }
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE
@@ -1371,17 +1254,26 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
 }
 
 template <int IFLAG, int FLUID, int EMIS>
-static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
+static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
                               const double *freqs, float *pixvals, int npix_tile, int nvals, int *ray_status, long long i1,
                               double *steps, long long ray_stride, long long field_stride,
                               int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
+  // extra=1 kernels exist for the polarized transfer of emissivities that have the full coefficient set (the API refuses it for
+  // nvals = 1, the Pandya fits and the scalar family: grt_api.cpp) -- nothing is instantiated that nothing can launch
+  constexpr bool HAS_EXTRA = (IFLAG != GRT_INT_QUAD) && EMIS != GRT_EMIS_POLSYNCHSYMTH && EMIS != GRT_EMIS_SYNCHTHAV;
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
-    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
-                       rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps,
-                       ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+    if constexpr (HAS_EXTRA) {
+      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, 1, 1);
+      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
+                         rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps,
+                         ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+    } else {
+      return hipErrorInvalidValue;
+    }
   } else if (nfreq == 1) {
+    note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, 1, 0);
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
                        *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
                        field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
@@ -1390,10 +1282,12 @@ static void launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
     // DELO (which also parks the neighbour's j, K per frequency) 8/13/32 -> 258/281/345 ms at 512^2
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
+    note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, FBN, 0);
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
                        dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
                        nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   }
+  return hipGetLastError();
 }
 
 // returns hipErrorInvalidValue for a (fluid, emissivity, integrator) combination that has no kernel
@@ -1410,9 +1304,8 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   if (emis == GRT_EMIS_SYNCHTHAVNOABS || emis == GRT_EMIS_BREMS || emis == GRT_EMIS_SYNCHTHBREMS || emis == GRT_EMIS_RHO) emis = GRT_EMIS_SYNCHTHAV;
 #define GRT_XFER_CASE(I, F, E)                                                                                          \
   if (iflag == I && fluid == F && emis == E) {                                                                          \
-    launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals,      \
+    return launch_transfer_t<I, F, E>(s, extra, cam, rays, live, nlive, fd, tb, em, plc, nfreq, freqs, pixvals, npix_tile, nvals, \
                                ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);   \
-    return hipGetLastError();                                                                                           \
   }
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_FFJET, GRT_EMIS_POLSYNCHPL)

@@ -96,9 +96,17 @@ def test_ffjet_vs_reference_golden(dev, nx, nup, iname):
     pix, loc, status, st = run((nx, nx, nup), iname)
     assert np.array_equal(status, g["npts"])                 # bit-exact stored-point counts
     assert st.ray_steps == int(g["npts"].sum())
-    # against the compiled reference: >= 75 % of the fp32 values are the same bits (measured 80-82 %), no value above 1e-6 of its
-    # Stokes peak is off by more than 1e-4 relative (measured <= 2.8e-5 = 333 fp32 ulp, on Q/U/V next to their zero crossings)
-    assert stokes_err(pix[0], g["ivals_" + iname], min_identical=0.75, max_rel=1e-4) < STOKES_TOL
+    # against the compiled reference: the floor on the fraction of fp32 values with the SAME BITS is what r04 measured minus two points
+    # (100 x 100 x 400: 0.8242 formal / 0.8250 delo; 32 x 32 x 100: 0.7986 / 0.8013); no value above 1e-6 of its Stokes peak is off by
+    # more than 1e-4 relative (measured <= 2.8e-5 = 333 fp32 ulp, on Q/U/V next to their zero crossings).  Where the other 18 % come
+    # from (tools/attribute_fp32_flips.py, profiles/r04_c_fp32_flip_attribution.log): r and theta of the device's geodesics equal the
+    # reference's to 3e-16 / 2e-15, but the running intensity of a ray differs by 2e-10 ... 5e-8 of its maximum -- median 4e-9, i.e. 7 % of
+    # an fp32 rounding interval for I and more for Q, U, V, which are differences -- accumulated over 50-200 steps, none of which adds more
+    # than a fifth of it: the affine parameter.  GEOKERR's lambda carries a per-ray constant of ~1e3 ... 1e5, so d(lambda) between
+    # neighbouring points (1e-2 ... 1) has 1e-9 ... 1e-6 of relative rounding noise IN THE REFERENCE; the fast classes evaluate lambda by
+    # other formulas (segment sums, Zeta function) that are as accurate but round differently, the literal restatement (oracle) rounds
+    # like the reference and reaches 99.5 %.
+    assert stokes_err(pix[0], g["ivals_" + iname], min_identical=0.80 if nx == 100 else 0.775, max_rel=1e-4) < STOKES_TOL
     assert np.array_equal(loc[:, 0], g["cam_alpha"].astype(np.float32))
     assert np.array_equal(loc[:, 1], g["cam_beta"].astype(np.float32))
 
@@ -858,10 +866,15 @@ def test_frequency_batches_on_every_fluid_model(tmp_path):
         capi.geo_reuse(False)
         nn = (12, 12, 100)
         grid = [2.3e11 * x for x in (1.0, 0.3, 0.45, 0.9, 1.3, 1.8, 2.2, 2.6, 3.0)]
-        cases = (("KORAL3D", "POLSYNCHTH", dict(mbh=4e6, nfac=1.5, gmin=-1.), 0.9375), ("HARM", "POLSYNCHTH", dict(mbh=4e6, gmin=1., mdot=1.57e15), 0.9375),
-                 ("HARM3D", "POLSYNCHTH", dict(mbh=4e6, gmin=2., mdot=1e20), 0.9375), ("IHARM", "POLSYNCHTH", dict(mbh=4e6, gmin=3., mdot=1e20), 0.9375),
-                 ("HARM3D", "HYBRIDTHPL", dict(mbh=4e6, gmin=2., mdot=1e20), 0.9375), ("IHARM", "MAXJUTT", dict(mbh=4e6, gmin=3., mdot=1e20), 0.9375),
-                 ("SPHACC", "POLSYNCHTH", dict(mbh=10., gmin=100.), 0.0), ("FFJET", "POLSYNCHPL", dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 0.998))
+        # r04: EVERY (fluid model, emissivity) pair that has a kernel (grt_kernels.hip:grt_launch_transfer) -- the launch log of the r03
+        # suite showed 91 of 176 instantiations never started by any GPU test (tests/test_zz_instantiation_coverage.py holds the list to zero)
+        K3 = dict(mbh=4e6, nfac=1.5, gmin=-1.); H2 = dict(mbh=4e6, gmin=1., mdot=1.57e15); H3 = dict(mbh=4e6, gmin=2., mdot=1e20); IH = dict(mbh=4e6, gmin=3., mdot=1e20)
+        SP = dict(mbh=10., gmin=100.)
+        cases = (("KORAL3D", "POLSYNCHTH", K3, 0.9375), ("HARM", "POLSYNCHTH", H2, 0.9375), ("HARM3D", "POLSYNCHTH", H3, 0.9375), ("IHARM", "POLSYNCHTH", IH, 0.9375),
+                 ("HARM", "HYBRIDTHPL", H2, 0.9375), ("HARM3D", "HYBRIDTHPL", H3, 0.9375), ("IHARM", "HYBRIDTHPL", IH, 0.9375),
+                 ("HARM", "MAXJUTT", H2, 0.9375), ("HARM3D", "MAXJUTT", H3, 0.9375), ("IHARM", "MAXJUTT", IH, 0.9375),
+                 ("HARM", "POLSYNCHSYMTH", H2, 0.9375), ("HARM3D", "POLSYNCHSYMTH", H3, 0.9375), ("IHARM", "POLSYNCHSYMTH", IH, 0.9375), ("SPHACC", "POLSYNCHSYMTH", SP, 0.0),
+                 ("SPHACC", "POLSYNCHTH", SP, 0.0), ("FFJET", "POLSYNCHPL", dict(mbh=3.4e9, nfac=2.0, bfac=70.0, gmin=100.), 0.998))
         for fname, ename, emk, a in cases:
             gv = (-25., 25., -25., 25.) if fname in ("SPHACC", "FFJET") else (-13., 13., -13., 13.)
             cam = capi.make_camera(1, gv, nn, a, 0.5, 0.04, -0.5)
@@ -869,7 +882,7 @@ def test_frequency_batches_on_every_fluid_model(tmp_path):
                                 otherargs=(1.5, 1.0, 0.5) if ename == "MAXJUTT" else (1.0, 1.0))
             for iname in ("delo", "formal"):
                 singles = [capi.trace_tile(cam, 1, 144, fname, em, [x], iname) for x in grid]
-                if True:
+                if ename != "POLSYNCHSYMTH":      # (extra=1 is refused for the Pandya fits, as for the scalar emissivities)
                     # the extra=1 instantiation (up to 512 registers at one wave per SIMD) integrates the same Stokes vector
                     ex, _, stx, _ = capi.trace_tile(cam, 1, 144, fname, em, grid[:1], iname, nvals=4, nextra=19)
                     assert np.array_equal(stx, singles[0][2]), (fname, ename, iname, "extra")
@@ -881,6 +894,26 @@ def test_frequency_batches_on_every_fluid_model(tmp_path):
                     assert np.array_equal(st, singles[0][2]), (fname, ename, iname, nf)
                     for k in range(nf):
                         assert np.array_equal(pix[k], singles[k][0][0], equal_nan=True), (fname, ename, iname, nf, k)
+            # nvals = 1: the quadrature kernels (either iname), batches of 13 against single-frequency runs
+            singles = [capi.trace_tile(cam, 1, 144, fname, em, [x], "formal", nvals=1) for x in grid]
+            for nf in (2, 9):
+                pix, _, st, _ = capi.trace_tile(cam, 1, 144, fname, em, grid[:nf], "delo", nvals=1)
+                assert np.array_equal(st, singles[0][2]), (fname, ename, "nvals=1", nf)
+                for k in range(nf):
+                    assert np.array_equal(pix[k], singles[k][0][0], equal_nan=True), (fname, ename, "nvals=1", nf, k)
+            with pytest.raises(capi.GrtError):      # extra=1 with nvals=1: the reference reads opacity columns that do not exist there
+                capi.trace_tile(cam, 1, 144, fname, em, grid[:1], "formal", nvals=1, nextra=19)
+        # the scalar emissivities (nvals = 1 only): one instantiation per fluid model, em.type selects
+        for fname, emk, a in (("HARM", H2, 0.9375), ("HARM3D", H3, 0.9375), ("IHARM", IH, 0.9375), ("SPHACC", SP, 0.0), ("KORAL3D", K3, 0.9375)):
+            gv = (-25., 25., -25., 25.) if fname == "SPHACC" else (-13., 13., -13., 13.)
+            cam = capi.make_camera(1, gv, nn, a, 0.5, 0.04, -0.5)
+            em = capi.make_emis("SYNCHTHAV", emk["mbh"], emk.get("nfac", 1.0), emk.get("bfac", 6.0), emk["gmin"], 1e5, 3.5, muval=0.25, mdot=emk.get("mdot", 0.0))
+            singles = [capi.trace_tile(cam, 1, 144, fname, em, [x], "formal", nvals=1) for x in grid]
+            for nf in (2, 9):
+                pix, _, st, _ = capi.trace_tile(cam, 1, 144, fname, em, grid[:nf], "formal", nvals=1)
+                assert np.array_equal(st, singles[0][2]), (fname, "SYNCHTHAV", nf)
+                for k in range(nf):
+                    assert np.array_equal(pix[k], singles[k][0][0], equal_nan=True), (fname, "SYNCHTHAV", nf, k)
     finally:
         capi.geo_reuse(True)
         dev.close()
@@ -2158,37 +2191,3 @@ def test_open_cases_of_the_r03_sweeps_vs_compiled_reference(fdev, tmp_path, name
             err = np.abs(pix[k][okm].astype(np.float64) - ref[k][okm]).max(axis=0) / pk[k]
             assert np.all(err <= bar[k]), (name, rec, k, err, bar[k])
     capi.record_steps(False)
-
-
-def test_top_chunks_served_by_the_tail_kernel_equal_the_one_ray_per_wave_walk(fdev, monkeypatch):
-    # r04: the partial top chunk of a ray's regular points (394 = 6 x 64 + 10 on the headline camera) is evaluated by
-    # grt_geo_tail_kernel, 64 / W rays to a wave with the per-ray constants read through per-lane LDS addresses, and grt_geo_kernel
-    # starts one chunk lower with the segment sums and Lambda(npts) it left in tailc.  Same device functions per lane: the geodesic
-    # record, the status and the image must have the bits of the plain walk (GRT_NO_GEO_TAIL=1), for both slot widths, with and
-    # without the azimuth, on cameras whose top chunks hold 16 / 10 (nup 400), 32 / 26 (nup 160), 8 / 2 (nup 200) and 64 (nup 128:
-    # full top chunk for the captured rays, 58 for the others -> nothing served) points.
-    from grtrans_amd import capi
-    fdev.load_ffjet()
-    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
-    for nup, spin, mu0, gv in ((400, 0.998, 0.906, (-40., 20., -20., 40.)), (160, 0.9375, 0.3, (-15., 15., -15., 15.)),
-                               (200, 0.5, -0.6, (-20., 20., -20., 20.)), (128, 0.998, 0.906, (-40., 20., -20., 40.))):
-        nn = (40, 40, nup)
-        cam = capi.make_camera(1, gv, nn, spin, mu0, 0.01, -0.5)
-        for rec in (True, False):
-            capi.record_steps(rec)
-            out = {}
-            for mode, env in (("plain", {"GRT_NO_GEO_TAIL": "1"}), ("auto", {}), ("w16", {"GRT_GEO_TAILW": "16"}), ("w32", {"GRT_GEO_TAILW": "32"})):
-                monkeypatch.delenv("GRT_NO_GEO_TAIL", raising=False); monkeypatch.delenv("GRT_GEO_TAILW", raising=False)
-                for k, v in env.items():
-                    monkeypatch.setenv(k, v)
-                capi.geo_reuse(False)
-                pix, _, status, _ = capi.trace_tile(cam, 1, nn[0] * nn[1], "FFJET", em, [FREQ], "formal")
-                steps = capi.download_steps(0, nn[0] * nn[1], cam.nup + cam.next) if rec else None
-                out[mode] = (pix, status, steps)
-            for mode in ("auto", "w16", "w32"):
-                assert np.array_equal(out[mode][1], out["plain"][1]), (nup, rec, mode)
-                assert np.array_equal(out[mode][0], out["plain"][0], equal_nan=True), (nup, rec, mode)
-                if rec:
-                    assert np.array_equal(out[mode][2], out["plain"][2], equal_nan=True), (nup, rec, mode)
-    monkeypatch.delenv("GRT_NO_GEO_TAIL", raising=False); monkeypatch.delenv("GRT_GEO_TAILW", raising=False)
-    capi.record_steps(False); capi.geo_reuse(True)
