@@ -1281,7 +1281,11 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
     // DELO (which also parks the neighbour's j, K per frequency) 8/13/32 -> 258/281/345 ms at 512^2
+#if defined(GRT_FBN_FORMAL) && defined(GRT_FBN_DELO)      // experiment builds: other batch sizes
+    constexpr int FBN = (IFLAG == GRT_INT_DELO) ? GRT_FBN_DELO : GRT_FBN_FORMAL;
+#else
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
+#endif
     note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, FBN, 0);
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
                        dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,

@@ -8,6 +8,13 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from grtrans_amd import capi
 from oracle import orabind
+# GRT_FUZZ_COND_REF=1 (r04): the conditioning / amplification classifier perturbs the COMPILED REFERENCE (oracle/_ref
+# through oracle/refbind.py) instead of the C++ restatement; the device is still compared with the restatement (which equals the
+# reference to 1e-9 on these problems: tests/test_oracle_vs_golden.py), so a waiver then rests on the reference's own behaviour
+COND_REF = bool(os.environ.get("GRT_FUZZ_COND_REF"))
+if COND_REF:
+    from oracle import refbind
+    assert refbind.available(), "GRT_FUZZ_COND_REF needs oracle/_ref (oracle/build_ref.sh)"
 ncams = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 import tempfile
@@ -89,6 +96,21 @@ for c in range(ncams):
             print("   non-finite masks differ at frequency %d, pixels %s: dev %s ref %s" % (k, bm[:4] + i1, pix[k][bm[:2]], ref[k][bm[:2]]))
         same_nan = same_nan and same_k
     flag = "" if (ok_n and err < tol and same_nan) else "  <-- MISMATCH"
+
+    def engine(**chg):      # the problem with some parameters changed, on the engine the classifier perturbs
+        kw = dict(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td)
+        kw.update(okw); kw.update(chg)
+        if COND_REF and fname in ("FFJET", "SPHACC"):
+            kw.pop("datadir")          # (the reference reads the FFJET table relative to its data directory)
+        return (refbind.Ref if COND_REF else orabind.Oracle)(**kw)
+
+    def etrace(e, fr):
+        p_, n_, _ = e.trace(i1, i2, fr, nthreads=1 if COND_REF else 0)
+        return np.asarray(p_, dtype=np.float64), n_, None
+    if flag and ok_n and COND_REF:
+        cref, crn, _ = etrace(engine(), freqs)      # the unperturbed answer of the engine the perturbations are compared with
+    else:
+        cref, crn = ref, rn
     if flag and ok_n:
         # the reference's own noise floor on this problem: the oracle against itself with every frequency moved by one ulp
         # either way and by 1e-13 (relative) either way -- less than anyone can specify an observing frequency to.  Two
@@ -100,29 +122,30 @@ for c in range(ncams):
         for rel in (None, None, 1e-13, -1e-13):
             up = rel is None and floor == 0.0
             fp = [float(np.nextafter(f, np.inf if up else 0.0)) if rel is None else float(f * (1 + rel)) for f in freqs]
-            rp, _, _ = o.trace(i1, i2, fp, nthreads=0)
+            rp, _, _ = etrace(engine(), fp) if COND_REF else o.trace(i1, i2, fp, nthreads=0)
             for k in range(len(freqs)):
-                okm = np.isfinite(ref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
+                okm = np.isfinite(cref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
                 if okm.any():
-                    floor = max(floor, (np.abs(rp[k][okm] - ref[k][okm]).max(axis=0) / (np.abs(ref[k][okm]).max(axis=0) + 1e-300)).max())
-                same_nan = same_nan or not np.array_equal(~np.isfinite(ref[k]), ~np.isfinite(rp[k]))
+                    floor = max(floor, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max())
+                same_nan = same_nan or not np.array_equal(~np.isfinite(cref[k]), ~np.isfinite(rp[k]))
         # ... and with the camera moved by one ulp in inclination (and spin): the reference's affine parameter carries
         # ~1e-9 of relative rounding noise (differences of elliptic integrals), d(lambda) between neighbouring points 1e-7,
         # which a Faraday-conversion depth of tens of radians per step turns into 1e-5 of V
         # (geokerr's lambda carries a constant of up to ~4e8 for near-polar cameras, so lambda itself is quantised at 6e-8
         # and dx between neighbouring points at up to 7e-7 of its value; one ulp of uout re-rolls that rounding)
-        for da, dm, du in ((0, 1, 0), (1, 0, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+        # (an equatorial camera has mu0 = 0, where "one ulp" is a denormal and changes nothing: the inclination also moves by 1e-15 rad, r04)
+        for da, dm, du in ((0, 1, 0), (1, 0, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (0, 2, 0), (0, -2, 0)):
             if da and a == 0.0:
                 continue
-            op = orabind.Oracle(nn=nn, iname=iname, spin=float(np.nextafter(a, 2.0)) if da else a, mu0=float(np.nextafter(mu0, dm * 2.0)) if dm else mu0,
-                                gridvals=gv, uout=float(np.nextafter(uout, du * 1.0)) if du else uout, fname=fname, ename=ename, datadir=td, **okw)
-            rp, rnp, _ = op.trace(i1, i2, freqs, nthreads=0)
-            if not np.array_equal(rnp, rn):
+            mu0p = (mu0 + (1e-15 if dm > 0 else -1e-15)) if abs(dm) == 2 else (float(np.nextafter(mu0, dm * 2.0)) if dm else mu0)
+            op = engine(spin=float(np.nextafter(a, 2.0)) if da else a, mu0=mu0p, uout=float(np.nextafter(uout, du * 1.0)) if du else uout)
+            rp, rnp, _ = etrace(op, freqs)
+            if not np.array_equal(rnp, crn):
                 continue
             for k in range(len(freqs)):
-                okm = np.isfinite(ref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
+                okm = np.isfinite(cref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
                 if okm.any():
-                    floor = max(floor, (np.abs(rp[k][okm] - ref[k][okm]).max(axis=0) / (np.abs(ref[k][okm]).max(axis=0) + 1e-300)).max())
+                    floor = max(floor, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max())
         o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)   # the library holds one problem
         if err < 10 * floor and same_nan:
             flag = "  (ill-conditioned in the reference: it moves by %.1e itself when the frequency changes by 1e-13 or the camera by one ulp)" % floor; cond += 1
@@ -133,11 +156,12 @@ for c in range(ncams):
             # multiplies whatever difference reaches the last steps by 10-100 per step.
             amp = 0.0
             for rel in (1e-8, -1e-8):
-                rp, _, _ = o.trace(i1, i2, [float(f * (1 + rel)) for f in freqs], nthreads=0)
+                fp = [float(f * (1 + rel)) for f in freqs]
+                rp, _, _ = etrace(engine(), fp) if COND_REF else o.trace(i1, i2, fp, nthreads=0)
                 for k in range(len(freqs)):
-                    okm = np.isfinite(ref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
+                    okm = np.isfinite(cref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
                     if okm.any():
-                        amp = max(amp, (np.abs(rp[k][okm] - ref[k][okm]).max(axis=0) / (np.abs(ref[k][okm]).max(axis=0) + 1e-300)).max() / 1e-8)
+                        amp = max(amp, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max() / 1e-8)
             if amp > 30.0 and err < amp * 1e-7:
                 flag = "  (amplified by the reference's own integrator: a 1e-8 change of the frequency moves its answer by %.0f x 1e-8)" % amp; ampl += 1
     bad += ("MISMATCH" in flag)
