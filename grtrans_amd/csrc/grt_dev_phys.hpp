@@ -580,7 +580,10 @@ GRT_HD void polsynchth(double nu, double n, double B, double T, double theta, do
 // SYM: POLSYNCHSYMTH (sympolemisth, polsynchemis.f90:915-969) -- the Pandya et al. (2016) fitting functions replace the
 // emissivities (absorption by Kirchhoff's law as before), the Faraday coefficients are the same.
 // HAVE_SC: the caller hands sin and cos of the field / wave-vector angle over (sth_in, cth_in) and theta is not looked at
-template <bool SYM = false, bool HAVE_SC = false>
+// TSKIP: the two wave-uniform short cuts below (exactly-zero extraterm, exactly-one step function).  They pay where the plasma is hot
+// and x small (HARM transfer 46.1 -> 43.6 ms); the SPHACC kernel, whose outer points are neither, is 1.7 % slower with them and
+// keeps the plain form.
+template <bool SYM = false, bool HAVE_SC = false, bool TSKIP = true>
 GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double theta, double *e, double sth_in = 0.0, double cth_in = 1.0) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi, k = PH_k;
   const double nucminval = 1.0, thetaemin = 1e-10, s3 = 1.7320508075688772;
@@ -629,9 +632,23 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   const double omega0 = B * (ec / m / c);
   const double x = thetae * fsqrt(1.4142135623730951 * sth * (omega0 * (1e3 / 2.0 / pi)) * frcp(nu));
   // jffunc, shgmfunc (polsynchemis.f90:799-822)
-  const double lx = log(x), lxe = log(x + 1e-16);
+  const double lx = log(x);
   const double e472 = exp(x * (-1.0 / 47.2));
-  const double extraterm = (.011 * e472 - 369.69342869090826 * exp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh((lx - 4.787491742782046) * 10.0));
+  // extraterm = (...) (1/2 + 1/2 tanh(10 (ln x - ln 120))) is EXACTLY zero below x = 13: tanh of an argument under -22 is -1.0 in both
+  // the device's and glibc's libm, and the bracket is finite (the 1e-16 under the logarithm keeps exp(-8/3 ln x) below 4e42).  At the
+  // observing frequencies of the BASELINE configurations x = theta_e sqrt(sqrt2 sin(th) 1e3 nu_B / nu) is of order 1-10, so a wave
+  // usually skips the logarithm, the exponential and the tanh (r04: ~150 of the ~2,800 VALU instructions of a thermal step).  The branch
+  // is wave-uniform; lanes of a wave that does not skip evaluate the expression as written.
+  const double targ = (lx - 4.787491742782046) * 10.0;
+  double extraterm = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!TSKIP || __builtin_amdgcn_ballot_w64(!(targ < -22.0)) != 0ull) {
+#else
+  if (!TSKIP || !(targ < -22.0)) {
+#endif
+    const double lxe = log(x + 1e-16);
+    extraterm = (.011 * e472 - 369.69342869090826 * exp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh(targ));
+  }
   const double jff = 2.011 * exp(exp(1.035 * lx) * (-1.0 / 4.7)) - cos(x / 2.0) * exp(exp(1.2 * lx) * (-1.0 / 2.73)) - .011 * e472 + extraterm;
   const double w = 2.0 * pi * nu, iw = frcp(w), iw3 = iw * iw * iw;
   // No DIVERGENT branch on thetae (r03).  The if-else that stood here was where hipcc's register allocator saved two loop-carried
@@ -649,7 +666,14 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
     const double it = frcp(warm ? thetae : 1.0);
     const double k0 = besselk0(it), k1 = besselk1(it), k2 = k0 + 2.0 * thetae * k1, ik2 = frcp(k2);     // besselk(2, 1/thetae)
     const double shgm = (double)0.43793091f * log(1.0 + (double)0.00185777f * exp((double)1.50316886f * lx));
-    const double step = 0.5 + 0.5 * tanh((thetae - 1.0) * 20.0);
+    // (the step function is exactly 1 above theta_e = 2.1 -- tanh(22) = 1.0 in double --: hot zones skip the tanh, wave-uniformly)
+    const double sarg = (thetae - 1.0) * 20.0;
+    double step = 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!TSKIP || __builtin_amdgcn_ballot_w64(warm && !(sarg > 22.0)) != 0ull) step = 0.5 + 0.5 * tanh(sarg);
+#else
+    if (!TSKIP || !(sarg > 22.0)) step = 0.5 + 0.5 * tanh(sarg);
+#endif
     const double w11 = e11c * (k1 * ik2 + 6.0 * thetae) * (sth * sth), w12 = e12c * (k0 - step * shgm) * ik2 * cth;
     eps11m22 = warm ? w11 : eps11m22;
     eps12 = warm ? w12 : eps12;
@@ -875,8 +899,12 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
   bool inside = x1 > x1lo;
   float td = (theta - t.uniqth[lx2 - 1]) / (t.uniqth[ux2 - 1] - t.uniqth[lx2 - 1]);
   float rd = (zr - t.uniqr[lx1c - 1]) / (t.uniqr[ux1c - 1] - t.uniqr[lx1c - 1]);
+#if defined(GRT_SAMPLE_CONST_ZONE)
+  const float *c00 = t.cells + (size_t)((nx1 / 2) + (nx1 / 2) * nx1) * 12, *c01 = c00 + (size_t)nx1 * 12;
+#else
   const float *c00 = t.cells + (size_t)((lx1c - 1) + (lx2 - 1) * nx1) * 12;   // (x1l, x2l); +12 -> x1u
   const float *c01 = t.cells + (size_t)((lx1c - 1) + (ux2 - 1) * nx1) * 12;   // (x1l, x2u)
+#endif
   float q[10];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -1084,8 +1112,12 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
   const float rh = 1.f + sqrtf(1.f - a * a);
   if (uniqr[lx1c - 1] <= rh) rd = 1.f;                                                     // :165-167
   const float *slice = t.cells + (size_t)tindx * nx1 * nx2 * 12;
+#if defined(GRT_SAMPLE_CONST_ZONE)   // experiment (timing only, DESIGN 4 "what the L2-resident table costs"): every lane gathers the same zone
+  const float *c00 = slice + (size_t)((nx1 / 2) * nx2 + nx2 / 2) * 12, *c01 = c00 + 12;
+#else
   const float *c00 = slice + (size_t)((lx1c - 1) * nx2 + (lx2c - 1)) * 12;   // (x1l, x2l)
   const float *c01 = slice + (size_t)((lx1c - 1) * nx2 + (ux2 - 1)) * 12;    // (x1l, x2u)
+#endif
   const float *c10 = c00 + (size_t)nx2 * 12, *c11 = c01 + (size_t)nx2 * 12;    // x1u
   float q[10];
 #if defined(__HIP_DEVICE_COMPILE__)

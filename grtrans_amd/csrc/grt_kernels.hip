@@ -235,8 +235,14 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 
 // FAST: 0 generic (every root case), 1 four real roots, 2 Schwarzschild cubic
 // NPH : 0 no azimuth, 2 azimuth (per-step record / extra=1), 3 azimuth + coordinate time (slow-light fluid models)
+// Waves per SIMD by instantiation (r04, after MachineLICM went): the image-only four-real-root kernel runs 20 % faster at THREE waves
+// (168 registers, 144 B/lane of scratch: 21.6 -> 17.2 ms at 1024^2 x 400); the record-mode kernel, which holds the azimuth's extra live
+// values, is 6 % slower there (38.1 -> 40.6 ms) and stays at two.
+#ifndef GRT_WPE_GEO_OF
+#define GRT_WPE_GEO_OF(FAST, NPH) (((FAST) == 1 && (NPH) == 0) ? 3 : GRT_WPE_GEO)
+#endif
 template <int FAST, int NPH>
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO) void grt_geo_kernel(
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
     long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
@@ -763,6 +769,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
       // not unrolled on purpose: FB copies of the coefficient + propagator code cost more (900 ms against 658 ms
       // for 25 frequencies at 1024x1024x400) than indexing the per-frequency intensities dynamically
 #pragma clang loop unroll(disable)
+      constexpr bool TSK = (FLUID != GRT_FLUID_SPHACC);      // polsynchth_fast's wave-uniform short cuts (see there)
       for (int f = 0; f < FB; ++f) {
         if (f < nf) {
           const double nu = freqs[f0 + f] * igs;
@@ -775,10 +782,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
             if (IFLAG == GRT_INT_QUAD && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL)
               e11[0] *= (double)1.7320508075688772f / 1.7320508075688772;
           }
-          else if (EMIS == GRT_EMIS_POLSYNCHTH && !WANT_ANG) polsynchth_fast<false, true>(nu, ncgs, bcgs, tcgs, 0.0, e11, fsqrt((1.0 - cang) * (1.0 + cang)), cang);
-          else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
-          else if (EMIS == GRT_EMIS_POLSYNCHSYMTH && !WANT_ANG) polsynchth_fast<true, true>(nu, ncgs, bcgs, tcgs, 0.0, e11, fsqrt((1.0 - cang) * (1.0 + cang)), cang);
-          else if (EMIS == GRT_EMIS_POLSYNCHSYMTH) polsynchth_fast<true>(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_POLSYNCHTH && !WANT_ANG) polsynchth_fast<false, true, TSK>(nu, ncgs, bcgs, tcgs, 0.0, e11, fsqrt((1.0 - cang) * (1.0 + cang)), cang);
+          else if (EMIS == GRT_EMIS_POLSYNCHTH) polsynchth_fast<false, false, TSK>(nu, ncgs, bcgs, tcgs, ang, e11);
+          else if (EMIS == GRT_EMIS_POLSYNCHSYMTH && !WANT_ANG) polsynchth_fast<true, true, TSK>(nu, ncgs, bcgs, tcgs, 0.0, e11, fsqrt((1.0 - cang) * (1.0 + cang)), cang);
+          else if (EMIS == GRT_EMIS_POLSYNCHSYMTH) polsynchth_fast<true, false, TSK>(nu, ncgs, bcgs, tcgs, ang, e11);
           else if (EMIS == GRT_EMIS_MAXJUTT) {
             // calc_maxjutt_subroutine (calc_maxjutt.f90:8-63): thermal components w_i n at T delta^i / sum_i w_i delta^i
             const GrtEmis emj = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
@@ -1284,7 +1291,10 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
 #if defined(GRT_FBN_FORMAL) && defined(GRT_FBN_DELO)      // experiment builds: other batch sizes
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? GRT_FBN_DELO : GRT_FBN_FORMAL;
 #else
-    constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : 13;
+    // r04 (no MachineLICM): formal 5 / 9 / 13 / 25 per batch -> 433 / 423 / 403 / 389 ms for 25 frequencies at 1024^2, DELO 5 / 6 / 8 / 13 ->
+    // 625 / 621 / 603 / 642 ms: one batch holds BASELINE config 5's whole frequency grid (the intensities of a batch live in scratch
+    // either way -- 800 B/lane at 25 --, what counts is how many frequencies share a point's fluid sample and tetrad)
+    constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : (IFLAG == GRT_INT_FORMAL ? 25 : 13);
 #endif
     note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, FBN, 0);
     hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
