@@ -111,6 +111,7 @@ struct Ctx {
   int force_time = 0;                   // grt_debug_ray: every point carries its coordinate time whatever the fluid model
   int geo_reuse = 1;                    // grt_set_geo_reuse
   int class_order = 3;
+  bool class_order_forced = false;     // GRT_CLASS_ORDER given: its wait bit holds for every pass size
   long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
   int n_class[2] = {0, 0};              // class sizes of the resident record
   std::vector<long long> last_tile;     // (lo, hi) pairs of the last trace call: the rows a time-origin table (grt_set_t0) refers to
@@ -175,6 +176,7 @@ int grt_init(int device) {
     // waits for the generic geodesic kernel
     const char *po = std::getenv("GRT_CLASS_ORDER");
     C.class_order = po ? std::atoi(po) : 7;
+    C.class_order_forced = po != nullptr;
     HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
   }
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
@@ -748,7 +750,10 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
-        if (!reuse && (C.class_order & 4) && turn == 0) {
+        // (r04: the wait pays on a whole image -- 74.7 against 75.0 ms at 1024^2 -- but a rank's share of an 8-GPU run is short enough
+        //  for the generic chain to hide under the fast one without it: predicted efficiency at N = 8 0.869 -> 0.891, N = 4 0.932 -> 0.935;
+        //  GRT_CLASS_ORDER set explicitly decides for every size)
+        if (!reuse && (C.class_order & 4) && turn == 0 && (C.class_order_forced || nch > 400000)) {
           // The generic geodesic kernel is ~1.4 ms of work for this camera but starves beside the fast-class kernel (it needs a
           // whole SIMD per wave plus scratch: profiles/r02_a timeline, 73-114 ms when overlapped), and its transfer kernel -- a
           // few blocks, but 454 sequential steps per lane = 3.4 ms of latency -- then trails the whole trace.  Let the

@@ -236,10 +236,11 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 // FAST: 0 generic (every root case), 1 four real roots, 2 Schwarzschild cubic
 // NPH : 0 no azimuth, 2 azimuth (per-step record / extra=1), 3 azimuth + coordinate time (slow-light fluid models)
 // Waves per SIMD by instantiation (r04, after MachineLICM went): the image-only four-real-root kernel runs 20 % faster at THREE waves
-// (168 registers, 144 B/lane of scratch: 21.6 -> 17.2 ms at 1024^2 x 400); the record-mode kernel, which holds the azimuth's extra live
+// (168 registers, 144 B/lane of scratch: 21.6 -> 17.2 ms at 1024^2 x 400) and so do the Schwarzschild-cubic kernels (SPHACC: 17.4 ->
+// 14.9 ms image only, 21.0 -> 18.8 ms with the record); the record-mode four-real-root kernel, which holds the azimuth's extra live
 // values, is 6 % slower there (38.1 -> 40.6 ms) and stays at two.
 #ifndef GRT_WPE_GEO_OF
-#define GRT_WPE_GEO_OF(FAST, NPH) (((FAST) == 1 && (NPH) == 0) ? 3 : GRT_WPE_GEO)
+#define GRT_WPE_GEO_OF(FAST, NPH) ((((FAST) == 1 && (NPH) == 0) || (FAST) == 2) ? 3 : GRT_WPE_GEO)
 #endif
 template <int FAST, int NPH>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)) void grt_geo_kernel(
@@ -768,8 +769,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
 
       // not unrolled on purpose: FB copies of the coefficient + propagator code cost more (900 ms against 658 ms
       // for 25 frequencies at 1024x1024x400) than indexing the per-frequency intensities dynamically
-#pragma clang loop unroll(disable)
       constexpr bool TSK = (FLUID != GRT_FLUID_SPHACC);      // polsynchth_fast's wave-uniform short cuts (see there)
+#pragma clang loop unroll(disable)
       for (int f = 0; f < FB; ++f) {
         if (f < nf) {
           const double nu = freqs[f0 + f] * igs;
