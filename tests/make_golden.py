@@ -173,6 +173,25 @@ def harm(nx, nup, nzone=64):
     np.savez_compressed(os.path.join(G, "harm_rays_%dx%dx%d.npz" % (nx, nx, nup)), freq=FREQ_HARM, nzone=nzone, **rays)
 
 
+def harm_config4_zones(nx=64, nup=400, nzone=256):
+    # BASELINE config 4's dump size (256 x 256 zones, the size bench.py and test_config4_full_size_properties use) on a 64 x 64 x 400
+    # camera of the same field of view: the compiled reference's image, so that the full-size test's flux and a 64 x 64 device image
+    # are held to the REFERENCE on that dump, not to the device's own small camera
+    import hashlib
+    import tempfile
+    import make_harm_dump
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = make_harm_dump.write(td, n=nzone)
+        out["dump_sha256"] = np.array(hashlib.sha256(open(path, "rb").read()).hexdigest())
+        for iname in ("formal", "delo"):
+            r = R.Ref(nn=(nx, nx, nup), iname=iname, datadir=td, **HARM)
+            pix, npts, _ = r.trace(1, nx * nx, [FREQ_HARM], nthreads=8)
+            out["ivals_" + iname] = pix[0]
+            out["npts"] = npts
+    np.savez_compressed(os.path.join(G, "harm_zones%d_%dx%dx%d.npz" % (nzone, nx, nx, nup)), freq=FREQ_HARM, nzone=nzone, **out)
+
+
 def nvals1():
     # nvals=1: emissivity/absorption of Stokes I only and the quadrature integrator (radtrans_integrate.f90:878)
     out = {}
@@ -885,6 +904,7 @@ if __name__ == "__main__":
     ffjet(32, 100)
     sphacc(64, 200)
     harm(48, 200)
+    harm_config4_zones()
     nvals1()
     extra()          # ref_driver.f90's restated diagnostics (kept as the npts source) ...
     extra_main()     # ... overwritten by the reference's own grtrans_driver

@@ -1876,8 +1876,10 @@ def test_config3_full_size_properties(fdev):
 
 def test_config4_full_size_properties(fdev, tmp_path):
     # BASELINE config 4 at its full size: HARM POLSYNCHTH nvals=4 nn=[512,512,400] on the 256 x 256-zone synthetic dump
-    # (dump040 itself does not ship with the reference).  The flux reference is the device's own 64 x 64 x 400 camera of the same
-    # dump: the compiled-reference golden is on the 64-zone dump (test_harm_polsynchth_vs_reference_golden holds that one).
+    # (dump040 itself does not ship with the reference).  r04: the flux reference is the COMPILED REFERENCE's 64 x 64 x 400 image of that
+    # same 256-zone dump (tests/golden/harm_zones256_64x64x400.npz), and the device's own 64 x 64 image is held to it pixel by pixel
+    # first -- the full-size image is then compared with the reference, not with the device itself.
+    import hashlib
     import sys
     from grtrans_amd import capi
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -1885,11 +1887,18 @@ def test_config4_full_size_properties(fdev, tmp_path):
     make_harm_dump.write(str(tmp_path), n=256)
     fdev.load_harm(os.path.join(str(tmp_path), "dump"), os.path.join(str(tmp_path), "dump040"), 40, 0.9375)
     em = capi.make_emis("POLSYNCHTH", 4e6, 1.0, 6.0, 1., 1e5, 3.5, muval=0.25, mdot=1.57e15)
+    g = np.load(os.path.join(G, "harm_zones256_64x64x400.npz"))
+    assert hashlib.sha256(open(os.path.join(str(tmp_path), "dump040"), "rb").read()).hexdigest() == str(g["dump_sha256"])
     small = capi.make_camera(1, (-13., 13., -13., 13.), (64, 64, 400), 0.9375, 0.6428, 0.04, -0.5)
     ref = {}
     for iname in ("formal", "delo"):
-        p = capi.trace_tile(small, 1, 4096, "HARM", em, [FREQ_HARM], iname)[0]
-        ref[iname] = np.nansum(p[0][:, 0].astype(float)) / 4096.0
+        p, _, st, _ = capi.trace_tile(small, 1, 4096, "HARM", em, [FREQ_HARM], iname)
+        assert np.array_equal(st, g["npts"])
+        want = g["ivals_" + iname]
+        assert np.array_equal(np.isfinite(p[0]), np.isfinite(want))
+        ok = np.isfinite(want).all(axis=1)
+        assert stokes_err(p[0][ok], want[ok]) < STOKES_TOL, iname
+        ref[iname] = np.nansum(want[:, 0].astype(float)) / 4096.0
     nn = (512, 512, 400)
     cam = capi.make_camera(1, (-13., 13., -13., 13.), nn, 0.9375, 0.6428, 0.04, -0.5)
 

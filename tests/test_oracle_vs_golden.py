@@ -591,3 +591,20 @@ def test_open_cases_of_the_r03_sweeps(tmp_path, name):
         assert np.array_equal(np.isfinite(pix[k]), np.isfinite(ref[k]))
         okm = np.isfinite(ref[k]).all(axis=1)
         assert np.all(np.abs(pix[k][okm] - ref[k][okm]).max(axis=0) / pk[k] < 2e-9), (name, k)
+
+
+def test_harm_on_the_config4_dump_size(tmp_path):
+    # the 256 x 256-zone dump BASELINE config 4 runs on (bench.py, the full-size GPU test), 64 x 64 x 400 camera: restatement against the
+    # compiled reference's image (tests/golden/harm_zones256_64x64x400.npz)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_harm_dump
+    make_harm_dump.write(str(tmp_path), n=256)
+    g = load("harm_zones256_64x64x400.npz")
+    for iname in ("formal", "delo"):
+        o = O.Oracle(nn=(64, 64, 400), iname=iname, datadir=str(tmp_path), **HARM)
+        pix, npts, _ = o.trace(1, 4096, [float(g["freq"])], nthreads=8)
+        assert np.array_equal(npts, g["npts"])
+        ref = g["ivals_" + iname].astype(float)
+        err = np.abs(pix[0].astype(float) - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 1e-6, (iname, err)
