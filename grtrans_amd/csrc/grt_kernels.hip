@@ -302,13 +302,21 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)
   // 29.0 -> 24.7 ms with the record
 #if defined(GRT_LDS_NPH3)
   constexpr bool LDSHYB = (FAST == 1 && (NPH == 2 || NPH == 3));
-#else
+#elif defined(GRT_LDSHYB_NPH2)   // the r03 / early-r04 record-mode kernel: ladders and series constants only
   constexpr bool LDSHYB = (FAST == 1 && NPH == 2);
-#endif
-#if defined(GRT_LDSRR_NPH3)    // experiment: the r03 failure (whole RealRay through LDS in the slow-light kernel)
-  constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 3)) || FAST == 2;
 #else
+  constexpr bool LDSHYB = false;
+#endif
+  // r04, once MachineLICM was off (Makefile): the record-mode kernel takes the WHOLE record from LDS as well -- the loads are no longer
+  // hoisted into registers held across the pass (231 VGPRs, 40 B/lane of scratch as before, 18 spilled SGPRs instead of 39), and 43 of
+  // the 94 scalar-memory waits of a pass had fewer than five vector instructions between the load and its wait: 37.9 -> 36.8 ms at
+  // 1024^2 x 400 (profiles/r04_e_variants_ldsrr2.log).  The slow-light kernel <1,3> keeps its scalar loads: no workload to time it on.
+#if defined(GRT_LDSRR_NPH3)    // experiment: the r03 failure (whole RealRay through LDS in the slow-light kernel)
+  constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 2 || NPH == 3)) || FAST == 2;
+#elif defined(GRT_LDSHYB_NPH2) || defined(GRT_LDS_NPH3)
   constexpr bool LDSRR = (FAST == 1 && NPH == 0) || FAST == 2;
+#else
+  constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 2)) || FAST == 2;
 #endif
   constexpr int RRW = ((FAST == 2 ? sizeof(CubRay) : sizeof(RealRay)) + 7) / 8;
   __shared__ double s_rr[(LDSRR || LDSHYB) ? GRT_WAVES_PER_BLOCK : 1][(LDSRR || LDSHYB) ? RRW : 1];
@@ -530,8 +538,17 @@ extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *li
 // segment, the tile is then read transposed (lane = ray).  The per-step I,Q,U,V record goes back through the
 // same tile buffers (a slot is overwritten only after its own lane has consumed it).
 // Frequencies are processed FB at a time (blockIdx.y = batch): the intensities of a batch live in registers.
-#define GRT_TS 8                 // tile row stride in doubles (8 steps; unpadded: 4 buffers x 8 waves must fit the 160 KB LDS,
-                                 // and the 8-way bank conflict of the transposed read is noise next to ~1e4 cycles of VALU per step)
+// Tile depth (TSH = log2 of the steps per tile, a template parameter of the kernel).  8 steps (TSH = 3) is the general one: unpadded, 4
+// buffers x 4 waves = 64 KB a block, two blocks a CU; the 8-way bank conflict of the transposed read is noise next to ~1e4 cycles of
+// VALU per step.  4 steps (TSH = 2) halves the tile buffers: three blocks fit a CU, and an instantiation that also fits 168 registers
+// runs THREE waves per SIMD.  r04, 1024^2 x 400 image only: FFJET formal 31.0 -> 29.9 ms, HARM formal 43.3 -> 39.7, SPHACC formal
+// 31.2 -> 29.8, the 25-frequency FFJET batch 359 -> 336 ms (it fits 157 registers as it is); DELO does not gain (168 registers cost it
+// 100 B/lane of scratch: 29.8 -> 30.2 ms).  NOT with the per-step record: its I,Q,U,V go back through the same tiles, 32-byte pieces of
+// 128-byte lines that leave L2 before their neighbours arrive (FFJET formal 33.4 -> 34.5 ms at three waves, 35.7 at two) -- the record
+// launches keep the 8-step tile.  Instantiated only where measured (xfer_tile4); profiles/r04_e_variants_tile4*.log.
+#ifndef GRT_TSH
+#define GRT_TSH 3                // the general tile depth
+#endif
 #define GRT_XFER_THREADS 256
 // EXTRA (FB = 1 only): the 19 ray diagnostics of EXTRA_QUANTS=1 (grtrans_driver.f90:230-292) as running sums of
 // the same far-end -> camera walk: six optical depths, emission-weighted means through the attenuated-sum
@@ -552,20 +569,21 @@ template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 
   return out;
 }
 
-template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA>
-__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void grt_transfer_kernel(
+template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA, int TSH>
+__global__ __launch_bounds__(GRT_XFER_THREADS, ((TSH == 2 && FB == 1) ? 3 : GRT_XFER_WPE(EMIS, FLUID))) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive_arg, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps,
     long long ray_stride, long long field_stride, int nfields, int tfield, unsigned long long *__restrict__ step_counter,
     const int *__restrict__ nlive_dev, int from_back) {
   constexpr int NW = GRT_XFER_THREADS / 64;
+  constexpr int TS = 1 << TSH;      // steps per tile = tile row stride in doubles
   // class size from the set-up kernel's device counter (no host round trip between the launches); the grid covers the
   // worst case nlive_arg and surplus blocks leave before they stage anything
   const int nlive = nlive_dev ? *nlive_dev : nlive_arg;
   if ((int)(blockIdx.x * GRT_XFER_THREADS) >= nlive) return;
   const double *lfreqs = freqs + nfreq;      // log(freqs), appended by the host
-  __shared__ double s_tile[NW][4][64 * GRT_TS];
+  __shared__ double s_tile[NW][4][64 * TS];
   __shared__ int s_ray[NW][64];
   __shared__ int s_n[NW][64];
   __shared__ float s_sphacc[FLUID == GRT_FLUID_SPHACC ? GRT_SPHACC_NTAB : 1];
@@ -627,7 +645,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
   s_n[wave][lane] = n;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
-    for (int e = 0; e < GRT_TS; ++e) s_tile[wave][c][lane * GRT_TS + e] = (c == 0) ? 10.0 : 1.0;   // benign r, theta for idle slots
+    for (int e = 0; e < TS; ++e) s_tile[wave][c][lane * TS + e] = (c == 0) ? 10.0 : 1.0;   // benign r, theta for idle slots
   const GrtRay &R = rays[rayidx];
   const double LBH = PH_G * em.mbh * PH_msun / PH_c2;
   const double alpha = R.alpha, beta = R.beta, q2 = R.q2, l = R.l, su = R.su, sm = R.sm;
@@ -663,46 +681,46 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
   double *tl0 = s_tile[wave][0], *tl1 = s_tile[wave][1], *tl2 = s_tile[wave][2], *tl3 = s_tile[wave][3];
   // the ray is walked in tiles of 8 points aligned to 8 (64-byte segments that never straddle a 128-byte line);
   // tile m holds 0-based points 8m..8m+7, the top tile mt may be partial
-  const int mt = (n - 1) >> 3;
+  const int mt = (n - 1) >> TSH;
 
-  const int ntile = ((nmax - 1) >> 3) + 1;
+  const int ntile = ((nmax - 1) >> TSH) + 1;
   for (int t = 0; t < ntile; ++t) {
     // ---- stage the next 8 points of each of the wave's 64 rays: lane -> (ray i*8 + lane/8, element lane%8)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rs = i * 8 + (lane >> 3), e = lane & 7;
+    for (int i = 0; i < TS; ++i) {
+      const int rs = i * (64 / TS) + (lane >> TSH), e = lane & (TS - 1);
       const int nr = s_n[wave][rs];
-      const int idxm = (((nr - 1) >> 3) - t) * 8 + e;     // 0-based stored-point index
+      const int idxm = (((nr - 1) >> TSH) - t) * TS + e;     // 0-based stored-point index
       if (idxm >= 0 && idxm < nr) {
         const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
-        tl0[rs * GRT_TS + e] = steps[GRT_F_R * field_stride + b];
-        tl1[rs * GRT_TS + e] = steps[GRT_F_TH * field_stride + b];
-        tl2[rs * GRT_TS + e] = steps[GRT_F_LAM * field_stride + b];
-        if (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) tl3[rs * GRT_TS + e] = steps[GRT_F_PHI * field_stride + b];
-        else if (slowlight) tl3[rs * GRT_TS + e] = steps[(long long)tfield * field_stride + b];
+        tl0[rs * TS + e] = steps[GRT_F_R * field_stride + b];
+        tl1[rs * TS + e] = steps[GRT_F_TH * field_stride + b];
+        tl2[rs * TS + e] = steps[GRT_F_LAM * field_stride + b];
+        if (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) tl3[rs * TS + e] = steps[GRT_F_PHI * field_stride + b];
+        else if (slowlight) tl3[rs * TS + e] = steps[(long long)tfield * field_stride + b];
       }
     }
     __builtin_amdgcn_wave_barrier();
     const int m = mt - t;                                  // this lane's tile (negative: ray already finished)
 #pragma clang loop unroll(disable)
-    for (int jj = 0; jj < 8; ++jj) {
-      const int e = 7 - jj;
+    for (int jj = 0; jj < TS; ++jj) {
+      const int e = TS - 1 - jj;
       const double cam_a = karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, a));
-      const int ip = 8 * m + e;                            // 0-based stored point of this lane's ray
+      const int ip = TS * m + e;                            // 0-based stored point of this lane's ray
       const bool valid = has_ray && m >= 0 && ip < n;
       const int k = ip + 1;
       // r and theta carry the turning-point parities of the point in their sign bits (grt_geo_kernel)
-      const double rs_ = valid ? tl0[lane * GRT_TS + e] : 10.0;  // idle lanes (shorter rays) keep benign inputs
-      const double ths_ = valid ? tl1[lane * GRT_TS + e] : 1.0;
+      const double rs_ = valid ? tl0[lane * TS + e] : 10.0;  // idle lanes (shorter rays) keep benign inputs
+      const double ths_ = valid ? tl1[lane * TS + e] : 1.0;
       // (r = 0 marks a point GEOR found no solution for, standard=2 only; inside a ray it is sampled at r = 1/u_f = -1 as before)
       const double r = (rs_ == 0.0) ? -1.0 : fabs(rs_), th = fabs(ths_);
-      const double lam_i = valid ? tl2[lane * GRT_TS + e] : lam_prev;
+      const double lam_i = valid ? tl2[lane * TS + e] : lam_prev;
       const int fl8 = (int)(__double2hiint(ths_) < 0) | ((int)(__double2hiint(rs_) < 0) << 1);
-      const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? tl3[lane * GRT_TS + e] : 0.0;
+      const double phi_i = (EXTRA || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? tl3[lane * TS + e] : 0.0;
       // HARM: the time rides in the fourth tile; KORAL3D needs that tile for phi and reads its time straight from the record
       // (extra=1 needs the fourth tile for phi as well: the time then comes straight from the record, as for KORAL3D)
-      const double t_i = !(slowlight && valid) ? 0.0 : ((FLUID == GRT_FLUID_KORAL3D || EXTRA) ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * GRT_TS + e]);
+      const double t_i = !(slowlight && valid) ? 0.0 : ((FLUID == GRT_FLUID_KORAL3D || EXTRA) ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * TS + e]);
       double kv[4], sth, cth;
       sincos(th, &sth, &cth);      // (the library's: the lean fast_sincos of the geodesic kernels is 5 % slower here, re-measured r03)
       calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
@@ -958,12 +976,12 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
         for (int c = 0; c < 9; ++c) xWp[c] = jI * qv[c];
       }
       if (record) {   // running intensity of the first frequency into the consumed tile slot
-        tl0[lane * GRT_TS + e] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
-        tl1[lane * GRT_TS + e] = I[0][1] * GRT_IUNSCALE * LBH;
-        tl2[lane * GRT_TS + e] = I[0][2] * GRT_IUNSCALE * LBH;
-        tl3[lane * GRT_TS + e] = I[0][3] * GRT_IUNSCALE * LBH;
+        tl0[lane * TS + e] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
+        tl1[lane * TS + e] = I[0][1] * GRT_IUNSCALE * LBH;
+        tl2[lane * TS + e] = I[0][2] * GRT_IUNSCALE * LBH;
+        tl3[lane * TS + e] = I[0][3] * GRT_IUNSCALE * LBH;
 #ifdef GRT_DEBUG_SEL
-        tl0[lane * GRT_TS + e] = dbg[0]; tl1[lane * GRT_TS + e] = dbg[1]; tl2[lane * GRT_TS + e] = dbg[2]; tl3[lane * GRT_TS + e] = dbg[3];
+        tl0[lane * TS + e] = dbg[0]; tl1[lane * TS + e] = dbg[1]; tl2[lane * TS + e] = dbg[2]; tl3[lane * TS + e] = dbg[3];
 #endif
       }
       if (valid) lam_prev = lam_i;
@@ -971,16 +989,16 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_WPE(EMIS, FLUID)) void g
     if (record) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rs = i * 8 + (lane >> 3), e = lane & 7;
+      for (int i = 0; i < TS; ++i) {
+        const int rs = i * (64 / TS) + (lane >> TSH), e = lane & (TS - 1);
         const int nr = s_n[wave][rs];
-        const int idxm = (((nr - 1) >> 3) - t) * 8 + e;
+        const int idxm = (((nr - 1) >> TSH) - t) * TS + e;
         if (idxm >= 0 && idxm < nr) {
           const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
-          steps[(GRT_F_I + 0) * field_stride + b] = tl0[rs * GRT_TS + e];
-          steps[(GRT_F_I + 1) * field_stride + b] = tl1[rs * GRT_TS + e];
-          steps[(GRT_F_I + 2) * field_stride + b] = tl2[rs * GRT_TS + e];
-          steps[(GRT_F_I + 3) * field_stride + b] = tl3[rs * GRT_TS + e];
+          steps[(GRT_F_I + 0) * field_stride + b] = tl0[rs * TS + e];
+          steps[(GRT_F_I + 1) * field_stride + b] = tl1[rs * TS + e];
+          steps[(GRT_F_I + 2) * field_stride + b] = tl2[rs * TS + e];
+          steps[(GRT_F_I + 3) * field_stride + b] = tl3[rs * TS + e];
         }
       }
     }
@@ -1261,6 +1279,20 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   return hipGetLastError();
 }
 
+// the instantiations that also exist with the 4-step tile (image-only launches; see GRT_TSH): the ones it was measured on
+template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4() {
+#if defined(GRT_NO_TILE4)
+  return false;
+#else
+  return IFLAG == GRT_INT_FORMAL && ((FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL) ||
+                                     (FLUID == GRT_FLUID_SPHACC && EMIS == GRT_EMIS_POLSYNCHTH) ||
+                                     (FLUID == GRT_FLUID_HARM && EMIS == GRT_EMIS_POLSYNCHTH));
+#endif
+}
+template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4_batch() {     // ... and the frequency-batch kernel of BASELINE config 5
+  return xfer_tile4<IFLAG, FLUID, EMIS>() && FLUID == GRT_FLUID_FFJET;
+}
+
 template <int IFLAG, int FLUID, int EMIS>
 static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam, const GrtRay *rays, const int *live, int nlive,
                               const GrtFluidDev *fd, const GrtTables *tb, const GrtEmis *em, const GrtPLConst *plc, int nfreq,
@@ -1268,23 +1300,36 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
                               double *steps, long long ray_stride, long long field_stride,
                               int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
+  const bool image_only = !(nfields > GRT_F_I);      // no per-step I,Q,U,V record to write (the kernel's `record`)
   // extra=1 kernels exist for the polarized transfer of emissivities that have the full coefficient set (the API refuses it for
   // nvals = 1, the Pandya fits and the scalar family: grt_api.cpp) -- nothing is instantiated that nothing can launch
   constexpr bool HAS_EXTRA = (IFLAG != GRT_INT_QUAD) && EMIS != GRT_EMIS_POLSYNCHSYMTH && EMIS != GRT_EMIS_SYNCHTHAV;
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
     if constexpr (HAS_EXTRA) {
-      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, 1, 1);
-      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
+      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 1, GRT_TSH);
+      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true, GRT_TSH>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
                          rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps,
                          ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
     } else {
       return hipErrorInvalidValue;
     }
   } else if (nfreq == 1) {
-    note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, 1, 0);
-    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
-                       *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
-                       field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+    bool done = false;
+    if constexpr (xfer_tile4<IFLAG, FLUID, EMIS>()) {
+      if (image_only) {
+        done = true;
+        note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 0, 2);
+        hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false, 2>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
+                           *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
+                           field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+      }
+    }
+    if (!done) {
+      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 0, GRT_TSH);
+      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false, GRT_TSH>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
+                         *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
+                         field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+    }
   } else {
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
@@ -1297,10 +1342,22 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
     // either way -- 800 B/lane at 25 --, what counts is how many frequencies share a point's fluid sample and tetrad)
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : (IFLAG == GRT_INT_FORMAL ? 25 : 13);
 #endif
-    note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dEE", IFLAG, FLUID, EMIS, FBN, 0);
-    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
-                       dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
-                       nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+    bool done = false;
+    if constexpr (xfer_tile4_batch<IFLAG, FLUID, EMIS>()) {
+      if (image_only) {
+        done = true;
+        note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, FBN, 0, 2);
+        hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false, 2>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
+                           dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
+                           nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+      }
+    }
+    if (!done) {
+      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, FBN, 0, GRT_TSH);
+      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false, GRT_TSH>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
+                         dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
+                         nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
+    }
   }
   return hipGetLastError();
 }

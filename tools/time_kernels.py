@@ -33,11 +33,13 @@ else:
         em = capi.make_emis(os.environ.get("GRT_ENAME", "POLSYNCHTH"), 4e6, 1.0, 6.0, 1.0, 1e5, 3.5, mdot=1e20)
 if os.environ.get("GRT_NOFILL"):          # experiment: no mu-fill segment (different stored points: timing only)
     cam.mufill, cam.kext, cam.next = 0, 0, 0
+nfreq = int(os.environ.get("GRT_NFREQ", "1"))       # 25: BASELINE config 5's log-spaced set 2.41e10..6.31e14
+freqs = [freq] if nfreq == 1 else [2.41e10 * (6.31e14 / 2.41e10) ** (k / (nfreq - 1.0)) for k in range(nfreq)]
 capi.record_steps(os.environ.get("GRT_RECORD", "0") == "1")
 capi.geo_reuse(False)
 best = None
 for it in range(3):
-    _, _, _, st = capi.trace_tile(cam, 1, nn[0] * nn[1], fluid, em, [freq], iname, resident=True)
+    _, _, _, st = capi.trace_tile(cam, 1, nn[0] * nn[1], fluid, em, freqs, iname, resident=True)
     r = dict(geo=st.ms_geo, xfer=st.ms_transfer, trace=st.ms_trace, total=st.ms_total, steps=st.ray_steps)
     if best is None or r["trace"] < best["trace"]:
         best = r
