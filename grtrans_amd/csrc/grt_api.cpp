@@ -93,7 +93,7 @@ struct Ctx {
   hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long *d_stepcount = nullptr;
   int record_steps = 0;
-  long long steps_rays = 0, steps_maxpts = 0;
+  long long steps_rays = 0, steps_maxpts = 0, steps_fstride = 0;
   std::vector<double> h_freqs;          // host staging of (freqs, log freqs): must outlive the async copy
   // The geodesic record resident in d_rays / d_live / d_steps / d_counters, and what it was computed for.  A trace
   // call with the same key (e.g. the next mdot of grtrans_main's loop, grtrans_driver.f90:134: one geodesic serves every
@@ -695,9 +695,11 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
-  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * chunk * rstride))) return rc;
-  C.steps_rays = (chunk == nrays) ? nrays : 0; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride;
-  const long long fstride = (long long)chunk * rstride;
+  // one field of the record: [ray slot][rstride points]; with the per-step record on, whole blocks of 64 slots (its I,Q,U,V fields are
+  // stored [block of 64 slots][point][slot in block]: grt_transfer_kernel)
+  const long long fstride = (C.record_steps ? ((long long)chunk + 63) / 64 * 64 : (long long)chunk) * rstride;
+  if ((rc = grow(C.d_steps, C.cap_steps, (size_t)nalloc * (size_t)fstride))) return rc;
+  C.steps_rays = (chunk == nrays) ? nrays : 0; C.steps_maxpts = maxpts; C.steps_fields = nfields; C.steps_stride = rstride; C.steps_fstride = fstride;
   GrtPLConst plc{};
   grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
   C.h_freqs.resize((size_t)2 * nfreq);     // context-owned staging: the asynchronous copy may outlive this frame
@@ -1040,15 +1042,16 @@ int grt_debug_ray(const grt_camera *cam, int64_t pixel, int fluid_model, const g
   fd.fj = C.ffjet; fd.sphacc = C.d_sphacc; fd.hm = C.harm;
   GrtPLConst plc{};
   grt_pl_const(C.h_tables, em->p1, em->gmin, em->gmax, plc);
-  const long long rstride = C.steps_stride, fstride = rstride;      // one ray in the buffers
+  const long long rstride = C.steps_stride, fstride = C.steps_fstride;      // one ray in the buffers (a 64-slot block of the record)
   HIPCHK(grt_launch_debug(C.stream, fluid_model, em->type, cam, C.d_rays, 0, &fd, &C.tables, em, &plc, freq, C.d_steps, rstride, fstride, 8,
                           (double *)dout.p, maxpts, (double *)dscal.p));
   HIPCHK(hipStreamSynchronize(C.stream));
-  std::vector<double> k((size_t)nrows * maxpts), rec((size_t)9 * rstride);
+  std::vector<double> k((size_t)nrows * maxpts), rec((size_t)9 * rstride);      // rec: the ray's row of each of the 9 fields
   double scal[4];
   HIPCHK(hipMemcpy(k.data(), dout.p, k.size() * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(scal, dscal.p, sizeof scal, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(rec.data(), C.d_steps, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(rec.data(), (size_t)rstride * sizeof(double), C.d_steps, (size_t)fstride * sizeof(double), (size_t)rstride * sizeof(double), 9,
+                     hipMemcpyDeviceToHost));
   *fac_out = scal[0];
   auto row = [&](int r) { return rows + (size_t)r * maxpts; };
   for (int i = 0; i < n; ++i) {      // geodesic blocks from the record (internal field order r, theta, lambda, phi, I..V, t)
@@ -1089,10 +1092,26 @@ int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
   if (!C.init || !C.d_steps || C.steps_fields < 8) return GRT_E_NOTINIT;
   if (ray0 < 0 || ray0 + nrays > C.steps_rays || maxpts != C.steps_maxpts) return GRT_E_BADARG;
   static const int src[8] = {0, 1, 3, 2, 4, 5, 6, 7};   // public r,theta,phi,lambda,I,Q,U,V <- internal order
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < 4; ++f)
     HIPCHK(hipMemcpy2D(out + (size_t)f * nrays * maxpts, (size_t)maxpts * sizeof(double),
-                       C.d_steps + ((size_t)src[f] * C.steps_rays + ray0) * C.steps_stride, (size_t)C.steps_stride * sizeof(double),
+                       C.d_steps + (size_t)src[f] * C.steps_fstride + (size_t)ray0 * C.steps_stride, (size_t)C.steps_stride * sizeof(double),
                        (size_t)maxpts * sizeof(double), (size_t)nrays, hipMemcpyDeviceToHost));
+  // I,Q,U,V are stored [block of 64 ray slots][point][slot in block] on the device (grt_transfer_kernel writes them from the registers, a
+  // wave's rays side by side, consecutive points 512 bytes apart); the public record is ray-major like the geometry fields
+  {
+    const int64_t b0 = ray0 / 64, b1 = (ray0 + nrays - 1) / 64;
+    const size_t blk = (size_t)64 * (size_t)C.steps_stride;
+    std::vector<double> tmp((size_t)(b1 - b0 + 1) * blk);
+    for (int f = 4; f < 8 && nrays > 0; ++f) {
+      HIPCHK(hipMemcpy(tmp.data(), C.d_steps + (size_t)src[f] * C.steps_fstride + (size_t)b0 * blk, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      double *o = out + (size_t)f * nrays * maxpts;
+      for (int64_t ry = 0; ry < nrays; ++ry) {
+        const int64_t sl = ray0 + ry;
+        const double *src_ = tmp.data() + (size_t)(sl / 64 - b0) * blk + (size_t)(sl % 64);
+        for (int k = 0; k < maxpts; ++k) o[(size_t)ry * maxpts + k] = src_[(size_t)k * 64];
+      }
+    }
+  }
   // on the device r and theta carry the turning-point parities of the point in their sign bits (grt_geo_kernel): not part of the record
   // (r = 0 marks a standard=2 point GEOR found no solution for: 1/u_f = -1 in the reference's arrays).  Only the ray's own
   // points are touched: slots behind npts stay as the buffer holds them (zero for a fresh record).

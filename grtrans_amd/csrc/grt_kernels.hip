@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)
   // hoisted into registers held across the pass (231 VGPRs, 40 B/lane of scratch as before, 18 spilled SGPRs instead of 39), and 43 of
   // the 94 scalar-memory waits of a pass had fewer than five vector instructions between the load and its wait: 37.9 -> 36.8 ms at
   // 1024^2 x 400 (profiles/r04_e_variants_ldsrr2.log).  The slow-light kernel <1,3> keeps its scalar loads: no workload to time it on.
+  // (The GrtRay through LDS in the image-only and the Schwarzschild-cubic kernels as well: no change, 17.2 / 14.8 ms either way.)
 #if defined(GRT_LDSRR_NPH3)    // experiment: the r03 failure (whole RealRay through LDS in the slow-light kernel)
   constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 2 || NPH == 3)) || FAST == 2;
 #elif defined(GRT_LDSHYB_NPH2) || defined(GRT_LDS_NPH3)
@@ -535,17 +536,22 @@ extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *li
 // scan, no idle lanes in the last chunk of a ray, and DELO / quadrature take their neighbour point from the
 // previous loop trip.  The geodesic record is [ray][point] (written coalesced by grt_geo_kernel: lanes =
 // points), so the wave stages it through LDS in tiles of 8 steps x 64 rays: 8 lanes fetch one ray's 64-byte
-// segment, the tile is then read transposed (lane = ray).  The per-step I,Q,U,V record goes back through the
-// same tile buffers (a slot is overwritten only after its own lane has consumed it).
+// segment, the tile is then read transposed (lane = ray).  The per-step I,Q,U,V record is written straight from the
+// registers: those four fields are stored [block of 64 ray slots][point][slot in block] (a wave's 64 rays are neighbouring
+// slots walking the same stored point: 512 contiguous bytes per store) -- grt_download_steps hands them out ray-major like the rest.
+// (Until r04 they went back through the tile buffers in [ray][point] order, 64-byte pieces per ray.)
 // Frequencies are processed FB at a time (blockIdx.y = batch): the intensities of a batch live in registers.
 // Tile depth (TSH = log2 of the steps per tile, a template parameter of the kernel).  8 steps (TSH = 3) is the general one: unpadded, 4
 // buffers x 4 waves = 64 KB a block, two blocks a CU; the 8-way bank conflict of the transposed read is noise next to ~1e4 cycles of
 // VALU per step.  4 steps (TSH = 2) halves the tile buffers: three blocks fit a CU, and an instantiation that also fits 168 registers
 // runs THREE waves per SIMD.  r04, 1024^2 x 400 image only: FFJET formal 31.0 -> 29.9 ms, HARM formal 43.3 -> 39.7, SPHACC formal
 // 31.2 -> 29.8, the 25-frequency FFJET batch 359 -> 336 ms (it fits 157 registers as it is); DELO does not gain (168 registers cost it
-// 100 B/lane of scratch: 29.8 -> 30.2 ms).  NOT with the per-step record: its I,Q,U,V go back through the same tiles, 32-byte pieces of
-// 128-byte lines that leave L2 before their neighbours arrive (FFJET formal 33.4 -> 34.5 ms at three waves, 35.7 at two) -- the record
-// launches keep the 8-step tile.  Instantiated only where measured (xfer_tile4); profiles/r04_e_variants_tile4*.log.
+// 100 B/lane of scratch: 29.8 -> 30.2 ms).  While the per-step I,Q,U,V record went back through the tiles the 4-step tile was NOT for
+// record launches: 32-byte pieces of 128-byte lines that leave L2 before their neighbours arrive (FFJET formal 33.4 -> 34.5 ms at three
+// waves, 35.7 at two).  Written straight from the registers in the blocked layout (above) the record costs the same either way, and
+// the three kernels run three waves in both modes: FFJET formal with the record 34.2 -> 32.2 ms, HARM 44.8 -> 41.8, SPHACC 33.0 -> 31.2,
+// DELO (8-step tile, two waves; only the direct stores) 32.6 -> 31.0.  Instantiated only where measured (xfer_tile4);
+// profiles/r04_e_variants_tile4*.log, r04_e_variants_point_major.log, r04_e_variants_blocked_layout.log.
 #ifndef GRT_TSH
 #define GRT_TSH 3                // the general tile depth
 #endif
@@ -975,32 +981,22 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, ((TSH == 2 && FB == 1) ? 3 : GRT_
 #pragma unroll
         for (int c = 0; c < 9; ++c) xWp[c] = jI * qv[c];
       }
-      if (record) {   // running intensity of the first frequency into the consumed tile slot
-        tl0[lane * TS + e] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
-        tl1[lane * TS + e] = I[0][1] * GRT_IUNSCALE * LBH;
-        tl2[lane * TS + e] = I[0][2] * GRT_IUNSCALE * LBH;
-        tl3[lane * TS + e] = I[0][3] * GRT_IUNSCALE * LBH;
+      if (record && valid) {
+        // running intensity of the first frequency, straight from the registers: the I,Q,U,V fields of the record are stored
+        // [block of 64 ray slots][point][slot in block] -- the 64 rays of a wave are neighbours in the pass and walk the same stored
+        // point together, so a store instruction writes whole 128-byte lines, and a ray's next point is 512 bytes further on
+        // ([point][slot] over the whole pass -- a ray's consecutive points 8 MB apart at 1024^2 -- measured 0.1-0.6 ms slower: profiles/r04_e_variants_blocked_layout.log)
+        double *o = steps + (GRT_F_I * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (long long)ip * 64 + (rayidx & 63));
 #ifdef GRT_DEBUG_SEL
-        tl0[lane * TS + e] = dbg[0]; tl1[lane * TS + e] = dbg[1]; tl2[lane * TS + e] = dbg[2]; tl3[lane * TS + e] = dbg[3];
+        o[0] = dbg[0]; o[field_stride] = dbg[1]; o[2 * field_stride] = dbg[2]; o[3 * field_stride] = dbg[3];
+#else
+        o[0] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
+        o[field_stride] = I[0][1] * GRT_IUNSCALE * LBH;
+        o[2 * field_stride] = I[0][2] * GRT_IUNSCALE * LBH;
+        o[3 * field_stride] = I[0][3] * GRT_IUNSCALE * LBH;
 #endif
       }
       if (valid) lam_prev = lam_i;
-    }
-    if (record) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < TS; ++i) {
-        const int rs = i * (64 / TS) + (lane >> TSH), e = lane & (TS - 1);
-        const int nr = s_n[wave][rs];
-        const int idxm = (((nr - 1) >> TSH) - t) * TS + e;
-        if (idxm >= 0 && idxm < nr) {
-          const long long b = (long long)s_ray[wave][rs] * ray_stride + idxm;
-          steps[(GRT_F_I + 0) * field_stride + b] = tl0[rs * TS + e];
-          steps[(GRT_F_I + 1) * field_stride + b] = tl1[rs * TS + e];
-          steps[(GRT_F_I + 2) * field_stride + b] = tl2[rs * TS + e];
-          steps[(GRT_F_I + 3) * field_stride + b] = tl3[rs * TS + e];
-        }
-      }
     }
   }
   if (!has_ray) return;
@@ -1036,9 +1032,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, ((TSH == 2 && FB == 1) ? 3 : GRT_
   }
   if (record && !ok0) {
     // a ray the reference skips (fac <= 0 or NaN, grtrans_driver.f90:183,314-317) keeps rt%I = 0 in its dump
+    double *o = steps + (GRT_F_I * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (rayidx & 63));     // (blocked layout, as above)
     for (int i = 0; i < n; ++i)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) steps[(GRT_F_I + c) * field_stride + base + i] = 0.0;
+      for (int c = 0; c < 4; ++c) o[c * field_stride + (long long)i * 64] = 0.0;
   }
   if (first_batch) {
     ray_status[rayidx] = (sumr < 0.0) ? -n : n;      // (written either way: a resident geodesic record is re-used by later calls, whose status must not inherit this one's)
@@ -1125,8 +1122,10 @@ __global__ __launch_bounds__(64, 2) void grt_debug_kernel(GrtCam cam, const GrtR
     o[20 * m_] = jj4[0]; o[21 * m_] = KK[0]; o[22 * m_] = jj4[1]; o[23 * m_] = jj4[3]; o[24 * m_] = KK[1]; o[25 * m_] = KK[3]; o[26 * m_] = KK[4];
     o[27 * m_] = KK[6];
     // r%I(c,:)/fac/LBH in INTEGRATION order (1 = the far end = stored point n): the record holds the running Stokes vector times L_BH
+    // (its I,Q,U,V fields in the blocked layout of grt_transfer_kernel: [block of 64 slots][point][slot in block])
 #pragma unroll
-    for (int c = 0; c < 4; ++c) out[(28 + c) * m_ + (n - 1 - i)] = steps[(GRT_F_I + c) * field_stride + base + i] / LBH;
+    for (int c = 0; c < 4; ++c)
+      out[(28 + c) * m_ + (n - 1 - i)] = steps[(GRT_F_I + c) * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (long long)i * 64 + (rayidx & 63)] / LBH;
     o[33 * m_] = jj4[2]; o[34 * m_] = KK[2]; o[35 * m_] = KK[5];
 #pragma unroll
     for (int c = 0; c < 11; ++c) o[(57 + c) * m_] = e11[c];
@@ -1279,7 +1278,7 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   return hipGetLastError();
 }
 
-// the instantiations that also exist with the 4-step tile (image-only launches; see GRT_TSH): the ones it was measured on
+// the instantiations that take the 4-step tile (see GRT_TSH): the ones it was measured on
 template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4() {
 #if defined(GRT_NO_TILE4)
   return false;
@@ -1300,7 +1299,6 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
                               double *steps, long long ray_stride, long long field_stride,
                               int nfields, int tfield, unsigned long long *step_counter, const int *nlive_dev, int from_back) {
   const unsigned gx = (unsigned)((nlive + GRT_XFER_THREADS - 1) / GRT_XFER_THREADS);
-  const bool image_only = !(nfields > GRT_F_I);      // no per-step I,Q,U,V record to write (the kernel's `record`)
   // extra=1 kernels exist for the polarized transfer of emissivities that have the full coefficient set (the API refuses it for
   // nvals = 1, the Pandya fits and the scalar family: grt_api.cpp) -- nothing is instantiated that nothing can launch
   constexpr bool HAS_EXTRA = (IFLAG != GRT_INT_QUAD) && EMIS != GRT_EMIS_POLSYNCHSYMTH && EMIS != GRT_EMIS_SYNCHTHAV;
@@ -1314,22 +1312,11 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
       return hipErrorInvalidValue;
     }
   } else if (nfreq == 1) {
-    bool done = false;
-    if constexpr (xfer_tile4<IFLAG, FLUID, EMIS>()) {
-      if (image_only) {
-        done = true;
-        note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 0, 2);
-        hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false, 2>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
-                           *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
-                           field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
-      }
-    }
-    if (!done) {
-      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 0, GRT_TSH);
-      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false, GRT_TSH>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
-                         *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
-                         field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
-    }
+    constexpr int TSH1 = xfer_tile4<IFLAG, FLUID, EMIS>() ? 2 : GRT_TSH;
+    note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 0, TSH1);
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, false, TSH1>), dim3(gx, 1), dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive,
+                       *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps, ray_stride,
+                       field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   } else {
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
@@ -1342,22 +1329,11 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
     // either way -- 800 B/lane at 25 --, what counts is how many frequencies share a point's fluid sample and tetrad)
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : (IFLAG == GRT_INT_FORMAL ? 25 : 13);
 #endif
-    bool done = false;
-    if constexpr (xfer_tile4_batch<IFLAG, FLUID, EMIS>()) {
-      if (image_only) {
-        done = true;
-        note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, FBN, 0, 2);
-        hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false, 2>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
-                           dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
-                           nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
-      }
-    }
-    if (!done) {
-      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, FBN, 0, GRT_TSH);
-      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false, GRT_TSH>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
-                         dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
-                         nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
-    }
+    constexpr int TSHB = xfer_tile4_batch<IFLAG, FLUID, EMIS>() ? 2 : GRT_TSH;
+    note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, FBN, 0, TSHB);
+    hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, FBN, false, TSHB>), dim3(gx, (unsigned)((nfreq + FBN - 1) / FBN)),
+                       dim3(GRT_XFER_THREADS), 0, s, *cam, rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile,
+                       nvals, ray_status, i1, steps, ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
   }
   return hipGetLastError();
 }

@@ -246,8 +246,10 @@ int grt_resident_pointers(float **d_pixvals, int32_t **d_ray_status);
  * that RCCL then gathers); count = number of floats */
 int grt_copy_resident_pixvals(void *d_dst, int64_t count);
 
-/* Optional per-step SoA record (r,theta,phi,lambda,I,Q,U,V) fp64, [8][nrays][maxpts] in HBM, of the
- * first frequency: what geodebug.out holds per ray (grtrans_driver.f90:94-110,370-373).  0 disables. */
+/* Optional per-step SoA record (r,theta,phi,lambda,I,Q,U,V) fp64 of the first frequency, resident in HBM: what geodebug.out
+ * holds per ray (grtrans_driver.f90:94-110,370-373).  0 disables.  grt_download_steps returns it as [8][nrays][maxpts]; on the
+ * device the geometry fields are [ray][point] and I,Q,U,V are [block of 64 rays][point][ray in block] (written by the transfer
+ * kernel with a wave's 64 rays side by side). */
 int grt_set_record_steps(int enable);
 int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out);
 

@@ -340,6 +340,36 @@ def test_harm_polsynchth_vs_reference_golden(dev, harm_dir, iname):
     assert stokes_err(pix[0], g["ivals_" + iname], min_identical=0.93, max_rel=1e-5) < STOKES_TOL
 
 
+def test_record_download_across_the_64_ray_blocks_of_its_stokes_fields(dev):
+    # On the device I,Q,U,V of the per-step record are stored [block of 64 rays][point][ray in block] (grt_transfer_kernel writes them
+    # from the registers); grt_download_steps hands out [8][nrays][maxpts].  A 150-ray pass (two whole blocks and a ragged third one):
+    # every multi-ray window equals the single-ray downloads, the last point of a ray is its pixel, a one-ray trace gives the same row.
+    from grtrans_amd import capi
+    dev.load_ffjet()
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (15, 10, 60), 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    capi.record_steps(True)
+    try:
+        for iname in ("formal", "delo"):
+            pix, _, status, _ = capi.trace_tile(cam, 1, 150, "FFJET", em, [FREQ], iname)
+            mp = cam.nup + cam.next
+            whole = capi.download_steps(0, 150, mp)
+            assert whole.shape == (8, 150, mp)
+            for (r0, nr) in ((0, 64), (60, 10), (63, 2), (64, 64), (100, 50), (149, 1), (1, 148)):
+                assert np.array_equal(capi.download_steps(r0, nr, mp), whole[:, r0:r0 + nr]), (iname, r0, nr)
+            live = np.flatnonzero(status > 0)
+            assert live.size > 100
+            for j in live[::7]:
+                # stored point 1 is the camera end: the running Stokes vector there is the pixel (fp32 in the image)
+                assert np.array_equal(whole[4:8, j, 0].astype(np.float32), pix[0, j]), (iname, j)
+            j = int(live[live.size // 2])
+            capi.trace_tile(cam, j + 1, j + 1, "FFJET", em, [FREQ], iname)
+            n = int(status[j])      # (slots behind npts keep what the buffer held)
+            assert np.array_equal(capi.download_steps(0, 1, mp)[:, 0, :n], whole[:, j, :n]), iname
+    finally:
+        capi.record_steps(False)
+
+
 def test_harm_per_step_record(dev, harm_dir):
     from grtrans_amd import capi
     g = np.load(os.path.join(G, "harm_rays_48x48x200.npz"))
