@@ -153,7 +153,13 @@ __global__ __launch_bounds__(256, GRT_WPE_SETUP) void grt_setup_kernel(GrtCam ca
   bool topfill = false;
   if (quart) { const RealLeg lg = real_leg(cam, R); topfill = lg.nfill > 0 && R.npts <= lg.lo + lg.nfill; }
   quart = quart && !topfill;
+  // ... or one real root and a complex pair (ncase 3: the plunging rays of a Schwarzschild camera; grt_dev_cubic.hpp)
+#if !defined(GRT_NO_CUBIC_CPLX)
+  const bool cubic = alive && !(need_time & 1) && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 &&
+                     (((R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12) || (R.ncase == 3 && R.tpr == 0));
+#else
   const bool cubic = alive && !(need_time & 1) && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+#endif
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel

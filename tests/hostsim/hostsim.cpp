@@ -240,7 +240,7 @@ int hs_ray_points_cubic(const GrtCam *cam, int ii, int maxn, double *u, double *
   GrtRay R;
   setup_ray(*cam, ii, R);
   *ncase = R.ncase;
-  const bool cubic = R.npts > 0 && cam->a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
+  const bool cubic = R.npts > 0 && cam->a == 0.0 && R.q2 != 0.0 && (((R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12) || (R.ncase == 3 && R.tpr == 0));
   if (!cubic) return -R.npts;
   CubRay K;
   cubray_init(*cam, R, K);

@@ -389,7 +389,10 @@ def test_schwarzschild_cubic_fast_path_matches_sequential_oracle(L):
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
     ncub = 0
-    for i in range(1, nn[0] * nn[1] + 1, 7):
+    ncase_seen = {1: 0, 2: 0, 3: 0}
+    # every 7th pixel, and every pixel of the patch around the image centre the plunging rays come from (ncase 3, r04: b < sqrt(27))
+    centre = [ix * nn[1] + iy + 1 for ix in range(24, 40) for iy in range(24, 40)]
+    for i in sorted(set(range(1, nn[0] * nn[1] + 1, 7)) | set(centre)):
         g = o.geokerr_ray(i)
         d = [np.zeros(maxn) for _ in range(5)]
         tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
@@ -397,12 +400,14 @@ def test_schwarzschild_cubic_fast_path_matches_sequential_oracle(L):
         if n <= 0:
             continue
         ncub += 1
+        ncase_seen[nc.value] = ncase_seen.get(nc.value, 0) + 1
         assert n == g["n"] and nc.value == g["ncase"]
         assert np.array_equal(tpm[:n], g["tpm"]) and np.array_equal(tpr[:n], g["tpr"])
         for k, key in enumerate(("u", "mu", "dt", "dphi", "lam")):
             if key != "dt":
                 assert np.max(np.abs(d[k][:n] - g[key])) <= 1e-10 * (np.max(np.abs(g[key])) + 1e-300), (i, key)
     assert ncub > 300
+    assert ncase_seen[3] > 40 and ncase_seen[1] + ncase_seen[2] > 300, ncase_seen
 
 
 def test_thindisk_single_point_pixels_match_oracle(L):

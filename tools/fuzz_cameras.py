@@ -50,6 +50,9 @@ only = set(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else Non
 bad = 0; cond = 0; ampl = 0
 for c in range(ncams):
     fname, ename, okw, ekw, freq, tol = MODELS[int(rng.integers(0, len(MODELS)))] if (len(sys.argv) > 3 and sys.argv[3] in ("all", "allext")) else MODELS[0]
+    if os.environ.get("GRT_FUZZ_MODEL"):      # only this fluid model's entries of the list (the draw above is still made: same stream)
+        sel = [m for m in MODELS if m[0] == os.environ["GRT_FUZZ_MODEL"]]
+        fname, ename, okw, ekw, freq, tol = sel[c % len(sel)]
     a = float(rng.choice([rng.uniform(0.01, 0.998), -rng.uniform(0.05, 0.99), 0.998, 0.5])) if fname == "FFJET" else 0.9375
     nst = okw.get("nvals", 4)
     if fname == "SPHACC":
@@ -134,11 +137,19 @@ for c in range(ncams):
         # (geokerr's lambda carries a constant of up to ~4e8 for near-polar cameras, so lambda itself is quantised at 6e-8
         # and dx between neighbouring points at up to 7e-7 of its value; one ulp of uout re-rolls that rounding)
         # (an equatorial camera has mu0 = 0, where "one ulp" is a denormal and changes nothing: the inclination also moves by 1e-15 rad, r04)
-        for da, dm, du in ((0, 1, 0), (1, 0, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (0, 2, 0), (0, -2, 0)):
+        # (r04, seed 777 camera 240 -- SPHACC, a = 0, mu0 = 0, 24 GHz: neither the spin nor the inclination re-rolls anything there, and two
+        #  re-rolls through uout left the ONE point that mattered alone: a grazing ray whose lambda, 9e8 with an ulp of 1.2e-7, steps by 0.08
+        #  per point, and whose last step has an optical depth of 3 -- one ulp of lambda at the camera end is 4e-6 of the pixel.  The
+        #  image bounds moved by one ulp either way re-roll every ray's constants: four more draws of the same rounding)
+        for da, dm, du, dg in ((0, 1, 0, 0), (1, 0, 0, 0), (0, -1, 0, 0), (0, 0, 1, 0), (0, 0, -1, 0), (0, 2, 0, 0), (0, -2, 0, 0),
+                               (0, 0, 0, 1), (0, 0, 0, -1), (0, 0, 0, 2), (0, 0, 0, -2)):
             if da and a == 0.0:
                 continue
             mu0p = (mu0 + (1e-15 if dm > 0 else -1e-15)) if abs(dm) == 2 else (float(np.nextafter(mu0, dm * 2.0)) if dm else mu0)
-            op = engine(spin=float(np.nextafter(a, 2.0)) if da else a, mu0=mu0p, uout=float(np.nextafter(uout, du * 1.0)) if du else uout)
+            gvp = gv
+            if dg:      # +-1: the alpha bounds, +-2: the beta bounds, one ulp outwards / inwards
+                gvp = tuple(float(np.nextafter(v, np.inf if dg > 0 else -np.inf)) if (k // 2 == abs(dg) - 1) else v for k, v in enumerate(gv))
+            op = engine(spin=float(np.nextafter(a, 2.0)) if da else a, mu0=mu0p, uout=float(np.nextafter(uout, du * 1.0)) if du else uout, gridvals=gvp)
             rp, rnp, _ = etrace(op, freqs)
             if not np.array_equal(rnp, crn):
                 continue
