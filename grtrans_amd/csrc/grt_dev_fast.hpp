@@ -798,7 +798,8 @@ GRT_HD RealLeg real_leg(const GrtCam &cam, const GrtRay &R) {
 // pre: the u-side quantities of a non-fill point, summed from segments by the caller (grt_geo_kernel); NULL = evaluate here
 template <int NPH>
 GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr,
-                           const RealRay *KLp = nullptr /* the same record in LDS: the Jacobi ladders and the Zeta / theta-series constants are read there */) {
+                           const RealRay *KLp = nullptr /* the same record in LDS: the Jacobi ladders and the Zeta / theta-series constants are read there */,
+                           bool usepre = true /* the kernel passes &S always and its `usable` here: a pointer chosen at run time (usable ? &S : 0) kept S in scratch */) {
   constexpr bool PHI = NPH > 0;
   const RealRay &KL = KLp ? *KLp : K;
   const double one = 1.0, two = 2.0;
@@ -832,7 +833,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
   for (int pass = 0; pass < 2; ++pass) {
     const bool doU = (pass == 0) != isfill;
     if (doU) {
-      if (pre && !isfill) U = *pre;
+      if (pre && usepre && !isfill) U = *pre;
       else if (K.cplx) cplx_upart<NPH>(K, un, U); else real_upart<NPH>(K, un, U);   // (one ray per wave: a uniform branch)
     }
     else if (need_mu) real_mupart<PHI>(K, mun, M, isfill);
@@ -909,7 +910,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 // image-only build (PHI=false), where its extra instruction-level parallelism wins over the smaller
 // two-pass form: 11.0 ms against 12.8 ms for 1.19e8 points (tools/run_variants.sh).
 template <bool PHI>
-GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr) {
+GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr, bool usepre = true) {
   const double one = 1.0, two = 2.0;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
   const bool fill = (R.tpr == 1 && cam.mufill && cam.nup > 1);
@@ -929,7 +930,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       un = two * R.ub - (cam.uout + (Kk - cam.offset) * R.du); tprs = R.tpr_out; tprp = 1;
     }
     if (!K.cplx && (c7 ? (un > root) : (un < root))) un = root;        // geokerr_wrapper.f:1079,1089
-    if (pre) U = *pre;
+    if (pre && usepre) U = *pre;
     else if (K.cplx) cplx_upart<(PHI ? 2 : 0)>(K, un, U); else real_upart<(PHI ? 2 : 0)>(K, un, U);   // wave-uniform
     iu = K.su * (K.iu0 - powm1(tprs) * U.iu1) * K.isqee;
     // mu_f from I_u (Eq. 30-42)

@@ -455,13 +455,15 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)
       }
 #endif
       if (valid) {
-        const UPart *pre = usable ? &S : nullptr;
+        // (&S always, `usable` beside it: chosen at run time -- usable ? &S : nullptr -- the pointer kept S, and what the allocator parked
+        //  around it, in scratch: the 272 B/lane of the image-only kernel VERDICT r03 asked about)
+        const UPart *pre = &S;
         if (FAST == 2) ray_point_cubic<PHI>(GRT_CAMREF, *Rp, *Cp, idx, P);
-        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(GRT_CAMREF, *Rp, *Kp, idx, P, pre);
+        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, usable);
 #if !defined(GRT_NO_GEO_LDS_RR)
-        else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_])); }
+        else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_]), usable); }
 #endif
-        else if (FAST == 1) ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre);
+        else if (FAST == 1) ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, nullptr, usable);
         else ray_point(GRT_CAMREF, *Rp, idx, P, NPH == 3 ? 3 : NPH);
       }
     }
