@@ -894,7 +894,30 @@ def open_cases():
     np.savez_compressed(os.path.join(G, "open_cases.npz"), **out)
 
 
+def delo_vacuum_pocket_ray():
+    """INPUT fixture (no expected values): the coefficient dump of one ray -- j, K as grtrans_driver hands them to integrate, lambda, tau --
+    from the oracle, for tests/test_hostsim_fast.py::test_delo_through_a_vacuum_pocket... (fuzz seed 1234, camera 300, pixel 42, 23 GHz)."""
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
+    import make_harm3d_dump
+    from oracle import orabind
+    td = tempfile.mkdtemp(prefix="grt_gold_")
+    make_harm3d_dump.write(td, n1=32, n2=32, n3=16)
+    gv = (-7.154324163139105, 8.484635693640907, -8.200640002803938, 7.438319853976074)
+    o = orabind.Oracle(nn=(12, 12, 60), iname="delo", spin=0.9375, mu0=0.0, gridvals=gv, uout=0.04, fname="HARM3D", ename="HYBRIDTHPL", datadir=td,
+                       dfile="dump3d", hfile="dump3d_header", findf=40, mbh=4e6, mdot=1e20, muval=0.25, gmin=2., p1=3.5)
+    od = o.ray_dump(42, 2.3e10)
+    n = od["npts"]
+    np.savez_compressed(os.path.join(G, "delo_vacuum_pocket_ray.npz"), j=np.asarray(od["j"])[:n], K=np.asarray(od["K"])[:n],
+                        lam=np.asarray(od["lam"])[:n], tau=np.asarray(od["tau"])[:n],
+                        note=np.array("oracle ray_dump of pixel 42 at 23 GHz: HARM3D HYBRIDTHPL DELO, tools/fuzz_cameras.py 700 1234 allext camera 300"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "delo_vacuum_pocket_ray":
+        delo_vacuum_pocket_ray()
+        sys.exit(0)
     if len(sys.argv) > 1:            # e.g. `python tests/make_golden.py config5 extra_main crosscheck_main`
         for name in sys.argv[1:]:
             globals()[name]()
@@ -927,5 +950,6 @@ if __name__ == "__main__":
     standard2()
     polar_camera()
     open_cases()
+    delo_vacuum_pocket_ray()
     crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

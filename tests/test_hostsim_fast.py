@@ -410,6 +410,39 @@ def test_schwarzschild_cubic_fast_path_matches_sequential_oracle(L):
     assert ncase_seen[3] > 40 and ncase_seen[1] + ncase_seen[2] > 300, ncase_seen
 
 
+def test_delo_through_a_vacuum_pocket_device_step_is_the_exact_solution_not_the_cofactor_one(L):
+    # r04, fuzz seed 1234 camera 300 (HARM3D, DELO, 23 GHz): a ray leaves an emitting zone into a near-vacuum pocket (alpha_I 1e-97,
+    # rho_V / alpha_I = 7.7e86) and enters another emitting zone seven points on.  The device's closed-form step (delo_apply, compiled
+    # for the host here) must follow the reference's recursion with every 4x4 system solved EXACTLY (tools/delo_exact_replay.py:
+    # rational arithmetic on the same double inputs) -- through an excursion to 1e74 -- and NOT the recursion with the reference's
+    # cofactor inverse in double precision, which loses the Stokes component along the Faraday axis at the first boundary (V = -1e-77
+    # instead of 5e-15) and whose pixel is therefore an artefact of that rounding.
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import delo_exact_replay as dex
+    d = np.load(os.path.join(ROOT, "tests", "golden", "delo_vacuum_pocket_ray.npz"))
+    j, K, lam, tau = d["j"], d["K"], d["lam"], d["tau"]
+    n = len(lam)
+    L.hs_delo_step.argtypes = [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    I = np.zeros(4)
+    dev = np.zeros((n, 4))
+    for k in range(n - 1, 0, -1):
+        nxt = np.zeros(4)
+        a0, a1 = np.ascontiguousarray(j[k - 1]), np.ascontiguousarray(j[k])
+        k0, k1 = np.ascontiguousarray(K[k - 1]), np.ascontiguousarray(K[k])
+        L.hs_delo_step(a0.ctypes.data, k0.ctypes.data, a1.ctypes.data, k1.ctypes.data, float(lam[k - 1] - lam[k]), float(tau[k] - tau[k - 1]),
+                       I.ctypes.data, nxt.ctypes.data)
+        I = nxt
+        dev[k - 1] = I
+    exa = dex.replay(lam, j, K, tau, True)
+    cof = dex.replay(lam, j, K, tau, False)
+    assert np.isfinite(dev).all() and np.isfinite(exa).all()
+    assert np.abs(exa).max() > 1e70 and np.abs(cof).max() < 1e15          # the excursion the exact recursion makes and the cofactor one does not
+    for k in range(n - 1):
+        assert np.abs(dev[k] - exa[k]).max() <= 1e-6 * np.abs(exa[k]).max() + 1e-300, (k, dev[k], exa[k])
+    assert abs(dev[0][0] / cof[0][0]) > 1e6                                # eight decades apart at the camera end
+
+
 def test_thindisk_single_point_pixels_match_oracle(L):
     # BASELINE config 1 (harm.in.dist): standard=2 camera, nup=1, THINDISK + BB, nvals=1; device function compiled for the host
     kw = dict(standard=2, spin=0.998, uout=1e-4, gridvals=(-25., 25., -25., 25.), nn=(40, 40, 1), fname="THINDISK", ename="BB",

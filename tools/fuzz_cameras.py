@@ -175,6 +175,33 @@ for c in range(ncams):
                         amp = max(amp, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max() / 1e-8)
             if amp > 30.0 and err < amp * 1e-7:
                 flag = "  (amplified by the reference's own integrator: a 1e-8 change of the frequency moves its answer by %.0f x 1e-8)" % amp; ampl += 1
+            elif iname == "delo" and nst == 4:
+                # r04 (seed 1234 camera 300): a DELO pixel that is stable under every perturbation above and still not the device's.  The
+                # reference's recursion on the ray's own coefficients with the 4x4 system of every step solved exactly (rational arithmetic
+                # on the same double inputs) against the same recursion with its cofactor inverse: where the two part company the
+                # reference's pixel is made by the rounding inside imatrix_4 (a near-vacuum point with rho_V / alpha_I ~ 1e87 between two
+                # emitting zones: the exact step keeps the Stokes component along the Faraday axis, the cofactor inverse returns 1e-77,
+                # and the next boundary multiplies what arrives by 4e88), tools/delo_exact_replay.py
+                import delo_exact_replay as dex
+                worst_rel, worst_at = 0.0, None
+                for k in range(len(freqs)):
+                    if perf[k].max() < tol:
+                        continue
+                    nanm = (~np.isfinite(ref[k])).any(axis=1) | (~np.isfinite(pix[k])).any(axis=1)
+                    dd = np.where(nanm, 0.0, np.abs(pix[k] - ref[k]).max(axis=1))
+                    w = int(np.argmax(dd)) + i1
+                    od = o.ray_dump(w, freqs[k])
+                    if od["npts"] < 2:
+                        continue
+                    n_ = od["npts"]
+                    cof = dex.replay(od["lam"][:n_], od["j"][:n_], od["K"][:n_], od["tau"][:n_], False)[0]
+                    exa = dex.replay(od["lam"][:n_], od["j"][:n_], od["K"][:n_], od["tau"][:n_], True)[0]
+                    rel = float(np.abs(np.nan_to_num(exa, nan=1e300) - np.nan_to_num(cof, nan=-1e300)).max() / (abs(cof[0]) + 1e-300))
+                    if rel > worst_rel:
+                        worst_rel, worst_at = rel, (w, freqs[k], cof, exa)
+                if worst_rel > 1e-3:
+                    flag = ("  (the reference's cofactor inverse is not converged: its own DELO recursion on pixel %d at %.3g Hz gives %s with imatrix_4 and %s with"
+                            " every 4x4 system solved exactly)" % (worst_at[0], worst_at[1], np.array2string(worst_at[2], precision=3), np.array2string(worst_at[3], precision=3))); cond += 1
     bad += ("MISMATCH" in flag)
     print("cam %2d %-8s %s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
           (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag, (" IQUV per frequency " + str(perf)) if flag else ""))
