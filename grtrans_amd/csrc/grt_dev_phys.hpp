@@ -345,7 +345,7 @@ GRT_NI void polsynchpl(const GrtTables &T, double nu, double nnth, double B, dou
 // Same formulas as polsynchemis.f90:527-631 (differences are rounding-level re-association).
 GRT_HD double interp_fast(double lx, int ix, int iy, const double *xv, int nx, const double *yv, const double *sv) {
   int indx = iy * nx + ix;                 // 1-based
-  return exp(yv[indx - 1] + sv[indx - 1] * (lx - xv[ix - 1]));
+  return fexp(yv[indx - 1] + sv[indx - 1] * (lx - xv[ix - 1]));      // (finite: lx is a logarithm of positive numbers, the tables are finite)
 }
 
 // The frequency-independent half of polsynchpl_fast, computed once per point and shared by all frequencies
@@ -381,7 +381,7 @@ GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoi
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
   const double l15 = 0.4054651081081644;                   // log(1.5)
   const double lx = P.lnub - lnu;
-  const double sq15 = exp(0.5 * (lx + l15));               // sqrt(1.5 x)
+  const double sq15 = fexp(0.5 * (lx + l15));               // sqrt(1.5 x)
   const double x = sq15 * sq15 * (2.0 / 3.0);              // x = nub / nu from the same exponential (one exp less per frequency)
   double lxmin = -lx - C.lmin, lxmax = -lx - C.lmax;      // log(nu/nucmin), log(nu/nucmax)
   int ix1, ix2;
@@ -395,12 +395,12 @@ GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoi
   double gapfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yap, T.syap) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yap, T.syap);
   double gvfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yv, T.syv) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yv, T.syv);
   double gavfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yav, T.syav) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yav, T.syav);
-  double pw = exp(C.alpha * (lx + l15));                   // (3 nub/2 nu)^((p-1)/2)
+  double pw = fexp(C.alpha * (lx + l15));                   // (3 nub/2 nu)^((p-1)/2)
   double jfac = P.A * (ec * ec / c * 1.7320508075688772 / 4.0) * pw * P.nubperp;
   double ji = jfac * gxfac;
   double jq = jfac * gpfac;
   double jv = jfac * (4.0 / 3.0) * P.itanth * sq15 * gvfac;
-  double kstarq = P.kperp * (x * x * x) * C.kq * (1.0 - exp((C.alpha - 0.5) * (lx + C.l2g)));
+  double kstarq = P.kperp * (x * x * x) * C.kq * (1.0 - fexp((C.alpha - 0.5) * (lx + C.l2g)));
   double kstarv = C.kv * P.kperp * (x * x) * P.itanth;
   double omega = nu * 2.0 * pi;
   // (2w/3w0)^(-p/2) = (1.5 x)^(p/2) = pw * sqrt(1.5 x)
@@ -781,7 +781,7 @@ GRT_NI void calc_O(const double *a, const double *rho, double dx, double O[4][4]
 // about 230 through the 48 matrix entries and the 16 entries of O; r03: transfer kernel of the headline camera 36.2 -> 35.3 ms with the record, 34.0 -> 32.8 ms image only).
 // Same algebra, another summation order: results agree with calc_O's to rounding (tests/test_hostsim_fast.py).
 GRT_NI void formal_apply(const double *a, const double *rho, double dx, const double *V, double *out) {
-  const double onopol = exp(-a[0] * dx);
+  const double onopol = fexp(-a[0] * dx);      // (finite arguments: products of coefficients and a step length; fexp saturates like exp)
   const double aq = a[1], au = a[2], av = a[3], rq = rho[0], ru = rho[1], rv = rho[2];
   const double v0 = V[0], v1 = V[1], v2 = V[2], v3 = V[3];
   const double a2 = aq * aq + au * au + av * av;
@@ -796,7 +796,7 @@ GRT_NI void formal_apply(const double *a, const double *rho, double dx, const do
   const double lam1 = fsqrt(rt + hd), lam2 = fsqrt(rt - hd);
   const double theta = lam1 * lam1 + lam2 * lam2;
   const double sig = fsign(1.0, ap), s1 = sig * lam1, s2 = sig * lam2;
-  const double ep = exp(lam1 * dx), em = frcp(ep), zz = lam1 * dx;
+  const double ep = fexp(lam1 * dx), em = frcp(ep), zz = lam1 * dx;
   double ch = 0.5 * (ep + em);
   double sh = (fabs(zz) < 1e-3) ? zz * (1.0 + zz * zz * (1.0 / 6.0) * (1.0 + zz * zz * 0.05)) : 0.5 * (ep - em);
   if (zz > 709.0) {      // (see calc_O: cosh / sinh stay finite where e^zz overflows)
@@ -804,7 +804,11 @@ GRT_NI void formal_apply(const double *a, const double *rho, double dx, const do
     ch = (0.5 * w) * w; sh = ch;
   }
   double co, si;
-#if defined(__HIP_DEVICE_COMPILE__)
+  // (r04: the lean sincos of the geodesic kernels -- no large-argument path; the Faraday angle of a step is an ordinary number -- 25
+  //  frequencies 355.9 -> 349.1 ms on one box; the single-frequency kernels do not notice.  GRT_FORMAL_LIB_SINCOS: the library's)
+#if !defined(GRT_FORMAL_LIB_SINCOS)
+  fast_sincos(lam2 * dx, &si, &co);
+#elif defined(__HIP_DEVICE_COMPILE__)
   sincos(lam2 * dx, &si, &co);
 #else
   si = sin(lam2 * dx); co = cos(lam2 * dx);
@@ -1666,7 +1670,7 @@ GRT_HD void delo_apply_core(const double *j0, const double *K0p, const double *j
   const double n3 = K1p[3] * I[0] + (I[1] * K1p[5] - I[2] * K1p[4]);
   double y[4];
   if (delta > thin) {
-    const double E = exp(-delta), F = 1.0 - E, G = (1.0 - (1.0 + delta) * E) * frcp(delta);
+    const double E = fexp(-delta), F = 1.0 - E, G = (1.0 - (1.0 + delta) * E) * frcp(delta);
     const double fg = (F - G) * frcp(ki), g1 = G * frcp(ki1);
     y[0] = fg * j0[0] + g1 * j1[0] + E * I[0] - g1 * n0;
     y[1] = fg * j0[1] + g1 * j1[1] + E * I[1] - g1 * n1;

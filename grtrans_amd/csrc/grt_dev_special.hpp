@@ -74,6 +74,29 @@ GRT_HD double frcp_s(double b) { return 1.0 / b; }
 GRT_HD double fdiv(double a, double b) { return a / b; }
 GRT_HD double fsqrt(double x) { return sqrt(x); }
 #endif
+// exp for arguments that are ordinary numbers (|x| < ~1e15; NaN propagates): the library's exp without its two range compares and three
+// selects -- 18 instructions instead of 23, and the power-law coefficients take 15 exponentials per frequency (polsynchpl_freq; r04: 25
+// frequencies 358 -> see DESIGN 6).  Cody-Waite reduction by ln2 (hi + lo with fma), exp(t) = 1 + t (1 + t q(t)) on |t| <= ln2/2 with q
+// of degree 9 interpolated at Chebyshev nodes (polynomial error 1.6e-17 relative), ldexp for the scale -- which saturates by itself: an
+// argument above 709.8 gives inf, one below -745.1 gives 0.  Against glibc over [-700, 700]: at most 0.96 ulp, 1 ulp off in 6 % of the
+// arguments (tests/test_hostsim_fast.py::test_fexp...).  NOT for arguments that may be infinite (exp(-inf) must be 0: this returns NaN).
+#if !defined(GRT_NO_FEXP)
+GRT_HD double fexp(double x) {
+  const double l2e = 1.4426950408889634, ln2h = 0x1.62e42fefa39efp-1, ln2l = 0x1.abc9e3b39803fp-56;
+  const double dn = rint(x * l2e);
+  double t = fma(-dn, ln2h, x);
+  t = fma(-dn, ln2l, t);
+  double p = 2.510038549551032e-08;
+  p = fma(t, p, 2.7620088445409746e-07); p = fma(t, p, 2.7557268459997064e-06); p = fma(t, p, 2.4801521295954376e-05);
+  p = fma(t, p, 0.00019841269863053618); p = fma(t, p, 0.0013888888917213717); p = fma(t, p, 0.0083333333333300615);
+  p = fma(t, p, 0.041666666666624129); p = fma(t, p, 0.16666666666666669); p = fma(t, p, 0.50000000000000011);
+  p = fma(t, p, 1.0);
+  p = fma(t, p, 1.0);
+  return ldexp(p, (int)dn);
+}
+#else
+GRT_HD double fexp(double x) { return exp(x); }
+#endif
 GRT_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
 GRT_HD double powm1(int n) { return (n & 1) ? -1.0 : 1.0; }
 GRT_HD int fint(double x) { return (int)x; }
@@ -291,8 +314,9 @@ GRT_HD double rf_c(double x, double y, double z) {
 // sin and cos for the arguments of this path (Jacobi arguments scaled to [0, pi], polar angles, Faraday angles of a step; the absolute
 // error stays at 1e-16 while |x| < 1e9 and grows as ulp(x) beyond, which is the uncertainty of such an argument anyway): Cody-Waite
 // reduction by pi/2 in two fused steps and the fdlibm kernels on [-pi/4, pi/4].  No large-argument path, no special cases -- the
-// library routine carries both, and their registers, into every kernel that calls it.  (Geodesic kernels only: measured on the
-// transfer kernel, lean exp / log / sincos / acos of the same kind were 3-7 % SLOWER than the library's there.)
+// library routine carries both, and their registers, into every kernel that calls it.  (r03 measured lean exp / log / sincos / acos of
+// this kind 3-7 % SLOWER than the library's in the transfer kernel -- with MachineLICM on, which parked their constants in spilled SGPRs;
+// with the pass off (r04) fexp and this routine pay there too: grt_dev_phys.hpp:polsynchpl_freq, formal_apply.)
 GRT_HD void fast_sincos(double x, double *sn, double *cs) {
   const double n = rint(x * 0.63661977236758138);
   double r = fma(-n, 1.5707963267948966, x);

@@ -443,6 +443,22 @@ def test_delo_through_a_vacuum_pocket_device_step_is_the_exact_solution_not_the_
     assert abs(dev[0][0] / cof[0][0]) > 1e6                                # eight decades apart at the camera end
 
 
+def test_fexp_is_exp_to_one_ulp_and_saturates_like_it(L):
+    # grt_dev_special.hpp:fexp -- the library exp without its range compares (15 exponentials per frequency in polsynchpl_freq): at most one
+    # ulp from the correctly rounded value over the whole range of a double's exponent, inf above 709.78, 0 below -745.13, NaN in NaN out
+    L.hs_fexp.restype = C.c_double
+    L.hs_fexp.argtypes = [C.c_double]
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-745.0, 709.0, 40000), rng.uniform(-40.0, 40.0, 40000), rng.uniform(-1.0, 1.0, 20000), [0.0, -0.0, 709.7, -745.1, 1e-300, -1e-300]])
+    got = np.array([L.hs_fexp(float(x)) for x in xs])
+    want = np.exp(xs.astype(np.longdouble))
+    ulp = np.spacing(np.abs(want.astype(np.float64)))
+    assert np.all(np.abs(got.astype(np.longdouble) - want) <= 1.0 * ulp), float(np.max(np.abs(got.astype(np.longdouble) - want) / ulp))
+    assert L.hs_fexp(0.0) == 1.0
+    assert L.hs_fexp(710.0) == np.inf and L.hs_fexp(5000.0) == np.inf and L.hs_fexp(-746.0) == 0.0 and L.hs_fexp(-1e6) == 0.0
+    assert np.isnan(L.hs_fexp(float("nan")))
+
+
 def test_thindisk_single_point_pixels_match_oracle(L):
     # BASELINE config 1 (harm.in.dist): standard=2 camera, nup=1, THINDISK + BB, nvals=1; device function compiled for the host
     kw = dict(standard=2, spin=0.998, uout=1e-4, gridvals=(-25., 25., -25., 25.), nn=(40, 40, 1), fname="THINDISK", ename="BB",
