@@ -736,7 +736,13 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, ((TSH == 2 && FB == 1) ? 3 : GRT_
       // (extra=1 needs the fourth tile for phi as well: the time then comes straight from the record, as for KORAL3D)
       const double t_i = !(slowlight && valid) ? 0.0 : ((FLUID == GRT_FLUID_KORAL3D || EXTRA) ? steps[(long long)tfield * field_stride + base + ip] : tl3[lane * TS + e]);
       double kv[4], sth, cth;
-      sincos(th, &sth, &cth);      // (the library's: the lean fast_sincos of the geodesic kernels is 5 % slower here, re-measured r03)
+      // (r03 measured the lean fast_sincos of the geodesic kernels 5 % SLOWER here -- with MachineLICM parking its constants in spilled SGPRs; with the
+      //  pass off it is 0.2-0.6 ms faster in every transfer kernel: profiles/r04_h_variants_lean_step_sincos.log.  theta is in [0, pi])
+#if !defined(GRT_XFER_LIB_SINCOS)
+      fast_sincos(th, &sth, &cth);
+#else
+      sincos(th, &sth, &cth);
+#endif
       calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
       sumr += valid ? r : 0.0;
       // fluid + frame (grtrans_driver.f90:126-130)

@@ -459,6 +459,29 @@ def test_fexp_is_exp_to_one_ulp_and_saturates_like_it(L):
     assert np.isnan(L.hs_fexp(float("nan")))
 
 
+def test_power_law_emissivity_follows_the_reference_across_its_own_discontinuity(L):
+    # r04, fuzz seed 2718 camera 620 (FFJET POLSYNCHPL, p = 5.5, 345 GHz): the reference's j_I jumps by 1.8 % across one node of its G(x) table
+    # lookup while alpha_I is continuous (polsynchemis.f90:62-92, 608-629 as the oracle restates them), and one point of a ray sat 3e-8 (relative, in
+    # B) from the jump: the device's inputs, equal to the reference's to the 1e-7 of the REAL(4) sampler, fell on the other side -- 1.3e-4 of the
+    # pixel.  The device function must follow the reference on BOTH sides (it does, to rounding); the jump itself is the reference's.
+    t = np.fromfile(os.path.join(ROOT, "grtrans_amd", "data", "polsynchpl_tables.bin"))
+    L.hs_pl_setup.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    L.hs_pl_setup(t.ctypes.data, 5.5, 100.0, 1e5)
+    L.hs_polsynchpl.argtypes = [C.c_double] * 4 + [C.c_void_p]
+    nu, n0, B0, th = 267079126421.41788, 8.2034788131713867, 6.803596243262291, 0.60558747948126357
+    base = np.asarray(O.polsynchpl(nu, n0, B0, th, 5.5, 100.0, 1e5)).ravel()
+    jumps = []
+    for db in (1e-6, 1e-8, 0.0, -1e-8, -3e-8, -1e-7, -1e-6):
+        ref = np.asarray(O.polsynchpl(nu, n0, B0 * (1 + db), th, 5.5, 100.0, 1e5)).ravel()
+        e = np.zeros(11)
+        L.hs_polsynchpl(nu, n0, B0 * (1 + db), th, e.ctypes.data)
+        nz = ref != 0.0
+        assert np.abs(e[nz] / ref[nz] - 1.0).max() < 1e-12, (db, e, ref)
+        jumps.append(ref[0] / base[0])
+    assert abs(jumps[3] - 1.0) < 1e-7 and abs(jumps[4] - 1.0179) < 1e-4 and abs(jumps[6] - 1.0179) < 1e-4, jumps
+    L.hs_pl_setup(t.ctypes.data, 3.5, 100.0, 1e5)          # (the module-level tables of hostsim: back to the p of the other tests)
+
+
 def test_thindisk_single_point_pixels_match_oracle(L):
     # BASELINE config 1 (harm.in.dist): standard=2 camera, nup=1, THINDISK + BB, nvals=1; device function compiled for the host
     kw = dict(standard=2, spin=0.998, uout=1e-4, gridvals=(-25., 25., -25., 25.), nn=(40, 40, 1), fname="THINDISK", ename="BB",

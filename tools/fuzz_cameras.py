@@ -110,6 +110,34 @@ for c in range(ncams):
     def etrace(e, fr):
         p_, n_, _ = e.trace(i1, i2, fr, nthreads=1 if COND_REF else 0)
         return np.asarray(p_, dtype=np.float64), n_, None
+    nan_note = ""
+    if flag and ok_n and not same_nan and iname == "delo" and nst == 4:
+        # r04 (seed 31415 camera 24): a DELO pixel that is NaN in the reference and finite on the device.  The reference's recursion on the
+        # ray's own coefficients overflows inside its cofactor inverse (tools/delo_exact_replay.py: non-finite with imatrix_4, finite with
+        # every 4x4 system solved exactly -- and the device pixel is the exact recursion's Stokes vector times one common factor)
+        import delo_exact_replay as dex
+        explained, total = 0, 0
+        for k in range(len(freqs)):
+            dm = np.where((~np.isfinite(ref[k])).any(axis=1) != (~np.isfinite(pix[k])).any(axis=1))[0]
+            for w0 in dm:
+                total += 1
+                if np.isfinite(ref[k][w0]).all():
+                    continue                   # NaN on the device only: never waived
+                od = o.ray_dump(int(w0) + i1, freqs[k])
+                n_ = od["npts"]
+                if n_ < 2:
+                    continue
+                cof = dex.replay(od["lam"][:n_], od["j"][:n_], od["K"][:n_], od["tau"][:n_], False)[0]
+                exa = dex.replay(od["lam"][:n_], od["j"][:n_], od["K"][:n_], od["tau"][:n_], True)[0]
+                if (not np.isfinite(cof).all()) and np.isfinite(exa).all() and exa[0] != 0.0:
+                    ratio = pix[k][w0].astype(np.float64) / exa
+                    if np.abs(ratio / ratio[0] - 1.0).max() < 1e-3:
+                        explained += 1
+        if total and explained == total:
+            same_nan = True
+            nan_note = "  [%d pixel(s) NaN in the reference only: its DELO recursion overflows inside imatrix_4, solved exactly it is finite and is the device's]" % total
+            if err < tol:
+                flag = ""
     if flag and ok_n and COND_REF:
         cref, crn, _ = etrace(engine(), freqs)      # the unperturbed answer of the engine the perturbations are compared with
     else:
@@ -165,16 +193,20 @@ for c in range(ncams):
             # the reference against itself with every frequency moved by 1e-8.  A well-conditioned pixel moves by a few 1e-8
             # (d ln I / d ln nu of order one); DELO in its alternating-growth regime (negative intensities; SPHACC at 24 GHz)
             # multiplies whatever difference reaches the last steps by 10-100 per step.
+            # (r04, seed 2718 camera 620: the reference's j_I of POLSYNCHPL is DISCONTINUOUS in nu_B/nu -- 1.8 % across one node of its G(x) table
+            #  lookup at p = 5.5, alpha_I continuous -- and one point of the ray sat 3e-8 from the jump: the device's inputs, which agree with the
+            #  reference's to the 1e-7 of the REAL(4) sampler, fell on the other side.  The probe therefore also moves the frequency by 1e-7 and 3e-7,
+            #  the level the inputs agree at)
             amp = 0.0
-            for rel in (1e-8, -1e-8):
+            for rel in (1e-8, -1e-8, 1e-7, -1e-7, 3e-7, -3e-7):
                 fp = [float(f * (1 + rel)) for f in freqs]
                 rp, _, _ = etrace(engine(), fp) if COND_REF else o.trace(i1, i2, fp, nthreads=0)
                 for k in range(len(freqs)):
                     okm = np.isfinite(cref[k]).all(axis=1) & np.isfinite(rp[k]).all(axis=1)
                     if okm.any():
-                        amp = max(amp, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max() / 1e-8)
-            if amp > 30.0 and err < amp * 1e-7:
-                flag = "  (amplified by the reference's own integrator: a 1e-8 change of the frequency moves its answer by %.0f x 1e-8)" % amp; ampl += 1
+                        amp = max(amp, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max() / abs(rel))
+            if amp > 30.0 and err < 3.0 * amp * 1e-7:
+                flag = "  (amplified by the reference itself: a change of the frequency by 1e-8 ... 3e-7 moves its answer by %.0f times as much)" % amp; ampl += 1
             elif iname == "delo" and nst == 4:
                 # r04 (seed 1234 camera 300): a DELO pixel that is stable under every perturbation above and still not the device's.  The
                 # reference's recursion on the ray's own coefficients with the 4x4 system of every step solved exactly (rational arithmetic
@@ -204,7 +236,7 @@ for c in range(ncams):
                             " every 4x4 system solved exactly)" % (worst_at[0], worst_at[1], np.array2string(worst_at[2], precision=3), np.array2string(worst_at[3], precision=3))); cond += 1
     bad += ("MISMATCH" in flag)
     print("cam %2d %-8s %s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
-          (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag, (" IQUV per frequency " + str(perf)) if flag else ""))
+          (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag + nan_note, (" IQUV per frequency " + str(perf)) if flag else ""))
     if only is not None:
         print("   exact: spin %r mu0 %r gridvals %r uout %r freqs %r" % (a, mu0, gv, uout, freqs))
     if only is not None:
