@@ -1299,7 +1299,8 @@ template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4() {
 #else
   return IFLAG == GRT_INT_FORMAL && ((FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL) ||
                                      (FLUID == GRT_FLUID_SPHACC && EMIS == GRT_EMIS_POLSYNCHTH) ||
-                                     (FLUID == GRT_FLUID_HARM && EMIS == GRT_EMIS_POLSYNCHTH));
+                                     (FLUID == GRT_FLUID_HARM && EMIS == GRT_EMIS_POLSYNCHTH) ||
+                                     (FLUID == GRT_FLUID_HARM3D && EMIS == GRT_EMIS_POLSYNCHTH));      // (167 registers, no scratch: 44.2 -> 42.6 / 45.5 -> 44.2 ms)
 #endif
 }
 template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4_batch() {     // ... and the frequency-batch kernel of BASELINE config 5

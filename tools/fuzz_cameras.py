@@ -107,6 +107,53 @@ for c in range(ncams):
             kw.pop("datadir")          # (the reference reads the FFJET table relative to its data directory)
         return (refbind.Ref if COND_REF else orabind.Oracle)(**kw)
 
+    lam_note = (0.0, 0.0)
+
+    def lam_ulp_explains():
+        # r04 (seed 99 camera 128; seed 777 camera 240 was the same on a Schwarzschild camera): GEOKERR's affine parameter is a number of order 1e9
+        # near the outer boundary -- one ulp is 1.2e-7 -- and neighbouring points of a grazing ray are 0.1 apart, so d(lambda) is quantised at
+        # 1e-6 of itself in the reference; a last step of optical depth ~3 hands that to the pixel.  The fast classes' lambda differs from the
+        # literal one by an ulp at a few points, and no re-roll of the camera need flip THE point that matters.  Measured directly: the
+        # reference's own integrator (oracle) on the worst pixel's coefficients with lambda moved by one ulp of its full-size value at one
+        # point at a time (tau follows by its trapezoid rule); waived when the device's difference on that pixel is within 4 such steps.
+        global lam_note
+        best = None
+        for k in range(len(freqs)):
+            if perf[k].max() < tol:
+                continue
+            nanm = (~np.isfinite(ref[k])).any(axis=1) | (~np.isfinite(pix[k])).any(axis=1)
+            dd = np.where(nanm, 0.0, np.abs(pix[k] - ref[k]).max(axis=1))
+            w0 = int(np.argmax(dd))
+            od = o.ray_dump(w0 + i1, freqs[k])
+            n_ = od["npts"]
+            if n_ < 3 or not np.isfinite(od["K"][:n_]).all():
+                return False
+            q = float(np.spacing(np.abs(np.asarray(o.geokerr_ray(w0 + i1)["lam"])).max()))
+            lam0, j0, K0, tau0 = (np.asarray(od[key][:n_], dtype=np.float64) for key in ("lam", "j", "K", "tau"))
+            aK = np.abs(K0[:, 0])
+            chk = -np.concatenate([[0.0], np.cumsum(np.diff(lam0) * 0.5 * (aK[:-1] + aK[1:]))])
+            if not np.allclose(chk, tau0, rtol=1e-9, atol=1e-300):
+                return False                      # (not the tau this rule knows how to move)
+            iflag = 1 if iname == "delo" else 2
+            base = orabind.integrate(iflag, lam0, j0, K0, tau0)[n_ - 1]
+            if not np.isfinite(base).all() or base[0] == 0.0:
+                return False
+            sens = 0.0
+            for kk in range(n_):
+                for sg in (q, -q):
+                    lam1 = lam0.copy(); lam1[kk] += sg
+                    tau1 = -np.concatenate([[0.0], np.cumsum(np.diff(lam1) * 0.5 * (aK[:-1] + aK[1:]))])
+                    I1 = orabind.integrate(iflag, lam1, j0, K0, tau1)[n_ - 1]
+                    if np.isfinite(I1).all():
+                        sens = max(sens, float(np.abs(I1 - base).max() / abs(base[0])))
+            dpix = float(np.abs(pix[k][w0].astype(np.float64) - ref[k][w0]).max() / (abs(ref[k][w0][0]) + 1e-300))
+            if best is None or dpix > best[1]:
+                best = (sens, dpix)
+        if best is None:
+            return False
+        lam_note = best
+        return best[1] <= 4.0 * best[0]
+
     def etrace(e, fr):
         p_, n_, _ = e.trace(i1, i2, fr, nthreads=1 if COND_REF else 0)
         return np.asarray(p_, dtype=np.float64), n_, None
@@ -169,14 +216,19 @@ for c in range(ncams):
         #  re-rolls through uout left the ONE point that mattered alone: a grazing ray whose lambda, 9e8 with an ulp of 1.2e-7, steps by 0.08
         #  per point, and whose last step has an optical depth of 3 -- one ulp of lambda at the camera end is 4e-6 of the pixel.  The
         #  image bounds moved by one ulp either way re-roll every ray's constants: four more draws of the same rounding)
+        # (seed 99 camera 128 -- the same grazing-ray mechanism on a Kerr camera, 3.5e-6 against a bar of 2e-6 -- slipped through eleven draws: the
+        #  flip that matters is the one at the LAST point of one ray, a few per cent of the draws.  Each bound also moves on its own, both ways: 19 draws)
         for da, dm, du, dg in ((0, 1, 0, 0), (1, 0, 0, 0), (0, -1, 0, 0), (0, 0, 1, 0), (0, 0, -1, 0), (0, 2, 0, 0), (0, -2, 0, 0),
-                               (0, 0, 0, 1), (0, 0, 0, -1), (0, 0, 0, 2), (0, 0, 0, -2)):
+                               (0, 0, 0, 1), (0, 0, 0, -1), (0, 0, 0, 2), (0, 0, 0, -2),
+                               (0, 0, 0, 3), (0, 0, 0, -3), (0, 0, 0, 4), (0, 0, 0, -4), (0, 0, 0, 5), (0, 0, 0, -5), (0, 0, 0, 6), (0, 0, 0, -6)):
             if da and a == 0.0:
                 continue
             mu0p = (mu0 + (1e-15 if dm > 0 else -1e-15)) if abs(dm) == 2 else (float(np.nextafter(mu0, dm * 2.0)) if dm else mu0)
             gvp = gv
-            if dg:      # +-1: the alpha bounds, +-2: the beta bounds, one ulp outwards / inwards
+            if dg and abs(dg) <= 2:      # +-1: the alpha bounds, +-2: the beta bounds, one ulp up / down
                 gvp = tuple(float(np.nextafter(v, np.inf if dg > 0 else -np.inf)) if (k // 2 == abs(dg) - 1) else v for k, v in enumerate(gv))
+            elif dg:                     # +-3 ... +-6: one bound alone
+                gvp = tuple(float(np.nextafter(v, np.inf if dg > 0 else -np.inf)) if (k == abs(dg) - 3) else v for k, v in enumerate(gv))
             op = engine(spin=float(np.nextafter(a, 2.0)) if da else a, mu0=mu0p, uout=float(np.nextafter(uout, du * 1.0)) if du else uout, gridvals=gvp)
             rp, rnp, _ = etrace(op, freqs)
             if not np.array_equal(rnp, crn):
@@ -207,6 +259,8 @@ for c in range(ncams):
                         amp = max(amp, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max() / abs(rel))
             if amp > 30.0 and err < 3.0 * amp * 1e-7:
                 flag = "  (amplified by the reference itself: a change of the frequency by 1e-8 ... 3e-7 moves its answer by %.0f times as much)" % amp; ampl += 1
+            elif nst == 4 and lam_ulp_explains():
+                flag = "  (one ulp of GEOKERR's lambda at one point of the worst pixel's ray moves the reference's own integral by %.1e of the pixel; the device's pixel differs by %.1e)" % lam_note; cond += 1
             elif iname == "delo" and nst == 4:
                 # r04 (seed 1234 camera 300): a DELO pixel that is stable under every perturbation above and still not the device's.  The
                 # reference's recursion on the ray's own coefficients with the 4x4 system of every step solved exactly (rational arithmetic
