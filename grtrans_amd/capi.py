@@ -230,6 +230,11 @@ def record_steps(enable):
     check(lib().grt_set_record_steps(C.c_int(1 if enable else 0)), "grt_set_record_steps")
 
 
+def geo_split(enable):
+    """1 (default): azimuth of the four-real-root class by grt_phi_kernel after the image-only geodesic kernel; 0: the fused kernel."""
+    check(lib().grt_set_geo_split(C.c_int(1 if enable else 0)), "grt_set_geo_split")
+
+
 def download_steps(ray0, nrays, maxpts):
     out = np.zeros((8, nrays, maxpts))
     check(lib().grt_download_steps(C.c_int64(ray0), C.c_int64(nrays), C.c_int(maxpts),

@@ -19,7 +19,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split, int *todo, int *todo_count);
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
                                       double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield);
@@ -86,6 +86,8 @@ struct Ctx {
   char *d_rrays = nullptr;
   size_t cap_rrays = 0;
   int *d_npts = nullptr, *d_live = nullptr, *d_counters = nullptr;
+  int *d_phitodo = nullptr;             // per ray of a pass: 1 = grt_phi_kernel left the ray's azimuth to the fused kernel
+  size_t cap_phitodo = 0;
   float *d_pixvals = nullptr;
   double *d_freqs = nullptr, *d_steps = nullptr;
   long long steps_stride = 0;
@@ -110,6 +112,7 @@ struct Ctx {
   long long t0_version = 0;
   int force_time = 0;                   // grt_debug_ray: every point carries its coordinate time whatever the fluid model
   int geo_reuse = 1;                    // grt_set_geo_reuse
+  int geo_split = 1;                    // grt_set_geo_split: record-mode trace of the four-real-root class as image-only kernel + grt_phi_kernel
   int class_order = 3;
   bool class_order_forced = false;     // GRT_CLASS_ORDER given: its wait bit holds for every pass size
   long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
@@ -177,6 +180,7 @@ int grt_init(int device) {
     const char *po = std::getenv("GRT_CLASS_ORDER");
     C.class_order = po ? std::atoi(po) : 7;
     C.class_order_forced = po != nullptr;
+    if (const char *gs = std::getenv("GRT_GEO_SPLIT")) C.geo_split = std::atoi(gs) ? 1 : 0;      // (A/B runs of the fused record-mode kernel)
     HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
   }
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
@@ -191,7 +195,7 @@ int grt_init(int device) {
 int grt_free(void) {
   if (!C.init) return 0;
   drain();
-  void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters,
+  void *ptrs[] = {C.d_rrays, C.d_cells, C.d_uniq, C.d_tables, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_phitodo,
                   C.d_pixvals, C.d_freqs, C.d_steps, C.d_stepcount, C.d_sphacc,
                   C.d_harm_cells, C.d_harm_coords, C.d_t0, C.d_rng, C.d_h3_cells, C.d_h3_coords, C.d_ih_cells, C.d_ih_coords, C.d_ko_cells, C.d_ko_coords};
   for (void *p : ptrs)
@@ -542,6 +546,12 @@ int grt_set_record_steps(int enable) {
   return 0;
 }
 
+int grt_set_geo_split(int enable) {
+  C.geo_split = enable ? 1 : 0;
+  C.geo.valid = false;                  // a resident record made the other way is not re-used across the switch
+  return 0;
+}
+
 // One call = the pixels of nranges inclusive 1-based ranges (lo[k]..hi[k], in this order: the rows of pixvals / ray_status follow
 // it), traced in ONE set of launches.  nranges == 1 is grt_trace_tile.
 static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, const int64_t *his, int fluid_model, const grt_emis *em, int nfreq,
@@ -555,8 +565,12 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   }
   if (total > 0x7fffffffLL) return GRT_E_BADARG;
   const int64_t i1 = los[0], i2 = his[0];       // (the single range when nranges == 1)
-  C.last_tile.clear();                          // (grt_debug_ray looks a pixel's row of the time-origin table up in it)
-  for (int k = 0; k < nranges; ++k) { C.last_tile.push_back(los[k]); C.last_tile.push_back(his[k]); }
+  // grt_debug_ray looks a pixel's row of the time-origin table up in the ranges of the last ACCEPTED trace: noted only once the
+  // arguments have passed every refusal below (a refused call must not change the mapping: ADVICE r04)
+  auto note_tile = [&]() {
+    C.last_tile.clear();
+    for (int k = 0; k < nranges; ++k) { C.last_tile.push_back(los[k]); C.last_tile.push_back(his[k]); }
+  };
   std::vector<long long> rkey;
   const long long *d_rng = nullptr;
   if (nranges > 1) {
@@ -584,6 +598,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
     if (bbpol && !C.have_chandra) return GRT_E_NOTABLES;
     if (sizeof(C.disk) != grt_sizeof_disk()) return GRT_E_BADARG;
     HIPCHK(hipSetDevice(C.device));
+    note_tile();
     C.geo.valid = false;
     const int nrays = (int)total;
     int rc;
@@ -672,6 +687,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   const int tfield = need_time ? nfields : -1;
   if (need_time && C.t0_n != 0 && C.t0_n != total) return GRT_E_BADARG;   // t0 table of another tile
   const double *d_t0 = (need_time && C.t0_n != 0) ? C.d_t0 : nullptr;
+  note_tile();                                    // nothing below refuses the arguments any more
   const int nalloc = nfields + (need_time ? 1 : 0);
   // The geodesic hand-over buffers grow with rays x points (12 KB per ray at nup=400): a tile whose buffers would pass the
   // cap (GRT_MAX_WORK_BYTES, default 96 GiB of the 288) is traced in passes over sub-ranges of its rays; pixvals and
@@ -693,6 +709,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
+  if ((rc = grow(C.d_phitodo, C.cap_phitodo, (size_t)chunk))) return rc;
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   // one field of the record: [ray slot][rstride points]; with the per-step record on, whole blocks of 64 slots (its I,Q,U,V fields are
@@ -748,7 +765,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       if (generic) {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps,
-                                   rstride, fstride, nfields, tfield, t0c, 0));
+                                   rstride, fstride, nfields, tfield, t0c, 0, 0, nullptr, nullptr));
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
@@ -771,7 +788,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       } else {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
-                                   nfields, tfield, t0c, 0));
+                                   nfields, tfield, t0c, 0, C.geo_split, C.d_phitodo, C.d_counters + 2));
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                                       C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
@@ -956,8 +973,8 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
   hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin, nullptr, 0);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr);
   if (e != hipSuccess) { drain(); return (int)e; }
   HIPCHK(hipStreamSynchronize(C.stream));
   // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them
@@ -1019,7 +1036,11 @@ int grt_debug_ray(const grt_camera *cam, int64_t pixel, int fluid_model, const g
   }
   C.record_steps = 1; C.force_time = 1; C.geo_reuse = 0;
   grt_stats st{};
+  // the one-pixel trace below is an internal call: the ranges of the run's last trace (the tile the time-origin table belongs to)
+  // stay what they were, so that a second grt_debug_ray -- this pixel again, or another pixel of the tile -- finds its row
+  const std::vector<long long> tile0 = C.last_tile;
   int rc = trace_common(cam, 1, &pixel, &pixel, fluid_model, em, 1, &freq, iflag, nvals, 0, &st);
+  C.last_tile = tile0;
   C.record_steps = rec0; C.force_time = ft0; C.geo_reuse = reuse0; C.geo.valid = false;
   if (rc) return rc;
   int32_t n = 0;
@@ -1099,16 +1120,22 @@ int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out) {
   // I,Q,U,V are stored [block of 64 ray slots][point][slot in block] on the device (grt_transfer_kernel writes them from the registers, a
   // wave's rays side by side, consecutive points 512 bytes apart); the public record is ray-major like the geometry fields
   {
+    // in bounded pieces: 256 blocks = 16,384 rays = 60 MB of host staging at 454 points, whatever the record's size
     const int64_t b0 = ray0 / 64, b1 = (ray0 + nrays - 1) / 64;
     const size_t blk = (size_t)64 * (size_t)C.steps_stride;
-    std::vector<double> tmp((size_t)(b1 - b0 + 1) * blk);
+    const int64_t PIECE = 256;
+    std::vector<double> tmp((size_t)std::min<int64_t>(b1 - b0 + 1, PIECE) * blk);
     for (int f = 4; f < 8 && nrays > 0; ++f) {
-      HIPCHK(hipMemcpy(tmp.data(), C.d_steps + (size_t)src[f] * C.steps_fstride + (size_t)b0 * blk, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
       double *o = out + (size_t)f * nrays * maxpts;
-      for (int64_t ry = 0; ry < nrays; ++ry) {
-        const int64_t sl = ray0 + ry;
-        const double *src_ = tmp.data() + (size_t)(sl / 64 - b0) * blk + (size_t)(sl % 64);
-        for (int k = 0; k < maxpts; ++k) o[(size_t)ry * maxpts + k] = src_[(size_t)k * 64];
+      for (int64_t bb = b0; bb <= b1; bb += PIECE) {
+        const int64_t be = std::min<int64_t>(bb + PIECE - 1, b1);
+        HIPCHK(hipMemcpy(tmp.data(), C.d_steps + (size_t)src[f] * C.steps_fstride + (size_t)bb * blk, (size_t)(be - bb + 1) * blk * sizeof(double), hipMemcpyDeviceToHost));
+        const int64_t s0 = std::max<int64_t>(ray0, bb * 64), s1 = std::min<int64_t>(ray0 + nrays - 1, be * 64 + 63);
+        for (int64_t sl = s0; sl <= s1; ++sl) {
+          const double *src_ = tmp.data() + (size_t)(sl / 64 - bb) * blk + (size_t)(sl % 64);
+          double *dst = o + (size_t)(sl - ray0) * maxpts;
+          for (int k = 0; k < maxpts; ++k) dst[k] = src_[(size_t)k * 64];
+        }
       }
     }
   }

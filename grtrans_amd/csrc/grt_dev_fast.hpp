@@ -186,6 +186,7 @@ struct RealRay {
   double sgna_pi;
   double jscale;                   // sqrt(mpos - mneg) (symmetric M) or |muplus|: the Jacobi argument's scale, formed once per ray (r04)
   double froot[4];                 // real_froots at the radial turning point (the upper neighbour of the last inbound point)
+  double hc2, hc3, hc4, hrp, hrm, hA, hB;   // grt_phi_kernel: U(u) = 1 + hc2 u^2 + hc3 u^3 + hc4 u^4; G_u = hA/(1 - hrp u) + hB/(1 - hrm u)
   AgmLadder agm_mu, agm_u;         // Landen ladders of the two Jacobi inversions (moduli m1m, m1u are per-ray constants)
   // ncase 5 (two real roots u1, u4 and a complex pair, or u2, u3 behind the horizon): the u integrals are Carlson
   // (1991) "one quadratic factor" forms with f + g u + u^2 the pair's factor (geokerr_wrapper.f ELLQUARTICCOMPLEX);
@@ -323,6 +324,12 @@ GRT_HD void realray_init(const GrtCam &cam, const GrtRay &R, RealRay &K) {
   agm_ladder(K.m1m, K.agm_mu);
   agm_ladder(K.m1u, K.agm_u);
   real_froots(K, (R.ncase == 7) ? R.u2 : R.u3, K.froot);
+  {
+    const double sq1 = sqrt(one - a * a), rp = one + sq1, rm = one - sq1;
+    K.hc2 = a * a - q2 - l2; K.hc3 = 2.0 * ((a - l) * (a - l) + q2); K.hc4 = ee;
+    K.hrp = rp; K.hrm = rm;
+    K.hA = (l * rp + 2.0 * (a - l)) / (rp - rm); K.hB = (l * rm + 2.0 * (a - l)) / (rm - rp);
+  }
   K.anc[0] = K.anc[1] = K.anc[2] = K.anc[3] = 0.0;
   K.tbeta = K.tmu3 * K.ii3mu; K.tC = 0.0; K.zok = 0; K.zpad = 0;
   K.pbeta = K.phimu3 * K.ii3mu; K.pC = 0.0; K.pG = 0.0; K.pok = 0; K.pn = 0; K.pomt1 = 1.0;
@@ -995,7 +1002,76 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
     if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
     dphi = phimu + phiu;
   }
-  P.u = un; P.mu = mun; P.dt = 0.0; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
+  // (P.dt carries I_u = I_mu of the point, not a coordinate time -- this form never evaluates one: the split record-mode trace stores
+  //  it for grt_phi_kernel, everybody else ignores it)
+  P.u = un; P.mu = mun; P.dt = iu; P.dphi = dphi; P.lam = lambdau + tmu; P.tpm = tpm; P.tpr = tprp;
 }
+
+// ---- the azimuth as an integral over I (r05: grt_phi_kernel) ---------------------------------------------------------------------------
+// With Mino's parameter I = I_u = I_mu (Eq. 12 of Dexter & Agol 2009: dI = du / sqrt(U) = dmu / sqrt(M)) the azimuth of a Kerr geodesic
+// obeys d(dphi)/dI = G_u(u) + l mu^2 / (1 - mu^2) with
+//     G_u(u) = (l + 2 (a - l) u) / (1 - 2u + a^2 u^2) = hA / (1 - r+ u) + hB / (1 - r- u)
+// (Delta / r^2 = (1 - r+ u)(1 - r- u); hA, hB are GEOPHITIME's cP, cQ over r+ - r-).  GEOPHITIME (geokerr_wrapper.f:1648-2357) evaluates
+// the u part of every stored point as two Carlson R_J integrals from the turning point; the fused record-mode kernel took them per
+// SEGMENT between neighbouring points (useg_lane<2>: two R_J series and two R_C per point, 4.8 ms of the 36 at 1024^2 x 400).  But G_u is
+// an analytic function of I all along a ray of this class (u stays below 1/r+: four real roots, the turning point outside the horizon) --
+// through the radial turning point too, where u(I) is smooth -- and the image-only geodesic kernel has already left I and u of every point
+// in the record.  The increment of the u part over a segment [I_k, I_k+1] is therefore a two-point Hermite (Obreshkov) quadrature in I
+// from G and its first three I-derivatives (D1, D2, D3 below) at the two stored points,
+//     h/2 (G + G+) + 3h^2/28 (D1 - D1+) + h^3/84 (D2 + D2+) + h^4/1680 (D3 - D3+),        error h^9 D8 / 2.5e7,
+// whose derivatives are polynomials in u, 1/(1 - r+- u) and du/dI = +-sqrt(U(u)) (d2u/dI2 = U'(u)/2: no sign, no root); with g', g'', ...
+// the u-derivatives of G_u:
+//     D1 = g' u_I,   D2 = g'' U + g' U'/2,   D3 = u_I (g''' U + 3/2 g'' U' + g' U''/2).
+// Host study over six cameras (tests/test_hostsim_fast.py::test_azimuth_by_hermite...): at nup = 400 the sum over a ray agrees with the
+// one-point Carlson evaluation to 2e-13 (median; that evaluation's own noise), the third-order rule already does; at nup = 100 / 40 the
+// fourth-order rule holds 99 % of the rays to 2e-12 / 1e-9, and the difference to the third-order rule (the kernel's error indicator)
+// is at least 50x the fourth-order rule's error: a ray with a segment where it exceeds the bar is left to the fused kernel.
+struct HermG { double g0, g1, g2, g3; };
+GRT_HD HermG hermite_gu(const RealRay &K, double u, double sgn /* sign of du/dI at the point */) {
+  const double U = 1.0 + u * u * (K.hc2 + u * (K.hc3 + u * K.hc4));
+  const double U1 = u * (2.0 * K.hc2 + u * (3.0 * K.hc3 + u * (4.0 * K.hc4)));
+  const double U2 = 2.0 * K.hc2 + u * (6.0 * K.hc3 + u * (12.0 * K.hc4));
+  const double ip = frcp(1.0 - K.hrp * u), im = frcp(1.0 - K.hrm * u);
+  const double ap = K.hA * ip, am = K.hB * im;                   // A/(1 - r+ u), B/(1 - r- u)
+  const double tp = K.hrp * ip, tm = K.hrm * im;                 // each u-derivative multiplies a term by k r/(1 - r u)
+  const double d1p = ap * tp, d1m = am * tm, d2p = d1p * tp, d2m = d1m * tm, d3p = d2p * tp, d3m = d2m * tm;
+  const double g1 = d1p + d1m, g2 = 2.0 * (d2p + d2m), g3 = 6.0 * (d3p + d3m);
+  const double sU = sgn * fsqrt(dmax(U, 0.0));
+  HermG o;
+  o.g0 = ap + am;
+  o.g1 = g1 * sU;
+  o.g2 = g2 * U + 0.5 * g1 * U1;
+  o.g3 = sU * (g3 * U + 1.5 * g2 * U1 + 0.5 * g1 * U2);
+  return o;
+}
+
+// The quadrature over one segment: g at the lower point, gu at the upper one, h = I(upper) - I(lower).  T3: the third-order rule
+// (derivatives up to the second), whose distance from the result is the error indicator.
+GRT_HD double hermite_seg(const HermG &g, const HermG &gu, double h, double &T3) {
+  const double h2 = h * h;
+  const double s0 = 0.5 * h * (g.g0 + gu.g0), d1 = h2 * (g.g1 - gu.g1), s2 = h2 * h * (g.g2 + gu.g2), d3 = h2 * h2 * (g.g3 - gu.g3);
+  T3 = s0 + 0.1 * d1 + (1.0 / 120.0) * s2;
+  return s0 + (3.0 / 28.0) * d1 + (1.0 / 84.0) * s2 + (1.0 / 1680.0) * d3;
+}
+
+// mu side of the azimuth of a point of a ray with a short theta series (RealRay.zok, pok), from I_u alone: the turning-point count and
+// the reduced Jacobi argument as ray_point_real_branchy forms them (Eq. 30-42), ONE sincos for z = pi v / 2K -- sncndn_ladder_z's first
+// step; mu itself is not needed, so the recurrence is not run -- and theta_P.  Returns phimu = -l I + l Pi.
+GRT_HD double phi_mu_theta(const RealRay &K, double iu) {
+  int tpm;
+  const double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
+  if (K.sm == 1) tpm = fint(r1) + fint((1 + fsign(1.0, r1)) / 2.0);      // (pok: symmetric M)
+  else tpm = fint((iu + K.i1mu) * K.ii3mu);
+  const double a2 = K.sm * powm1(tpm);
+  const double a3 = 2.0 * fint((2.0 * (double)tpm + 3.0 - K.sm) / 4.0) - 1.0;
+  const double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
+  double s0, c0;
+  fast_sincos(K.agm_mu.c * (K.jscale * iarg), &s0, &c0);
+  return -K.l * iu + K.l * theta_P(K, s0, c0, tpm, iu);
+}
+
+// wave-uniform: does grt_phi_kernel serve this ray?  Not the plunging rays (ncase 5: G_u has its pole at the horizon they end on), rays
+// without a short theta series, l = 0 (GEOPHITIME adds pi per polar turning point there), su != 1.
+GRT_HD bool phi_hermite_ray(const RealRay &K) { return !K.cplx && K.zok && K.pok && K.l != 0.0 && K.su == 1.0; }
 
 }  // namespace grtd

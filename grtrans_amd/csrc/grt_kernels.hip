@@ -248,7 +248,12 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 #ifndef GRT_WPE_GEO_OF
 #define GRT_WPE_GEO_OF(FAST, NPH) ((((FAST) == 1 && (NPH) == 0) || (FAST) == 2) ? 3 : GRT_WPE_GEO)
 #endif
-template <int FAST, int NPH>
+// SPLIT (FAST = 1, NPH = 0 only; r05): the record-mode trace of the four-real-root class in two kernels -- this one, the image-only form
+// at three waves per SIMD, also stores I_u of every point in the record's phi slot; grt_phi_kernel turns it into the azimuth in place.
+// PHIONLY (FAST = 1, NPH = 2 only): the fused record-mode kernel for the rays grt_phi_kernel left over (launched with that kernel's list and
+// counter as live[] / nlive_dev, on a small grid that strides); it stores their phi only -- r, theta, lambda of every ray of the class
+// stay the image-only kernel's.
+template <int FAST, int NPH, bool SPLIT = false, bool PHIONLY = false>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
@@ -476,18 +481,130 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)
       sp[4 * field_stride] = P.dt; sp[5 * field_stride] = (double)P.tpm; sp[6 * field_stride] = (double)P.tpr;
     } else if (valid) {   // geodesics.f90:333-347
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
+      if (!PHIONLY) {
       const double rr = (P.u > 0.0) ? frcp(P.u) : 0.0;            // u_f = -1 (GEOR found no solution, standard=2): r = 0 marks the point for grt_trim_kernel
       const double th = (FAST == 1) ? fast_acos(P.mu) : acos(P.mu);     // (the lean one pays in the four-real-root kernels only: measured)
       sp[GRT_F_R * field_stride] = (P.tpr & 1) ? -rr : rr;
       sp[GRT_F_TH * field_stride] = (P.tpm & 1) ? -th : th;
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
-      if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
+      }
+      if (SPLIT) sp[GRT_F_PHI * field_stride] = P.dt;      // I_u of the point (ray_point_real_branchy): grt_phi_kernel's input
+      else if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
       if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)
     }
   }
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
-  } while (FAST == 0 && slot0 < *nlive_dev * nchg);     // only the generic class strides (capped grid); a fast-class wave serves one ray
+  } while ((FAST == 0 || PHIONLY) && slot0 < *nlive_dev * nchg);     // only the generic class (and the phi-only left-overs) stride on a capped grid; a fast-class wave serves one ray
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grt_phi_kernel (r05): the azimuth of the four-real-root class on its own.  One wave per fast-class ray, one stored point per lane,
+// 64-point chunks in plain point order from the top of the ray down.  Input: what grt_geo_kernel<1, 0, true> left in the record --
+// I_u of every point in the phi slot, r (1/u, the radial turning-point parity in its sign bit); output: phi = phi_ref - dphi in the same
+// slot, written by the lane that read it.
+//   u side: the increments between neighbouring points by the two-point Hermite rule over I (grt_dev_fast.hpp:hermite_gu) -- no square
+//           roots of the linear factors, no R_F / R_J series, no R_C; one plain suffix sum down the wave from the ray's top point, whose
+//           value the set-up kernel evaluated with the Carlson forms (RealRay.anc[2]);
+//   mu side: Jacobi's Pi from the theta series (theta_P) at the reduced argument formed from I_u as ray_point_real_branchy forms it;
+//           mu itself is not needed, so the ladder recurrence is not run: one sincos per point.
+// Rays this kernel does not serve are appended to todo[] (todo_count) and traced by the fused kernel in its phi-only form
+// (grt_geo_kernel<1, 2, false, true>) right afterwards: plunging rays (ncase 5: G_u has its pole at the horizon they end on), rays without a short theta series
+// (RealRay.pok), l = 0, su != 1, and any ray with a segment where the fourth- and third-order rules differ by more than GRT_PHI_TOL (the error
+// indicator: nup of a few tens on a strongly bent ray).
+// Why two kernels: the azimuth's live values took the fused record-mode kernel <1,2> to 236 registers = two waves per SIMD, and the
+// two-pass form it needs costs 9.8 ms over the image-only twin before any azimuth is computed (profiles/r05a_geo_budget.txt); apart,
+// the image-only kernel runs unchanged at three waves and this one is ~300 instructions per 64 points.
+// One quirk of the reference is kept: GEOPHITIME drops the u-side terms of a point within 1e-12 of the turning point of a ncase-7 ray
+// (geokerr_wrapper.f:2200: its phi there is ~3e-6 off the smooth curve) -- such a point takes phiu1 = 0 here as well.
+#ifndef GRT_PHI_TOL
+#define GRT_PHI_TOL 2.0e-10
+#endif
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, 4) void grt_phi_kernel(
+    GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
+    const int *__restrict__ nlive_dev, int *__restrict__ todo, int *__restrict__ todo_count, double *__restrict__ steps, long long ray_stride,
+    long long field_stride) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot0 = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
+  if (slot0 >= *nlive_dev) return;
+  const int rayidx = live[__builtin_amdgcn_readfirstlane(slot0)];
+  const GrtRay *Rp = rays + rayidx;
+  const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)rayidx * GRT_RR_STRIDE);
+  // (the per-ray records are read through the scalar cache: wave-uniform addresses in the constant address space)
+  {
+    const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rp;
+    const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kp;
+    asm volatile("" : "+s"(r_), "+s"(k_));
+    Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_;
+  }
+  const RealRay &K = *Kp;
+  const int n = Rp->npts;
+  if (!phi_hermite_ray(K) || n < 1) {      // wave-uniform: the fused kernel's ray
+    if (lane == 0) todo[atomicAdd(todo_count, 1)] = rayidx;
+    return;
+  }
+  double phi_ref = cam.phi0;
+  if (fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);      // geodesics.f90:339-341
+  // u-side azimuth of the ray's top stored point (realray_anchor), as ray_point_real assembles it
+  const RealLeg leg = real_leg(cam, *Rp);
+  const int tprs_top = (n <= leg.lo || Rp->tpr == 0) ? 0 : Rp->tpr_out;
+  const double kphi = K.su * K.isqee * K.ur;
+  const double phiu_top = kphi * (K.phiu0 - powm1(tprs_top) * K.anc[2]);
+  const double phiu_tp = kphi * K.phiu0;                      // the reference's value for a point ON the turning point (see above)
+  const bool c7 = (K.ncase == 7);
+  double *base = steps + (long long)rayidx * ray_stride;
+  // upper neighbour of lane 63 = lane 0 of the chunk above
+  double cI = 0.0, cS = 0.0;
+  HermG cG; cG.g0 = cG.g1 = cG.g2 = cG.g3 = 0.0;
+  double errmax = 0.0;
+  for (int c = (n - 1) >> 6; c >= 0; --c) {
+    const int idx = 64 * c + lane + 1;
+    const bool valid = idx <= n;
+    double *sp = base + (idx - 1);
+    const double iu = valid ? sp[GRT_F_PHI * field_stride] : 0.0;
+    const double rs_ = valid ? sp[GRT_F_R * field_stride] : 10.0;
+    const double u = frcp(fabs(rs_));
+    const HermG g = hermite_gu(K, u, (__double2hiint(rs_) < 0) ? -1.0 : 1.0);
+    // the upper neighbour's values: one lane up, lane 63 from the chunk above
+    double Iu = __shfl_down(iu, 1);
+    HermG gu;
+    gu.g0 = __shfl_down(g.g0, 1); gu.g1 = __shfl_down(g.g1, 1); gu.g2 = __shfl_down(g.g2, 1); gu.g3 = __shfl_down(g.g3, 1);
+    if (lane == 63) { Iu = cI; gu = cG; }
+    double T = 0.0;
+    if (valid && idx < n) {
+      double T3;
+      T = hermite_seg(g, gu, Iu - iu, T3);
+      errmax = dmax(errmax, fabs(T - T3));
+    }
+    // plain suffix sum down the wave: S_k = T_k + T_k+1 + ... + T_63 (+ the chunk above)
+    double S = T;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_down(S, d);
+      if (lane + d < 64) S += o;
+    }
+    S += cS;
+    cS = __shfl(S, 0); cI = __shfl(iu, 0);
+    cG.g0 = __shfl(g.g0, 0); cG.g1 = __shfl(g.g1, 0); cG.g2 = __shfl(g.g2, 0); cG.g3 = __shfl(g.g3, 0);
+    if (valid) {
+      double phiu = phiu_top - S;
+      if (c7 && !(fabs(u - K.u2) > 1e-12)) phiu = phiu_tp;
+      sp[GRT_F_PHI * field_stride] = phi_ref - (phi_mu_theta(K, iu) + phiu);
+    }
+  }
+  // the error indicator, over the wave: a ray that fails is traced again by the fused kernel (which overwrites phi)
+  for (int d = 32; d >= 1; d >>= 1) errmax = dmax(errmax, __shfl_xor(errmax, d));
+  if (lane == 0 && errmax > GRT_PHI_TOL) todo[atomicAdd(todo_count, 1)] = rayidx;
+}
+
+extern "C" hipError_t grt_launch_phi(hipStream_t s, const GrtCam *cam, const GrtRay *rays, const void *rrays, const int *live,
+                                     const int *nlive_dev, int nrays, int *todo, int *todo_count, double *steps, long long ray_stride,
+                                     long long field_stride) {
+  if (nrays <= 0) return hipSuccess;
+  note_launch("grt_phi_kernel");
+  hipLaunchKernelGGL(grt_phi_kernel, dim3((unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK)), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
+                     *cam, rays, (const char *)rrays, live, nlive_dev, todo, todo_count, steps, ray_stride, field_stride);
+  return hipGetLastError();
 }
 
 // standard=2 with nup > 1 (geodesics.f90:298-347): GEOR returns u_f < 0 where the ray does not reach the requested mu; such
@@ -1260,9 +1377,11 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 
 // nlive_dev: device counter of the class (counters[0] fast, counters[1] generic); nrays: rays of the pass = worst case
 // the grid is sized for, and the length of live[] (the generic class is read from its back)
+// split (fast class, Kerr camera, azimuth wanted, no coordinate time): the image-only kernel storing I_u, then grt_phi_kernel
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw) {
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split,
+                                     int *todo, int *todo_count) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
   // the generic class is small as a rule: a capped grid that strides over its (ray, chunk) items
@@ -1279,11 +1398,24 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   // a Schwarzschild camera that needs the coordinate time has no fast class (grt_setup_kernel: `cubic` requires !(need_time & 1)):
   // its fast-class launch has nothing to do
   if (kind == 2 && nph == 3) return hipSuccess;
+  // (a pole-on camera has mpos = 1 on every ray: no theta series, nothing for grt_phi_kernel to do)
+  if (kind == 1 && nph == 2 && split && !raw && todo && todo_count && fabs(cam->mu0) != 1.0) {
+    note_launch("grt_geo_kernelILi1ELi0ELb1ELb0EE");
+    hipLaunchKernelGGL((grt_geo_kernel<1, 0, true>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = grt_launch_phi(s, cam, rays, rrays, live, nlive_dev, nrays, todo, todo_count, steps, ray_stride, field_stride);
+    if (e != hipSuccess) return e;
+    note_launch("grt_geo_kernelILi1ELi2ELb0ELb1EE");
+    hipLaunchKernelGGL((grt_geo_kernel<1, 2, false, true>), dim3(nblk > 2048u ? 2048u : nblk), b, 0, s, *cam, rays, rr, (const int *)todo, (const int *)todo_count, nrays, steps,
+                       ray_stride, field_stride, nfields, tfield, t0, raw);
+    return hipGetLastError();
+  }
   bool launched = false;
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P) {                                                                                          \
     launched = true;                                                                                                    \
-    note_launch("grt_geo_kernelILi%dELi%dEE", F, P);                                                                    \
+    note_launch("grt_geo_kernelILi%dELi%dELb0ELb0EE", F, P);                                                                    \
     hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw); \
   }
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)

@@ -218,6 +218,91 @@ int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
   return R.npts;
 }
 
+// exploration / test access for the azimuth as an integral over I (grt_phi_kernel, r05): per stored point 8 columns -- I_u = I_mu (as the
+// image-only kernel exports it), u, mu, the radial turning-point count passed (0/1), tpm, dphi of the one-point Legendre/Carlson
+// evaluation (ray_point_real<2> without the ladder short cuts), isfill, and the u-side piece of that dphi (tools/hermite_study.py)
+int hs_phi_debug(const GrtCam *cam, int ii, int maxn, double *out, double *consts) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
+  if (!fast || R.npts < 1) return -R.npts;
+  RealRay K;
+  realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
+  consts[0] = K.a; consts[1] = K.l; consts[2] = K.q2; consts[3] = K.su; consts[4] = K.sm; consts[5] = R.ncase; consts[6] = K.pok; consts[7] = K.mpos;
+  consts[8] = K.u1; consts[9] = K.u2; consts[10] = K.u3; consts[11] = K.u4;
+  RealRay K0 = K;
+  K0.zok = 0; K0.pok = 0;
+  for (int idx = 1; idx <= R.npts && idx <= maxn; ++idx) {
+    double *o = out + (size_t)(idx - 1) * 8;
+    GeoPoint P, Pb;
+    ray_point_real<2>(*cam, R, K0, idx, P);
+    ray_point_real_branchy<false>(*cam, R, K, idx, Pb);
+    o[0] = Pb.dt; o[1] = P.u; o[2] = P.mu; o[3] = P.tpr; o[4] = P.tpm; o[5] = P.dphi;
+    const bool fill = (R.tpr == 1 && cam->mufill && cam->nup > 1);
+    const int lo = fill ? (R.kmax - cam->kext) : R.kmax;
+    o[6] = fill && idx > lo && idx <= lo + cam->next && R.tpr != 0;
+    {      // the u-side piece of dphi on its own (one-point Carlson evaluation)
+      UPart U;
+      if (K.cplx) cplx_upart<2>(K, P.u, U); else real_upart<2>(K, P.u, U);
+      const bool isf = o[6] != 0.0;
+      const int tprs = isf ? P.tpr : ((idx <= lo || R.tpr == 0) ? 0 : R.tpr_out);
+      o[7] = K.su * (K.phiu0 - powm1(tprs) * U.phiu1) * K.isqee * K.ur;
+    }
+  }
+  return R.npts;
+}
+
+// The split record-mode trace (r05), emulated: the image-only form (hs_ray_points_seg with nph = 0 semantics: ray_point_real_branchy on
+// the segment sums) leaves u, the radial parity and I_u of every point; grt_phi_kernel's arithmetic (hermite_gu / hermite_seg /
+// phi_mu_theta, the same functions the kernel calls) turns them into dphi with a sequential suffix sum from the top point.
+// Returns npts; -npts for a ray the kernel leaves to the fused form (not a fast-class ray, no theta series, ..., or *errmax > tol);
+// u_rec = 1/(1/u) as the kernel reads it back from the record.
+int hs_phi_split(const GrtCam *cam, int ii, int maxn, double tol, double *dphi, double *errmax) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  *errmax = 0.0;
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
+  if (!fast || R.npts < 1) return -R.npts;
+  RealRay K;
+  realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
+  const RealLeg leg = real_leg(*cam, R);
+  if (leg.nfill > 0 && R.npts <= leg.lo + leg.nfill) return -R.npts;      // (top point inside the mu-fill segment: generic class)
+  if (!phi_hermite_ray(K)) return -R.npts;
+  const int n = R.npts;
+  std::vector<double> I(n + 1), rs(n + 1);
+  for (int idx = 1; idx <= n; ++idx) {
+    GeoPoint P;
+    ray_point_real_branchy<false>(*cam, R, K, idx, P);       // (one-point u side: the segment sums agree to 1e-15, tested separately)
+    I[idx] = P.dt;
+    const double rr = 1.0 / P.u;
+    rs[idx] = (P.tpr & 1) ? -rr : rr;
+  }
+  const int tprs_top = (n <= leg.lo || R.tpr == 0) ? 0 : R.tpr_out;
+  const double kphi = K.su * K.isqee * K.ur;
+  const double phiu_top = kphi * (K.phiu0 - powm1(tprs_top) * K.anc[2]), phiu_tp = kphi * K.phiu0;
+  double S = 0.0;
+  HermG gu; gu.g0 = gu.g1 = gu.g2 = gu.g3 = 0.0;
+  for (int idx = n; idx >= 1; --idx) {
+    const double u = 1.0 / fabs(rs[idx]);
+    const HermG g = hermite_gu(K, u, rs[idx] < 0.0 ? -1.0 : 1.0);
+    if (idx < n) {
+      double T3;
+      const double T = hermite_seg(g, gu, I[idx + 1] - I[idx], T3);
+      if (fabs(T - T3) > *errmax) *errmax = fabs(T - T3);
+      S += T;
+    }
+    gu = g;
+    double phiu = phiu_top - S;
+    if (K.ncase == 7 && !(fabs(u - K.u2) > 1e-12)) phiu = phiu_tp;
+    if (idx <= maxn) dphi[idx - 1] = phi_mu_theta(K, I[idx]) + phiu;
+  }
+  return (*errmax > tol) ? -n : n;
+}
+
 // PHI=false variant: only u, mu, lambda, tpm, tpr are meaningful
 int hs_ray_points_fast_nophi(const GrtCam *cam, int ii, int maxn, double *u, double *mu, double *lam, int *tpm, int *tpr) {
   GrtRay R;

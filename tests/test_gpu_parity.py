@@ -792,6 +792,88 @@ def _geodebug_blocks(tokens):
     return n, t[:11], out
 
 
+@pytest.mark.parametrize("name,args", [
+    ("headline", (1, (-40., 20., -20., 40.), (96, 96, 400), 0.998, 0.906, 0.01, -0.5)),
+    ("nup100", (1, (-40., 20., -20., 40.), (64, 64, 100), 0.998, 0.906, 0.01, -0.5)),
+    ("nup40", (1, (-40., 20., -20., 40.), (64, 64, 40), 0.998, 0.906, 0.01, -0.5)),
+    ("close", (1, (-13., 13., -13., 13.), (64, 64, 400), 0.9375, 0.6428, 0.04, -0.5)),
+    ("retrograde near pole-on", (1, (-8., 8., -8., 8.), (64, 64, 200), -0.9, 0.99, 0.04, -0.5)),
+    ("edge-on", (1, (-20., 20., -20., 20.), (64, 64, 200), 0.5, 0.0, 0.02, -0.5)),
+    ("pole-on", (1, (-20., 20., -20., 20.), (48, 48, 200), 0.7, 1.0, 0.02, -0.5))])
+def test_azimuth_kernel_agrees_with_the_fused_record_mode_kernel(name, args):
+    # r05: with the azimuth wanted, the four-real-root class is traced by the image-only geodesic kernel (which leaves I_u in the record)
+    # and grt_phi_kernel -- u side by a two-point Hermite rule over I, mu side from the theta series -- plus the fused kernel in its
+    # phi-only form on the rays that kernel leaves over (plunging rays, no short theta series, error indicator above its bar: most rays
+    # at nup = 40).  grt_set_geo_split(0) traces everything with the fused kernel <1,2> (r04's): two independent evaluations of
+    # GEOPHITIME's phi (geokerr_wrapper.f:1648-2357; one of them Carlson's R_J per segment) must agree to rounding on every stored
+    # point, the turning-point parities and counts exactly; r, theta, lambda come from two forms of the same arithmetic.
+    from grtrans_amd import capi
+    dev = capi.Device(0)
+    dev.load_ffjet(); dev.load_tables()
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    cam = capi.make_camera(*args)
+    npx = args[2][0] * args[2][1]
+    capi.record_steps(True); capi.geo_reuse(False)
+    try:
+        res = {}
+        for split in (1, 0):
+            capi.geo_split(split)
+            pix, _, status, _ = capi.trace_tile(cam, 1, npx, "FFJET", em, [FREQ], "formal")
+            res[split] = (pix.copy(), status.copy(), capi.download_steps(0, npx, cam.nup + cam.next))
+    finally:
+        capi.geo_split(1); capi.record_steps(False); capi.geo_reuse(True)
+        dev.close()
+    (p1, s1, r1), (p0, s0, r0) = res[1], res[0]
+    assert np.array_equal(s1, s0)
+    n = np.abs(s1)
+    assert (n > 0).sum() > 0.5 * npx
+    mask = np.arange(r1.shape[2])[None, :] < n[:, None]
+    for f, bar in ((0, 1e-13), (1, 1e-11), (3, 1e-9)):      # r, theta, lambda (public order: r, theta, phi, lambda)
+        rel = np.abs(r1[f][mask] - r0[f][mask]) / np.maximum(np.abs(r0[f][mask]), 1e-300)
+        assert rel.max() <= bar, (name, f, rel.max())
+    dphi = np.abs(r1[2] - r0[2])[mask]
+    assert dphi.max() <= 1e-9 and np.quantile(dphi, 0.999) <= 1e-11, (name, dphi.max(), np.quantile(dphi, 0.999))
+    peak = np.abs(p0).max(axis=(0, 1)) + 1e-300
+    assert (np.abs(p1.astype(float) - p0).max(axis=(0, 1)) / peak).max() <= 2e-7, name
+
+
+def test_debug_ray_twice_with_a_time_origin_table_installed():
+    # grt_debug_ray finds the pixel's row of the nload>1 time-origin table through the ranges of the run's last
+    # trace; its own one-pixel trace used to overwrite them, so a SECOND call resolved the same pixel to row 0 (silently the wrong
+    # origin) and any other pixel of the tile was refused; a refused trace overwrote them too.  Row 1 of the dump is the point's
+    # coordinate time x(1) = DTI(1) - DTI(i) - t0 (geodesics.f90:345): with a table installed it moves by exactly -t0[row].
+    from grtrans_amd import capi
+    nn = (32, 32, 100)
+    dev = capi.Device(0)
+    dev.load_ffjet(); dev.load_tables()
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), nn, 0.998, 0.906, 0.01, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5, mdot=1.57e15)
+    capi.set_t0(None)
+    plain = {p: capi.debug_ray(cam, p, "FFJET", em, FREQ, "formal") for p in (500, 530)}
+    i1, i2 = 481, 544                                       # the tile the run traced: rows 0..63 of the table
+    capi.trace_tile(cam, i1, i2, "FFJET", em, [FREQ], "formal")
+    t0 = 10.0 + 3.0 * np.arange(i2 - i1 + 1)
+    capi.set_t0(t0)
+    try:
+        for p in (500, 500, 530, 500):                      # the same pixel twice, another pixel of the tile, the first again
+            n, hdr, rows, fac = capi.debug_ray(cam, p, "FFJET", em, FREQ, "formal")
+            n0, _, rows0, fac0 = plain[p]
+            assert n == n0 and fac == fac0
+            assert np.allclose(rows[1] - rows0[1], -t0[p - i1], rtol=0, atol=1e-9), (p, (rows[1] - rows0[1])[:3], -t0[p - i1])
+            assert np.array_equal(rows[2:5], rows0[2:5])    # r, theta, phi do not depend on the origin
+        # a refused trace (no kernel for this pair) leaves the mapping alone as well
+        with pytest.raises(capi.GrtError):
+            capi.trace_tile(cam, 1, 8, "FFJET", capi.make_emis("POLSYNCHTH", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5), [FREQ], "formal")
+        n, hdr, rows, fac = capi.debug_ray(cam, 530, "FFJET", em, FREQ, "formal")
+        assert np.allclose(rows[1] - plain[530][2][1], -t0[530 - i1], rtol=0, atol=1e-9)
+        # a pixel outside the tile has no row: refused, not row 0
+        with pytest.raises(capi.GrtError):
+            capi.debug_ray(cam, 100, "FFJET", em, FREQ, "formal")
+    finally:
+        capi.set_t0(None)
+        dev.close()
+
+
 # per block of geodebug.out: tolerance as a fraction of the block's largest magnitude.  Geodesic and frame quantities 1e-9 (phi 1e-8);
 # fluid variables (REAL(4) samples at r, theta that agree with the reference's to 1e-9, not to the bit) and everything derived from them
 # 2e-6 (the Stokes bar); aahat / aa / khat / bhat 1e-9

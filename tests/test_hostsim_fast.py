@@ -724,6 +724,52 @@ def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin
         assert nfast > 100 and nzeta > 30 and nphi > 30 and 2 <= nterms <= 8
 
 
+@pytest.mark.parametrize("spin,mu0,gv,nn,uout,stride", CAMS[:4] + [(-0.9, 0.99, (-8., 8., -8., 8.), (48, 48, 200), 0.04, 7),
+                                                                  (0.998, 0.906, (-40., 20., -20., 40.), (64, 64, 100), 0.01, 13),
+                                                                  (0.9375, 0.6428, (-13., 13., -13., 13.), (48, 48, 40), 0.04, 7)])
+def test_azimuth_by_hermite_quadrature_over_mino_time_matches_sequential_oracle(L, spin, mu0, gv, nn, uout, stride):
+    # grt_phi_kernel (r05): the azimuth of a four-real-root ray from I_u and u of its stored points -- the u part by a two-point Hermite
+    # rule over I between neighbours (hermite_gu / hermite_seg), the mu part from the theta series at the argument formed from I_u
+    # (phi_mu_theta) -- emulated with the kernel's own functions (hostsim.cpp:hs_phi_split) against the oracle's GEOPHITIME.  Rays the
+    # kernel leaves to the fused form (plunging rays, no short theta series, the error indicator above its bar) return -npts.
+    cam = (C.c_char * L.hs_sizeof_cam())()
+    gva = np.array(gv, dtype=float); nna = np.array(nn, dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    L.hs_make_cam(cam, 1, dp(gva), ip(nna), C.c_double(spin), C.c_double(mu0), C.c_double(uout), C.c_double(-0.5))
+    L.hs_phi_split.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    o = O.Oracle(nn=nn, spin=spin, mu0=mu0, gridvals=gv, uout=uout)
+    maxn = nn[2] * 2 + 64
+    TOL = 2e-10                        # GRT_PHI_TOL of grt_kernels.hip
+    served = left = 0
+    worst = 0.0
+    for i in range(1, nn[0] * nn[1] + 1, stride):
+        d = np.zeros(maxn); em = C.c_double(0)
+        n = L.hs_phi_split(cam, i, maxn, TOL, dp(d), C.byref(em))
+        if n == 0:
+            continue
+        if n < 0:
+            left += 1
+            continue
+        g = o.geokerr_ray(i)
+        assert n == g["n"]
+        served += 1
+        # the reference drops the u-side terms of a point within 1e-12 of the turning point (kept); everywhere the bar of the segment test
+        scale = np.max(np.abs(g["dphi"])) + 1e-300
+        err = np.max(np.abs(d[:n] - g["dphi"])) / scale
+        worst = max(worst, err)
+        if err > 1e-10:
+            # near-polar rays: the theta series of BOTH forms sits 2e-10 off the oracle there (the conditioning DESIGN 3 describes,
+            # tools/polar_phi.py) -- the split form has to land on the fused one
+            dd = [np.zeros(maxn) for _ in range(5)]
+            tpm = np.zeros(maxn, dtype=np.int32); tpr = np.zeros(maxn, dtype=np.int32); nc = C.c_int()
+            assert L.hs_ray_points_seg(cam, i, maxn, 2, *[dp(x) for x in dd], ip(tpm), ip(tpr), C.byref(nc)) == n
+            assert np.max(np.abs(d[:n] - dd[3][:n])) / scale <= 1e-12 and err <= 1e-9, (i, err, em.value)
+    assert served > 50, (served, left)
+    if nn[2] >= 160:                   # at the usual nup nearly every four-real-root ray is served; at nup = 40 the indicator sends most back
+        assert served > 2 * left or abs(mu0) > 0.95, (served, left)
+
+
 @pytest.mark.parametrize("key", ["a", "b"])
 def test_standard2_mu_stepping_points_vs_reference_geokerr(L, key):
     # standard=2 with nup > 1: GEOKERR's USEGEOR branch (geokerr_wrapper.f:421-461; mu steps from mu0 to the equatorial plane,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME "-DFLAG=.. ..."  -> build/variants/lib_NAME.so (experiment builds for tools/time_kernels.py)
+# [GRT_VARIANT_PATCH=tools/experiments/x.patch] tools/build_variant.sh NAME "-DFLAG=.. ..."  -> build/variants/lib_NAME.so (experiment builds for tools/time_kernels.py)
 # The sources are snapshotted first (build/variants/src_NAME), so the tree may be edited while a variant compiles.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -8,6 +8,10 @@ rm -rf $ROOT/build/variants/src_$1/grtrans_amd/csrc
 mkdir -p $ROOT/build/variants/src_$1/grtrans_amd/csrc
 cp $ROOT/grtrans_amd/csrc/*.h $ROOT/grtrans_amd/csrc/*.hpp $ROOT/grtrans_amd/csrc/*.hip $ROOT/grtrans_amd/csrc/*.cpp $ROOT/build/variants/src_$1/grtrans_amd/csrc/
 cp $ROOT/include/*.h $ROOT/build/variants/src_$1/include/
+# GRT_VARIANT_PATCH=tools/experiments/x.patch[,y.patch]: experiment code lives in patches, not in the shipped sources
+if [ -n "$GRT_VARIANT_PATCH" ]; then
+  for P in ${GRT_VARIANT_PATCH//,/ }; do (cd $ROOT/build/variants/src_$1 && patch -p1 --no-backup-if-mismatch -s < $ROOT/$P) || { echo "patch $P failed"; exit 1; }; done
+fi
 cd $ROOT/build/variants/src_$1/grtrans_amd/csrc
 O=$ROOT/build/variants/obj_$1
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast-honor-pragmas ${GRT_VARIANT_LICM--mllvm -disable-machine-licm} -I. -Wno-unused-result $2"

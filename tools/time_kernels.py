@@ -38,7 +38,7 @@ freqs = [freq] if nfreq == 1 else [2.41e10 * (6.31e14 / 2.41e10) ** (k / (nfreq 
 capi.record_steps(os.environ.get("GRT_RECORD", "0") == "1")
 capi.geo_reuse(False)
 best = None
-for it in range(3):
+for it in range(int(os.environ.get("GRT_TK_ITERS", "3"))):
     _, _, _, st = capi.trace_tile(cam, 1, nn[0] * nn[1], fluid, em, freqs, iname, resident=True)
     r = dict(geo=st.ms_geo, xfer=st.ms_transfer, trace=st.ms_trace, total=st.ms_total, steps=st.ray_steps)
     if best is None or r["trace"] < best["trace"]:
