@@ -45,6 +45,18 @@ static void note_launch(const char *fmt, ...) {
 }
 
 #define GRT_WAVES_PER_BLOCK 4
+// Waves per SIMD a kernel is compiled for (the register budget of its allocation).  GRT_DIFF_BUILD (tools/build_diff.sh ->
+// build/diff/libgrtrans_amd_diff.so, test infrastructure): the same sources with EVERY kernel at another occupancy -- two where the
+// product takes three or four, three where it takes two -- i.e. another register allocation, spill set and schedule around the same
+// arithmetic.  tests/test_gpu_parity.py::test_differential_compilation runs random cameras through both objects: stored-point and
+// turning-point counts bit-equal, Stokes to 1e-12 of each peak.  The live-value-overwritten family of code-generation defects
+// ((3) a live-range copy under a partial exec mask, (5) a live integer overwritten by a register copy) moves with the
+// allocation and shows up there without any reference.
+#if defined(GRT_DIFF_BUILD)
+#define GRT_OCC(n) ((n) == 2 ? 3 : 2)
+#else
+#define GRT_OCC(n) (n)
+#endif
 #ifndef GRT_WPE_GEO
 #define GRT_WPE_GEO 2     // waves per SIMD the register allocator must make room for
 #endif
@@ -103,7 +115,7 @@ __device__ __forceinline__ long long range_pixel(const long long *__restrict__ t
 #ifndef GRT_WPE_SETUP
 #define GRT_WPE_SETUP 2
 #endif
-__global__ __launch_bounds__(256, GRT_WPE_SETUP) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
+__global__ __launch_bounds__(256, GRT_OCC(GRT_WPE_SETUP)) void grt_setup_kernel(GrtCam cam, long long i1, int nrays, GrtRay *__restrict__ rays,
                                                          int *__restrict__ ray_npts, int *__restrict__ live,
                                                          int *__restrict__ counters, char *__restrict__ rrays, int need_time /* bit 0: coordinate time wanted (no cubic class), bit 1: azimuth wanted */, double polar_l2,
                                                          GrtRayIn rin, const long long *__restrict__ rng, int nrng) {
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256, GRT_WPE_SETUP) void grt_setup_kernel(GrtCam ca
 
 // nload > 1 (pgrtrans.f90:172-189 -> initialize_geo_tabs, geodesics.f90:113-128): the time origin of a ray is the
 // coordinate time of the single point of its nup=1, no-mu-fill geodesic = the first-point dt the set-up caches.
-__global__ __launch_bounds__(256, 2) void grt_t0_kernel(GrtCam cam, long long i1, int nrays, double *__restrict__ t0) {
+__global__ __launch_bounds__(256, GRT_OCC(2)) void grt_t0_kernel(GrtCam cam, long long i1, int nrays, double *__restrict__ t0) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nrays) return;
   GrtCam c1 = cam;
@@ -254,7 +266,7 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 // counter as live[] / nlive_dev, on a small grid that strides); it stores their phi only -- r, theta, lambda of every ray of the class
 // stay the image-only kernel's.
 template <int FAST, int NPH, bool SPLIT = false, bool PHIONLY = false>
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)) void grt_geo_kernel(
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FAST, NPH))) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
     long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_WPE_GEO_OF(FAST, NPH)
 #ifndef GRT_PHI_TOL
 #define GRT_PHI_TOL 2.0e-10
 #endif
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, 4) void grt_phi_kernel(
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int *__restrict__ todo, int *__restrict__ todo_count, double *__restrict__ steps, long long ray_stride,
     long long field_stride) {
@@ -701,7 +713,15 @@ template <typename T> __device__ __forceinline__ T karg_load(const char GRT_AS4 
 }
 
 template <int IFLAG, int FLUID, int EMIS, int FB, bool EXTRA, int TSH>
-__global__ __launch_bounds__(GRT_XFER_THREADS, ((TSH == 2 && FB == 1) ? 3 : GRT_XFER_WPE(EMIS, FLUID))) void grt_transfer_kernel(
+// (GRT_DIFF_BUILD: the tile depth of every instantiation is the OTHER one -- launch_transfer_t -- and every 4-step-tile kernel is compiled
+//  for three waves, every 8-step one for two: with 79 KB of LDS a block the 8-step kernels cannot run three, and a bound they cannot
+//  meet sends the allocator into the 512-register regime with values parked in AGPRs, the regime r03 left)
+#if defined(GRT_DIFF_BUILD)
+#define GRT_XFER_OCC(TSH, FB, EMIS, FLUID) ((TSH) == 2 ? 3 : 2)
+#else
+#define GRT_XFER_OCC(TSH, FB, EMIS, FLUID) (((TSH) == 2 && (FB) == 1) ? 3 : GRT_XFER_WPE(EMIS, FLUID))
+#endif
+__global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID)) void grt_transfer_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const int *__restrict__ live, int nlive_arg, GrtFluidDev fd, GrtTables tb,
     GrtEmis em, GrtPLConst plc, int nfreq, const double *__restrict__ freqs, float *__restrict__ pixvals, int npix_tile,
     int nvals, int *__restrict__ ray_status, long long i1, double *__restrict__ steps,
@@ -1185,7 +1205,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, ((TSH == 2 && FB == 1) ? 3 : GRT_
 // (j, K after rotate_emis / invariant_emis, j / fac and K L_BH as the driver holds them when it writes); scal[0] = fac, scal[1] = L_BH.
 #define GRT_DBG_ROWS 68      // 57 printed rows + 11 scratch rows (the raw coefficients, for a ray the driver does not integrate)
 template <int FLUID, int EMIS>
-__global__ __launch_bounds__(64, 2) void grt_debug_kernel(GrtCam cam, const GrtRay *__restrict__ rays, int rayidx, GrtFluidDev fd, GrtTables tb,
+__global__ __launch_bounds__(64, GRT_OCC(2)) void grt_debug_kernel(GrtCam cam, const GrtRay *__restrict__ rays, int rayidx, GrtFluidDev fd, GrtTables tb,
                                                        GrtEmis em, GrtPLConst plc, double freq, const double *__restrict__ steps,
                                                        long long ray_stride, long long field_stride, int tfield, double *__restrict__ out,
                                                        int maxpts, double *__restrict__ scal) {
@@ -1429,14 +1449,15 @@ template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4() {
 #if defined(GRT_NO_TILE4)
   return false;
 #else
-  return IFLAG == GRT_INT_FORMAL && ((FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL) ||
+  return (GRT_OCC(3) == 2) != (IFLAG == GRT_INT_FORMAL && ((FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL) ||
                                      (FLUID == GRT_FLUID_SPHACC && EMIS == GRT_EMIS_POLSYNCHTH) ||
                                      (FLUID == GRT_FLUID_HARM && EMIS == GRT_EMIS_POLSYNCHTH) ||
-                                     (FLUID == GRT_FLUID_HARM3D && EMIS == GRT_EMIS_POLSYNCHTH));      // (167 registers, no scratch: 44.2 -> 42.6 / 45.5 -> 44.2 ms)
+                                     (FLUID == GRT_FLUID_HARM3D && EMIS == GRT_EMIS_POLSYNCHTH)));      // (167 registers, no scratch: 44.2 -> 42.6 / 45.5 -> 44.2 ms)
+                                                                                                         // (GRT_DIFF_BUILD: every OTHER instantiation)
 #endif
 }
 template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4_batch() {     // ... and the frequency-batch kernel of BASELINE config 5
-  return xfer_tile4<IFLAG, FLUID, EMIS>() && FLUID == GRT_FLUID_FFJET;
+  return (GRT_OCC(3) == 2) != ((GRT_OCC(3) == 2) != xfer_tile4<IFLAG, FLUID, EMIS>() && FLUID == GRT_FLUID_FFJET);
 }
 
 template <int IFLAG, int FLUID, int EMIS>
@@ -1451,8 +1472,9 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
   constexpr bool HAS_EXTRA = (IFLAG != GRT_INT_QUAD) && EMIS != GRT_EMIS_POLSYNCHSYMTH && EMIS != GRT_EMIS_SYNCHTHAV;
   if (extra) {     // one frequency per blockIdx.y, diagnostics accumulated in registers
     if constexpr (HAS_EXTRA) {
-      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 1, GRT_TSH);
-      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true, GRT_TSH>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
+      constexpr int TSHX = (GRT_OCC(3) == 2) ? 2 : GRT_TSH;      // (GRT_DIFF_BUILD: the 4-step tile)
+      note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, 1, 1, TSHX);
+      hipLaunchKernelGGL((grt_transfer_kernel<IFLAG, FLUID, EMIS, 1, true, TSHX>), dim3(gx, (unsigned)nfreq), dim3(GRT_XFER_THREADS), 0, s, *cam,
                          rays, live, nlive, *fd, *tb, *em, *plc, nfreq, freqs, pixvals, npix_tile, nvals, ray_status, i1, steps,
                          ray_stride, field_stride, nfields, tfield, step_counter, nlive_dev, from_back);
     } else {

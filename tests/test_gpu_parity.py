@@ -11,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FREQ = 3.45e11
 STOKES_TOL = 2e-6      # measured on MI355X with bit-identical REAL(4) islands: <= 6.6e-7 of peak over every case below
 
@@ -835,6 +836,40 @@ def test_azimuth_kernel_agrees_with_the_fused_record_mode_kernel(name, args):
     assert dphi.max() <= 1e-9 and np.quantile(dphi, 0.999) <= 1e-11, (name, dphi.max(), np.quantile(dphi, 0.999))
     peak = np.abs(p0).max(axis=(0, 1)) + 1e-300
     assert (np.abs(p1.astype(float) - p0).max(axis=(0, 1)) / peak).max() <= 2e-7, name
+
+
+def test_differential_compilation_same_inputs_through_two_code_objects(tmp_path):
+    # VERDICT r04 weak #3 / next #3a: correctness of the shipped object has twice depended on what the register allocator did with a live
+    # value (DESIGN 6 defects (3), (5): a copy under a partial exec mask; a live integer overwritten by a register copy) -- a family no
+    # reference-free test could see.  tools/build_diff.sh compiles the SAME sources with every kernel at another occupancy (GRT_OCC: two
+    # waves where the product takes three, three where it takes two, the other tile depth in the transfer kernels): another allocation,
+    # spill set and schedule around the same arithmetic.  600 random cameras over every (fluid model, emissivity, integrator,
+    # frequency-batch, extra=1, nvals=1) kernel family, plus GEOKERR's raw arrays, through both objects (tools/diff_sweep.py, one process
+    # each): stored-point counts, turning-point counts, root cases and NaN masks bit-equal; the fp64 per-step record to 1e-12 of each
+    # field's peak; the fp32 images equal up to one rounding of the last bit.
+    import subprocess
+    import sys
+    diff = os.path.join(ROOT, "build", "diff", "libgrtrans_amd_diff.so")
+    if not os.path.exists(diff):
+        pytest.skip("build/diff/libgrtrans_amd_diff.so not built here (tools/build_diff.sh; __graft_entry__.build() makes it)")
+    outs = []
+    for tag, lib in (("product", None), ("diff", diff)):
+        env = dict(os.environ)
+        env.pop("GRTRANS_AMD_LIB", None)
+        if lib:
+            env["GRTRANS_AMD_LIB"] = lib
+        o = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diff_sweep.py"), o, "600", "20261003"], check=True, env=env, timeout=1500)
+        outs.append(np.load(o, allow_pickle=False))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import diff_compare
+    problems, st = diff_compare.compare(outs[0], outs[1])
+    assert st["cameras"] == 600 and st["img_values"] > 300000
+    assert not problems, problems[:5]
+    assert st["img_bit_equal"] >= 0.9999 * st["img_values"], st
+    if os.environ.get("GRT_TEST_ERRLOG"):
+        with open(os.environ["GRT_TEST_ERRLOG"], "a") as f:
+            f.write("differential compilation: %r\n" % st)
 
 
 def test_debug_ray_twice_with_a_time_origin_table_installed():

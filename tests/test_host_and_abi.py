@@ -507,3 +507,36 @@ def test_a_rank_that_exits_98_or_3_ends_the_launched_job_nonzero_in_bounded_time
                             "--master-port", str(port), str(helper), str(code)], capture_output=True, text=True, timeout=100)
         assert r.returncode != 0, r.stdout + r.stderr
         assert time.time() - t0 < 60.0
+
+
+def test_differential_comparer_sees_a_seeded_fault_and_not_a_last_bit(tmp_path):
+    # negative / positive control of tools/diff_compare.py (the comparer of the differential-compilation GPU test): one stored-point
+    # count off by one, one turning-point count off by one, one record value 1e-9 of its peak off, one image value 1e-6 off and a
+    # NaN that moved are each reported; one fp32 image value moved by one unit in the last place is not.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import diff_compare
+    rng = np.random.default_rng(5)
+    base = {"log": np.array(["cam 0 test"]), "c0_status": rng.integers(40, 400, 144).astype(np.int32),
+            "c0_pix": rng.normal(size=(2, 144, 4)).astype(np.float32), "c0_rec": rng.normal(size=(8, 144, 60)),
+            "c0_gk_tpmi": rng.integers(0, 3, (144, 60)).astype(np.int32), "c0_gk_lam": rng.normal(size=(144, 60))}
+    base["c0_pix"][0, 7] = np.nan
+
+    def run(mut):
+        other = {k: v.copy() for k, v in base.items()}
+        mut(other)
+        np.savez(tmp_path / "a.npz", **base); np.savez(tmp_path / "b.npz", **other)
+        return diff_compare.compare(np.load(tmp_path / "a.npz"), np.load(tmp_path / "b.npz"))[0]
+
+    assert run(lambda o: None) == []
+
+    def ulp(o):
+        v = o["c0_pix"].view(np.uint32); v[1, 3, 2] += 1
+    assert run(ulp) == []
+
+    def st(o): o["c0_status"][5] += 1
+    def tp(o): o["c0_gk_tpmi"][3, 9] += 1
+    def rec(o): o["c0_rec"][4, 10, 10] += 1e-9 * np.abs(o["c0_rec"][4]).max()
+    def img(o): o["c0_pix"][0, 20, 1] += np.float32(1e-6) * np.abs(o["c0_pix"][0, :, 1][np.isfinite(o["c0_pix"][0, :, 1])]).max()
+    def nan(o): o["c0_pix"][0, 7] = 0.0; o["c0_pix"][0, 8] = np.nan
+    for m in (st, tp, rec, img, nan):
+        assert len(run(m)) == 1, m.__name__
