@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <limits>
 #include "grt_types.h"
 #include "grt_harm_pack.hpp"
 #include "grt_pl_pack.hpp"
@@ -227,6 +228,32 @@ int grt_upload_ffjet(int nx, const float *rc, const float *thc, const float *rho
     uniq[nx1 + i] = thc[(size_t)i * nx1];          // uniqth (:68)
     uniq[2 * nx1 + i] = std::log(rc[i]);           // uniqx1 (:71), REAL(4) log
   }
+  // thresholds of the radial index (GrtFFJet.rthr): the reference's REAL(4) expression, evaluated here exactly as the sampler's plain
+  // form evaluates it ((float)log((double)r); no contraction on the host), bisected over the bit patterns of positive floats
+  uniq.resize((size_t)4 * nx1 + 4, 0.f);
+  float r_inside = 0.f;
+  {
+    const float x1lo = uniq[2 * nx1], x1hi = uniq[3 * nx1 - 1];
+    auto index_of = [&](float zr) -> long long {
+      const volatile float x1 = (float)std::log((double)zr);
+      const volatile float t1 = x1 - x1lo, t2 = x1hi - x1lo;
+      const volatile float t3 = t1 / t2;
+      const volatile float t4 = t3 * (float)(nx1 - 1);
+      return (long long)(int)t4 + 1;
+    };
+    auto first_true = [&](auto pred) -> float {      // smallest positive finite float with pred true (pred monotonic: false ... true)
+      uint32_t lo = 0x00000001u, hi = 0x7f7fffffu;     // denormal min .. FLT_MAX
+      auto f = [](uint32_t b) { float v; std::memcpy(&v, &b, 4); return v; };
+      if (pred(f(lo))) return f(lo);
+      if (!pred(f(hi))) return std::numeric_limits<float>::infinity();
+      while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (pred(f(mid))) hi = mid; else lo = mid; }
+      return f(hi);
+    };
+    for (int j = 2; j <= nx1 - 1; ++j) uniq[(size_t)3 * nx1 + j] = first_true([&](float zr) { return index_of(zr) >= j; });
+    uniq[(size_t)3 * nx1] = 0.f; uniq[(size_t)3 * nx1 + 1] = 0.f;                       // (slots 0, 1 unused: the index never falls below 1)
+    uniq[(size_t)4 * nx1] = std::numeric_limits<float>::infinity();                      // (sentinel behind the last threshold)
+    r_inside = first_true([&](float zr) { const volatile float x1 = (float)std::log((double)zr); return x1 > x1lo; });
+  }
   if (C.d_cells) { (void)hipFree(C.d_cells); C.d_cells = nullptr; }
   if (C.d_uniq) { (void)hipFree(C.d_uniq); C.d_uniq = nullptr; }
   HIPCHK(hipMalloc((void **)&C.d_cells, cells.size() * sizeof(float)));
@@ -237,6 +264,8 @@ int grt_upload_ffjet(int nx, const float *rc, const float *thc, const float *rho
   C.ffjet.uniqr = C.d_uniq;
   C.ffjet.uniqth = C.d_uniq + nx1;
   C.ffjet.uniqx1 = C.d_uniq + 2 * nx1;
+  C.ffjet.rthr = C.d_uniq + 3 * nx1;
+  C.ffjet.r_inside = r_inside;
   C.ffjet.nx1 = nx1;
   C.have_ffjet = true;
   return 0;

@@ -11,6 +11,15 @@
 #pragma once
 #include "grt_dev_geo.hpp"
 
+// GRT_DIFF_BUILD (tools/build_diff.sh, the differential-compilation check): the REAL(4) islands in their plain, reference-literal forms
+// -- fp64 library acos and log, scalar blends -- so that the 600-camera comparison of the two objects (tests/test_gpu_parity.py::
+// test_differential_compilation...) also holds the product's short cuts (acosf_abs_from_trig, GrtFFJet.rthr, bilin2) to bit-equal images.
+#if defined(GRT_DIFF_BUILD)
+#define GRT_NO_ACOS_SERIES
+#define GRT_NO_RTHR
+#define GRT_NO_PACKED_BLEND
+#endif
+
 namespace grtd {
 
 // REAL(4) islands must round every product and sum separately, as the reference's compiler does
@@ -35,13 +44,44 @@ GRT_HD float powf_cr(float x, float y) { return (float)pow((double)x, (double)y)
 // th_f = th + d with |d| <= ulp32(pi)/2 = 1.2e-7, so cos(th_f) = cth - (sth d + cth d^2/2) and sin(th_f) = sth + (cth d - sth d^2/2) to
 // 3e-22 absolute (the d^3 terms), i.e. within 1.5 fp64 ulp -- what (float)cos((double)th_f) of the library gives to 1 ulp.  Saves the
 // two fp64 library evaluations every sampler spent on the single-precision metric and LNRF frame (r03: 90 of 2600 instructions per step).
-struct F32Trig { float c, s; };
+struct F32Trig { float c, s; double cd, sd, thf; };      // cd, sd: cos, sin of th_f = thf in fp64 (before the rounding to REAL(4))
 GRT_HD F32Trig f32_trig(double th, double sth, double cth) {
-  const double d = (double)(float)th - th, h = 0.5 * d * d;
+  const double thf = (double)(float)th, d = thf - th, h = 0.5 * d * d;
   F32Trig t;
-  t.c = (float)(cth - (sth * d + cth * h));
-  t.s = (float)(sth + (cth * d - sth * h));
+  t.cd = cth - (sth * d + cth * h);
+  t.sd = sth + (cth * d - sth * h);
+  t.c = (float)t.cd;
+  t.s = (float)t.sd;
+  t.thf = thf;
   return t;
+}
+
+// acosf_cr(fabsf(ft.c)) -- the folded polar angle x2 = acos|cos th_f| the FFJET sampler interpolates in (fluid_model_ffjet.f90:84-86) --
+// without the fp64 library acos (87 of the step's instructions, r05).  z = |ft.c| is the REAL(4) rounding of c = |cos th_f|, which is
+// known in fp64 (ft.cd), and so is the angle whose cosine c is: th* = th_f folded into [0, pi/2].  With delta = c - z (|delta| <= 3e-8),
+// s = |sin th_f| and t = delta / s:   acos z = th* + t - c t^2 / (2 s) + (1 + 2 c^2) t^3 / (6 s^2) + O(t^4 / s^3).
+// Within 0.05 rad of the axis, where 1/s amplifies the rounding of c: acos z = 2 asin(sqrt((1 - z)/2)) with 1 - z exact in fp64 and
+// the first four terms of the asin series (argument below 0.025: remainder 1e-18).  Against an 80-bit acos over 2e6 angles: 1.2e-14 /
+// 2.4e-16 absolute, the REAL(4) result the same in every case.
+GRT_HD float acosf_abs_from_trig(const F32Trig &ft) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_ACOS_SERIES)
+  const double z = (double)fabsf(ft.c), c = fabs(ft.cd), sn = fabs(ft.sd);
+  double val;
+  const bool pole = sn < 0.05;
+  {
+    const double thstar = (ft.cd >= 0.0) ? ft.thf : 3.141592653589793 - ft.thf;
+    const double rs = frcp(dmax(sn, 0.05)), t = (c - z) * rs;
+    val = thstar + t * (1.0 + t * rs * (-0.5 * c + (1.0 + 2.0 * c * c) * (1.0 / 6.0) * t * rs));
+  }
+  if (__builtin_amdgcn_ballot_w64(pole) != 0ull) {      // (wave-uniform branch: a few per cent of the waves)
+    const double y = fsqrt(0.5 * (1.0 - z)), y2 = y * y;
+    const double pv = 2.0 * y * (1.0 + y2 * (1.0 / 6.0 + y2 * (3.0 / 40.0 + y2 * (15.0 / 336.0))));
+    val = pole ? pv : val;
+  }
+  return (float)val;
+#else
+  return acosf_cr(fabsf(ft.c));
+#endif
 }
 
 struct Metric { double g[10]; };   // slots 1,4,5,8,10 (0-based 0,3,4,7,9) non-zero
@@ -167,7 +207,7 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
   if (Kap1 != 0.0 || Kap2 != 0.0) {
     transport_perpk(k, r, sth, cth, a, m, Kap1, Kap2, al1, al2, al3);
   } else {
-    al1 = 0.0; al2 = 0.0; al3 = frcp(fsqrt(m.g[9]));
+    al1 = 0.0; al2 = 0.0; al3 = frsqrt(m.g[9]);
   }
   double aa[4] = {0.0, al1, al2, al3};
   double delta = r * r + a * a - 2.0 * r;
@@ -175,7 +215,7 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
   double nm2 = gmm * (1.0 + umc * um);
   double np2 = -(utc * ut + upc * up) * delta * sth * sth;
   // x / sqrt(n): one reciprocal square root per tetrad leg instead of a division per component
-  const double inr = frcp(fsqrt(nr2)), inm = frcp(fsqrt(nm2)), inp = frcp(fsqrt(np2));
+  const double inr = frsqrt(nr2), inm = frsqrt(nm2), inp = frsqrt(np2);
   double ekt[4] = {-1.0 * u[0], -1.0 * u[1], -1.0 * u[2], -1.0 * u[3]};
   double ekr[4] = {(urc * ut) * inr, -(utc * ut + upc * up) * inr, 0.0, (urc * up) * inr};
   double ekm[4] = {(umc * ut) * inm, (umc * ur) * inm, (1 + umc * um) * inm, (umc * up) * inm};
@@ -189,7 +229,7 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
   double aahat2 = ahatm - khatm * ahatt * ikt;
   double aahat3 = ahatp - khatp * ahatt * ikt;
   double knorm = khatr * khatr + khatm * khatm + khatp * khatp;
-  const double ikn = frcp(fsqrt(knorm));
+  const double ikn = frsqrt(knorm);
   double bb1 = -(aahat2 * khatp - aahat3 * khatm) * ikn;
   double bb2 = -(aahat3 * khatr - aahat1 * khatp) * ikn;
   double bb3 = -(aahat1 * khatm - aahat2 * khatr) * ikn;
@@ -201,7 +241,7 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
     const double inn = frcp(aadotbp * aadotbp + bpdotbb * bpdotbb);
     s2xi = -2.0 * aadotbp * bpdotbb * inn;
     c2xi = (bpdotbb * bpdotbb - aadotbp * aadotbp) * inn;
-    angnorm = bdotk * ikn * frcp(fsqrt(bdotb));
+    angnorm = bdotk * ikn * frsqrt(bdotb);
   } else {
     s2xi = 0.0; c2xi = 1.0; angnorm = 0.5;
   }
@@ -271,6 +311,18 @@ struct FluidPoint {
   float rho = 0, p = 0, bmag = 0;
   double u[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
 };
+
+// The same blend for two table fields at once: REAL(4) products and sums in pairs (v_pk_mul_f32 / v_pk_add_f32 on gfx950; every lane
+// element rounds like the scalar instruction, and with contraction off nothing is fused).  v0..v3: the two fields' values at the four
+// corners in the order of bilin's v[].
+typedef float grt_f2 __attribute__((vector_size(8)));
+GRT_HD grt_f2 bilin2(grt_f2 v0, grt_f2 v1, grt_f2 v2, grt_f2 v3, float xd, float yd) {
+  GRT_NO_CONTRACT
+  const float oy = 1.f - yd, ox = 1.f - xd;
+  const grt_f2 w1 = v0 * oy + v1 * yd;
+  const grt_f2 w2 = v2 * oy + v3 * yd;
+  return w1 * ox + w2 * xd;
+}
 
 GRT_HD float bilin(const float *v, float xd, float yd) {   // interpolate.f90:171
   GRT_NO_CONTRACT
@@ -889,18 +941,43 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
   const int nx1 = t.nx1, nx2 = t.nx1;
   float theta = (float)th_d;
   float zm = ft ? ft->c : cosf_cr(theta);
-  float x2 = acosf_cr(fabsf(zm));
+  float x2 = ft ? acosf_abs_from_trig(*ft) : acosf_cr(fabsf(zm));
   theta = x2;
   float zr = (float)r;
-  float x1 = logf_cr(zr);
   const float x1lo = t.uniqx1[0], x1hi = t.uniqx1[nx1 - 1], thlo = t.uniqth[0], thhi = t.uniqth[nx2 - 1];
-  int lx1 = (int)((x1 - x1lo) / (x1hi - x1lo) * (nx1 - 1)) + 1;
+  int lx1c;
+  bool inside;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_RTHR)
+  {
+    // the radial index as a count of thresholds (GrtFFJet.rthr): a guess from the hardware's log2, then at most one step either way
+    const float xg = __log2f(zr) * 0.6931471805599453f;
+    int j = (int)((xg - x1lo) * ((float)(nx1 - 1) / (x1hi - x1lo))) + 1;
+    j = j < 1 ? 1 : (j > nx1 - 1 ? nx1 - 1 : j);
+    const float tj = t.rthr[j], tj1 = t.rthr[j + 1];
+    j = (j > 1 && zr < tj) ? j - 1 : ((j < nx1 - 1 && zr >= tj1) ? j + 1 : j);
+    lx1c = j;
+    inside = zr >= t.r_inside;
+    // (the guess is good to 1e-5 of a bin; should it ever be further off than one bin, the reference's own expression decides)
+    const bool okj = (j <= 1 || zr >= t.rthr[j]) && (j >= nx1 - 1 || zr < t.rthr[j + 1]);
+    if (__builtin_amdgcn_ballot_w64(!okj && zr == zr) != 0ull) {
+      const float x1 = logf_cr(zr);
+      const int lx1 = (int)((x1 - x1lo) / (x1hi - x1lo) * (nx1 - 1)) + 1;
+      lx1c = lx1 < 1 ? 1 : (lx1 > nx1 - 1 ? nx1 - 1 : lx1);
+      inside = x1 > x1lo;
+    }
+  }
+#else
+  {
+    const float x1 = logf_cr(zr);
+    const int lx1 = (int)((x1 - x1lo) / (x1hi - x1lo) * (nx1 - 1)) + 1;
+    lx1c = lx1 < 1 ? 1 : (lx1 > nx1 - 1 ? nx1 - 1 : lx1);   // address clamp only (see oracle note)
+    inside = x1 > x1lo;
+  }
+#endif
   int lx2 = (int)((x2 - thlo) / (thhi - thlo) * (nx2 - 1)) + 1;
   lx2 = (lx2 <= nx2 - 1) ? ((lx2 >= 1) ? lx2 : 1) : (nx2 - 1);
   int ux2 = lx2 + 1;
-  int lx1c = lx1 < 1 ? 1 : (lx1 > nx1 - 1 ? nx1 - 1 : lx1);   // address clamp only (see oracle note)
   int ux1c = lx1c + 1;
-  bool inside = x1 > x1lo;
   float td = (theta - t.uniqth[lx2 - 1]) / (t.uniqth[ux2 - 1] - t.uniqth[lx2 - 1]);
   float rd = (zr - t.uniqr[lx1c - 1]) / (t.uniqr[ux1c - 1] - t.uniqr[lx1c - 1]);
 #if defined(GRT_SAMPLE_CONST_ZONE)
@@ -910,6 +987,17 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
   const float *c01 = t.cells + (size_t)((lx1c - 1) + (ux2 - 1) * nx1) * 12;   // (x1l, x2u)
 #endif
   float q[10];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_PACKED_BLEND)
+  {      // two fields per blend (the cell records are 48-byte aligned: pairs of floats load as one 8-byte word)
+    typedef grt_f2 __attribute__((may_alias)) f2a;
+    const f2a *p00 = reinterpret_cast<const f2a *>(c00), *p01 = reinterpret_cast<const f2a *>(c01);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const grt_f2 b = bilin2(p00[k], p01[k], p00[6 + k], p01[6 + k], rd, td);      // order of fluid_model_ffjet.f90:98
+      q[2 * k] = b[0]; q[2 * k + 1] = b[1];
+    }
+  }
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -917,6 +1005,7 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
     float v[4] = {c00[k], c01[k], c00[12 + k], c01[12 + k]};   // order of fluid_model_ffjet.f90:98
     q[k] = bilin(v, rd, td);
   }
+#endif
   f.rho = inside ? q[0] : 0.f;
   f.p = inside ? q[1] : 1.f;
   f.b[0] = (double)(inside ? q[2] : 1.f);
@@ -1124,6 +1213,22 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
 #endif
   const float *c10 = c00 + (size_t)nx2 * 12, *c11 = c01 + (size_t)nx2 * 12;    // x1u
   float q[10];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_PACKED_BLEND)
+  {      // two fields per blend (bilin2's note: REAL(4) products and sums in pairs, nothing fused)
+    typedef grt_f2 __attribute__((may_alias)) f2a;
+    const f2a *p00 = reinterpret_cast<const f2a *>(c00), *p01 = reinterpret_cast<const f2a *>(c01);
+    const f2a *p10 = reinterpret_cast<const f2a *>(c10), *p11 = reinterpret_cast<const f2a *>(c11);
+    const float otd = 1.f - td, ord_ = 1.f - rd;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const grt_f2 i1 = p00[k] * otd + p01[k] * td;
+      const grt_f2 i2 = p10[k] * otd + p11[k] * td;
+      const grt_f2 w1 = i1 * ord_ + i2 * rd;
+      const grt_f2 w = w1 * (1.f - 0.f) + w1 * 0.f;      // trilininterp with a zero time weight and both slices equal (interpolate.f90:185-203)
+      q[2 * k] = w[0]; q[2 * k + 1] = w[1];
+    }
+  }
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -1134,6 +1239,7 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
     float w1 = i1 * (1.f - rd) + i2 * rd;
     q[k] = w1 * (1.f - 0.f) + w1 * 0.f;
   }
+#endif
   const bool inside = x1 > uniqx1[0];
   f.rho = inside ? q[0] : 0.f;
   f.p = inside ? q[1] : 1.f;

@@ -28,7 +28,8 @@ using namespace grtd;
 
 // GRT_LOG_LAUNCHES=path (test tooling, tests/test_gpu_parity.py instantiation coverage): every launch below appends the mangled-name
 // stem of the kernel it starts, e.g. grt_transfer_kernelILi2ELi13ELi4ELi1ELb0EE, so that the ~180 instantiations of this file can be
-// checked against what the GPU suite actually runs.  One getenv per process; nothing is written without the variable.
+// checked against what the GPU suite actually runs -- and, r05, against WHICH test ran it (GRT_TEST_ID, set per test by tests/conftest.py).
+// One getenv per process for the path; nothing is written without the variable.
 #include <cstdio>
 #include <cstdarg>
 static void note_launch(const char *fmt, ...) {
@@ -39,6 +40,7 @@ static void note_launch(const char *fmt, ...) {
     va_start(ap, fmt);
     std::vfprintf(f, fmt, ap);
     va_end(ap);
+    if (const char *t = std::getenv("GRT_TEST_ID")) std::fprintf(f, "\t%s", t);      // (tests/conftest.py: the test that caused the launch)
     std::fputc('\n', f);
     std::fclose(f);
   }

@@ -50,7 +50,13 @@ struct GrtRayIn {
 struct GrtFFJet {               // device pointers; cell-interleaved copy of the BL09 table
   const float *cells;           // [nx1*nx1][12]: rho,p,b0,br,bth,bph,u0,vr,vth,vph,pad,pad
   const float *uniqr, *uniqth, *uniqx1;
-  int32_t nx1, pad;
+  int32_t nx1;
+  float r_inside;               // smallest REAL(4) r with log(r) > uniqx1(1): the sampler's `inside` test without the logarithm
+  // r05: rthr[j] (j = 2 .. nx1-1) = the smallest REAL(4) r whose radial index int((log r - x1lo)/(x1hi - x1lo) (nx1-1)) + 1 -- the
+  // reference's expression, REAL(4) logarithm and all (fluid_model_ffjet.f90:76-79) -- is at least j: the index of a sample is then a
+  // count of thresholds (found from a hardware log2 guess and two comparisons), bit for bit the index the expression gives, and the
+  // step loses its fp64 logarithm.  Built on upload by bisection over the float bit patterns (the expression is monotonic in r).
+  const float *rthr;
 };
 
 struct GrtHarm {                // device pointers; nt 2-D HARM slices, fluid_model_harm.f90:15-21

@@ -25,3 +25,17 @@ def pytest_sessionstart(session):
         fd, path = tempfile.mkstemp(prefix="grt_launches_", suffix=".log")
         os.close(fd)
         os.environ["GRT_LOG_LAUNCHES"] = path
+
+
+@pytest.fixture(autouse=True)
+def _launch_log_test_id(request):
+    # every launch the library logs carries the test that caused it (grt_kernels.hip:note_launch reads GRT_TEST_ID; child processes --
+    # the Fortran host, rank workers, tools -- inherit it): the coverage check asks not only that an instantiation ran but that a test
+    # which compares with the compiled reference, its goldens or the oracle ran it
+    old = os.environ.get("GRT_TEST_ID")
+    os.environ["GRT_TEST_ID"] = getattr(request.node, "originalname", None) or request.node.name
+    yield
+    if old is None:
+        os.environ.pop("GRT_TEST_ID", None)
+    else:
+        os.environ["GRT_TEST_ID"] = old

@@ -2,7 +2,16 @@
 of each Stokes peak (1e-5 for Q/U/V of the Faraday-thick HARM3D hybrid case).  A robustness sweep over spins (both signs), inclinations, fields of view and uout; run on a GPU box:
     python tools/fuzz_cameras.py [ncams] [seed] [ff|all|ext|allext] [cam,cam,..]
 ("all": also SPHACC and the GRMHD samplers on small synthetic dumps; "ext": also vary the power-law index, the number of
-frequencies and the pixel range; a list of camera indices prints per-step detail for the worst pixel of those cameras)"""
+frequencies and the pixel range; a list of camera indices prints per-step detail for the worst pixel of those cameras)
+
+GRT_FUZZ_INJECT=pix:1e-5 | pix:1e-4 | npts (r05, the classifier's MISS RATE): a known error is put into the DEVICE result of every camera
+before it is compared -- one Stokes value of one live pixel moved by that fraction of its peak, or one ray's stored-point count by one --
+and the sweep reports how many cameras are still flagged MISMATCH after classification.  A camera the classifier waives here is a
+camera on which a real device error of that size would go unseen.
+GRT_FUZZ_DEVICE_DUMP=file.npz: the device's results of every camera are also written there; GRT_FUZZ_DEVICE_LOAD=file.npz: they are READ
+from there instead of being computed -- no GPU needed: the classifier (the oracle's and the compiled reference's perturbation runs, all CPU)
+can then be re-run, changed and measured anywhere on the same device results.
+GRT_FUZZ_WAIVER_BUDGET=f: exit 2 when more than the fraction f of the cameras is waived (default 0.12)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -21,14 +30,18 @@ import tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import make_harm_dump, make_harm3d_dump, make_iharm_dump, make_koral3d_dump
 DRY = bool(os.environ.get("GRT_FUZZ_DRY"))      # replay the draws only: print the exact parameters of the listed cameras (no device, no oracle)
+DUMP = os.environ.get("GRT_FUZZ_DEVICE_DUMP"); LOAD = os.environ.get("GRT_FUZZ_DEVICE_LOAD")
+dumped = {}
+loaded = np.load(LOAD) if LOAD else None
+NODEV = DRY or bool(LOAD)
 td = tempfile.mkdtemp(prefix="grt_fuzz_")
-if DRY:
+if NODEV:
     capi = None
 make_harm_dump.write(td, n=64)
 d3, h3 = make_harm3d_dump.write(td, n1=32, n2=32, n3=16)
 di, hi = make_iharm_dump.write(td, n1=32, n2=32, n3=16, metric=1)
 dk, hk = make_koral3d_dump.write(td, n1=32, n2=32, n3=16)
-if not DRY:
+if not NODEV:
     dev = capi.Device(0); dev.load_ffjet(); dev.load_tables(); dev.load_sphacc()
     dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
     dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375); dev.load_koral3d(dk, hk, 40, 0.9375)
@@ -48,6 +61,9 @@ MODELS = [
 EXT = len(sys.argv) > 3 and sys.argv[3] in ("ext", "allext")      # also vary the power-law index, frequency count and tile
 only = set(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else None      # examine these camera indices in detail
 bad = 0; cond = 0; ampl = 0
+INJ = os.environ.get("GRT_FUZZ_INJECT", "")
+ninj = 0; ninj_flagged = 0
+rules = {"perturbation floor": 0, "amplified": 0, "lambda ulp": 0, "delo exact replay": 0, "nan replay": 0}
 for c in range(ncams):
     fname, ename, okw, ekw, freq, tol = MODELS[int(rng.integers(0, len(MODELS)))] if (len(sys.argv) > 3 and sys.argv[3] in ("all", "allext")) else MODELS[0]
     if os.environ.get("GRT_FUZZ_MODEL"):      # only this fluid model's entries of the list (the draw above is still made: same stream)
@@ -76,14 +92,38 @@ for c in range(ncams):
     if DRY:
         print("cam %d: %r" % (c, dict(fname=fname, ename=ename, okw=okw, ekw=ekw, spin=a, mu0=mu0, gridvals=gv, uout=uout, nn=nn, iname=iname, rec=rec, p1=p1, freqs=freqs, i1=i1, i2=i2, tol=tol)))
         continue
-    o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)
-    ref, rn, _ = o.trace(i1, i2, freqs, nthreads=0)
-    capi.record_steps(rec)
-    cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
-    em = capi.make_emis(ename, ekw["mbh"], ekw.get("nfac", 1.0), ekw.get("bfac", 6.0), ekw["gmin"], 1e5, p1, muval=0.25, mdot=ekw.get("mdot", 0.0))
-    if os.environ.get("GRT_FUZZ_VERBOSE"):
-        print("next: cam %d %s %s a=%r mu0=%r gv=%r uout=%r nn=%r %s rec=%d p=%r freqs=%r i=%d..%d" % (c, fname, ename, a, mu0, gv, uout, nn, iname, rec, p1, freqs, i1, i2), flush=True)
-    pix, _, status, _ = capi.trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=okw.get("nvals", 4))
+    DUMP_ONLY = bool(DUMP and os.environ.get("GRT_FUZZ_DUMP_ONLY"))      # (device results only: the classification is run elsewhere from the file)
+    if not DUMP_ONLY:
+        o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)
+        ref, rn, _ = o.trace(i1, i2, freqs, nthreads=0)
+    if LOAD:
+        pix, status = loaded["c%d_pix" % c].copy(), loaded["c%d_status" % c].copy()
+    else:
+        capi.record_steps(rec)
+        cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
+        em = capi.make_emis(ename, ekw["mbh"], ekw.get("nfac", 1.0), ekw.get("bfac", 6.0), ekw["gmin"], 1e5, p1, muval=0.25, mdot=ekw.get("mdot", 0.0))
+        if os.environ.get("GRT_FUZZ_VERBOSE"):
+            print("next: cam %d %s %s a=%r mu0=%r gv=%r uout=%r nn=%r %s rec=%d p=%r freqs=%r i=%d..%d" % (c, fname, ename, a, mu0, gv, uout, nn, iname, rec, p1, freqs, i1, i2), flush=True)
+        pix, _, status, _ = capi.trace_tile(cam, i1, i2, fname, em, freqs, iname, nvals=okw.get("nvals", 4))
+    if DUMP:
+        dumped["c%d_pix" % c] = pix.copy(); dumped["c%d_status" % c] = status.copy()
+        if DUMP_ONLY:
+            continue
+    injected = False
+    if INJ:
+        irng = np.random.default_rng(77000 + c)
+        livepix = np.where((status > 0) & np.isfinite(pix).all(axis=(0, 2)) & np.isfinite(np.asarray(ref)).all(axis=(0, 2)))[0]
+        if len(livepix):
+            w_inj = int(irng.choice(livepix))
+            if INJ == "npts":
+                status = status.copy(); status[w_inj] += int(irng.choice([-1, 1]))
+            else:
+                k_inj, s_inj = int(irng.integers(len(freqs))), int(irng.integers(nst))
+                fin_ = np.isfinite(np.asarray(ref[k_inj])).all(axis=1)
+                pk_ = np.abs(np.asarray(ref[k_inj])[fin_]).max(axis=0)
+                pk_ = np.maximum(pk_, 1e-2 * pk_[0])
+                pix = pix.copy(); pix[k_inj][w_inj][s_inj] += np.float32(float(INJ.split(":")[1]) * pk_[s_inj] * float(irng.choice([-1.0, 1.0])))
+            injected = True; ninj += 1
     ok_n = np.array_equal(status, rn)
     # pixels where the integrator overflowed (NaN or inf, as in the reference) must be the same pixels; the rest is compared
     err, same_nan, perf = 0.0, True, {}
@@ -183,6 +223,7 @@ for c in range(ncams):
         if total and explained == total:
             same_nan = True
             nan_note = "  [%d pixel(s) NaN in the reference only: its DELO recursion overflows inside imatrix_4, solved exactly it is finite and is the device's]" % total
+            rules["nan replay"] += 1
             if err < tol:
                 flag = ""
     if flag and ok_n and COND_REF:
@@ -239,7 +280,7 @@ for c in range(ncams):
                     floor = max(floor, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max())
         o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=mu0, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, **okw)   # the library holds one problem
         if err < 10 * floor and same_nan:
-            flag = "  (ill-conditioned in the reference: it moves by %.1e itself when the frequency changes by 1e-13 or the camera by one ulp)" % floor; cond += 1
+            flag = "  (ill-conditioned in the reference: it moves by %.1e itself when the frequency changes by 1e-13 or the camera by one ulp)" % floor; cond += 1; rules["perturbation floor"] += 1
         elif same_nan:
             # amplification of a perturbation at the level the device's coefficient functions agree with the reference's (1e-7):
             # the reference against itself with every frequency moved by 1e-8.  A well-conditioned pixel moves by a few 1e-8
@@ -258,9 +299,9 @@ for c in range(ncams):
                     if okm.any():
                         amp = max(amp, (np.abs(rp[k][okm] - cref[k][okm]).max(axis=0) / (np.abs(cref[k][okm]).max(axis=0) + 1e-300)).max() / abs(rel))
             if amp > 30.0 and err < 3.0 * amp * 1e-7:
-                flag = "  (amplified by the reference itself: a change of the frequency by 1e-8 ... 3e-7 moves its answer by %.0f times as much)" % amp; ampl += 1
+                flag = "  (amplified by the reference itself: a change of the frequency by 1e-8 ... 3e-7 moves its answer by %.0f times as much)" % amp; ampl += 1; rules["amplified"] += 1
             elif nst == 4 and lam_ulp_explains():
-                flag = "  (one ulp of GEOKERR's lambda at one point of the worst pixel's ray moves the reference's own integral by %.1e of the pixel; the device's pixel differs by %.1e)" % lam_note; cond += 1
+                flag = "  (one ulp of GEOKERR's lambda at one point of the worst pixel's ray moves the reference's own integral by %.1e of the pixel; the device's pixel differs by %.1e)" % lam_note; cond += 1; rules["lambda ulp"] += 1
             elif iname == "delo" and nst == 4:
                 # r04 (seed 1234 camera 300): a DELO pixel that is stable under every perturbation above and still not the device's.  The
                 # reference's recursion on the ray's own coefficients with the 4x4 system of every step solved exactly (rational arithmetic
@@ -287,8 +328,9 @@ for c in range(ncams):
                         worst_rel, worst_at = rel, (w, freqs[k], cof, exa)
                 if worst_rel > 1e-3:
                     flag = ("  (the reference's cofactor inverse is not converged: its own DELO recursion on pixel %d at %.3g Hz gives %s with imatrix_4 and %s with"
-                            " every 4x4 system solved exactly)" % (worst_at[0], worst_at[1], np.array2string(worst_at[2], precision=3), np.array2string(worst_at[3], precision=3))); cond += 1
+                            " every 4x4 system solved exactly)" % (worst_at[0], worst_at[1], np.array2string(worst_at[2], precision=3), np.array2string(worst_at[3], precision=3))); cond += 1; rules["delo exact replay"] += 1
     bad += ("MISMATCH" in flag)
+    ninj_flagged += int(injected and "MISMATCH" in flag)
     print("cam %2d %-8s %s a=%+.3f mu0=%+.3f fov=%.1f uout=%.2f nn=%s %s rec=%d p=%.1f nf=%d i=%d..%d: npts %s nan-mask %s err %.2e%s%s" %
           (c, fname, ename, a, mu0, half, uout, nn, iname, rec, p1, len(freqs), i1, i2, ok_n, same_nan, err, flag + nan_note, (" IQUV per frequency " + str(perf)) if flag else ""))
     if only is not None:
@@ -344,6 +386,17 @@ for c in range(ncams):
             print("      worst theta point %d of %d: dev th %.12g ref th %.12g | r dev %.12g ref %.12g" % (k, n, recd[1][k], x[k, 2], recd[0][k], x[k, 1]))
 if DRY:
     sys.exit(0)
-capi.record_steps(False)
-dev.close()
+if DUMP:
+    np.savez_compressed(DUMP, **dumped)
+if not NODEV:
+    capi.record_steps(False)
+    dev.close()
 print("MISMATCHES:", bad, " ill-conditioned in the reference itself:", cond, " amplified (kappa > 30):", ampl)
+nw = sum(rules.values())
+print("waivers by rule:", rules, " = %d of %d cameras (%.1f %%)" % (nw, ncams, 100.0 * nw / max(ncams, 1)))
+if INJ:
+    print("INJECTED %s into %d cameras: %d still flagged after classification = %.1f %% (missed: %d)" % (INJ, ninj, ninj_flagged, 100.0 * ninj_flagged / max(ninj, 1), ninj - ninj_flagged))
+budget = float(os.environ.get("GRT_FUZZ_WAIVER_BUDGET", "0.12"))
+if not INJ and only is None and nw > budget * ncams:
+    print("WAIVER BUDGET EXCEEDED: %d waived of %d (budget %.0f %%)" % (nw, ncams, 100 * budget))
+    sys.exit(2)
