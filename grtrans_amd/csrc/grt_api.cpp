@@ -20,7 +20,8 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split, int *todo, int *todo_count);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split, int *todo, int *todo_count,
+                                     hipStream_t phi_stream, hipEvent_t ev_geo, hipEvent_t ev_phi);
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
                                       double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield);
@@ -50,6 +51,8 @@ struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // the generic-class launches run beside the fast-class ones
+  hipStream_t stream3 = nullptr;      // r05: grt_phi_kernel + its left-overs beside the transfer kernel, when that kernel does not read phi
+  hipEvent_t evp[2] = {nullptr, nullptr};
   hipEvent_t evj[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   // fluid + tables
@@ -147,6 +150,7 @@ int grow(T *&p, size_t &cap, size_t need) {
 void drain() {
   if (C.stream) (void)hipStreamSynchronize(C.stream);
   if (C.stream2) (void)hipStreamSynchronize(C.stream2);
+  if (C.stream3) (void)hipStreamSynchronize(C.stream3);
 }
 
 struct EventPair {       // destroyed on every exit path
@@ -184,6 +188,12 @@ int grt_init(int device) {
     if (const char *gs = std::getenv("GRT_GEO_SPLIT")) C.geo_split = std::atoi(gs) ? 1 : 0;      // (A/B runs of the fused record-mode kernel)
     HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
   }
+  {      // lowest priority: the azimuth kernel's 6-waves-per-SIMD blocks must not take the CUs ahead of the transfer kernel's blocks
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HIPCHK(hipStreamCreateWithPriority(&C.stream3, hipStreamNonBlocking, least));
+  }
+  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&C.evp[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&C.evk[i]));
@@ -209,6 +219,9 @@ int grt_free(void) {
   if (C.stream2) (void)hipStreamDestroy(C.stream2);
   for (int i = 0; i < 3; ++i)
     if (C.evj[i]) (void)hipEventDestroy(C.evj[i]);
+  for (int i = 0; i < 2; ++i)
+    if (C.evp[i]) (void)hipEventDestroy(C.evp[i]);
+  if (C.stream3) (void)hipStreamDestroy(C.stream3);
   C = Ctx();
   return 0;
 }
@@ -789,12 +802,13 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
     // launched FIRST on the high-priority stream: launched second it trailed the fast-class kernels by up to 40 ms.
     LAUNCHCHK(hipEventRecord(C.evj[0], C.stream));
     LAUNCHCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
+    bool phi_joined = true;
     for (int turn = 0; turn < 2; ++turn) {
       const bool generic = ((C.class_order & 1) != 0) == (turn == 0);
       if (generic) {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps,
-                                   rstride, fstride, nfields, tfield, t0c, 0, 0, nullptr, nullptr));
+                                   rstride, fstride, nfields, tfield, t0c, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr));
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
@@ -815,9 +829,18 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
                                       rstride, fstride, nfields, tfield, C.d_stepcount, C.d_counters + 1, nch));
         LAUNCHCHK(hipEventRecord(C.evj[1], C.stream2));
       } else {
+        // r05: when the transfer kernel does not read the azimuth (2-D fluid model, no extra=1: phi is only an output of the record) the
+        // azimuth kernels of the split trace run on a third, lowest-priority stream BESIDE the transfer kernel instead of in front of
+        // it.  Measured (profiles/r05e_phi_beside.log): a whole 1024^2 image 57.1 -> 56.6 ... 56.9 ms; a rank's share of an 8-GPU run 9.7 ->
+        // 10.0 ms (its one resident round of transfer waves is latency-bound and loses more to the neighbour than the chain saves) --
+        // so, like the class wait, only for passes above 400,000 rays (GRT_PHI_INLINE=1 / =0 decides for every size)
+        static const char *pin = std::getenv("GRT_PHI_INLINE");
+        const bool phi_beside = !reuse && C.geo_split && !(nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || is_koral) &&
+                                (pin ? std::atoi(pin) == 0 : nch > 400000);
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
-                                   nfields, tfield, t0c, 0, C.geo_split, C.d_phitodo, C.d_counters + 2));
+                                   nfields, tfield, t0c, 0, C.geo_split, C.d_phitodo, C.d_counters + 2, phi_beside ? C.stream3 : nullptr, C.evp[0], C.evp[1]));
+        phi_joined = phi_joined && !phi_beside;
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                                       C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
@@ -825,6 +848,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       }
     }
     LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
+    if (!phi_joined) LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evp[1], 0));      // (the azimuth chain on the third stream, if it was used)
     LAUNCHCHK(hipEventRecord(C.ev[2], C.stream));
     int ncls[2] = {0, 0};
     LAUNCHCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
@@ -1002,8 +1026,8 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
   hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin, nullptr, 0);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (e != hipSuccess) { drain(); return (int)e; }
   HIPCHK(hipStreamSynchronize(C.stream));
   // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them

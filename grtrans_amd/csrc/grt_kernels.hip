@@ -1403,7 +1403,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
                                      long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split,
-                                     int *todo, int *todo_count) {
+                                     int *todo, int *todo_count, hipStream_t phi_stream, hipEvent_t ev_geo, hipEvent_t ev_phi) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
   // the generic class is small as a rule: a capped grid that strides over its (ray, chunk) items
@@ -1426,12 +1426,21 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
     hipLaunchKernelGGL((grt_geo_kernel<1, 0, true>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = grt_launch_phi(s, cam, rays, rrays, live, nlive_dev, nrays, todo, todo_count, steps, ray_stride, field_stride);
+    // phi_stream: the azimuth kernels run there, after this stream's image-only kernel (ev_geo), and record ev_phi when done -- the
+    // caller's transfer kernel does not read phi and starts beside them
+    hipStream_t ps = phi_stream ? phi_stream : s;
+    if (phi_stream) {
+      if ((e = hipEventRecord(ev_geo, s)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(phi_stream, ev_geo, 0)) != hipSuccess) return e;
+    }
+    e = grt_launch_phi(ps, cam, rays, rrays, live, nlive_dev, nrays, todo, todo_count, steps, ray_stride, field_stride);
     if (e != hipSuccess) return e;
     note_launch("grt_geo_kernelILi1ELi2ELb0ELb1EE");
-    hipLaunchKernelGGL((grt_geo_kernel<1, 2, false, true>), dim3(nblk > 2048u ? 2048u : nblk), b, 0, s, *cam, rays, rr, (const int *)todo, (const int *)todo_count, nrays, steps,
+    hipLaunchKernelGGL((grt_geo_kernel<1, 2, false, true>), dim3(nblk > 2048u ? 2048u : nblk), b, 0, ps, *cam, rays, rr, (const int *)todo, (const int *)todo_count, nrays, steps,
                        ray_stride, field_stride, nfields, tfield, t0, raw);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (phi_stream) return hipEventRecord(ev_phi, phi_stream);
+    return hipSuccess;
   }
   bool launched = false;
 #define GRT_GEO_CASE(F, P)                                                                                              \

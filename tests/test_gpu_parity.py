@@ -6,6 +6,7 @@ The reference computes the fluid variables in REAL(4) and its power-law emissivi
 frequency crosses a bin of the G(x) tables, so the REAL(4) islands must be bit-identical on the device (built with
 -ffp-contract=fast-honor-pragmas; test_fp32_islands_* and test_table_bin_flip_cameras hold that)."""
 import os
+import re
 import numpy as np
 import pytest
 
@@ -1734,6 +1735,26 @@ def test_random_cameras_vs_oracle(mode, ncam, seed):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = [l for l in r.stdout.strip().splitlines() if l.startswith("MISMATCHES:")][-1]
     assert last.startswith("MISMATCHES: 0"), r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("kind,ncam,need", [("npts", 30, 1.0), ("pix:1e-4", 40, 0.95)])
+def test_fuzz_classifier_still_flags_an_injected_device_error(kind, ncam, need):
+    # VERDICT r04 weak #1 / next #3b: the sweep's "no mismatch" rests on a classifier that waives cameras on which the REFERENCE is
+    # ill-conditioned; nothing measured how many real device errors it would waive with them.  GRT_FUZZ_INJECT puts a known error into the
+    # device result of every camera before the comparison -- one ray's stored-point count off by one; one Stokes value of one live pixel
+    # moved by 1e-4 of its peak (50x the bar) -- and counts the cameras still flagged after classification.  With the r04 rules (camera-wide
+    # bars) 79 % of the 1e-4 errors were flagged (200 cameras, profiles/r05c_inject_*); with the per-pixel bars of r05 99 % are
+    # (profiles/r05e_inject_pix_1e-4_per_pixel_rules.log), with 0 / 0 / 0 / 1 cameras flagged on four clean seeds of 200.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_cameras.py"), str(ncam), "424", "allext"],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, GRT_FUZZ_INJECT=kind))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("INJECTED")][-1]
+    m = re.search(r"into (\d+) cameras: (\d+) still flagged", line)
+    ninj, nflag = int(m.group(1)), int(m.group(2))
+    assert ninj >= 0.9 * ncam and nflag >= need * ninj, line
 
 
 def test_scalar_emissivities_nvals1_vs_reference_golden(tmp_path):
