@@ -41,7 +41,11 @@ WORKLOADS = {
 }
 BYTES_PER_STEP = 64.0          # one fp64 SoA record (r,theta,phi,lambda,I,Q,U,V) per ray-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
+# fp64 vector (non-matrix) peak.  Source: AMD's MI355X product brief lists 78.6 TFLOP/s "peak double precision vector (FP64)"; the same figure
+# follows from the guide's numbers (/opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD16 at 2.4 GHz, fp64 FMA at full rate):
+# 256 x 64 lanes x 2 flop x 2.4e9 = 78.6e12 = half the 157.3 TFLOP/s fp32 vector figure the guide states (packed fp32).  The guide itself
+# does not print the fp64 number.
+FP64_VALU_PEAK_TFLOPS = 78.6
 TILE_COLS_DEFAULT = 1          # strong scaling share-out: single image columns round-robin (the generic ray class sits in a few columns)
 
 

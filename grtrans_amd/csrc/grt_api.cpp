@@ -668,6 +668,10 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   }
   // (fluid, emissivity) pairs that have a kernel; everything else is refused, never emulated
   const bool pair_ok = (fluid_model == GRT_FLUID_FFJET && em->type == GRT_EMIS_POLSYNCHPL) ||
+                       // r05: the power law on the GRMHD samplers that define a non-thermal density (KORAL3D, SPHACC and -- for the thermal
+                       // emissivities -- FFJET get a density of zero from the reference's unit conversions, fluid.f90:1150,1257,1171: an
+                       // identically zero image, no kernel)
+                       ((fluid_model == GRT_FLUID_HARM || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM) && em->type == GRT_EMIS_POLSYNCHPL) ||
                        (fluid_model == GRT_FLUID_SPHACC && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM && em->type == GRT_EMIS_POLSYNCHTH) ||
                        (fluid_model == GRT_FLUID_HARM3D && em->type == GRT_EMIS_POLSYNCHTH) ||

@@ -605,21 +605,12 @@ GRT_HD void useg_lane(const GrtCam &cam, const GrtRay &R, const RealRay &K, int 
     return;
   }
   if (!K.cplx && ua == root) return;    // clamped onto the turning point: S = 0
-#if !defined(GRT_NO_USEG_MERGE)
   // ONE copy of the pair integrals (r04): the last inbound point's upper neighbour is the turning point itself -- a select on the
   // upper limit, not a second inlined evaluation that the chunk holding that point ran in addition to everybody else's
   const bool lastinb = inb && R.tpr != 0 && idx == lo;
   const double un = leg_u(cam, R, K, lastinb ? idx : idx + 1, inb);
   reset = lastinb;
   upair_diff<NPH>(K, ua, lastinb ? root : un, o);
-#else
-  if (inb && R.tpr != 0 && idx == lo) { // last inbound point: its upper neighbour is the turning point itself
-    upair_diff<NPH>(K, ua, root, o);
-    return;
-  }
-  reset = false;
-  upair_diff<NPH>(K, ua, leg_u(cam, R, K, idx + 1, inb), o);
-#endif
 }
 
 // useg_lane in two halves for the shared-square-root form: the classification (which limits, which special case) here, the pair
@@ -855,11 +846,7 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
         double a2 = K.sm * powm1(tpm);
         double a3 = two * fint((two * (double)tpm + 3.0 - K.sm) / 4.0) - one;
         double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);   // a2 = +-1: 1/a2 == a2
-#if !defined(GRT_NO_JSCALE)
         jarg = K.jscale * iarg;
-#else
-        jarg = (K.sym ? sqrt(K.mpos - K.mneg) : fabs(K.muplus)) * iarg;
-#endif
       } else {
         double b1 = K.sm, b2 = K.sm * powm1(tpm + 1), b3 = 2.0 * fint((2 * tpm - K.sm + 1) / 4.0);
         iu = b1 * K.i1mu + b2 * M.i2mu + b3 * K.i3mu;                      // I_mu
@@ -950,11 +937,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
     double sn, cn, dn;
     if (K.sym) {
       double zz, s0, c0;
-#if !defined(GRT_NO_JSCALE)
       sncndn_ladder_z(K.agm_mu, K.jscale * iarg, K.m1m, sn, cn, dn, zz, s0, c0);
-#else
-      sncndn_ladder_z(K.agm_mu, fsqrt(K.mpos - K.mneg) * iarg, K.m1m, sn, cn, dn, zz, s0, c0);
-#endif
       mun = K.muminus * cn;
       Tz = zeta_T(K, zz, tpm, iu);
       if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);

@@ -858,13 +858,7 @@ GRT_NI void formal_apply(const double *a, const double *rho, double dx, const do
   double co, si;
   // (r04: the lean sincos of the geodesic kernels -- no large-argument path; the Faraday angle of a step is an ordinary number -- 25
   //  frequencies 355.9 -> 349.1 ms on one box; the single-frequency kernels do not notice.  GRT_FORMAL_LIB_SINCOS: the library's)
-#if !defined(GRT_FORMAL_LIB_SINCOS)
   fast_sincos(lam2 * dx, &si, &co);
-#elif defined(__HIP_DEVICE_COMPILE__)
-  sincos(lam2 * dx, &si, &co);
-#else
-  si = sin(lam2 * dx); co = cos(lam2 * dx);
-#endif
   const double ith = frcp(theta);
   // exp(-a_I dx) x (c1, c2/theta, c3/theta, 2 c4/theta): the damping goes in first, so that cosh ~ 1e308 of a Faraday- and
   // optically-thick step meets exp(-a_I dx) = 0 before it meets the intensities (calc_O scales O the same way)
@@ -980,12 +974,8 @@ GRT_NI void ffjet_sample(const GrtFFJet &t, double r, double th_d, float a, Flui
   int ux1c = lx1c + 1;
   float td = (theta - t.uniqth[lx2 - 1]) / (t.uniqth[ux2 - 1] - t.uniqth[lx2 - 1]);
   float rd = (zr - t.uniqr[lx1c - 1]) / (t.uniqr[ux1c - 1] - t.uniqr[lx1c - 1]);
-#if defined(GRT_SAMPLE_CONST_ZONE)
-  const float *c00 = t.cells + (size_t)((nx1 / 2) + (nx1 / 2) * nx1) * 12, *c01 = c00 + (size_t)nx1 * 12;
-#else
   const float *c00 = t.cells + (size_t)((lx1c - 1) + (lx2 - 1) * nx1) * 12;   // (x1l, x2l); +12 -> x1u
   const float *c01 = t.cells + (size_t)((lx1c - 1) + (ux2 - 1) * nx1) * 12;   // (x1l, x2u)
-#endif
   float q[10];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_PACKED_BLEND)
   {      // two fields per blend (the cell records are 48-byte aligned: pairs of floats load as one 8-byte word)
@@ -1205,12 +1195,8 @@ GRT_NI void harm_sample(const GrtHarm &t, const float *crd, double r, double th_
   const float rh = 1.f + sqrtf(1.f - a * a);
   if (uniqr[lx1c - 1] <= rh) rd = 1.f;                                                     // :165-167
   const float *slice = t.cells + (size_t)tindx * nx1 * nx2 * 12;
-#if defined(GRT_SAMPLE_CONST_ZONE)   // experiment (timing only, DESIGN 4 "what the L2-resident table costs"): every lane gathers the same zone
-  const float *c00 = slice + (size_t)((nx1 / 2) * nx2 + nx2 / 2) * 12, *c01 = c00 + 12;
-#else
   const float *c00 = slice + (size_t)((lx1c - 1) * nx2 + (lx2c - 1)) * 12;   // (x1l, x2l)
   const float *c01 = slice + (size_t)((lx1c - 1) * nx2 + (ux2 - 1)) * 12;    // (x1l, x2u)
-#endif
   const float *c10 = c00 + (size_t)nx2 * 12, *c11 = c01 + (size_t)nx2 * 12;    // x1u
   float q[10];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_PACKED_BLEND)

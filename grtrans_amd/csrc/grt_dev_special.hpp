@@ -24,9 +24,7 @@ GRT_HD double sq(double x) { return x * x; }
 GRT_HD double frcp(double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
-#if !defined(GRT_RCP_1NR)
   r = fma(fma(-b, r, 1.0), r, r);
-#endif
   return r;
 }
 // frcp for arguments that may be 0 or infinite: the Newton steps turn the hardware's correct 1/0 = inf, 1/inf = 0 into NaN
@@ -47,17 +45,12 @@ GRT_HD double fsqrt(double x) {
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);
-#if !defined(GRT_SQRT_1NR)
   g = fma(fma(-g, g, x), h, g);
-#endif
   return (x == 0.0) ? 0.0 : g;
 }
 // fsqrt for arguments that are never zero (sums of squares plus one, reciprocals of positive means, the radicands of a segment
 // between two DIFFERENT stored points): without the x == 0 guard -- a compare and two selects per call, ~12 calls per stored point
 GRT_HD double fsqrt_nz(double x) {
-#if defined(GRT_NO_SQRT_NZ)
-  return fsqrt(x);
-#else
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
@@ -65,7 +58,6 @@ GRT_HD double fsqrt_nz(double x) {
   g = fma(fma(-g, g, x), h, g);
   g = fma(fma(-g, g, x), h, g);
   return g;
-#endif
 }
 // 1 / sqrt(x) from the hardware's reciprocal square root and two Newton steps (<= 1 ulp): 9 instructions where frcp(fsqrt(x)) is 18 --
 // the comoving tetrad normalises five vectors per step (r05)
@@ -91,7 +83,6 @@ GRT_HD double fsqrt(double x) { return sqrt(x); }
 // of degree 9 interpolated at Chebyshev nodes (polynomial error 1.6e-17 relative), ldexp for the scale -- which saturates by itself: an
 // argument above 709.8 gives inf, one below -745.1 gives 0.  Against glibc over [-700, 700]: at most 0.96 ulp, 1 ulp off in 6 % of the
 // arguments (tests/test_hostsim_fast.py::test_fexp...).  NOT for arguments that may be infinite (exp(-inf) must be 0: this returns NaN).
-#if !defined(GRT_NO_FEXP)
 GRT_HD double fexp(double x) {
   const double l2e = 1.4426950408889634, ln2h = 0x1.62e42fefa39efp-1, ln2l = 0x1.abc9e3b39803fp-56;
   const double dn = rint(x * l2e);
@@ -105,9 +96,6 @@ GRT_HD double fexp(double x) {
   p = fma(t, p, 1.0);
   return ldexp(p, (int)dn);
 }
-#else
-GRT_HD double fexp(double x) { return exp(x); }
-#endif
 GRT_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
 GRT_HD double powm1(int n) { return (n & 1) ? -1.0 : 1.0; }
 GRT_HD int fint(double x) { return (int)x; }
@@ -475,11 +463,7 @@ GRT_HD void sncndn_ladder_z(const AgmLadder &L, double uu, double emmc, double &
       c = dn * c;
       const double r = frcp(b + a);
       dn = (L.en[ii - 1] + a) * r;
-#if !defined(GRT_NO_LADDER_RCP)
       a = c * L.iem[ii - 1];          // (b is a constant of the ray: its reciprocal comes with the ladder; 1.5 ulp instead of 1)
-#else
-      a = fdiv(c, b);
-#endif
       z = L.opk[ii - 1] * z + (b - L.en[ii - 1]) * r * a;
     }
     zeta = z;

@@ -82,9 +82,6 @@ static void note_launch(const char *fmt, ...) {
 // correct and bit-equal run to run.  Two kernels out of ~150 whose results depend on how the allocator parks values in AGPRs are
 // two too many for a code whose tests cannot visit every (kernel, input) pair: the thermal kernels pay 1-2 % for it
 // (HARM 512x512x400 transfer 18.5 -> 18.7 ms image only, 19.1 -> 19.5 ms with the record).
-#ifdef GRT_XFER_WPE_ALL      // experiment builds: one occupancy for every instantiation
-#define GRT_XFER_WPE(EMIS, FLUID) GRT_XFER_WPE_ALL
-#endif
 #ifndef GRT_XFER_WPE
 #define GRT_XFER_WPE(EMIS, FLUID) 2
 #endif
@@ -158,22 +155,14 @@ __global__ __launch_bounds__(256, GRT_OCC(GRT_WPE_SETUP)) void grt_setup_kernel(
   // one such ray (l = -4e-5) whose azimuth came out of the fast path 1.49 rad off after crossing the equator on the device
   const bool polar = R.l * R.l < polar_l2 * (R.q2 + cam.a * cam.a);
   bool quart = alive && !polar && !cam.usegeor && (((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1.e-12) ||
-#if !defined(GRT_NO_CPLX_FAST)
                                (R.ncase == 5 && R.tpr == 0 && cam.a != 0.0 && R.q2 != 0.0));
-#else
-                               false);
-#endif
   // (a ray that ENDS inside its mu-fill segment -- never seen -- would have Lambda(npts) in the second phase: generic class)
   bool topfill = false;
   if (quart) { const RealLeg lg = real_leg(cam, R); topfill = lg.nfill > 0 && R.npts <= lg.lo + lg.nfill; }
   quart = quart && !topfill;
   // ... or one real root and a complex pair (ncase 3: the plunging rays of a Schwarzschild camera; grt_dev_cubic.hpp)
-#if !defined(GRT_NO_CUBIC_CPLX)
   const bool cubic = alive && !(need_time & 1) && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 &&
                      (((R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12) || (R.ncase == 3 && R.tpr == 0));
-#else
-  const bool cubic = alive && !(need_time & 1) && !cam.usegeor && cam.a == 0.0 && R.q2 != 0.0 && (R.ncase == 1 || R.ncase == 2) && fabs(R.u3 - R.u2) > 1.e-12;
-#endif
   const bool fastc = quart || cubic;
   const bool slowc = alive && !fastc;
   if (quart) {   // wave-uniform constants of the fast path, read back through scalar loads by the trace kernel
@@ -233,11 +222,9 @@ extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long 
 // (v,f)_k o (v,f)_k+d = (v_k + (f_k ? 0 : v_k+d), f_k | f_k+d).
 template <int NQ>
 __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int lane) {
-#if !defined(GRT_NO_SCAN_LAUNDER)
   // the six lane-index compares stay HERE (r04): hoisted out of the chunk loop they were twelve SGPRs parked in VGPR lanes, and every
   // use a v_readlane on the vector pipe; re-formed per pass they are six v_cmp with a result that dies at once
   asm volatile("" : "+v"(lane));
-#endif
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const bool have = lane + d < 64;
@@ -296,7 +283,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
   const GrtRay *Rp = rays + rayidx;
   const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)(FAST ? rayidx : 0) * GRT_RR_STRIDE);
   const CubRay *Cp = reinterpret_cast<const CubRay *>(Kp);
-#if !defined(GRT_NO_GEO_LDS_RR)
   // Image-only four-real-root kernel (NPH = 0): the wave copies its ray's RealRay (2 KB) into LDS once and every per-ray constant is a
   // broadcast ds_read where it is used, instead of ~90 scalar loads per 64-point pass whose latency two waves per SIMD could not hide
   // (r03: 29.1 -> 23.9 ms at 1024x1024x400; images bit-equal to the scalar-load build and to the record-mode kernel's).  The whole
@@ -311,11 +297,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
   const RealRay *Kg = Kp;
   const GrtRay *Rg = Rp;
   constexpr int RW = (sizeof(GrtRay) + 7) / 8;
-#if defined(GRT_LDS_NPH3)      // experiment: the slow-light kernel <1,3> with the LDS copies of <1,2> (r03: garbage turning-point counts in the mu-fill segment)
-  constexpr bool LDSR = (FAST == 1 && (NPH == 2 || NPH == 3));
-#else
   constexpr bool LDSR = (FAST == 1 && NPH == 2);
-#endif
   __shared__ double s_r[LDSR ? GRT_WAVES_PER_BLOCK : 1][LDSR ? RW : 1];
   if (LDSR) {
     typedef double __attribute__((may_alias)) grt_word2;
@@ -325,25 +307,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
   }
   // ... and the Schwarzschild-cubic class (CubRay, 648 B) in both of its forms: SPHACC 1024^2 x 400 geodesics 24.3 -> 20.8 ms image only,
   // 29.0 -> 24.7 ms with the record
-#if defined(GRT_LDS_NPH3)
-  constexpr bool LDSHYB = (FAST == 1 && (NPH == 2 || NPH == 3));
-#elif defined(GRT_LDSHYB_NPH2)   // the r03 / early-r04 record-mode kernel: ladders and series constants only
-  constexpr bool LDSHYB = (FAST == 1 && NPH == 2);
-#else
   constexpr bool LDSHYB = false;
-#endif
   // r04, once MachineLICM was off (Makefile): the record-mode kernel takes the WHOLE record from LDS as well -- the loads are no longer
   // hoisted into registers held across the pass (231 VGPRs, 40 B/lane of scratch as before, 18 spilled SGPRs instead of 39), and 43 of
   // the 94 scalar-memory waits of a pass had fewer than five vector instructions between the load and its wait: 37.9 -> 36.8 ms at
   // 1024^2 x 400 (profiles/r04_e_variants_ldsrr2.log).  The slow-light kernel <1,3> keeps its scalar loads: no workload to time it on.
   // (The GrtRay through LDS in the image-only and the Schwarzschild-cubic kernels as well: no change, 17.2 / 14.8 ms either way.)
-#if defined(GRT_LDSRR_NPH3)    // experiment: the r03 failure (whole RealRay through LDS in the slow-light kernel)
-  constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 2 || NPH == 3)) || FAST == 2;
-#elif defined(GRT_LDSHYB_NPH2) || defined(GRT_LDS_NPH3)
-  constexpr bool LDSRR = (FAST == 1 && NPH == 0) || FAST == 2;
-#else
   constexpr bool LDSRR = (FAST == 1 && (NPH == 0 || NPH == 2)) || FAST == 2;
-#endif
   constexpr int RRW = ((FAST == 2 ? sizeof(CubRay) : sizeof(RealRay)) + 7) / 8;
   __shared__ double s_rr[(LDSRR || LDSHYB) ? GRT_WAVES_PER_BLOCK : 1][(LDSRR || LDSHYB) ? RRW : 1];
   if (LDSRR || LDSHYB) {
@@ -356,13 +326,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
   }
-#endif
-#if defined(GRT_GEO_CAMK)
-  const GrtCam *camp = nullptr;
-#define GRT_CAMREF (*camp)
-#else
 #define GRT_CAMREF cam
-#endif
   const int n = Rp->npts;
   double LamN = 0.0;                              // (ray_stride is a multiple of 64 points: every full chunk row is a 512-byte aligned run of four 128-byte lines)
   constexpr int NQ = (NPH == 3) ? 4 : (NPH == 2 ? 3 : 2);   // u-side quantities of the segment scheme: iu1, tu11[, phiu1[, tu1]]
@@ -381,7 +345,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
   leg.lo = n; leg.nfill = 0; leg.fill = false;
   if (FAST == 1) leg = real_leg(cam, *Rp);
   const int nreg = n - leg.nfill;
-  double cF[4] = {1.0, 1.0, 1.0, 1.0};      // (GRT_USEG_SHARE) real_froots of the lowest point of the chunk above
   // The partial TOP chunk of the regular points (394 = 6 x 64 + 10 for the escaping rays of the headline camera) costs a full pass: a
   // masked-off 16-lane group is not skipped by the hardware (tools/exec_skip_bench.hip).  r04 gave those chunks to a separate kernel,
   // four rays to a wave with per-lane LDS addresses for the per-ray constants: this kernel lost 4.1 ms, that one took 3.5-4.0 ms
@@ -398,31 +361,14 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
     // re-read through the scalar cache where used instead of being hoisted and parked in registers
     {
       // (constant address space: the loads below become scalar loads of the wave's ray; see grt_fresh)
-#if !defined(GRT_NO_GEO_LDS_RR)
       const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rg;
-#else
-      const GrtRay GRT_AS4 *r_ = (const GrtRay GRT_AS4 *)Rp;
-#endif
-#if !defined(GRT_NO_GEO_LDS_RR)
       const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kg;
-#else
-      const RealRay GRT_AS4 *k_ = (const RealRay GRT_AS4 *)Kp;
-#endif
       asm volatile("" : "+s"(r_), "+s"(k_));
       Rp = (const GrtRay *)r_; Kp = (const RealRay *)k_; Cp = reinterpret_cast<const CubRay *>(Kp);
-#if defined(GRT_GEO_CAMK)
-      // the camera struct re-read from the kernarg segment per chunk (as the transfer kernel does): its ~60 SGPRs are not held, and
-      // spilled to VGPR lanes, across the whole pass
-      const GrtCam GRT_AS4 *c_ = (const GrtCam GRT_AS4 *)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(c_));
-      camp = (const GrtCam *)c_;
-#endif
-#if !defined(GRT_NO_GEO_LDS_RR)
       Kg = Kp;
       Rg = Rp;
       if (LDSR) { int o2_ = 0; asm volatile("" : "+v"(o2_)); Rp = reinterpret_cast<const GrtRay *>(&s_r[wave][o2_]); }
       if (LDSRR) { int o_ = 0; asm volatile("" : "+v"(o_)); Kp = reinterpret_cast<const RealRay *>(&s_rr[wave][o_]); Cp = reinterpret_cast<const CubRay *>(Kp); }
-#endif
     }
     const int pos = toppass ? cnt : 64 * c + lane + 1;
     const bool valid = pos <= cnt;
@@ -432,32 +378,10 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
     {
       UPart S;
       bool usable = false;
-#if !defined(GRT_NO_USEG)
       if (FAST == 1 && !fillph) {
         // u-side integrals from segments between neighbouring points, summed down the wave (grt_dev_fast.hpp:useg_lane)
         bool reset;
-#if defined(GRT_USEG_SHARE)
-        // the square roots of the four linear factors once per POINT: a segment takes its upper limit's from the lane above
-        // (lane 63: from the chunk above; the last inbound point: the turning point's, a constant of the ray)
-        USegClass cl;
-        useg_classify(GRT_CAMREF, *Rp, *Kp, valid ? idx : 0, cl, S, reset, usable);
-        if (Kp->cplx) {
-          if (cl.pair) upair_diff<NPH>(*Kp, cl.ua, cl.ub, S);
-        } else {
-          double fo[4], fn[4];
-          real_froots(*Kp, cl.ua, fo);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const double up = __shfl_down(fo[q], 1);
-            fn[q] = cl.lastinb ? Kp->froot[q] : ((lane == 63) ? cF[q] : up);
-          }
-          if (cl.pair) real_upair_pre<NPH>(*Kp, cl.ua, cl.ub, fo, fn, S);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) cF[q] = __shfl(fo[q], 0);
-        }
-#else
         useg_lane<NPH>(GRT_CAMREF, *Rp, *Kp, valid ? idx : 0, S, reset, usable);
-#endif
         double v[NQ];
         v[0] = S.iu1; v[1] = S.tu11;
         if (NQ > 2) v[2] = S.phiu1;
@@ -472,16 +396,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
         if (NQ > 2) S.phiu1 = v[2];
         if (NQ > 3) S.tu1 = v[3];
       }
-#endif
       if (valid) {
         // (&S always, `usable` beside it: chosen at run time -- usable ? &S : nullptr -- the pointer kept S, and what the allocator parked
         //  around it, in scratch: the 272 B/lane of the image-only kernel VERDICT r03 asked about)
         const UPart *pre = &S;
         if (FAST == 2) ray_point_cubic<PHI>(GRT_CAMREF, *Rp, *Cp, idx, P);
         else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, usable);
-#if !defined(GRT_NO_GEO_LDS_RR)
         else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_]), usable); }
-#endif
         else if (FAST == 1) ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, nullptr, usable);
         else ray_point(GRT_CAMREF, *Rp, idx, P, NPH == 3 ? 3 : NPH);
       }
@@ -731,6 +652,12 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
     const int *__restrict__ nlive_dev, int from_back) {
   constexpr int NW = GRT_XFER_THREADS / 64;
   constexpr int TS = 1 << TSH;      // steps per tile = tile row stride in doubles
+#if defined(GRT_NO_BLOCKED_BATCH)
+  constexpr bool BLOCKED = false;
+#else
+  // the tile-blocked frequency loop (see the main loop): the FFJET power-law frequency-batch kernels, formal and DELO
+  constexpr bool BLOCKED = FB > 1 && !EXTRA && FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL && (IFLAG == GRT_INT_FORMAL || IFLAG == GRT_INT_DELO);
+#endif
   // class size from the set-up kernel's device counter (no host round trip between the launches); the grid covers the
   // worst case nlive_arg and surplus blocks leave before they stage anything
   const int nlive = nlive_dev ? *nlive_dev : nlive_arg;
@@ -856,6 +783,150 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
     }
     __builtin_amdgcn_wave_barrier();
     const int m = mt - t;                                  // this lane's tile (negative: ray already finished)
+    if constexpr (BLOCKED) {
+      // ---- r05: the tile-blocked frequency loop of the FFJET power-law batch kernels (BASELINE config 5) --------------------------------
+      // The plain batch walk below visits the frequencies of a batch at every step and so moves every frequency's running state
+      // (I, and for DELO the previous point's j and K: 15 doubles) through scratch once per STEP: 30 loads / stores per frequency and step,
+      // 2.8 TB of L2 traffic for 25 frequencies at 1024^2 x 400, and DELO -- whose single-frequency step is cheaper than the formal one --
+      // took 586 ms against 334.  Here the loops are interchanged per tile: phase 1 walks the tile's TS points once and
+      // keeps what the frequencies share (the power law's per-point half, redshift, polarization basis, step length: 10 doubles a point)
+      // in registers; phase 2 takes one frequency at a time through the TS points with its state in registers -- loaded and stored once
+      // per tile and frequency.  Same functions in the same order per (point, frequency): bit-equal to single-frequency runs
+      // (test_frequency_batches_match_single_runs, test_config5_frequency_grid_vs_compiled_reference).
+      double pd[TS][10];
+      int pfl[TS];
+#pragma unroll
+      for (int k2 = 0; k2 < TS; ++k2) {
+        pfl[k2] = 0;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) pd[k2][c] = 0.0;
+      }
+#pragma clang loop unroll(disable)
+      for (int jj = 0; jj < TS; ++jj) {
+        const int e = TS - 1 - jj;
+        const double cam_a = karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, a));
+        const int ip = TS * m + e;
+        const bool valid = has_ray && m >= 0 && ip < n;
+        const double rs_ = valid ? tl0[lane * TS + e] : 10.0;
+        const double ths_ = valid ? tl1[lane * TS + e] : 1.0;
+        const double r = (rs_ == 0.0) ? -1.0 : fabs(rs_), th = fabs(ths_);
+        const double lam_i = valid ? tl2[lane * TS + e] : lam_prev;
+        const int fl8 = (int)(__double2hiint(ths_) < 0) | ((int)(__double2hiint(rs_) < 0) << 1);
+        double kv[4], sth, cth;
+        fast_sincos(th, &sth, &cth);
+        calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);
+        sumr += valid ? r : 0.0;
+        FluidPoint fl;
+        const F32Trig ftv = f32_trig(th, sth, cth);
+        ffjet_sample(fd.fj, r, th, (float)cam_a, fl, &ftv);
+        double s2xi, c2xi, ang, g, cang;
+        comoving_ortho<false>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
+        const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
+        const double ncgsnth = (double)fl.rho * emk.nfac, bcgs = (double)fl.bmag * emk.bfac;
+        PLPoint plp;
+        polsynchpl_point_sc(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, fsqrt((1.0 - cang) * (1.0 + cang)), cang, plp, false);
+        const double cur[10] = {plp.itanth, plp.nubperp, plp.lnub, plp.A, g, log(g), s2xi, c2xi, lam_i - lam_prev, valid ? (lam_1 - lam_i) : 0.0};
+        const int curf = (valid ? 1 : 0) | ((valid && (ip + 1 < n)) ? 2 : 0);
+#pragma unroll
+        for (int k2 = 0; k2 < TS; ++k2)
+          if (jj == k2) {      // (jj is wave-uniform: scalar branches; pd is only ever indexed by constants and stays in registers)
+            pfl[k2] = curf;
+#pragma unroll
+            for (int c = 0; c < 10; ++c) pd[k2][c] = cur[c];
+          }
+        if (valid) lam_prev = lam_i;
+      }
+      const GrtEmis emf = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
+#pragma clang loop unroll(disable)
+      for (int f = 0; f < FB; ++f) {
+        if (f < nf) {
+          double Il[4], jl[4], Kl[7], facl = facs[f];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Il[c] = I[f][c];
+          if (IFLAG != GRT_INT_FORMAL) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jl[c] = jn[f][c];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) Kl[c] = Kn[f][c];
+          }
+          const double fr = freqs[f0 + f], lfr = lfreqs[f0 + f];
+#pragma clang loop unroll(disable)
+          for (int jj = 0; jj < TS; ++jj) {
+            double cur[10];
+            int curf = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < TS; ++k2)
+              if (jj == k2) {
+                curf = pfl[k2];
+#pragma unroll
+                for (int c = 0; c < 10; ++c) cur[c] = pd[k2][c];
+              }
+            const bool valid = (curf & 1) != 0, step = (curf & 2) != 0;
+            PLPoint plp;
+            plp.itanth = cur[0]; plp.nubperp = cur[1]; plp.lnub = cur[2]; plp.A = cur[3];
+            plp.kperp = plp.A * (PH_e * PH_e / PH_m / PH_c) * frcp(plp.nubperp);      // (as polsynchpl_point_sc forms them)
+            plp.omega0 = plp.nubperp * 2.0 * PH_pi;
+            const double g = cur[4], lg = cur[5], s2xi = cur[6], c2xi = cur[7], dx = cur[8];
+            const double igs = frcp(g);
+            GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
+            plck.iy = 0;
+            double e11[11];
+            polsynchpl_freq(tbl, plck, plp, fr * igs, lfr - lg, e11);
+            facl += valid ? e11[0] * cur[9] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+              if (!emf.coefindx[c]) e11[4 + c] = 0.0;
+            double jj4[4] = {e11[0], c2xi * e11[1] - s2xi * e11[2], s2xi * e11[1] + c2xi * e11[2], e11[3]};
+            double KK[7] = {e11[4], c2xi * e11[5] - s2xi * e11[6], s2xi * e11[5] + c2xi * e11[6], e11[7],
+                            c2xi * e11[8] - s2xi * e11[9], s2xi * e11[8] + c2xi * e11[9], e11[10]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jj4[c] = jj4[c] * g * g * GRT_JSCALE;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) KK[c] = KK[c] * igs * LBH;
+            if constexpr (IFLAG == GRT_INT_FORMAL) {
+              if (step) {
+                const double V[4] = {jj4[0] * dx + Il[0], jj4[1] * dx + Il[1], jj4[2] * dx + Il[2], jj4[3] * dx + Il[3]};
+                double In[4];
+                formal_apply(KK, KK + 4, dx, V, In);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Il[c] = In[c];
+              }
+            } else {
+              if (step) {
+                const double delta = dx * ((fabs(KK[0]) + fabs(Kl[0])) / 2.0);
+                const double Iv[4] = {Il[0], Il[1], Il[2], Il[3]};
+                double In[4];
+                delo_apply(jj4, KK, jl, Kl, dx, delta, Iv, In);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Il[c] = In[c];
+              }
+              if (valid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) jl[c] = jj4[c];
+#pragma unroll
+                for (int c = 0; c < 7; ++c) Kl[c] = KK[c];
+              }
+            }
+            if (record && f == 0 && valid) {      // the per-step record of the first frequency (blocked layout, as below)
+              const int ip = TS * m + (TS - 1 - jj);
+              double *o = steps + (GRT_F_I * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (long long)ip * 64 + (rayidx & 63));
+              o[0] = Il[0] * GRT_IUNSCALE * LBH; o[field_stride] = Il[1] * GRT_IUNSCALE * LBH;
+              o[2 * field_stride] = Il[2] * GRT_IUNSCALE * LBH; o[3 * field_stride] = Il[3] * GRT_IUNSCALE * LBH;
+            }
+          }
+          facs[f] = facl;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) I[f][c] = Il[c];
+          if (IFLAG != GRT_INT_FORMAL) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jn[f][c] = jl[c];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) Kn[f][c] = Kl[c];
+          }
+        }
+      }
+      continue;      // next tile
+    }
 #pragma clang loop unroll(disable)
     for (int jj = 0; jj < TS; ++jj) {
       const int e = TS - 1 - jj;
@@ -877,22 +948,14 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
       double kv[4], sth, cth;
       // (r03 measured the lean fast_sincos of the geodesic kernels 5 % SLOWER here -- with MachineLICM parking its constants in spilled SGPRs; with the
       //  pass off it is 0.2-0.6 ms faster in every transfer kernel: profiles/r04_h_variants_lean_step_sincos.log.  theta is in [0, pi])
-#if !defined(GRT_XFER_LIB_SINCOS)
       fast_sincos(th, &sth, &cth);
-#else
-      sincos(th, &sth, &cth);
-#endif
       calc_nullp(q2, l, cam_a, r, cth, su * powm1(fl8 >> 1), sm * powm1(fl8 & 1), kv);   // geodesics.f90:362-364
       sumr += valid ? r : 0.0;
       // fluid + frame (grtrans_driver.f90:126-130)
       FluidPoint fl;
       // cos / sin of the REAL(4) angle the single-precision metric and LNRF frame of every sampler take, from sth, cth (grt_dev_phys.hpp)
-#if !defined(GRT_NO_F32TRIG)
       const F32Trig ftv = f32_trig(th, sth, cth);
       const F32Trig *ft = &ftv;
-#else
-      const F32Trig *ft = nullptr;
-#endif
       if (FLUID == GRT_FLUID_FFJET) ffjet_sample(fd.fj, r, th, (float)cam_a, fl, ft);
       else if (FLUID == GRT_FLUID_SPHACC) sphacc_sample(s_sphacc, r, fl);
       else if (FLUID == GRT_FLUID_HARM)
@@ -904,22 +967,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
       if (FLUID == GRT_FLUID_KORAL3D)
         koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela,                                  // kela carries Be
                        slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0, ft);
-#if defined(GRT_STAGE_STOP) && GRT_STAGE_STOP == 1      // experiment builds (tools/stage_budget.sh): the step ends after the fluid sample
-      facs[0] += 1.0;
-      I[0][0] += kv[0] + kv[1] + kv[2] + kv[3] + (double)(fl.rho + fl.bmag + fl.u[0] + fl.u[1] + fl.u[2] + fl.u[3] + fl.b[0] + fl.b[1] + fl.b[2] + fl.b[3]);
-      if (valid) lam_prev = lam_i;
-      continue;
-#endif
       double s2xi, c2xi, ang, g, cang;
       // the power-law emissivity takes sin and cos of the field / wave-vector angle, not the angle: no acos + sincos pair per step
       constexpr bool WANT_ANG = EXTRA || !((EMIS == GRT_EMIS_POLSYNCHPL && FLUID == GRT_FLUID_FFJET) || EMIS == GRT_EMIS_POLSYNCHTH || EMIS == GRT_EMIS_POLSYNCHSYMTH);
       comoving_ortho<WANT_ANG>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
-#if defined(GRT_STAGE_STOP) && GRT_STAGE_STOP == 2      // ... after the tetrad / polarization basis
-      facs[0] += 1.0;
-      I[0][0] += s2xi + c2xi + g + cang + (WANT_ANG ? ang : 0.0) + (double)(fl.rho + fl.bmag);
-      if (valid) lam_prev = lam_i;
-      continue;
-#endif
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
       double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
       const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
@@ -940,9 +991,6 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
       double xJK[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // EXTRA: j_I and K(1:7) of the first frequency after rotate/invariant/cgs
-#ifdef GRT_DEBUG_SEL
-      double dbg[4] = {0, 0, 0, 0};   // experiment builds (tools/build_variant.sh): per-step internals in place of the running I
-#endif
 
       // not unrolled on purpose: FB copies of the coefficient + propagator code cost more (900 ms against 658 ms
       // for 25 frequencies at 1024x1024x400) than indexing the per-frequency intensities dynamically
@@ -987,31 +1035,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
 #pragma unroll
             for (int c = 4; c < 11; ++c) e11[c] += epl[c];
           }
-#ifdef GRT_DEBUG_SEL
-          if (f == 0) {
-            if (GRT_DEBUG_SEL == 0) { dbg[0] = g; dbg[1] = ang; dbg[2] = s2xi; dbg[3] = c2xi; }
-            if (GRT_DEBUG_SEL == 1) { dbg[0] = ncgsnth; dbg[1] = bcgs; dbg[2] = e11[0]; dbg[3] = e11[4]; }
-            if (GRT_DEBUG_SEL == 2) { dbg[0] = e11[1]; dbg[1] = e11[3]; dbg[2] = e11[5]; dbg[3] = e11[7]; }
-            if (GRT_DEBUG_SEL == 3) { dbg[0] = e11[8]; dbg[1] = e11[10]; dbg[2] = fl.u[0]; dbg[3] = fl.b[0]; }
-            if (GRT_DEBUG_SEL == 4) { dbg[0] = kv[0]; dbg[1] = kv[1]; dbg[2] = kv[2]; dbg[3] = kv[3]; }
-            if (GRT_DEBUG_SEL == 5) { dbg[0] = fl.b[1]; dbg[1] = fl.b[2]; dbg[2] = fl.b[3]; dbg[3] = fl.bmag; }
-            if (GRT_DEBUG_SEL == 6) { dbg[0] = fl.u[1]; dbg[1] = fl.u[2]; dbg[2] = fl.u[3]; dbg[3] = fl.rho; }
-          }
-#endif
-#if defined(GRT_STAGE_STOP) && GRT_STAGE_STOP == 3      // ... after the emission / absorption / Faraday coefficients
-          { double acc = s2xi + c2xi;
-#pragma unroll
-            for (int c = 0; c < 11; ++c) acc += e11[c];
-            I[f][0] += acc; facs[f] += 1.0; }
-          continue;
-#endif
-#ifdef GRT_DEBUG_SEL
-          if (f == 0 && GRT_DEBUG_SEL == 7) { dbg[0] = facs[0]; dbg[1] = valid ? e11[0] * (lam_1 - lam_i) : 0.0; }
-#endif
           facs[f] += valid ? e11[0] * (lam_1 - lam_i) : 0.0;
-#ifdef GRT_DEBUG_SEL
-          if (f == 0 && GRT_DEBUG_SEL == 7) { dbg[2] = facs[0]; dbg[3] = (double)k; }
-#endif
           if constexpr (IFLAG == GRT_INT_QUAD) {
             // nvals=1 (emis.f90:566-569): j_I and alpha_I only, no rotation, coefindx not applied.  The quadrature
             // I = sum dx/2 (f_k + f_k+1), f = j exp(-tau), run from the far end, is the scalar recurrence
@@ -1067,38 +1091,22 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
             if constexpr (IFLAG == GRT_INT_FORMAL) {
               // I <- O_k (j_k dx_k + I)   (radtrans_integrate.f90:863-871)
               if (step) {
-#if defined(GRT_FORMAL_VIA_O)      // experiment switch: the step through the 16 entries of O
-                double O[4][4];
-                calc_O(KK, KK + 4, dx, O);
-                const double v0 = jj4[0] * dx + I[f][0], v1 = jj4[1] * dx + I[f][1], v2 = jj4[2] * dx + I[f][2], v3 = jj4[3] * dx + I[f][3];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) I[f][c] = O[c][0] * v0 + O[c][1] * v1 + O[c][2] * v2 + O[c][3] * v3;
-#else
                 const double V[4] = {jj4[0] * dx + I[f][0], jj4[1] * dx + I[f][1], jj4[2] * dx + I[f][2], jj4[3] * dx + I[f][3]};
                 double In[4];
                 formal_apply(KK, KK + 4, dx, V, In);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) I[f][c] = In[c];
-#endif
               }
             } else {
               // DELO couples point k with k+1 = the previous trip (radtrans_integrate.f90:811-837);
               // tau(k+1)-tau(k) of grtrans_driver.f90:219-220 is local: dx * mean |alpha_I|
               if (step) {
                 const double delta = dx * ((fabs(KK[0]) + fabs(Kn[f][0])) / 2.0);
-#if defined(GRT_DELO_VIA_MAP)      // experiment switch: the step as the affine map P + Q I through the 4x4 cofactor inverse
-                Affine M;
-                delo_map(jj4, KK, jn[f], Kn[f], dx, delta, M);
-                const double v0 = I[f][0], v1 = I[f][1], v2 = I[f][2], v3 = I[f][3];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) I[f][c] = M.A[c][0] * v0 + M.A[c][1] * v1 + M.A[c][2] * v2 + M.A[c][3] * v3 + M.b[c];
-#else
                 const double Iv[4] = {I[f][0], I[f][1], I[f][2], I[f][3]};
                 double In[4];
                 delo_apply(jj4, KK, jn[f], Kn[f], dx, delta, Iv, In);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) I[f][c] = In[c];
-#endif
               }
               if (valid) {
 #pragma unroll
@@ -1140,14 +1148,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
         // point together, so a store instruction writes whole 128-byte lines, and a ray's next point is 512 bytes further on
         // ([point][slot] over the whole pass -- a ray's consecutive points 8 MB apart at 1024^2 -- measured 0.1-0.6 ms slower: profiles/r04_e_variants_blocked_layout.log)
         double *o = steps + (GRT_F_I * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (long long)ip * 64 + (rayidx & 63));
-#ifdef GRT_DEBUG_SEL
-        o[0] = dbg[0]; o[field_stride] = dbg[1]; o[2 * field_stride] = dbg[2]; o[3 * field_stride] = dbg[3];
-#else
         o[0] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
         o[field_stride] = I[0][1] * GRT_IUNSCALE * LBH;
         o[2 * field_stride] = I[0][2] * GRT_IUNSCALE * LBH;
         o[3 * field_stride] = I[0][3] * GRT_IUNSCALE * LBH;
-#endif
       }
       if (valid) lam_prev = lam_i;
     }
@@ -1169,9 +1173,8 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
   if (EXTRA) {
     const int nx = nvals, ns = nvals - 19;      // the launcher passes the full row width nvals+nextra as `nvals`
     float *o = pixvals + ((long long)f0 * npix_tile + pixslot) * nx;
-    // (the quadrature's banked exponent, as in the plain write above: the running value is I e^{-P})
-    const double unbank = (IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0;
-    for (int c = 0; c < ns && c < 4; ++c) o[c] = (float)(ok0 ? I[0][c] * GRT_IUNSCALE * LBH * unbank : 0.0);
+    // (no quadrature form: extra=1 exists for nvals = 4 only -- launch_transfer_t)
+    for (int c = 0; c < ns && c < 4; ++c) o[c] = (float)(ok0 ? I[0][c] * GRT_IUNSCALE * LBH : 0.0);
     double xt[19];
 #pragma unroll
     for (int c = 0; c < 6; ++c) xt[c] = xT[c];
@@ -1468,7 +1471,8 @@ template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4() {
 #endif
 }
 template <int IFLAG, int FLUID, int EMIS> constexpr bool xfer_tile4_batch() {     // ... and the frequency-batch kernel of BASELINE config 5
-  return (GRT_OCC(3) == 2) != ((GRT_OCC(3) == 2) != xfer_tile4<IFLAG, FLUID, EMIS>() && FLUID == GRT_FLUID_FFJET);
+  // (r05: DELO as well -- the tile-blocked frequency loop keeps 10 doubles a point of the tile in registers: four points, not eight)
+  return (GRT_OCC(3) == 2) != (FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL && (IFLAG == GRT_INT_FORMAL || IFLAG == GRT_INT_DELO));
 }
 
 template <int IFLAG, int FLUID, int EMIS>
@@ -1501,13 +1505,14 @@ static hipError_t launch_transfer_t(hipStream_t s, int extra, const GrtCam *cam,
     // frequency batches (blockIdx.y); the fluid/tetrad work of a point is shared inside a batch
     // batch sizes measured at 25 frequencies (tools/build_variant.sh): formal 8/13/32 -> 630/564/557 ms at 1024^2,
     // DELO (which also parks the neighbour's j, K per frequency) 8/13/32 -> 258/281/345 ms at 512^2
-#if defined(GRT_FBN_FORMAL) && defined(GRT_FBN_DELO)      // experiment builds: other batch sizes
-    constexpr int FBN = (IFLAG == GRT_INT_DELO) ? GRT_FBN_DELO : GRT_FBN_FORMAL;
-#else
     // r04 (no MachineLICM): formal 5 / 9 / 13 / 25 per batch -> 433 / 423 / 403 / 389 ms for 25 frequencies at 1024^2, DELO 5 / 6 / 8 / 13 ->
     // 625 / 621 / 603 / 642 ms: one batch holds BASELINE config 5's whole frequency grid (the intensities of a batch live in scratch
     // either way -- 800 B/lane at 25 --, what counts is how many frequencies share a point's fluid sample and tetrad)
+#if defined(GRT_NO_BLOCKED_BATCH)
     constexpr int FBN = (IFLAG == GRT_INT_DELO) ? 8 : (IFLAG == GRT_INT_FORMAL ? 25 : 13);
+#else
+    // (r05: with the tile-blocked frequency loop DELO's state goes through scratch once per tile, not per step: one batch of 25 for it too)
+    constexpr int FBN = (IFLAG == GRT_INT_DELO) ? ((FLUID == GRT_FLUID_FFJET && EMIS == GRT_EMIS_POLSYNCHPL) ? 25 : 8) : (IFLAG == GRT_INT_FORMAL ? 25 : 13);
 #endif
     constexpr int TSHB = xfer_tile4_batch<IFLAG, FLUID, EMIS>() ? 2 : GRT_TSH;
     note_launch("grt_transfer_kernelILi%dELi%dELi%dELi%dELb%dELi%dEE", IFLAG, FLUID, EMIS, FBN, 0, TSHB);
@@ -1591,6 +1596,18 @@ extern "C" hipError_t grt_launch_transfer(hipStream_t s, int iflag, int fluid, i
   GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHSYMTH)
   GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHSYMTH)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_SPHACC, GRT_EMIS_POLSYNCHSYMTH)
+  // r05: POLSYNCHPL on the GRMHD samplers whose unit conversion defines a non-thermal density (HARM 2-D: the thermal one; HARM3D / IHARM:
+  // nonthermale_b2) -- the reference dispatches fluid model and emissivity independently (grtrans_driver.f90:122-159, emis.f90:461-571).
+  // Correctness first: the general 8-step-tile instantiation with the table rows in LDS beside the coordinate vectors, no tuning.
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_FORMAL, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_DELO, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHPL)
+  GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_POLSYNCHPL)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM, GRT_EMIS_SYNCHTHAV)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_HARM3D, GRT_EMIS_SYNCHTHAV)
   GRT_XFER_CASE(GRT_INT_QUAD, GRT_FLUID_IHARM, GRT_EMIS_SYNCHTHAV)

@@ -4,6 +4,7 @@
 # + rotate / invariant / propagator.  FFJET kernels only (GRT_FAST_BUILD).  Built in parallel from copies of csrc; run
 # tools/stage_budget_run.sh on the GPU box for the times and the SQ instruction counts per stage.
 set -e
+export GRT_VARIANT_PATCH=${GRT_VARIANT_PATCH:-tools/experiments/r04_switches.patch}      # GRT_STAGE_STOP lives in the experiments patch since r05
 R="$(cd "$(dirname "$0")/.." && pwd)"
 mkdir -p $R/build/variants
 for n in ${STAGES:-1 2 3 4}; do
