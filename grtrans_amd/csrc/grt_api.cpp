@@ -755,7 +755,7 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
   if ((rc = grow(C.d_rrays, C.cap_rrays, (size_t)chunk * grt_sizeof_realray()))) return rc;
   if ((rc = grow(C.d_npts, C.cap_npts, (size_t)nrays))) return rc;
   if ((rc = grow(C.d_live, C.cap_live, (size_t)chunk))) return rc;
-  if ((rc = grow(C.d_phitodo, C.cap_phitodo, (size_t)chunk))) return rc;
+  if ((rc = grow(C.d_phitodo, C.cap_phitodo, (size_t)2 * chunk))) return rc;      // left-over list, then the plunging-ray list (grt_launch_phi)
   if ((rc = grow(C.d_pixvals, C.cap_pix, (size_t)nrays * nfreq * (nvals + nextra)))) return rc;
   if ((rc = grow(C.d_freqs, C.cap_freq, (size_t)2 * nfreq))) return rc;   // freqs, then log(freqs)
   // one field of the record: [ray slot][rstride points]; with the per-step record on, whole blocks of 64 slots (its I,Q,U,V fields are

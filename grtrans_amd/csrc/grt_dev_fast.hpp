@@ -1055,6 +1055,8 @@ GRT_HD double phi_mu_theta(const RealRay &K, double iu) {
 
 // wave-uniform: does grt_phi_kernel serve this ray?  Not the plunging rays (ncase 5: G_u has its pole at the horizon they end on), rays
 // without a short theta series, l = 0 (GEOPHITIME adds pi per polar turning point there), su != 1.
-GRT_HD bool phi_hermite_ray(const RealRay &K) { return !K.cplx && K.zok && K.pok && K.l != 0.0 && K.su == 1.0; }
+// r05e: the plunging rays are served too -- the Hermite rule holds along most of such a ray, and grt_phi_kernel takes the segments where
+// its indicator fails (the last few before the horizon) from Carlson's forms (cplx_upair), lane by lane.
+GRT_HD bool phi_hermite_ray(const RealRay &K) { return K.zok && K.pok && K.l != 0.0 && K.su == 1.0; }
 
 }  // namespace grtd

@@ -455,13 +455,21 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
 #ifndef GRT_PHI_TOL
 #define GRT_PHI_TOL 2.0e-10
 #endif
+#ifndef GRT_PHI_TOL_SEG      // plunging rays: a segment whose indicator passes this is recomputed with Carlson's forms (cheap: be strict)
+#define GRT_PHI_TOL_SEG 1.0e-11
+#endif
+// CPLX = false: the four-real-root rays of live[]; a plunging ray (two real roots and a complex pair) is handed on through clist[] to the
+// CPLX = true instantiation, launched behind this one on a small striding grid: that one carries Carlson's segment forms for the last
+// points before the horizon (128 registers, where this one needs 74 and runs six waves per SIMD -- one kernel for both cost the headline
+// camera 1 ms and saved the HARM camera, 11 % plunging rays, 2.4: profiles/r05g_phi_plunging.log).
+template <bool CPLX>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
-    const int *__restrict__ nlive_dev, int *__restrict__ todo, int *__restrict__ todo_count, double *__restrict__ steps, long long ray_stride,
-    long long field_stride) {
+    const int *__restrict__ nlive_dev, int *__restrict__ todo, int *__restrict__ todo_count, int *__restrict__ clist, int *__restrict__ clist_count,
+    double *__restrict__ steps, long long ray_stride, long long field_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot0 = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
-  if (slot0 >= *nlive_dev) return;
+  int slot0 = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
+  for (; slot0 < *nlive_dev; slot0 += CPLX ? gridDim.x * GRT_WAVES_PER_BLOCK : (1 << 30)) {      // (CPLX: a capped grid that strides over its list)
   const int rayidx = live[__builtin_amdgcn_readfirstlane(slot0)];
   const GrtRay *Rp = rays + rayidx;
   const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)rayidx * GRT_RR_STRIDE);
@@ -476,7 +484,11 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
   const int n = Rp->npts;
   if (!phi_hermite_ray(K) || n < 1) {      // wave-uniform: the fused kernel's ray
     if (lane == 0) todo[atomicAdd(todo_count, 1)] = rayidx;
-    return;
+    continue;
+  }
+  if (!CPLX && K.cplx) {                   // a plunging ray: the other instantiation's
+    if (lane == 0) clist[atomicAdd(clist_count, 1)] = rayidx;
+    continue;
   }
   double phi_ref = cam.phi0;
   if (fabs(cam.mu0) == 1.0) phi_ref += fsign(1.0, cam.mu0) * atan2(Rp->beta, Rp->alpha);      // geodesics.f90:339-341
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
   const bool c7 = (K.ncase == 7);
   double *base = steps + (long long)rayidx * ray_stride;
   // upper neighbour of lane 63 = lane 0 of the chunk above
-  double cI = 0.0, cS = 0.0;
+  double cI = 0.0, cS = 0.0, cU = 0.0;
   HermG cG; cG.g0 = cG.g1 = cG.g2 = cG.g3 = 0.0;
   double errmax = 0.0;
   for (int c = (n - 1) >> 6; c >= 0; --c) {
@@ -506,10 +518,27 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
     gu.g0 = __shfl_down(g.g0, 1); gu.g1 = __shfl_down(g.g1, 1); gu.g2 = __shfl_down(g.g2, 1); gu.g3 = __shfl_down(g.g3, 1);
     if (lane == 63) { Iu = cI; gu = cG; }
     double T = 0.0;
+    double uu = __shfl_down(u, 1);
+    if (lane == 63) uu = cU;
     if (valid && idx < n) {
       double T3;
       T = hermite_seg(g, gu, Iu - iu, T3);
-      errmax = dmax(errmax, fabs(T - T3));
+      double ind = fabs(T - T3);
+      if (CPLX) {
+        // A plunging ray (two real roots and a complex pair: it ends on the horizon, where G_u has its pole): the segments whose
+        // indicator fails -- the last few -- take Carlson's forms between the two recorded points (cplx_upair; wave-uniform test, the lanes
+        // that pass sit idle meanwhile: one chunk of a ray's seven as a rule).  T = phiu(upper) - phiu(lower) = kphi (S(u) - S(u_upper)).
+        const bool redo = ind > GRT_PHI_TOL_SEG;
+        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+          if (redo) {
+            UPart D;
+            upair_diff<2>(K, u, uu, D);
+            T = kphi * D.phiu1;
+            ind = 0.0;
+          }
+        }
+      }
+      errmax = dmax(errmax, ind);
     }
     // plain suffix sum down the wave: S_k = T_k + T_k+1 + ... + T_63 (+ the chunk above)
     double S = T;
@@ -519,7 +548,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
       if (lane + d < 64) S += o;
     }
     S += cS;
-    cS = __shfl(S, 0); cI = __shfl(iu, 0);
+    cS = __shfl(S, 0); cI = __shfl(iu, 0); cU = __shfl(u, 0);
     cG.g0 = __shfl(g.g0, 0); cG.g1 = __shfl(g.g1, 0); cG.g2 = __shfl(g.g2, 0); cG.g3 = __shfl(g.g3, 0);
     if (valid) {
       double phiu = phiu_top - S;
@@ -530,15 +559,25 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
   // the error indicator, over the wave: a ray that fails is traced again by the fused kernel (which overwrites phi)
   for (int d = 32; d >= 1; d >>= 1) errmax = dmax(errmax, __shfl_xor(errmax, d));
   if (lane == 0 && errmax > GRT_PHI_TOL) todo[atomicAdd(todo_count, 1)] = rayidx;
+  }
 }
 
 extern "C" hipError_t grt_launch_phi(hipStream_t s, const GrtCam *cam, const GrtRay *rays, const void *rrays, const int *live,
                                      const int *nlive_dev, int nrays, int *todo, int *todo_count, double *steps, long long ray_stride,
                                      long long field_stride) {
   if (nrays <= 0) return hipSuccess;
-  note_launch("grt_phi_kernel");
-  hipLaunchKernelGGL(grt_phi_kernel, dim3((unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK)), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
-                     *cam, rays, (const char *)rrays, live, nlive_dev, todo, todo_count, steps, ray_stride, field_stride);
+  // todo[] holds the left-over list in its first nrays slots and the plunging-ray list behind them; the counters sit side by side
+  int *clist = todo + nrays, *clist_count = todo_count + 1;
+  const unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
+  note_launch("grt_phi_kernelILb0EE");
+  hipLaunchKernelGGL((grt_phi_kernel<false>), dim3(nblk), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
+                     *cam, rays, (const char *)rrays, live, nlive_dev, todo, todo_count, clist, clist_count, steps, ray_stride, field_stride);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  note_launch("grt_phi_kernelILb1EE");
+  hipLaunchKernelGGL((grt_phi_kernel<true>), dim3(nblk > 4096u ? 4096u : nblk), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
+                     *cam, rays, (const char *)rrays, (const int *)clist, (const int *)clist_count, todo, todo_count, clist, clist_count, steps, ray_stride,
+                     field_stride);
   return hipGetLastError();
 }
 

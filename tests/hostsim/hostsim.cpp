@@ -284,18 +284,24 @@ int hs_phi_split(const GrtCam *cam, int ii, int maxn, double tol, double *dphi, 
   const int tprs_top = (n <= leg.lo || R.tpr == 0) ? 0 : R.tpr_out;
   const double kphi = K.su * K.isqee * K.ur;
   const double phiu_top = kphi * (K.phiu0 - powm1(tprs_top) * K.anc[2]), phiu_tp = kphi * K.phiu0;
-  double S = 0.0;
+  double S = 0.0, uup = 0.0;
   HermG gu; gu.g0 = gu.g1 = gu.g2 = gu.g3 = 0.0;
   for (int idx = n; idx >= 1; --idx) {
     const double u = 1.0 / fabs(rs[idx]);
     const HermG g = hermite_gu(K, u, rs[idx] < 0.0 ? -1.0 : 1.0);
     if (idx < n) {
       double T3;
-      const double T = hermite_seg(g, gu, I[idx + 1] - I[idx], T3);
-      if (fabs(T - T3) > *errmax) *errmax = fabs(T - T3);
+      double T = hermite_seg(g, gu, I[idx + 1] - I[idx], T3);
+      double ind = fabs(T - T3);
+      if (K.cplx && ind > 1.0e-11) {      // GRT_PHI_TOL_SEG: a plunging ray's last segments from Carlson's forms, as grt_phi_kernel<true> takes them
+        UPart D;
+        upair_diff<2>(K, u, uup, D);
+        T = kphi * D.phiu1; ind = 0.0;
+      }
+      if (ind > *errmax) *errmax = ind;
       S += T;
     }
-    gu = g;
+    gu = g; uup = u;
     double phiu = phiu_top - S;
     if (K.ncase == 7 && !(fabs(u - K.u2) > 1e-12)) phiu = phiu_tp;
     if (idx <= maxn) dphi[idx - 1] = phi_mu_theta(K, I[idx]) + phiu;
