@@ -709,11 +709,15 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
   __shared__ float s_harm[(FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D) ? 2 * GRT_HARM_MAXCOORD : 1];
   // polsynchpl: the p-bin's row of every log-G table and slope table (3 x 181 + 11 x 81 doubles = 11.2 KB) lives in
   // LDS: 36 look-ups per step and frequency become ds_reads and the 14 table pointers leave the SGPR file
+  // (not beside the 8 KB of coordinate vectors of the GRMHD samplers: with the 8-step tiles that is 87 KB a block -- one block a CU, one wave
+  //  per SIMD, and the allocator then parks values in AGPRs, the regime r03 left; those instantiations read the tables through L1 as the
+  //  hybrid emissivities do)
+  constexpr bool PL_LDS = EMIS == GRT_EMIS_POLSYNCHPL && (FLUID == GRT_FLUID_FFJET || FLUID == GRT_FLUID_SPHACC);
   constexpr int PLG = 181, PLX = 81, PLN = 3 * PLG + 11 * PLX;
-  __shared__ double s_pl[EMIS == GRT_EMIS_POLSYNCHPL ? PLN : 1];
+  __shared__ double s_pl[PL_LDS ? PLN : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   GrtTables tbl = tb;
-  if (EMIS == GRT_EMIS_POLSYNCHPL) {
+  if (PL_LDS) {
     const int iy = plc.iy;
     for (int i = threadIdx.x; i < PLG; i += blockDim.x) {
       s_pl[i] = tb.gx[i]; s_pl[PLG + i] = tb.gy[iy * PLG + i]; s_pl[2 * PLG + i] = tb.sgy[iy * PLG + i];
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
   if (FLUID == GRT_FLUID_SPHACC) {   // the 1-D Bondi tables live in LDS for the bisection searches
     for (int i = threadIdx.x; i < GRT_SPHACC_NTAB; i += blockDim.x) s_sphacc[i] = fd.sphacc[i];
   }
-  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D || FLUID == GRT_FLUID_SPHACC || EMIS == GRT_EMIS_POLSYNCHPL) __syncthreads();
+  if (FLUID == GRT_FLUID_HARM || FLUID == GRT_FLUID_HARM3D || FLUID == GRT_FLUID_IHARM || FLUID == GRT_FLUID_KORAL3D || FLUID == GRT_FLUID_SPHACC || PL_LDS) __syncthreads();
   const int slot = blockIdx.x * GRT_XFER_THREADS + threadIdx.x;
   const bool has_ray = slot < nlive;
   const int f0 = blockIdx.y * FB;
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
           double e11[11];
           if (EMIS == GRT_EMIS_POLSYNCHPL) {
             GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
-            plck.iy = 0;                                   // the LDS copy holds the p-bin's row only
+            if (PL_LDS) plck.iy = 0;                       // the LDS copy holds the p-bin's row only
             polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
             // SYNCHPL (nvals = 1; same instantiation): j_I with the REAL(4) sqrt(3.) of polsynchemis.f90:665
             if (IFLAG == GRT_INT_QUAD && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL)
