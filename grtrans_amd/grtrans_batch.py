@@ -417,6 +417,7 @@ class grtrans:
     def convert_to_lum(self):
         """spectrum and intensities to L_iso in cgs units (grtrans_batch.py:545-552)"""
         fac = 4 * np.pi * self._lbh() ** 2
+        # (pixels run beta-fastest: the alpha step is ny pixels on.  The reference writes ab[self.nx,0] -- equal for its square test images)
         da = self.ab[self.ny, 0] - self.ab[0, 0]
         db = self.ab[1, 1] - self.ab[0, 1]
         self.spec = self.spec * fac

@@ -431,7 +431,10 @@ def test_harness_unit_conversions_and_polarization_fractions():
     assert np.allclose(x.freqs, 1e10 * 100.0 ** (np.arange(5) / 4.0), rtol=1e-14) and x.freqs[-1] == pytest.approx(1e12, rel=1e-14)
     x.calc_freqs(1)
     assert np.array_equal(x.freqs, [1e10])
-    nx = ny = 6
+    # a RECTANGULAR image: pixels run beta-fastest (camera.f90: ny values of beta per alpha column), so the alpha step is
+    # ab[ny,0] - ab[0,0].  The reference's harness takes ab[self.nx,0] - ab[0,0] (grtrans_batch.py:503,548,559) -- the same number for the
+    # square images its test problems use, a latent slip otherwise; this harness uses the stride the pixel order defines
+    nx, ny = 7, 5
     rng = np.random.default_rng(3)
     a, b = np.meshgrid(np.linspace(-5, 5, nx), np.linspace(-4, 4, ny), indexing="ij")
     x.ab = np.stack([a.ravel(), b.ravel()], axis=1)
@@ -540,3 +543,15 @@ def test_differential_comparer_sees_a_seeded_fault_and_not_a_last_bit(tmp_path):
     def nan(o): o["c0_pix"][0, 7] = 0.0; o["c0_pix"][0, 8] = np.nan
     for m in (st, tp, rec, img, nan):
         assert len(run(m)) == 1, m.__name__
+
+
+def test_makefile_keeps_the_required_flags_when_hipflags_is_overridden():
+    # correctness of the shipped object rests on -mllvm -disable-machine-licm (and on -ffp-contract=fast-honor-pragmas for the
+    # REAL(4) islands); a user overriding HIPFLAGS must not lose them silently.  `make -n` with HIPFLAGS replaced: every device compile
+    # line still carries both.
+    out = subprocess.run(["make", "-n", "-B", "-C", os.path.join(ROOT, "grtrans_amd", "csrc"), "HIPFLAGS=--offload-arch=gfx950 -O1 -I.", "grt_kernels.o", "grt_api.o", "grt_gather.o"],
+                         capture_output=True, text=True, check=True).stdout
+    lines = [l for l in out.splitlines() if "hipcc" in l and " -c " in l]
+    assert len(lines) >= 3
+    for l in lines:
+        assert "-disable-machine-licm" in l and "-ffp-contract=fast-honor-pragmas" in l, l
