@@ -376,10 +376,8 @@ def main():
                        "ray_step_frequencies_per_s": value * args.nfreq, "per_rank_ms_and_ray_steps": per_rank_ms,
                        "gather_ms": gather_ms, "gather_via": gather_via, "setup_kernel_ms": ms_setup / args.steps,
                        "geo_kernel_ms": ms_geo / args.steps, "transfer_kernel_ms": ms_xfer / args.steps,
-                       "kernel_ms_note": "geo_kernel_ms: HIP events around the image-only geodesic kernel of the fast ray class; transfer_kernel_ms: "
-                                         "the rest of the trace phase -- the transfer kernels, and for a whole image with the record the azimuth kernels "
-                                         "(grt_phi_kernel, ~6.4 ms of work) that run beside them on their own stream (DESIGN 4; GRT_PHI_INLINE=1 puts "
-                                         "them in front: geo ~23.5, transfer ~29 ms)",
+                       "kernel_ms_note": "geo_kernel_ms: HIP events around the fast ray class's geodesic launches (image-only kernel, and with the "
+                                         "record grt_phi_kernel + left-overs behind it); transfer_kernel_ms: the rest of the trace phase",
                        "image_only_mode": image_only, "build_id": bid},
             "roofline": {"bound": "hbm", "kernel": "grt_geo_kernel+grt_transfer_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -835,12 +835,13 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
       } else {
         // r05: when the transfer kernel does not read the azimuth (2-D fluid model, no extra=1: phi is only an output of the record) the
         // azimuth kernels of the split trace run on a third, lowest-priority stream BESIDE the transfer kernel instead of in front of
-        // it.  Measured (profiles/r05e_phi_beside.log): a whole 1024^2 image 57.1 -> 56.6 ... 56.9 ms; a rank's share of an 8-GPU run 9.7 ->
-        // 10.0 ms (its one resident round of transfer waves is latency-bound and loses more to the neighbour than the chain saves) --
-        // so, like the class wait, only for passes above 400,000 rays (GRT_PHI_INLINE=1 / =0 decides for every size)
+        // it.  Measured (profiles/r05e_phi_beside.log, r05i_kernel_stats_phi_inline.csv): a whole 1024^2 image 56.0 ms either way within the
+        // boxes' spread (57.1 -> 56.6 ... 56.9 at first); a rank's share of an 8-GPU run 9.7 -> 10.0 ms (its one resident round of transfer
+        // waves is latency-bound and loses more to the neighbour than the chain saves).  The step is work-conserving: the chain stays IN
+        // FRONT of the transfer kernel (kernel durations then add up to the step); GRT_PHI_INLINE=0 puts it beside for experiments.
         static const char *pin = std::getenv("GRT_PHI_INLINE");
         const bool phi_beside = !reuse && C.geo_split && !(nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || is_koral) &&
-                                (pin ? std::atoi(pin) == 0 : nch > 400000);
+                                (pin && std::atoi(pin) == 0);
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
                                    nfields, tfield, t0c, 0, C.geo_split, C.d_phitodo, C.d_counters + 2, phi_beside ? C.stream3 : nullptr, C.evp[0], C.evp[1]));
