@@ -701,20 +701,30 @@ GRT_HD double zeta_T(const RealRay &K, double z, int tpm, double iu) {
 
 // P = c1 phimu1 + c2 phimuf + c3 phimu3 of a regular point from the theta series (RealRay.pcs): s0, c0 = sin, cos of z = pi jarg/2K
 // (the first step of the ladder).  arg Theta(v + i b) is odd and periodic in v like Zeta: same orientation rule as zeta_T.
-GRT_HD double theta_P(const RealRay &K, double s0, double c0, int tpm, double iu) {
+// (COEF: where the series coefficients come from -- the record itself, or grt_phi_kernel's copy of them in the lanes of a register)
+struct ThetaCoefRecord {
+  const RealRay &K;
+  GRT_HD double pcs(int j) const { return K.pcs[j]; }
+  GRT_HD double psn(int j) const { return K.psn[j]; }
+};
+template <class COEF>
+GRT_HD double theta_P_c(const RealRay &K, double s0, double c0, int tpm, double iu, const COEF &C) {
   // Re Theta = 1 + pcs[0] cos 2z + ... written as (1 + pcs[0]) - 2 pcs[0] sin^2 z + ...: the first coefficient approaches -1 for rays
   // close to the axis (b -> K'), and 1 + pcs[0] is a per-ray constant formed without the cancellation
   const double c2 = 1.0 - 2.0 * s0 * s0, s2 = 2.0 * s0 * c0;
-  double re = K.pomt1 - 2.0 * K.pcs[0] * s0 * s0, im = K.psn[0] * s2;
+  double re = K.pomt1 - 2.0 * C.pcs(0) * s0 * s0, im = C.psn(0) * s2;
   double cjm = c2, sjm = s2, cj = 2.0 * c2 * c2 - 1.0, sj = 2.0 * c2 * s2;
   for (int j = 1; j < K.pn; ++j) {               // wave-uniform trip count (two to four terms for most rays)
-    re += K.pcs[j] * cj; im += K.psn[j] * sj;
+    re += C.pcs(j) * cj; im += C.psn(j) * sj;
     const double cn_ = 2.0 * c2 * cj - cjm, sn_ = 2.0 * c2 * sj - sjm;
     cjm = cj; sjm = sj; cj = cn_; sj = sn_;
   }
   const double A = fast_atan2(im, re);
   const double As = ((K.sm < 0) != ((tpm & 1) != 0)) ? -A : A;
   return K.pG * As + K.pbeta * iu + K.pC;
+}
+GRT_HD double theta_P(const RealRay &K, double s0, double c0, int tpm, double iu) {
+  return theta_P_c(K, s0, c0, tpm, iu, ThetaCoefRecord{K});
 }
 
 // Fixes RealRay.tC (and pC, with the theta-series constants) at the ray's top stored point (set-up kernel, after realray_anchor):
@@ -1014,7 +1024,8 @@ GRT_HD HermG hermite_gu(const RealRay &K, double u, double sgn /* sign of du/dI 
   const double U = 1.0 + u * u * (K.hc2 + u * (K.hc3 + u * K.hc4));
   const double U1 = u * (2.0 * K.hc2 + u * (3.0 * K.hc3 + u * (4.0 * K.hc4)));
   const double U2 = 2.0 * K.hc2 + u * (6.0 * K.hc3 + u * (12.0 * K.hc4));
-  const double ip = frcp(1.0 - K.hrp * u), im = frcp(1.0 - K.hrm * u);
+  const double dp = 1.0 - K.hrp * u, dm = 1.0 - K.hrm * u, iq = frcp(dp * dm);      // one reciprocal for both poles
+  const double ip = iq * dm, im = iq * dp;
   const double ap = K.hA * ip, am = K.hB * im;                   // A/(1 - r+ u), B/(1 - r- u)
   const double tp = K.hrp * ip, tm = K.hrm * im;                 // each u-derivative multiplies a term by k r/(1 - r u)
   const double d1p = ap * tp, d1m = am * tm, d2p = d1p * tp, d2m = d1m * tm, d3p = d2p * tp, d3m = d2m * tm;
@@ -1040,7 +1051,8 @@ GRT_HD double hermite_seg(const HermG &g, const HermG &gu, double h, double &T3)
 // mu side of the azimuth of a point of a ray with a short theta series (RealRay.zok, pok), from I_u alone: the turning-point count and
 // the reduced Jacobi argument as ray_point_real_branchy forms them (Eq. 30-42), ONE sincos for z = pi v / 2K -- sncndn_ladder_z's first
 // step; mu itself is not needed, so the recurrence is not run -- and theta_P.  Returns phimu = -l I + l Pi.
-GRT_HD double phi_mu_theta(const RealRay &K, double iu) {
+template <class COEF>
+GRT_HD double phi_mu_theta_c(const RealRay &K, double iu, const COEF &C) {
   int tpm;
   const double a1 = K.sm, r1 = (iu - K.i1mu) * K.ii3mu;
   if (K.sm == 1) tpm = fint(r1) + fint((1 + fsign(1.0, r1)) / 2.0);      // (pok: symmetric M)
@@ -1050,8 +1062,9 @@ GRT_HD double phi_mu_theta(const RealRay &K, double iu) {
   const double iarg = fabs(K.a) * a2 * (iu - a1 * K.i1mu - a3 * K.i3mu);
   double s0, c0;
   fast_sincos(K.agm_mu.c * (K.jscale * iarg), &s0, &c0);
-  return -K.l * iu + K.l * theta_P(K, s0, c0, tpm, iu);
+  return -K.l * iu + K.l * theta_P_c(K, s0, c0, tpm, iu, C);
 }
+GRT_HD double phi_mu_theta(const RealRay &K, double iu) { return phi_mu_theta_c(K, iu, ThetaCoefRecord{K}); }
 
 // wave-uniform: does grt_phi_kernel serve this ray?  Not the plunging rays (ncase 5: G_u has its pole at the horizon they end on), rays
 // without a short theta series, l = 0 (GEOPHITIME adds pi per polar turning point there), su != 1.

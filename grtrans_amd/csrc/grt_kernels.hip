@@ -21,6 +21,7 @@
 // lane plus scratch); the 24 B/step that cross HBM between them are part of the record anyway.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstddef>
 #include "grt_dev_cubic.hpp"
 #include "grt_dev_disk.hpp"
 
@@ -247,7 +248,11 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 // 14.9 ms image only, 21.0 -> 18.8 ms with the record); the record-mode four-real-root kernel, which holds the azimuth's extra live
 // values, is 6 % slower there (38.1 -> 40.6 ms) and stays at two.
 #ifndef GRT_WPE_GEO_OF
-#define GRT_WPE_GEO_OF(FAST, NPH) ((((FAST) == 1 && (NPH) == 0) || (FAST) == 2) ? 3 : GRT_WPE_GEO)
+// r05k: the image-only four-real-root kernel at FIVE waves (82 registers, the same 240 B/lane of never-executed fall-back scratch, no
+// AGPRs): 16.2 -> 14.8 ms at four, 14.3 at five or six, at 1024^2 x 400 (profiles/r05k_occ_sweep.log) -- since r04 the kernel had lost the
+// azimuth's and the record's live values and nobody had asked the question again.  The Schwarzschild-cubic kernels: 13.0 / 9.65 ms
+// (SPHACC, record / image) at three, four or five -- they stay at three.
+#define GRT_WPE_GEO_OF(FAST, NPH) (((FAST) == 1 && (NPH) == 0) ? 5 : (((FAST) == 2) ? 3 : GRT_WPE_GEO))
 #endif
 // SPLIT (FAST = 1, NPH = 0 only; r05): the record-mode trace of the four-real-root class in two kernels -- this one, the image-only form
 // at three waves per SIMD, also stores I_u of every point in the record's phi slot; grt_phi_kernel turns it into the azimuth in place.
@@ -452,6 +457,45 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
 // the image-only kernel runs unchanged at three waves and this one is ~300 instructions per 64 points.
 // One quirk of the reference is kept: GEOPHITIME drops the u-side terms of a point within 1e-12 of the turning point of a ncase-7 ray
 // (geokerr_wrapper.f:2200: its phi there is ~3e-6 off the smooth curve) -- such a point takes phiu1 = 0 here as well.
+// Cross-lane helpers of grt_phi_kernel.  gfx950 is a GFX9 part: DPP has the whole-wave shift by one (wave_shl:1, lane k reads lane k + 1;
+// lane 63 keeps the destination's old value) and the shifts inside a row of 16 lanes (row_shl:n with bound_ctrl: a lane past the row's end
+// reads 0).  Both verified on the MI355X (tools/experiments/dpp_probe.hip).  All 64 lanes must be active at the call.
+__device__ __forceinline__ double wave_up1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double row_up0(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double x, int l) {      // wave-uniform: lane l's x
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double first_lane(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+struct ThetaCoefLanes {      // theta_P_c's coefficient source: lane j holds pcs[j], lane 8 + j psn[j]
+  double v;
+  __device__ __forceinline__ double pcs(int j) const { return lane_value(v, j); }
+  __device__ __forceinline__ double psn(int j) const { return lane_value(v, 8 + j); }
+};
+// S_k = x_k + x_k+1 + ... + x_63 + above
+__device__ __forceinline__ double wave_suffix_sum(double x, double above, int lane) {
+  double s = x;
+  s += row_up0<0x101>(s);
+  s += row_up0<0x102>(s);
+  s += row_up0<0x104>(s);
+  s += row_up0<0x108>(s);
+  const double a2 = above + lane_value(s, 48), a1 = a2 + lane_value(s, 32), a0 = a1 + lane_value(s, 16);
+  const double add = (lane < 16) ? a0 : (lane < 32) ? a1 : (lane < 48) ? a2 : above;
+  return s + add;
+}
+
 #ifndef GRT_PHI_TOL
 #define GRT_PHI_TOL 2.0e-10
 #endif
@@ -468,9 +512,25 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
     const int *__restrict__ nlive_dev, int *__restrict__ todo, int *__restrict__ todo_count, int *__restrict__ clist, int *__restrict__ clist_count,
     double *__restrict__ steps, long long ray_stride, long long field_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int slot0 = blockIdx.x * GRT_WAVES_PER_BLOCK + wave;
-  for (; slot0 < *nlive_dev; slot0 += CPLX ? gridDim.x * GRT_WAVES_PER_BLOCK : (1 << 30)) {      // (CPLX: a capped grid that strides over its list)
-  const int rayidx = live[__builtin_amdgcn_readfirstlane(slot0)];
+  // a resident grid that strides over its list (r05k: one ray a wave left a fifth of the wave slots empty between a wave's end and the
+  // next one's first instruction -- 1M waves of 35 us each); the next ray's index is fetched while this one is worked on
+  int slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * GRT_WAVES_PER_BLOCK + wave);
+  const int nlist = *nlive_dev, stride = gridDim.x * GRT_WAVES_PER_BLOCK;
+  // ... two rays ahead, and the next ray's records are pulled towards the L2 one ray ahead (one dword of every 64-byte line, lane by line):
+  // a ray's constants are read through the scalar cache by a chain of a dozen dependent loads, each of which would otherwise go to HBM
+  int raynext = slot0 < nlist ? live[slot0] : 0, raynext2 = slot0 + stride < nlist ? live[slot0 + stride] : 0;
+  for (; slot0 < nlist; slot0 += stride) {
+  const int rayidx = raynext;
+  raynext = raynext2;
+  if (slot0 + 2 * stride < nlist) raynext2 = live[slot0 + 2 * stride];
+  int touched = 0;
+  if (slot0 + stride < nlist) {
+    constexpr int KL = (int)((sizeof(RealRay) + 63) / 64), RL = (int)((sizeof(GrtRay) + 63) / 64);
+    static_assert(KL + RL <= 64, "one lane a line");
+    const char *line = lane < KL ? rrays + (size_t)raynext * GRT_RR_STRIDE + 64 * lane
+                                 : reinterpret_cast<const char *>(rays + raynext) + 64 * (lane - KL);
+    if (lane < KL + RL) touched = *reinterpret_cast<const volatile int *>(line);
+  }
   const GrtRay *Rp = rays + rayidx;
   const RealRay *Kp = reinterpret_cast<const RealRay *>(rrays + (size_t)rayidx * GRT_RR_STRIDE);
   // (the per-ray records are read through the scalar cache: wave-uniform addresses in the constant address space)
@@ -500,27 +560,47 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
   const double phiu_tp = kphi * K.phiu0;                      // the reference's value for a point ON the turning point (see above)
   const bool c7 = (K.ncase == 7);
   double *base = steps + (long long)rayidx * ray_stride;
-  // upper neighbour of lane 63 = lane 0 of the chunk above
-  double cI = 0.0, cS = 0.0, cU = 0.0;
-  HermG cG; cG.g0 = cG.g1 = cG.g2 = cG.g3 = 0.0;
+  // Chunks of 63 SEGMENTS (r05k): lane k of chunk c holds point 63 c + k + 1, so lane 63 is the point lane 0 of the chunk above held --
+  // recomputed (1/64 more arithmetic) instead of carried: the upper neighbour of every lane is then one lane up in the same chunk
+  // (wave_up1: two DPP moves a double, no LDS round trip), and the values carried from chunk to chunk are the running sum and that
+  // point's I_u (its slot of the record holds the azimuth by then: the conversion is in place).
+  double cS = 0.0, cI = 0.0;
   double errmax = 0.0;
-  for (int c = (n - 1) >> 6; c >= 0; --c) {
-    const int idx = 64 * c + lane + 1;
+  const int ctop = (n >= 2) ? (n - 2) / 63 : 0;
+  // the theta series' coefficients (RealRay.pcs[8], psn[8], contiguous) in lanes 0..15 of one register: the series loop indexes them by
+  // its counter, which from the record was a memory load -- and a full wait -- per term and point inside the chunk loop
+  ThetaCoefLanes coef;
+  static_assert(offsetof(RealRay, psn) == offsetof(RealRay, pcs) + 8 * sizeof(double), "pcs[8] and psn[8] are read as one array of 16");
+  coef.v = lane < 16 ? reinterpret_cast<const double *>(reinterpret_cast<const char *>(Kp) + offsetof(RealRay, pcs))[lane] : 0.0;
+  // the loads of a chunk are issued one chunk ahead: behind the chunk's store they waited for that store's acknowledgement as well
+  // (the vector memory counter retires in order)
+  double iu_n, rs_n;
+  {
+    const int idx = 63 * ctop + lane + 1;
+    const double *sp = base + (idx - 1);
+    iu_n = idx <= n ? sp[GRT_F_PHI * field_stride] : 0.0;
+    rs_n = idx <= n ? sp[GRT_F_R * field_stride] : 10.0;
+  }
+  for (int c = ctop; c >= 0; --c) {
+    const int idx = 63 * c + lane + 1;
     const bool valid = idx <= n;
     double *sp = base + (idx - 1);
-    const double iu = valid ? sp[GRT_F_PHI * field_stride] : 0.0;
-    const double rs_ = valid ? sp[GRT_F_R * field_stride] : 10.0;
+    double iu = iu_n;
+    const double rs_ = rs_n;
+    if (c > 0) {      // (every point of a lower chunk exists; its lane 63 is this chunk's lane 0, whose slot will hold the azimuth by then)
+      const double *sq = sp - 63;
+      iu_n = lane < 63 ? sq[GRT_F_PHI * field_stride] : 0.0;
+      rs_n = sq[GRT_F_R * field_stride];
+    }
+    if (lane == 63 && c < ctop) iu = cI;
     const double u = frcp(fabs(rs_));
     const HermG g = hermite_gu(K, u, (__double2hiint(rs_) < 0) ? -1.0 : 1.0);
-    // the upper neighbour's values: one lane up, lane 63 from the chunk above
-    double Iu = __shfl_down(iu, 1);
+    const double Iu = wave_up1(iu);
     HermG gu;
-    gu.g0 = __shfl_down(g.g0, 1); gu.g1 = __shfl_down(g.g1, 1); gu.g2 = __shfl_down(g.g2, 1); gu.g3 = __shfl_down(g.g3, 1);
-    if (lane == 63) { Iu = cI; gu = cG; }
+    gu.g0 = wave_up1(g.g0); gu.g1 = wave_up1(g.g1); gu.g2 = wave_up1(g.g2); gu.g3 = wave_up1(g.g3);
+    const double uu = CPLX ? wave_up1(u) : 0.0;
     double T = 0.0;
-    double uu = __shfl_down(u, 1);
-    if (lane == 63) uu = cU;
-    if (valid && idx < n) {
+    if (valid && idx < n && lane < 63) {
       double T3;
       T = hermite_seg(g, gu, Iu - iu, T3);
       double ind = fabs(T - T3);
@@ -540,25 +620,20 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
       }
       errmax = dmax(errmax, ind);
     }
-    // plain suffix sum down the wave: S_k = T_k + T_k+1 + ... + T_63 (+ the chunk above)
-    double S = T;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double o = __shfl_down(S, d);
-      if (lane + d < 64) S += o;
-    }
-    S += cS;
-    cS = __shfl(S, 0); cI = __shfl(iu, 0); cU = __shfl(u, 0);
-    cG.g0 = __shfl(g.g0, 0); cG.g1 = __shfl(g.g1, 0); cG.g2 = __shfl(g.g2, 0); cG.g3 = __shfl(g.g3, 0);
-    if (valid) {
+    // suffix sum down the wave, S_k = T_k + ... + T_62 + (the chunk above): inside each row of 16 lanes by DPP row shifts (a lane
+    // past the row's end reads 0), then the totals of the rows above -- lane 0 of each row holds its row's -- added in
+    const double S = wave_suffix_sum(T, cS, lane);
+    cS = first_lane(S); cI = first_lane(iu);
+    if (valid && (lane < 63 || c == ctop)) {      // (lane 63 below the top chunk: the chunk above stored that point)
       double phiu = phiu_top - S;
       if (c7 && !(fabs(u - K.u2) > 1e-12)) phiu = phiu_tp;
-      sp[GRT_F_PHI * field_stride] = phi_ref - (phi_mu_theta(K, iu) + phiu);
+      sp[GRT_F_PHI * field_stride] = phi_ref - (phi_mu_theta_c(K, iu, coef) + phiu);
     }
   }
   // the error indicator, over the wave: a ray that fails is traced again by the fused kernel (which overwrites phi)
   for (int d = 32; d >= 1; d >>= 1) errmax = dmax(errmax, __shfl_xor(errmax, d));
   if (lane == 0 && errmax > GRT_PHI_TOL) todo[atomicAdd(todo_count, 1)] = rayidx;
+  asm volatile("" ::"v"(touched));      // (the prefetch's destination register lives until here)
   }
 }
 
@@ -570,7 +645,17 @@ extern "C" hipError_t grt_launch_phi(hipStream_t s, const GrtCam *cam, const Grt
   int *clist = todo + nrays, *clist_count = todo_count + 1;
   const unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
   note_launch("grt_phi_kernelILb0EE");
-  hipLaunchKernelGGL((grt_phi_kernel<false>), dim3(nblk), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
+  // resident blocks: what the occupancy calculator allows per CU times the CUs (asked once)
+  static unsigned resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grt_phi_kernel<false>, 64 * GRT_WAVES_PER_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
+    resident = 4u * (unsigned)per_cu * (unsigned)prop.multiProcessorCount;      // (measured: 1x 24.9 ms of geodesics, 2x 23.8, 4x 23.6, one ray a wave 23.8)
+    if (const char *e = std::getenv("GRT_PHI_GRID")) { const int v = std::atoi(e); if (v > 0) resident = (unsigned)v; }
+  }
+  hipLaunchKernelGGL((grt_phi_kernel<false>), dim3(nblk > resident ? resident : nblk), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
                      *cam, rays, (const char *)rrays, live, nlive_dev, todo, todo_count, clist, clist_count, steps, ray_stride, field_stride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
