@@ -393,7 +393,7 @@ GRT_NI void polsynchpl(const GrtTables &T, double nu, double nnth, double B, dou
 }
 
 // polsynchpl with the constant factors folded into GrtPLConst and the table slopes precomputed:
-// one log, one sincos, one sqrt and 15 exp per point instead of 2 log, 3 trig, ~10 pow and 12 exp.
+// one log, one sincos, one sqrt and 14 exp per point instead of 2 log, 3 trig, ~10 pow and 12 exp.
 // Same formulas as polsynchemis.f90:527-631 (differences are rounding-level re-association).
 GRT_HD double interp_fast(double lx, int ix, int iy, const double *xv, int nx, const double *yv, const double *sv) {
   int indx = iy * nx + ix;                 // 1-based
@@ -447,12 +447,15 @@ GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoi
   double gapfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yap, T.syap) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yap, T.syap);
   double gvfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yv, T.syv) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yv, T.syv);
   double gavfac = interp_fast(lxmax, ix2, C.iy, T.xv, 81, T.yav, T.syav) - interp_fast(lxmin, ix1, C.iy, T.xv, 81, T.yav, T.syav);
-  double pw = fexp(C.alpha * (lx + l15));                   // (3 nub/2 nu)^((p-1)/2)
+  // (3 nub/2 nu)^((p-1)/2) = sqrt(1.5 x) (1.5 x)^(alpha-1/2), and the cut-off term of kstarq below is the same power of another multiple
+  // of x: two exponentials instead of three (r05l)
+  const double e2 = fexp((C.alpha - 0.5) * (lx + l15));
+  double pw = sq15 * e2;
   double jfac = P.A * (ec * ec / c * 1.7320508075688772 / 4.0) * pw * P.nubperp;
   double ji = jfac * gxfac;
   double jq = jfac * gpfac;
   double jv = jfac * (4.0 / 3.0) * P.itanth * sq15 * gvfac;
-  double kstarq = P.kperp * (x * x * x) * C.kq * (1.0 - fexp((C.alpha - 0.5) * (lx + C.l2g)));
+  double kstarq = P.kperp * (x * x * x) * C.kq * (1.0 - e2 * C.kqe);      // (nu_i/nu)^(alpha-1/2) = (1.5 x)^(alpha-1/2) (gmin^2/1.5)^(alpha-1/2)
   double kstarv = C.kv * P.kperp * (x * x) * P.itanth;
   double omega = nu * 2.0 * pi;
   // (2w/3w0)^(-p/2) = (1.5 x)^(p/2) = pw * sqrt(1.5 x)

@@ -78,7 +78,7 @@ GRT_HD double fdiv(double a, double b) { return a / b; }
 GRT_HD double fsqrt(double x) { return sqrt(x); }
 #endif
 // exp for arguments that are ordinary numbers (|x| < ~1e15; NaN propagates): the library's exp without its two range compares and three
-// selects -- 18 instructions instead of 23, and the power-law coefficients take 15 exponentials per frequency (polsynchpl_freq; r04: 25
+// selects -- 18 instructions instead of 23, and the power-law coefficients take 14 exponentials per frequency (polsynchpl_freq; r04: 25
 // frequencies 358 -> see DESIGN 6).  Cody-Waite reduction by ln2 (hi + lo with fma), exp(t) = 1 + t (1 + t q(t)) on |t| <= ln2/2 with q
 // of degree 9 interpolated at Chebyshev nodes (polynomial error 1.6e-17 relative), ldexp for the scale -- which saturates by itself: an
 // argument above 709.8 gives inf, one below -745.1 gives 0.  Against glibc over [-700, 700]: at most 0.96 ulp, 1 ulp off in 6 % of the

@@ -255,7 +255,7 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 #define GRT_WPE_GEO_OF(FAST, NPH) (((FAST) == 1 && (NPH) == 0) ? 5 : (((FAST) == 2) ? 3 : GRT_WPE_GEO))
 #endif
 // SPLIT (FAST = 1, NPH = 0 only; r05): the record-mode trace of the four-real-root class in two kernels -- this one, the image-only form
-// at three waves per SIMD, also stores I_u of every point in the record's phi slot; grt_phi_kernel turns it into the azimuth in place.
+// (five waves per SIMD since r05k), also stores I_u of every point in the record's phi slot; grt_phi_kernel turns it into the azimuth in place.
 // PHIONLY (FAST = 1, NPH = 2 only): the fused record-mode kernel for the rays grt_phi_kernel left over (launched with that kernel's list and
 // counter as live[] / nlive_dev, on a small grid that strides); it stores their phi only -- r, theta, lambda of every ray of the class
 // stay the image-only kernel's.
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
 // indicator: nup of a few tens on a strongly bent ray).
 // Why two kernels: the azimuth's live values took the fused record-mode kernel <1,2> to 236 registers = two waves per SIMD, and the
 // two-pass form it needs costs 9.8 ms over the image-only twin before any azimuth is computed (profiles/r05a_geo_budget.txt); apart,
-// the image-only kernel runs unchanged at three waves and this one is ~300 instructions per 64 points.
+// the image-only kernel runs unchanged (at three waves then, five since r05k) and this one is ~400 instructions per 63 segments.
 // One quirk of the reference is kept: GEOPHITIME drops the u-side terms of a point within 1e-12 of the turning point of a ncase-7 ray
 // (geokerr_wrapper.f:2200: its phi there is ~3e-6 off the smooth curve) -- such a point takes phiu1 = 0 here as well.
 // Cross-lane helpers of grt_phi_kernel.  gfx950 is a GFX9 part: DPP has the whole-wave shift by one (wave_shl:1, lane k reads lane k + 1;
@@ -504,7 +504,7 @@ __device__ __forceinline__ double wave_suffix_sum(double x, double above, int la
 #endif
 // CPLX = false: the four-real-root rays of live[]; a plunging ray (two real roots and a complex pair) is handed on through clist[] to the
 // CPLX = true instantiation, launched behind this one on a small striding grid: that one carries Carlson's segment forms for the last
-// points before the horizon (128 registers, where this one needs 74 and runs six waves per SIMD -- one kernel for both cost the headline
+// points before the horizon (125 registers, where this one needs 67 and runs seven waves per SIMD -- one kernel for both cost the headline
 // camera 1 ms and saved the HARM camera, 11 % plunging rays, 2.4: profiles/r05g_phi_plunging.log).
 template <bool CPLX>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_kernel(
@@ -1038,8 +1038,9 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
             if (record && f == 0 && valid) {      // the per-step record of the first frequency (blocked layout, as below)
               const int ip = TS * m + (TS - 1 - jj);
               double *o = steps + (GRT_F_I * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (long long)ip * 64 + (rayidx & 63));
-              o[0] = Il[0] * GRT_IUNSCALE * LBH; o[field_stride] = Il[1] * GRT_IUNSCALE * LBH;
-              o[2 * field_stride] = Il[2] * GRT_IUNSCALE * LBH; o[3 * field_stride] = Il[3] * GRT_IUNSCALE * LBH;
+              // (2^-128 L_BH as one factor: the power of two is exact, so the product rounds once either way -- one multiplication a value)
+              o[0] = Il[0] * (GRT_IUNSCALE * LBH); o[field_stride] = Il[1] * (GRT_IUNSCALE * LBH);
+              o[2 * field_stride] = Il[2] * (GRT_IUNSCALE * LBH); o[3 * field_stride] = Il[3] * (GRT_IUNSCALE * LBH);
             }
           }
           facs[f] = facl;
@@ -1276,10 +1277,11 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
         // point together, so a store instruction writes whole 128-byte lines, and a ray's next point is 512 bytes further on
         // ([point][slot] over the whole pass -- a ray's consecutive points 8 MB apart at 1024^2 -- measured 0.1-0.6 ms slower: profiles/r04_e_variants_blocked_layout.log)
         double *o = steps + (GRT_F_I * field_stride + (long long)(rayidx >> 6) * (64 * ray_stride) + (long long)ip * 64 + (rayidx & 63));
-        o[0] = I[0][0] * GRT_IUNSCALE * LBH * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
-        o[field_stride] = I[0][1] * GRT_IUNSCALE * LBH;
-        o[2 * field_stride] = I[0][2] * GRT_IUNSCALE * LBH;
-        o[3 * field_stride] = I[0][3] * GRT_IUNSCALE * LBH;
+        // (2^-128 L_BH as one factor: the power of two is exact, so the product rounds once either way -- one multiplication a value)
+        o[0] = I[0][0] * (GRT_IUNSCALE * LBH) * ((IFLAG == GRT_INT_QUAD && jn[0][1] != 0.0) ? exp(-jn[0][1]) : 1.0);
+        o[field_stride] = I[0][1] * (GRT_IUNSCALE * LBH);
+        o[2 * field_stride] = I[0][2] * (GRT_IUNSCALE * LBH);
+        o[3 * field_stride] = I[0][3] * (GRT_IUNSCALE * LBH);
       }
       if (valid) lam_prev = lam_i;
     }

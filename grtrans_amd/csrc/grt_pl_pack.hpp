@@ -38,6 +38,7 @@ inline void grt_pl_const(const double *tables2020, double p, double gmin, double
   plc.kq = std::pow(gmin, -2.0 * al + 1.0) / (al - 0.5);
   plc.kv = 2.0 * (al + 1.5) / (al + 1.0) * std::log(gmin) * std::pow(gmin, -2.0 * (al + 1.0));
   plc.l2g = 2.0 * std::log(gmin);
+  plc.kqe = std::exp((al - 0.5) * (plc.l2g - std::log(1.5)));
   plc.gx0 = tables2020[0]; plc.gxs = 181.0 / (tables2020[180] - tables2020[0]);
   plc.xv0 = tables2020[724]; plc.xvs = 81.0 / (tables2020[804] - tables2020[724]);
   plc.iy = (p < 5.0) ? ((p > 3.2) ? 1 : 0) : 2;      // find_inds_gxp, polsynchemis.f90:74

@@ -104,6 +104,7 @@ struct GrtPLConst {
   double alpha;       // (p-1)/2
   double kq, kv;      // gmin^(-2a+1)/(a-1/2),  2(a+3/2)/(a+1) log(gmin) gmin^(-2(a+1))
   double l2g;         // 2 log(gmin)
+  double kqe;         // (gmin^2/1.5)^(alpha-1/2): the cut-off term of kstarq from the power of 1.5 x the emissivity already has
   double gx0, gxs, xv0, xvs;   // table origins and index scales nx/(x[n-1]-x[0])
   int32_t iy, pad;    // p bin of the tables
 };
