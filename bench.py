@@ -377,7 +377,7 @@ def main():
                        "gather_ms": gather_ms, "gather_via": gather_via, "setup_kernel_ms": ms_setup / args.steps,
                        "geo_kernel_ms": ms_geo / args.steps, "transfer_kernel_ms": ms_xfer / args.steps,
                        "kernel_ms_note": "geo_kernel_ms: HIP events around the fast ray class's geodesic launches (image-only kernel, and with the "
-                                         "record grt_phi_kernel + left-overs behind it); transfer_kernel_ms: the rest of the trace phase",
+                                         "record its in-line azimuth, grt_phi_kernel on the plunging rays and the left-overs behind it); transfer_kernel_ms: the rest of the trace phase",
                        "image_only_mode": image_only, "build_id": bid},
             "roofline": {"bound": "hbm", "kernel": "grt_geo_kernel+grt_transfer_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

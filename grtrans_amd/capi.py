@@ -231,7 +231,8 @@ def record_steps(enable):
 
 
 def geo_split(enable):
-    """1 (default): azimuth of the four-real-root class by grt_phi_kernel after the image-only geodesic kernel; 0: the fused kernel."""
+    """1 (default): azimuth of the four-real-root class in line in the image-only geodesic kernel (a Hermite sum over Mino time + the
+    theta series; plunging rays by grt_phi_kernel); 0: the fused record-mode kernel (Carlson's forms)."""
     check(lib().grt_set_geo_split(C.c_int(1 if enable else 0)), "grt_set_geo_split")
 
 

@@ -116,7 +116,7 @@ struct Ctx {
   long long t0_version = 0;
   int force_time = 0;                   // grt_debug_ray: every point carries its coordinate time whatever the fluid model
   int geo_reuse = 1;                    // grt_set_geo_reuse
-  int geo_split = 1;                    // grt_set_geo_split: record-mode trace of the four-real-root class as image-only kernel + grt_phi_kernel
+  int geo_split = 1;                    // grt_set_geo_split: record-mode trace of the four-real-root class by the image-only kernel with the azimuth in line (r05m); 0: the fused kernel
   int class_order = 3;
   bool class_order_forced = false;     // GRT_CLASS_ORDER given: its wait bit holds for every pass size
   long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
@@ -185,7 +185,7 @@ int grt_init(int device) {
     const char *po = std::getenv("GRT_CLASS_ORDER");
     C.class_order = po ? std::atoi(po) : 7;
     C.class_order_forced = po != nullptr;
-    if (const char *gs = std::getenv("GRT_GEO_SPLIT")) C.geo_split = std::atoi(gs) ? 1 : 0;      // (A/B runs of the fused record-mode kernel)
+    if (const char *gs = std::getenv("GRT_GEO_SPLIT")) C.geo_split = std::atoi(gs) ? 1 : 0;      // (A/B runs of the fused record-mode kernel)      // (A/B runs of the fused record-mode kernel)
     HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
   }
   {      // lowest priority: the azimuth kernel's 6-waves-per-SIMD blocks must not take the CUs ahead of the transfer kernel's blocks

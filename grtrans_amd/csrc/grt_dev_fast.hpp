@@ -754,12 +754,16 @@ GRT_HD void realray_anchor_z(const GrtCam &cam, const GrtRay &R, RealRay &K, boo
   K.zok = 1;
   if (!want_phi || K.nn == 1.0 || !(K.mpos < 1.0)) return;            // mpos = 1: the phi terms are switched off (geokerr_wrapper.f:2408-2412)
   // theta-series constants: nome q = exp(-pi K'/K) from the two means AGM(1,k') (the ladder's) and AGM(1,k)
-  const double k2 = 1.0 - K.m1m, k = sqrt(k2), agp = K.agm_mu.c;
+  // k^2 = 1 - m1m = mpos/(mpos - mneg) formed WITHOUT the subtraction from 1 (this function serves symmetric M only: K.sym): for a nearly
+  // Schwarzschild camera mneg ~ -(q2 + l^2)/a^2 is ~1e7 and k^2 ~ 1e-8 -- as 1 - m1m it carried a relative error of 1e-16/k^2, which the
+  // series' prefactor pG ~ k/dp took over in full: the azimuth of every regular point of such a camera sat 1e-9 ... 1e-7 off the reference
+  // (|a| = 0.0247 ... 0.0013; r05m, tools/sweep_split.py found it on the mu-fill points, where the fused kernel takes Carlson's forms)
+  const double k2 = K.mpos / (K.mpos - K.mneg), k = sqrt(k2), agp = K.agm_mu.c;
   double ga = 1.0, gb = k;
   for (int it = 0; it < 40 && fabs(ga - gb) > 1e-16 * ga; ++it) { const double t = 0.5 * (ga + gb); gb = sqrt(ga * gb); ga = t; }
   const double lnq = -3.141592653589793 * agp / ga;                   // K'/K = AGM(1,k')/AGM(1,k)
   const double nchar = -K.nn;                                         // n = mpos/(1-mpos) > 0
-  const double h = sqrt(nchar + k2), sp = sqrt(nchar) / h, cp = k / h, dp = sqrt(1.0 - K.m1m * sp * sp);
+  const double h = sqrt(nchar + k2), sp = sqrt(nchar) / h, cp = k / h, dp = sqrt(cp * cp + k2 * sp * sp);      // (1 - m1m sp^2, same remark)
   // K' - b = F(psi, k') with tan psi = 1/sqrt(n) (tan am tan psi = 1/k): the small quantity when the ray runs close to the axis
   const double h1 = sqrt(1.0 + nchar), spsi = 1.0 / h1, cpsi = sqrt(nchar) / h1;
   const double delta = spsi * rf_c(cpsi * cpsi, 1.0 - K.m1m * spsi * spsi, 1.0);
@@ -913,7 +917,11 @@ GRT_HD void ray_point_real(const GrtCam &cam, const GrtRay &R, const RealRay &K,
 // Branch-per-segment form of ray_point_real (each stage inlined once per segment type).  Kept for the
 // image-only build (PHI=false), where its extra instruction-level parallelism wins over the smaller
 // two-pass form: 11.0 ms against 12.8 ms for 1.19e8 points (tools/run_variants.sh).
-template <bool PHI>
+GRT_HD double phi_mu_theta(const RealRay &K, double iu);
+// MUPHI (r05m, PHI = false only: the image-only kernel with the azimuth in line, grt_geo_kernel<1,0,...,AZI>): P.dphi = the MU side of the
+// azimuth, -l I + l Pi, from the theta series -- at a regular point with the sincos the ladder has just taken, at a point of the mu-fill
+// segment through phi_mu_theta -- for a ray with RealRay.zok and pok (0 otherwise); the u side is the kernel's Hermite sum over I.
+template <bool PHI, bool MUPHI = false>
 GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const RealRay &K, int idx, GeoPoint &P, const UPart *pre = nullptr, bool usepre = true) {
   const double one = 1.0, two = 2.0;
   const int kext = cam.kext, next = cam.next, kmax = R.kmax;
@@ -950,7 +958,7 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
       sncndn_ladder_z(K.agm_mu, K.jscale * iarg, K.m1m, sn, cn, dn, zz, s0, c0);
       mun = K.muminus * cn;
       Tz = zeta_T(K, zz, tpm, iu);
-      if (PHI && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);
+      if ((PHI || MUPHI) && K.pok) Pz = theta_P(K, s0, c0, tpm, iu);
     } else {
       sncndn_ladder<true>(K.agm_mu, fabs(K.muplus) * iarg, K.m1m, sn, cn, dn);
       mun = fdiv(K.muminus, dn);
@@ -994,6 +1002,10 @@ GRT_HD void ray_point_real_branchy(const GrtCam &cam, const GrtRay &R, const Rea
     double phimu = -K.l * iu + K.l * Pm;
     if (K.l == 0.0) phiu = phiu - K.sgna_pi * tpm;
     dphi = phimu + phiu;
+  }
+  if (MUPHI) {
+    dphi = 0.0;
+    if (K.zok && K.pok) dphi = isfill ? phi_mu_theta(K, iu) : (-K.l * iu + K.l * Pz);
   }
   // (P.dt carries I_u = I_mu of the point, not a coordinate time -- this form never evaluates one: the split record-mode trace stores
   //  it for grt_phi_kernel, everybody else ignores it)

@@ -217,6 +217,58 @@ extern "C" hipError_t grt_launch_t0(hipStream_t s, const GrtCam *cam, long long 
   return hipGetLastError();
 }
 
+// Cross-lane helpers of grt_phi_kernel and of the in-line azimuth of grt_geo_kernel<1,0,...,AZI>.  gfx950 is a GFX9 part: DPP has the whole-wave shift by one (wave_shl:1, lane k reads lane k + 1;
+// lane 63 keeps the destination's old value) and the shifts inside a row of 16 lanes (row_shl:n with bound_ctrl: a lane past the row's end
+// reads 0).  Both verified on the MI355X (tools/experiments/dpp_probe.hip).  All 64 lanes must be active at the call.
+__device__ __forceinline__ double wave_up1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double row_up0(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double x, int l) {      // wave-uniform: lane l's x
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double first_lane(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+struct ThetaCoefLanes {      // theta_P_c's coefficient source: lane j holds pcs[j], lane 8 + j psn[j]
+  double v;
+  __device__ __forceinline__ double pcs(int j) const { return lane_value(v, j); }
+  __device__ __forceinline__ double psn(int j) const { return lane_value(v, 8 + j); }
+};
+// S_k = x_k + x_k+1 + ... + x_63 + above
+__device__ __forceinline__ double wave_suffix_sum(double x, double above, int lane) {
+  double s = x;
+  s += row_up0<0x101>(s);
+  s += row_up0<0x102>(s);
+  s += row_up0<0x104>(s);
+  s += row_up0<0x108>(s);
+  const double a2 = above + lane_value(s, 48), a1 = a2 + lane_value(s, 32), a0 = a1 + lane_value(s, 16);
+  const double add = (lane < 16) ? a0 : (lane < 32) ? a1 : (lane < 48) ? a2 : above;
+  return s + add;
+}
+
+// lane k reads lane k + 1, lane 63 takes `carry` (the DPP move's old destination value)
+__device__ __forceinline__ double wave_up1c(double x, double carry) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(carry), lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+#ifndef GRT_PHI_TOL
+#define GRT_PHI_TOL 2.0e-10
+#endif
+#ifndef GRT_PHI_TOL_SEG      // plunging rays: a segment whose indicator passes this is recomputed with Carlson's forms (cheap: be strict)
+#define GRT_PHI_TOL_SEG 1.0e-11
+#endif
 // Segmented suffix sum over the 64 lanes of a wave for the segment scheme (grt_dev_fast.hpp:useg_lane): lane k ends with
 // v_k + v_k+1 + ... up to and including the first lane >= k whose flag is set; the flag ends as "a reset lies at or above me
 // in this chunk" (lanes without one take the carry of the chunk above).  Kogge-Stone with the operator
@@ -254,16 +306,27 @@ __device__ __forceinline__ void seg_suffix_scan(double (&v)[NQ], bool &f, int la
 // (SPHACC, record / image) at three, four or five -- they stay at three.
 #define GRT_WPE_GEO_OF(FAST, NPH) (((FAST) == 1 && (NPH) == 0) ? 5 : (((FAST) == 2) ? 3 : GRT_WPE_GEO))
 #endif
+#ifndef GRT_WPE_GEO_AZI      // ... with the azimuth in line (r05m): 119 registers at four waves 21.0 ms of record-mode geodesics, 93 at five 20.0, 80 + 48 B/lane at six 20.9
+#define GRT_WPE_GEO_AZI 5
+#endif
 // SPLIT (FAST = 1, NPH = 0 only; r05): the record-mode trace of the four-real-root class in two kernels -- this one, the image-only form
 // (five waves per SIMD since r05k), also stores I_u of every point in the record's phi slot; grt_phi_kernel turns it into the azimuth in place.
 // PHIONLY (FAST = 1, NPH = 2 only): the fused record-mode kernel for the rays grt_phi_kernel left over (launched with that kernel's list and
 // counter as live[] / nlive_dev, on a small grid that strides); it stores their phi only -- r, theta, lambda of every ray of the class
 // stay the image-only kernel's.
-template <int FAST, int NPH, bool SPLIT = false, bool PHIONLY = false>
-__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FAST, NPH))) void grt_geo_kernel(
+// AZI (with SPLIT; r05m): the azimuth IN LINE -- the Hermite sum of grt_phi_kernel taken in this kernel's own pass, where u, I_u, the
+// turning-point count and the sincos of the reduced Jacobi argument are in registers, instead of a second kernel that re-creates them from
+// the record (430 instructions per 63 segments there, ~190 per 64 points here).  The kernel serves a ray's regular points compacted and its
+// mu-fill segment in a phase of its own: the sum over segments skips the junction in the first phase, the second adds the segment's own
+// pieces and its two edges, and the points below the junction -- stored without the segment's total -- are corrected in place at the end.
+// Plunging rays keep I_u in the phi slot for grt_phi_kernel<true> (list clist = todo + nrays), rays without a short theta series and rays
+// whose error indicator fails go to the left-over list (todo) of the fused phi-only kernel, as grt_phi_kernel<false> sends them.
+template <int FAST, int NPH, bool SPLIT = false, bool PHIONLY = false, bool AZI = false>
+__global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(AZI ? GRT_WPE_GEO_AZI : GRT_WPE_GEO_OF(FAST, NPH))) void grt_geo_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int nrays, double *__restrict__ steps, long long ray_stride,
-    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw) {
+    long long field_stride, int nfields, int tfield, const double *__restrict__ t0, int raw, int *__restrict__ todo, int *__restrict__ todo_count) {
+  static_assert(!AZI || (SPLIT && FAST == 1 && NPH == 0 && !PHIONLY), "the in-line azimuth is a mode of the image-only four-real-root kernel");
   constexpr bool PHI = NPH > 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // the class size is read on the device (the set-up kernel's counter): the host never waits for it between the launches.
@@ -350,6 +413,26 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
   leg.lo = n; leg.nfill = 0; leg.fill = false;
   if (FAST == 1) leg = real_leg(cam, *Rp);
   const int nreg = n - leg.nfill;
+  // in-line azimuth: this ray's mode and the constants of its u-side sum (as grt_phi_kernel forms them)
+  bool inl = false;
+  double phiu_top = 0.0, phiu_tp = 0.0, errmax = 0.0, cS = 0.0, cI = 0.0, iuA = 0.0, usA = 1.0, SA = 0.0, iuB = 0.0, usB = 1.0;
+  HermG cG; cG.g0 = cG.g1 = cG.g2 = cG.g3 = 0.0;
+  bool c7q = false;
+  if (AZI) {
+    const RealRay &K0 = *Kg;
+    if (!phi_hermite_ray(K0) || n < 1) {
+      if (lane == 0) todo[atomicAdd(todo_count, 1)] = rayidx;
+    } else if (K0.cplx) {
+      if (lane == 0) todo[nrays + atomicAdd(todo_count + 1, 1)] = rayidx;
+    } else {
+      inl = true;
+      const int tprs_top = (n <= leg.lo || Rg->tpr == 0) ? 0 : Rg->tpr_out;
+      const double kphi = K0.su * K0.isqee * K0.ur;
+      phiu_top = kphi * (K0.phiu0 - powm1(tprs_top) * K0.anc[2]);
+      phiu_tp = kphi * K0.phiu0;                      // the reference's value for a point ON the turning point (grt_phi_kernel)
+      c7q = (K0.ncase == 7);
+    }
+  }
   // The partial TOP chunk of the regular points (394 = 6 x 64 + 10 for the escaping rays of the headline camera) costs a full pass: a
   // masked-off 16-lane group is not skipped by the hardware (tools/exec_skip_bench.hip).  r04 gave those chunks to a separate kernel,
   // four rays to a wave with per-lane LDS addresses for the per-ray constants: this kernel lost 4.1 ms, that one took 3.5-4.0 ms
@@ -406,7 +489,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
         //  around it, in scratch: the 272 B/lane of the image-only kernel VERDICT r03 asked about)
         const UPart *pre = &S;
         if (FAST == 2) ray_point_cubic<PHI>(GRT_CAMREF, *Rp, *Cp, idx, P);
-        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, usable);
+        else if (FAST == 1 && NPH == 0) ray_point_real_branchy<false, AZI>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, usable);
         else if (FAST == 1 && LDSHYB) { int o3_ = 0; asm volatile("" : "+v"(o3_)); ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, reinterpret_cast<const RealRay *>(&s_rr[wave][o3_]), usable); }
         else if (FAST == 1) ray_point_real<NPH>(GRT_CAMREF, *Rp, *Kp, idx, P, pre, nullptr, usable);
         else ray_point(GRT_CAMREF, *Rp, idx, P, NPH == 3 ? 3 : NPH);
@@ -414,6 +497,40 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
     }
     if (toppass) { LamN = P.lam; continue; }
     if (ph == 0 && c == ctop) LamN = __shfl(P.lam, (cnt - 1) & 63);     // the ray's top stored point (regular: set-up kernel)
+    double phi_out = 0.0;
+    if (AZI && inl) {      // (wave-uniform; all 64 lanes are active here)
+      const RealRay &K = *Kp;
+      const double iu = valid ? P.dt : 0.0, uq = valid ? P.u : 0.5, sq_ = (valid && (P.tpr & 1)) ? -1.0 : 1.0;
+      const HermG g = hermite_gu(K, uq, sq_);
+      // the upper neighbour along the ray: one lane up (lane 63: lane 0 of the chunk above); of the mu-fill segment's top point: the regular
+      // point above the segment
+      double Iu = wave_up1c(iu, cI);
+      HermG gu;
+      gu.g0 = wave_up1c(g.g0, cG.g0); gu.g1 = wave_up1c(g.g1, cG.g1); gu.g2 = wave_up1c(g.g2, cG.g2); gu.g3 = wave_up1c(g.g3, cG.g3);
+      if (fillph && c == ctop) {
+        const HermG gA = hermite_gu(K, fabs(usA), usA < 0.0 ? -1.0 : 1.0);
+        if (pos == cnt) { Iu = iuA; gu = gA; }
+        cS = SA;
+      }
+      // a lane's segment: up to its upper neighbour.  None above the ray's top point; none, in the first phase, across the junction
+      const bool seg = valid && (fillph || (pos < cnt && !(leg.nfill > 0 && pos == leg.lo)));
+      double T = 0.0;
+      if (seg) {
+        double T3;
+        T = hermite_seg(g, gu, Iu - iu, T3);
+        errmax = dmax(errmax, fabs(T - T3));
+      }
+      const double Ssum = wave_suffix_sum(T, cS, lane);
+      cS = first_lane(Ssum); cI = first_lane(iu);
+      cG.g0 = first_lane(g.g0); cG.g1 = first_lane(g.g1); cG.g2 = first_lane(g.g2); cG.g3 = first_lane(g.g3);
+      if (!fillph && leg.nfill > 0) {      // the two regular points at the junction (compacted positions lo and lo + 1), kept for the second phase
+        if (c == (leg.lo >> 6)) { const int l_ = leg.lo & 63; iuA = lane_value(iu, l_); usA = lane_value(sq_ * uq, l_); SA = lane_value(Ssum, l_); }
+        if (leg.lo >= 1 && c == ((leg.lo - 1) >> 6)) { const int l_ = (leg.lo - 1) & 63; iuB = lane_value(iu, l_); usB = lane_value(sq_ * uq, l_); }
+      }
+      double phiu = phiu_top - Ssum;
+      if (c7q && !(fabs(uq - K.u2) > 1e-12)) phiu = phiu_tp;
+      phi_out = phi_ref - (P.dphi + phiu);
+    }
     // the turning-point parities ride in the sign bits of r (radial) and theta (polar): both are positive quantities
     if (NPH == 3 && valid && raw) {   // grt_geokerr_rays: GEOKERR's own output arrays UFI, MUFI, LAMBDAI, DPHI, DTI, TPMI, TPRI
       double *sp = steps + (long long)rayidx * ray_stride + (idx - 1);
@@ -428,11 +545,41 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
       sp[GRT_F_TH * field_stride] = (P.tpm & 1) ? -th : th;
       sp[GRT_F_LAM * field_stride] = LamN - P.lam;
       }
-      if (SPLIT) sp[GRT_F_PHI * field_stride] = P.dt;      // I_u of the point (ray_point_real_branchy): grt_phi_kernel's input
+      if (SPLIT) sp[GRT_F_PHI * field_stride] = (AZI && inl) ? phi_out : P.dt;      // (I_u of the point, ray_point_real_branchy: grt_phi_kernel's input)
       else if (nfields > GRT_F_PHI) sp[GRT_F_PHI * field_stride] = phi_ref - P.dphi;
       if (NPH == 3) sp[tfield * field_stride] = Rp->dt1 - P.dt - (t0 ? t0[rayidx] : 0.0);   // x%data(1) = DTI(1)-DTI(i)-t0 (geodesics.f90:345)
     }
   }
+  if (AZI && inl && fillph && leg.lo >= 1) {
+    // The mu-fill segment is done: lane 0 of its last chunk was its first point (cS, cI, cG).  The edge below it -- from the regular point
+    // under the junction -- closes the sum, and the regular points below the junction, stored without the segment's total, take it now.
+    const RealRay &K = *Kg;
+    const HermG gB = hermite_gu(K, fabs(usB), usB < 0.0 ? -1.0 : 1.0);
+    double T3;
+    const double Tb = hermite_seg(gB, cG, cI - iuB, T3);
+    errmax = dmax(errmax, fabs(Tb - T3));
+    const double dS = (cS + Tb) - SA;
+    // (this wave's own stores of the first phase are read back, lane by lane the address it wrote: program order of one lane's accesses to
+    //  one address holds without a cache write-back -- an agent-scope fence here cost 24 ms at 1024^2)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const double root = c7q ? K.u2 : K.u3;
+    for (int c = (leg.lo - 1) >> 6; c >= 0; --c) {
+      const int pos = 64 * c + lane + 1;
+      if (pos <= leg.lo) {
+        // (the reference's value for a point ON the turning point of a ncase-7 ray does not take part in the sum: u as ray_point_real_branchy forms it)
+        double un = cam.uout + (pos - cam.offset) * Rg->du;
+        if (c7q ? (un > root) : (un < root)) un = root;
+        if (!(c7q && !(fabs(un - K.u2) > 1e-12))) {
+          double *sp = steps + (long long)rayidx * ray_stride + (pos - 1) + GRT_F_PHI * field_stride;
+          *sp = *sp + dS;
+        }
+      }
+    }
+  }
+  }
+  if (AZI && inl) {      // the error indicator over the wave: a ray that fails is traced again by the fused phi-only kernel (which overwrites phi)
+    for (int d = 32; d >= 1; d >>= 1) errmax = dmax(errmax, __shfl_xor(errmax, d));
+    if (lane == 0 && errmax > GRT_PHI_TOL) todo[atomicAdd(todo_count, 1)] = rayidx;
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
   } while ((FAST == 0 || PHIONLY) && slot0 < *nlive_dev * nchg);     // only the generic class (and the phi-only left-overs) stride on a capped grid; a fast-class wave serves one ray
@@ -457,51 +604,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(GRT_WPE_GEO_OF(FA
 // the image-only kernel runs unchanged (at three waves then, five since r05k) and this one is ~400 instructions per 63 segments.
 // One quirk of the reference is kept: GEOPHITIME drops the u-side terms of a point within 1e-12 of the turning point of a ncase-7 ray
 // (geokerr_wrapper.f:2200: its phi there is ~3e-6 off the smooth curve) -- such a point takes phiu1 = 0 here as well.
-// Cross-lane helpers of grt_phi_kernel.  gfx950 is a GFX9 part: DPP has the whole-wave shift by one (wave_shl:1, lane k reads lane k + 1;
-// lane 63 keeps the destination's old value) and the shifts inside a row of 16 lanes (row_shl:n with bound_ctrl: a lane past the row's end
-// reads 0).  Both verified on the MI355X (tools/experiments/dpp_probe.hip).  All 64 lanes must be active at the call.
-__device__ __forceinline__ double wave_up1(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ double row_up0(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_value(double x, int l) {      // wave-uniform: lane l's x
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-__device__ __forceinline__ double first_lane(double x) {
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
-}
-struct ThetaCoefLanes {      // theta_P_c's coefficient source: lane j holds pcs[j], lane 8 + j psn[j]
-  double v;
-  __device__ __forceinline__ double pcs(int j) const { return lane_value(v, j); }
-  __device__ __forceinline__ double psn(int j) const { return lane_value(v, 8 + j); }
-};
-// S_k = x_k + x_k+1 + ... + x_63 + above
-__device__ __forceinline__ double wave_suffix_sum(double x, double above, int lane) {
-  double s = x;
-  s += row_up0<0x101>(s);
-  s += row_up0<0x102>(s);
-  s += row_up0<0x104>(s);
-  s += row_up0<0x108>(s);
-  const double a2 = above + lane_value(s, 48), a1 = a2 + lane_value(s, 32), a0 = a1 + lane_value(s, 16);
-  const double add = (lane < 16) ? a0 : (lane < 32) ? a1 : (lane < 48) ? a2 : above;
-  return s + add;
-}
-
-#ifndef GRT_PHI_TOL
-#define GRT_PHI_TOL 2.0e-10
-#endif
-#ifndef GRT_PHI_TOL_SEG      // plunging rays: a segment whose indicator passes this is recomputed with Carlson's forms (cheap: be strict)
-#define GRT_PHI_TOL_SEG 1.0e-11
-#endif
+// (r05m: only CPLX = true is instantiated -- the four-real-root rays take this sum in line in grt_geo_kernel<1,0,...,AZI>, which fills clist[].)
 // CPLX = false: the four-real-root rays of live[]; a plunging ray (two real roots and a complex pair) is handed on through clist[] to the
 // CPLX = true instantiation, launched behind this one on a small striding grid: that one carries Carlson's segment forms for the last
 // points before the horizon (125 registers, where this one needs 67 and runs seven waves per SIMD -- one kernel for both cost the headline
@@ -637,28 +740,13 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
   }
 }
 
-extern "C" hipError_t grt_launch_phi(hipStream_t s, const GrtCam *cam, const GrtRay *rays, const void *rrays, const int *live,
-                                     const int *nlive_dev, int nrays, int *todo, int *todo_count, double *steps, long long ray_stride,
-                                     long long field_stride) {
+// the plunging rays of the four-real-root class (two real roots and a complex pair): the list grt_geo_kernel<1,0,...,AZI> has filled
+// (todo[] holds the left-over list in its first nrays slots and the plunging-ray list behind them; the counters sit side by side)
+extern "C" hipError_t grt_launch_phi(hipStream_t s, const GrtCam *cam, const GrtRay *rays, const void *rrays, int nrays, int *todo,
+                                     int *todo_count, double *steps, long long ray_stride, long long field_stride) {
   if (nrays <= 0) return hipSuccess;
-  // todo[] holds the left-over list in its first nrays slots and the plunging-ray list behind them; the counters sit side by side
   int *clist = todo + nrays, *clist_count = todo_count + 1;
   const unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
-  note_launch("grt_phi_kernelILb0EE");
-  // resident blocks: what the occupancy calculator allows per CU times the CUs (asked once)
-  static unsigned resident = 0;
-  if (resident == 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grt_phi_kernel<false>, 64 * GRT_WAVES_PER_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
-    resident = 4u * (unsigned)per_cu * (unsigned)prop.multiProcessorCount;      // (measured: 1x 24.9 ms of geodesics, 2x 23.8, 4x 23.6, one ray a wave 23.8)
-    if (const char *e = std::getenv("GRT_PHI_GRID")) { const int v = std::atoi(e); if (v > 0) resident = (unsigned)v; }
-  }
-  hipLaunchKernelGGL((grt_phi_kernel<false>), dim3(nblk > resident ? resident : nblk), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
-                     *cam, rays, (const char *)rrays, live, nlive_dev, todo, todo_count, clist, clist_count, steps, ray_stride, field_stride);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
   note_launch("grt_phi_kernelILb1EE");
   hipLaunchKernelGGL((grt_phi_kernel<true>), dim3(nblk > 4096u ? 4096u : nblk), dim3(64 * GRT_WAVES_PER_BLOCK), 0, s,
                      *cam, rays, (const char *)rrays, (const int *)clist, (const int *)clist_count, todo, todo_count, clist, clist_count, steps, ray_stride,
@@ -1555,8 +1643,10 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
   if (kind == 2 && nph == 3) return hipSuccess;
   // (a pole-on camera has mpos = 1 on every ray: no theta series, nothing for grt_phi_kernel to do)
   if (kind == 1 && nph == 2 && split && !raw && todo && todo_count && fabs(cam->mu0) != 1.0) {
-    note_launch("grt_geo_kernelILi1ELi0ELb1ELb0EE");
-    hipLaunchKernelGGL((grt_geo_kernel<1, 0, true>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw);
+    // r05m: the azimuth in line (AZI).  (r05a-l ran grt_phi_kernel<false> behind the plain image-only kernel here: 14.8 + 5.7 ms where this
+    // kernel takes 18.8; that instantiation went with the mode -- the plunging rays keep grt_phi_kernel<true>.)
+    note_launch("grt_geo_kernelILi1ELi0ELb1ELb0ELb1EE");
+    hipLaunchKernelGGL((grt_geo_kernel<1, 0, true, false, true>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw, todo, todo_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // phi_stream: the azimuth kernels run there, after this stream's image-only kernel (ev_geo), and record ev_phi when done -- the
@@ -1566,11 +1656,11 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
       if ((e = hipEventRecord(ev_geo, s)) != hipSuccess) return e;
       if ((e = hipStreamWaitEvent(phi_stream, ev_geo, 0)) != hipSuccess) return e;
     }
-    e = grt_launch_phi(ps, cam, rays, rrays, live, nlive_dev, nrays, todo, todo_count, steps, ray_stride, field_stride);
+    e = grt_launch_phi(ps, cam, rays, rrays, nrays, todo, todo_count, steps, ray_stride, field_stride);
     if (e != hipSuccess) return e;
-    note_launch("grt_geo_kernelILi1ELi2ELb0ELb1EE");
+    note_launch("grt_geo_kernelILi1ELi2ELb0ELb1ELb0EE");
     hipLaunchKernelGGL((grt_geo_kernel<1, 2, false, true>), dim3(nblk > 2048u ? 2048u : nblk), b, 0, ps, *cam, rays, rr, (const int *)todo, (const int *)todo_count, nrays, steps,
-                       ray_stride, field_stride, nfields, tfield, t0, raw);
+                       ray_stride, field_stride, nfields, tfield, t0, raw, (int *)nullptr, (int *)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phi_stream) return hipEventRecord(ev_phi, phi_stream);
     return hipSuccess;
@@ -1579,8 +1669,8 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
 #define GRT_GEO_CASE(F, P)                                                                                              \
   if (kind == F && nph == P) {                                                                                          \
     launched = true;                                                                                                    \
-    note_launch("grt_geo_kernelILi%dELi%dELb0ELb0EE", F, P);                                                                    \
-    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw); \
+    note_launch("grt_geo_kernelILi%dELi%dELb0ELb0ELb0EE", F, P);                                                                    \
+    hipLaunchKernelGGL((grt_geo_kernel<F, P>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw, (int *)nullptr, (int *)nullptr); \
   }
   GRT_GEO_CASE(1, 2) GRT_GEO_CASE(1, 0) GRT_GEO_CASE(1, 3) GRT_GEO_CASE(2, 2) GRT_GEO_CASE(2, 0) GRT_GEO_CASE(0, 2) GRT_GEO_CASE(0, 0) GRT_GEO_CASE(0, 3)
 #undef GRT_GEO_CASE

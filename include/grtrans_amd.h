@@ -251,10 +251,11 @@ int grt_copy_resident_pixvals(void *d_dst, int64_t count);
  * device the geometry fields are [ray][point] and I,Q,U,V are [block of 64 rays][point][ray in block] (written by the transfer
  * kernel with a wave's 64 rays side by side). */
 int grt_set_record_steps(int enable);
-/* 1 (default): when the azimuth is wanted (per-step record, extra=1, 3-D fluid models) the four-real-root ray class is traced by two
- * kernels -- the image-only geodesic kernel, which also leaves I_u of every point in the record, and grt_phi_kernel, which turns it
- * into GEOPHITIME's phi (geokerr_wrapper.f:1648-2357) in place; 0: the fused record-mode kernel (kept as the A/B reference: the two
- * must agree to rounding).  Slow-light traces (coordinate time wanted) and the other ray classes are fused either way. */
+/* 1 (default): when the azimuth is wanted (per-step record, extra=1, 3-D fluid models) the four-real-root ray class is traced by the
+ * image-only geodesic kernel with GEOPHITIME's phi (geokerr_wrapper.f:1648-2357) taken in line -- a Hermite sum over Mino time for the
+ * u side, the theta series for the mu side (r05m; r05a-l: a second kernel, grt_phi_kernel, which still serves the plunging rays);
+ * 0: the fused record-mode kernel with Carlson's forms (kept as the A/B reference: the two must agree to rounding).
+ * Slow-light traces (coordinate time wanted) and the other ray classes are fused either way. */
 int grt_set_geo_split(int enable);
 int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out);
 

@@ -221,6 +221,20 @@ int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
 // exploration / test access for the azimuth as an integral over I (grt_phi_kernel, r05): per stored point 8 columns -- I_u = I_mu (as the
 // image-only kernel exports it), u, mu, the radial turning-point count passed (0/1), tpm, dphi of the one-point Legendre/Carlson
 // evaluation (ray_point_real<2> without the ladder short cuts), isfill, and the u-side piece of that dphi (tools/hermite_study.py)
+// the theta-series constants of a ray (realray_anchor_z): l, pG, pbeta, pC, i3mu, pn, pok, zok, m1m, nn, mpos, mneg, |pcs[0]|, pomt1
+int hs_theta_consts(const GrtCam *cam, int ii, double *c) {
+  GrtRay R;
+  setup_ray(*cam, ii, R);
+  bool fast = ((R.ncase == 7 || R.ncase == 8) && fabs(R.u3 - R.u2) > 1e-12) || (R.ncase == 5 && R.tpr == 0 && cam->a != 0.0 && R.q2 != 0.0);
+  if (!fast || R.npts < 1) return -1;
+  RealRay K;
+  realray_init(*cam, R, K);
+  realray_anchor(*cam, R, K);
+  realray_anchor_z(*cam, R, K);
+  c[0] = K.l; c[1] = K.pG; c[2] = K.pbeta; c[3] = K.pC; c[4] = K.i3mu; c[5] = K.pn; c[6] = K.pok; c[7] = K.zok; c[8] = K.m1m; c[9] = K.nn;
+  c[10] = K.mpos; c[11] = K.mneg; c[12] = fabs(K.pcs[0]); c[13] = K.pomt1; c[14] = K.phimu3; c[15] = K.ii3mu;
+  return R.ncase;
+}
 int hs_phi_debug(const GrtCam *cam, int ii, int maxn, double *out, double *consts) {
   GrtRay R;
   setup_ray(*cam, ii, R);

@@ -726,7 +726,12 @@ def test_segment_scheme_of_the_geodesic_kernel_matches_sequential_oracle(L, spin
 
 @pytest.mark.parametrize("spin,mu0,gv,nn,uout,stride", CAMS[:4] + [(-0.9, 0.99, (-8., 8., -8., 8.), (48, 48, 200), 0.04, 7),
                                                                   (0.998, 0.906, (-40., 20., -20., 40.), (64, 64, 100), 0.01, 13),
-                                                                  (0.9375, 0.6428, (-13., 13., -13., 13.), (48, 48, 40), 0.04, 7)])
+                                                                  (0.9375, 0.6428, (-13., 13., -13., 13.), (48, 48, 40), 0.04, 7),
+                                                                  # r05m: nearly Schwarzschild -- k^2 of the mu side ~ 4e-8.  The theta series'
+                                                                  # prefactor was formed from 1 - m1m and every regular point's azimuth sat 1e-9 off
+                                                                  # (7e-8 at nup = 40) until tools/sweep_split.py saw the mu-fill points disagree
+                                                                  (-0.0014, -0.6009, (-4.65, 4.65, -4.65, 4.65), (24, 24, 427), 0.02, 5),
+                                                                  (0.0023, -0.9626, (-19., 19., -19., 19.), (24, 24, 100), 0.02, 5)])
 def test_azimuth_by_hermite_quadrature_over_mino_time_matches_sequential_oracle(L, spin, mu0, gv, nn, uout, stride):
     # grt_phi_kernel (r05): the azimuth of a four-real-root ray from I_u and u of its stored points -- the u part by a two-point Hermite
     # rule over I between neighbours (hermite_gu / hermite_seg), the mu part from the theta series at the argument formed from I_u

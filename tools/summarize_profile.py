@@ -46,13 +46,13 @@ if not args:
     # default workload: the record-mode trace phase = the largest dispatch of each of the four trace kernels
     def mx(sub, c):
         return sum(v[c]["max"] for k, v in out.items() if sub in k and c in v)
-    # (r05: the fast class's record-mode geodesics are three launches -- image-only kernel storing I_u, grt_phi_kernel, the fused kernel
+    # (r05m: the fast class's record-mode geodesics are three launches -- image-only kernel with the azimuth in line, grt_phi_kernel<true> on the plunging rays, the fused kernel
     #  in its phi-only form on the left-over rays)
-    GEO = ("grt_geo_kernel<1, 0, true, false>", "grt_phi_kernel", "grt_geo_kernel<1, 2, false, true>", "grt_geo_kernel<0, 2, false, false>")
+    GEO = ("grt_geo_kernel<1, 0, true, false, true>", "grt_phi_kernel", "grt_geo_kernel<1, 2, false, true, false>", "grt_geo_kernel<0, 2, false, false, false>")
     rec = lambda c: (sum(mx(g, c) for g in GEO) + mx("grt_transfer_kernel", c))   # noqa: E731
     fetch_kb, write_kb = rec("FETCH_SIZE"), rec("WRITE_SIZE")
     steps = bench["config"]["ray_steps_per_step_per_gpu"] if bench else 474894124
-    json.dump({"scope": "trace phase of one record-mode step at 1024x1024x400: grt_geo_kernel<1,0,true> + grt_phi_kernel + grt_geo_kernel<1,2,false,true> "
+    json.dump({"scope": "trace phase of one record-mode step at 1024x1024x400: grt_geo_kernel<1,0,true,false,AZI> (azimuth in line) + grt_phi_kernel<true> + grt_geo_kernel<1,2,false,true> "
                         "+ grt_geo_kernel<0,2> + the largest grt_transfer_kernel dispatch (fast class, record on); the generic-class transfer launch is below 1 % of it",
                "build_id": benchmod.build_id(),
                "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
@@ -63,11 +63,11 @@ if not args:
                "source": "profiles/%s_pmc.json (separate --pmc passes, tools/profile_round.sh)" % tag},
               open(os.path.join(S, "traffic.json"), "w"), indent=1)
     # shader clock while the dominant kernel runs: GRBM_GUI_ACTIVE counts busy cycles summed over the 8 XCDs
-    gui = mx("grt_geo_kernel<1, 0, true, false>", "GRBM_GUI_ACTIVE")
+    gui = mx("grt_geo_kernel<1, 0, true, false, true>", "GRBM_GUI_ACTIVE")
     dur_ns = None
     try:
         for r in csv.DictReader(open(os.path.join(S, tag + "_kernel_stats.csv"))):
-            if "grt_geo_kernel<1, 0, true, false>" in r["Name"]:
+            if "grt_geo_kernel<1, 0, true, false, true>" in r["Name"]:
                 dur_ns = float(r["AverageNs"])
     except Exception:
         pass
@@ -77,7 +77,7 @@ if not args:
                "fma_f64_wave_insts": rec("SQ_INSTS_VALU_FMA_F64"), "mul_f64_wave_insts": rec("SQ_INSTS_VALU_MUL_F64"),
                "add_f64_wave_insts": rec("SQ_INSTS_VALU_ADD_F64"), "trans_f64_wave_insts": rec("SQ_INSTS_VALU_TRANS_F64"),
                "valu_wave_insts": rec("SQ_INSTS_VALU"), "sclk_hz": sclk,
-               "sclk_note": "GRBM_GUI_ACTIVE of grt_geo_kernel<1,0,true> / 8 XCDs / its average duration in the kernel trace",
+               "sclk_note": "GRBM_GUI_ACTIVE of grt_geo_kernel<1,0,true,false,true> / 8 XCDs / its average duration in the kernel trace",
                "per_kernel": {k: {c: v[c]["max"] for c in v if c.startswith("SQ_INSTS_VALU")} for k, v in out.items() if "geo_kernel" in k or "transfer" in k or "phi_kernel" in k},
                "source": "profiles/%s_pmc.json" % tag},
               open(os.path.join(S, "valu.json"), "w"), indent=1)
