@@ -586,34 +586,23 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(AZI ? GRT_WPE_GEO
 }
 
 // ---------------------------------------------------------------------------------------------------
-// grt_phi_kernel (r05): the azimuth of the four-real-root class on its own.  One wave per fast-class ray, one stored point per lane,
-// 64-point chunks in plain point order from the top of the ray down.  Input: what grt_geo_kernel<1, 0, true> left in the record --
-// I_u of every point in the phi slot, r (1/u, the radial turning-point parity in its sign bit); output: phi = phi_ref - dphi in the same
-// slot, written by the lane that read it.
-//   u side: the increments between neighbouring points by the two-point Hermite rule over I (grt_dev_fast.hpp:hermite_gu) -- no square
-//           roots of the linear factors, no R_F / R_J series, no R_C; one plain suffix sum down the wave from the ray's top point, whose
-//           value the set-up kernel evaluated with the Carlson forms (RealRay.anc[2]);
-//   mu side: Jacobi's Pi from the theta series (theta_P) at the reduced argument formed from I_u as ray_point_real_branchy forms it;
-//           mu itself is not needed, so the ladder recurrence is not run: one sincos per point.
-// Rays this kernel does not serve are appended to todo[] (todo_count) and traced by the fused kernel in its phi-only form
-// (grt_geo_kernel<1, 2, false, true>) right afterwards: plunging rays (ncase 5: G_u has its pole at the horizon they end on), rays without a short theta series
-// (RealRay.pok), l = 0, su != 1, and any ray with a segment where the fourth- and third-order rules differ by more than GRT_PHI_TOL (the error
-// indicator: nup of a few tens on a strongly bent ray).
-// Why two kernels: the azimuth's live values took the fused record-mode kernel <1,2> to 236 registers = two waves per SIMD, and the
-// two-pass form it needs costs 9.8 ms over the image-only twin before any azimuth is computed (profiles/r05a_geo_budget.txt); apart,
-// the image-only kernel runs unchanged (at three waves then, five since r05k) and this one is ~400 instructions per 63 segments.
-// One quirk of the reference is kept: GEOPHITIME drops the u-side terms of a point within 1e-12 of the turning point of a ncase-7 ray
-// (geokerr_wrapper.f:2200: its phi there is ~3e-6 off the smooth curve) -- such a point takes phiu1 = 0 here as well.
-// (r05m: only CPLX = true is instantiated -- the four-real-root rays take this sum in line in grt_geo_kernel<1,0,...,AZI>, which fills clist[].)
-// CPLX = false: the four-real-root rays of live[]; a plunging ray (two real roots and a complex pair) is handed on through clist[] to the
-// CPLX = true instantiation, launched behind this one on a small striding grid: that one carries Carlson's segment forms for the last
-// points before the horizon (125 registers, where this one needs 67 and runs seven waves per SIMD -- one kernel for both cost the headline
-// camera 1 ms and saved the HARM camera, 11 % plunging rays, 2.4: profiles/r05g_phi_plunging.log).
+// grt_phi_kernel: the azimuth of the PLUNGING rays of the four-real-root class (two real roots and a complex pair: they end on the horizon,
+// where G_u has its pole) from what grt_geo_kernel<1,0,SPLIT,.,AZI> left in the record for them -- I_u of every point in the phi slot, r
+// (1/u, the radial turning-point parity in its sign bit); output: phi = phi_ref - dphi in the same slot, written by the lane that read it.
+// One wave per ray of clist[] on a striding grid, chunks of 63 segments in plain point order from the top of the ray down.
+//   u side: the increments between neighbouring points by the two-point Hermite rule over I (grt_dev_fast.hpp:hermite_gu); a segment whose
+//           indicator exceeds GRT_PHI_TOL_SEG -- the last few before the horizon -- from Carlson's forms between its two points
+//           (upair_diff); one plain suffix sum down the wave from the ray's top point (RealRay.anc[2]);
+//   mu side: Jacobi's Pi from the theta series (theta_P) at the reduced argument formed from I_u as ray_point_real_branchy forms it.
+// A ray whose indicator still fails is appended to todo[] and traced by the fused kernel in its phi-only form (grt_geo_kernel<1,2,.,PHIONLY>).
+// History: r05a-l ran a second instantiation (CPLX = false) of this kernel over EVERY four-real-root ray behind the plain image-only kernel;
+// r05m took that sum into the image-only kernel's own pass (AZI); CPLX = true is the one form left.
 template <bool CPLX>
 __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_kernel(
     GrtCam cam, const GrtRay *__restrict__ rays, const char *__restrict__ rrays, const int *__restrict__ live,
     const int *__restrict__ nlive_dev, int *__restrict__ todo, int *__restrict__ todo_count, int *__restrict__ clist, int *__restrict__ clist_count,
     double *__restrict__ steps, long long ray_stride, long long field_stride) {
+  static_assert(CPLX, "the four-real-root rays take this sum in line in grt_geo_kernel<1,0,SPLIT,.,AZI>");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // a resident grid that strides over its list (r05k: one ray a wave left a fifth of the wave slots empty between a wave's end and the
   // next one's first instruction -- 1M waves of 35 us each); the next ray's index is fetched while this one is worked on
@@ -647,10 +636,6 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
   const int n = Rp->npts;
   if (!phi_hermite_ray(K) || n < 1) {      // wave-uniform: the fused kernel's ray
     if (lane == 0) todo[atomicAdd(todo_count, 1)] = rayidx;
-    continue;
-  }
-  if (!CPLX && K.cplx) {                   // a plunging ray: the other instantiation's
-    if (lane == 0) clist[atomicAdd(clist_count, 1)] = rayidx;
     continue;
   }
   double phi_ref = cam.phi0;
