@@ -10,6 +10,7 @@
 // what allows the points of one ray to be spread over the 64 lanes of a wave.
 #pragma once
 #include "grt_dev_ell.hpp"
+#include "grt_dev_cr.hpp"
 
 namespace grtd {
 // ---- reference-literal code: NO FMA contraction from here to the matching "contract(fast)" -------------------------------------
@@ -110,10 +111,11 @@ GRT_HD void geomu(double &u0, double &uf, double mu0, double &muf, double a, dou
     double rr = (two * (cc * cc * cc) / (dd * dd * dd) + 27.0 / dd) / 54.0;
     double dis = rr * rr - qq * qq * qq;
     if (dis < -1.e-16) {
-      double theta = acos(rr / pow(qq, 1.5));
-      c.u1 = -two * sqrt(qq) * cos(theta / 3.0) - cc / dd / 3.0;
-      c.u2 = -two * sqrt(qq) * cos((theta - two * pi) / 3.0) - cc / dd / 3.0;
-      c.u3 = -two * sqrt(qq) * cos((theta + two * pi) / 3.0) - cc / dd / 3.0;
+      // (acos, cos, ** 1.5 correctly rounded -- grt_dev_cr.hpp: the device library's last bit decides KMAX for an odd nup)
+      double theta = cr_acos(rr / cr_pow15(qq));
+      c.u1 = -two * sqrt(qq) * cr_cos(theta / 3.0) - cc / dd / 3.0;
+      c.u2 = -two * sqrt(qq) * cr_cos((theta - two * pi) / 3.0) - cc / dd / 3.0;
+      c.u3 = -two * sqrt(qq) * cr_cos((theta + two * pi) / 3.0) - cc / dd / 3.0;
       iu1 = 0.0;
       for (;;) {
         if (u0 <= c.u2) {
@@ -753,10 +755,11 @@ GRT_ALWAYS_INLINE GRT_HD void geor(double &u0, double &uf, double mu0, double mu
     double rr = (two * (cc * cc * cc) / (dd * dd * dd) + 27.0 / dd) / 54.0;
     double dis = rr * rr - qq * qq * qq;
     if (dis < -1.e-16) {
-      double theta = acos(rr / pow(qq, 1.5));
-      c.u1 = -two * sqrt(qq) * cos(theta / 3.0) - cc / dd / 3.0;
-      c.u2 = -two * sqrt(qq) * cos((theta - two * pi) / 3.0) - cc / dd / 3.0;
-      c.u3 = -two * sqrt(qq) * cos((theta + two * pi) / 3.0) - cc / dd / 3.0;
+      // (acos, cos, ** 1.5 correctly rounded -- grt_dev_cr.hpp: the device library's last bit decides KMAX for an odd nup)
+      double theta = cr_acos(rr / cr_pow15(qq));
+      c.u1 = -two * sqrt(qq) * cr_cos(theta / 3.0) - cc / dd / 3.0;
+      c.u2 = -two * sqrt(qq) * cr_cos((theta - two * pi) / 3.0) - cc / dd / 3.0;
+      c.u3 = -two * sqrt(qq) * cr_cos((theta + two * pi) / 3.0) - cc / dd / 3.0;
       for (;;) {
         if (u0 <= c.u2) {
           c.ncase = 1;

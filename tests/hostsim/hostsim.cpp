@@ -221,6 +221,19 @@ int hs_mu_debug(const GrtCam *cam, int ii, int maxn, double *out) {
 // exploration / test access for the azimuth as an integral over I (grt_phi_kernel, r05): per stored point 8 columns -- I_u = I_mu (as the
 // image-only kernel exports it), u, mu, the radial turning-point count passed (0/1), tpm, dphi of the one-point Legendre/Carlson
 // evaluation (ray_point_real<2> without the ladder short cuts), isfill, and the u-side piece of that dphi (tools/hermite_study.py)
+// grt_dev_cr.hpp: which = 0 cr_acos, 1 cr_cos, 2 cr_pow15 (and 10, 11, 12: this host's libm for the same function)
+void hs_cr_eval(int which, int n, const double *x, double *y) {
+  for (int i = 0; i < n; ++i) {
+    switch (which) {
+      case 0: y[i] = cr_acos(x[i]); break;
+      case 1: y[i] = cr_cos(x[i]); break;
+      case 2: y[i] = cr_pow15(x[i]); break;
+      case 10: y[i] = acos(x[i]); break;
+      case 11: y[i] = cos(x[i]); break;
+      default: y[i] = pow(x[i], 1.5); break;
+    }
+  }
+}
 // the theta-series constants of a ray (realray_anchor_z): l, pG, pbeta, pC, i3mu, pn, pok, zok, m1m, nn, mpos, mneg, |pcs[0]|, pomt1
 int hs_theta_consts(const GrtCam *cam, int ii, double *c) {
   GrtRay R;

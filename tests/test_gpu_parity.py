@@ -880,6 +880,13 @@ def test_record_geometry_vs_oracle_on_random_cameras():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_record_vs_oracle.py"), "60", "5"], capture_output=True, text=True, env=env, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], r.stdout[-1500:]
+    # ... and the same cameras at a = 0 exactly (the Schwarzschild-cubic kernels; GEOKERR's trigonometric cubic): seed 21's cameras 28, 39
+    # and 44 (nup = 427) each had a ray whose mu-fill segment started one stored point early until the cubic's acos / cos / x^1.5 were
+    # rounded correctly on the device (grt_dev_cr.hpp)
+    env["GRT_SWEEP_SPIN"] = "0.0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_record_vs_oracle.py"), "50", "21"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], r.stdout[-1500:]
 
 
 def test_differential_compilation_same_inputs_through_two_code_objects(tmp_path):

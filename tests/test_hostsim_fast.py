@@ -775,6 +775,31 @@ def test_azimuth_by_hermite_quadrature_over_mino_time_matches_sequential_oracle(
         assert served > 2 * left or abs(mu0) > 0.95, (served, left)
 
 
+def test_correctly_rounded_cubic_functions(L):
+    # grt_dev_cr.hpp (r05n): acos, cos and x^1.5 of GEOKERR's trigonometric cubic solution (a = 0) in double-double arithmetic.  The
+    # reference takes them from the host's libm; the device library's neighbouring double moved u_b's last bit and, for an odd nup, KMAX
+    # with it (tools/sweep_record_vs_oracle.py at a = 0, nup = 427: the mu-fill segment one stored point early on 3 of 8 cameras).
+    # Pinned here: correctly rounded on every sampled argument (mpmath), and equal to this host's glibc on all but a few in a thousand --
+    # glibc 2.35 itself is off the correctly rounded value on 0.07 % (acos), 0.15 % (cos), 0.08 % (pow) of arguments.
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rng = np.random.default_rng(3)
+    N = 60000
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    cases = ((0, rng.uniform(-1, 1, N), mp.acos), (1, rng.uniform(-2.2, 3.2, N), mp.cos), (2, 10 ** rng.uniform(-6, 2, N), lambda t: mp.mpf(t) ** mp.mpf(1.5)))
+    for w, x, f in cases:
+        y = np.zeros(N); z = np.zeros(N)
+        L.hs_cr_eval(w, N, dp(x), dp(y)); L.hs_cr_eval(10 + w, N, dp(x), dp(z))
+        mis = np.nonzero(y != z)[0]
+        assert len(mis) < 0.005 * N, (w, len(mis))
+        for i in list(mis[:100]) + list(rng.integers(0, N, 400)):
+            assert float(f(mp.mpf(float(x[i])))) == y[i], (w, float(x[i]), y[i])
+    # the edges the cubic hands over: |x| = 1 for acos (theta = 0 or pi), tiny and huge qq
+    e = np.array([1.0, -1.0, 0.0, 0.5, -0.5]); y = np.zeros(5)
+    L.hs_cr_eval(0, 5, dp(e), dp(y))
+    assert [float(mp.acos(mp.mpf(float(v)))) for v in e] == list(y)
+
+
 @pytest.mark.parametrize("key", ["a", "b"])
 def test_standard2_mu_stepping_points_vs_reference_geokerr(L, key):
     # standard=2 with nup > 1: GEOKERR's USEGEOR branch (geokerr_wrapper.f:421-461; mu steps from mu0 to the equatorial plane,

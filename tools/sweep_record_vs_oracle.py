@@ -19,6 +19,8 @@ capi.record_steps(True); capi.geo_reuse(False)
 bad = 0; worst = dict(r=0.0, th=0.0, phi=0.0, lam=0.0); nrays = npts = 0
 for k in range(N):
     a = float(rng.uniform(-0.998, 0.998)) if rng.random() > 0.25 else float(rng.choice([0.998, -0.998, 0.0014, -0.0013, 0.02, 0.5, 0.9375, 1e-4]))
+    if os.environ.get("GRT_SWEEP_SPIN"):      # every camera at this spin (the draws above are still made: same stream)
+        a = float(os.environ["GRT_SWEEP_SPIN"])
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
     fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
     nup = int(rng.choice([40, 100, 200, 400, 427, 512, 900]))
