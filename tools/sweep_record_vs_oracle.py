@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from grtrans_amd import capi
 from oracle import orabind as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+NUPS = [int(v) for v in os.environ.get("GRT_SWEEP_NUPS", "40,100,200,400,427,512,900").split(",")]      # (odd values: KMAX sits on an integer)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = capi.Device(0); dev.load_tables(); dev.load_ffjet()
 em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
@@ -23,7 +24,7 @@ for k in range(N):
         a = float(os.environ["GRT_SWEEP_SPIN"])
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
     fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
-    nup = int(rng.choice([40, 100, 200, 400, 427, 512, 900]))
+    nup = int(rng.choice(NUPS))
     uout = float(rng.choice([0.01, 0.02, 0.04]))
     nn = (7, 7, nup)
     gv = (cx - fov / 2, cx + fov / 2, cy - fov / 2, cy + fov / 2)
