@@ -889,6 +889,18 @@ def test_record_geometry_vs_oracle_on_random_cameras():
     assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], r.stdout[-1500:]
 
 
+def test_geokerr_raw_arrays_vs_oracle_on_random_cameras():
+    # tools/sweep_geokerr_rays_vs_oracle.py: random cameras through grt_geokerr_rays (the NPH = 3 forms of the set-up / geodesic kernels: they
+    # also carry the coordinate time the slow-light fluid models use) against the oracle ray by ray: npts, ncase, TPMI, TPRI bit-equal,
+    # u 1e-10, mu 1e-9, dt 1e-9, dphi 1e-8, lam 1e-9 of each array's largest value.  850 cameras / 41,600 rays in
+    # profiles/r05o_geokerr_rays_*: no integer off, dt <= 3e-15, dphi <= 6e-10.
+    import subprocess
+    env = dict(os.environ); env.pop("GRT_LOG_LAUNCHES", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_geokerr_rays_vs_oracle.py"), "60", "51"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], r.stdout[-1500:]
+
+
 def test_differential_compilation_same_inputs_through_two_code_objects(tmp_path):
     # VERDICT r04 weak #3 / next #3a: correctness of the shipped object has twice depended on what the register allocator did with a live
     # value (DESIGN 6 defects (3), (5): a copy under a partial exec mask; a live integer overwritten by a register copy) -- a family no
