@@ -868,13 +868,29 @@ OPEN_CASES = {
 }
 
 
-def open_cases():
+# r05: the two FFJET cameras the per-pixel rules of tools/fuzz_cameras.py leave above the line: POLSYNCHPL with p = 5.5 at a tenth
+# of the nominal frequency, Faraday-thick rays whose Q, U, V oscillate from step to step
+OPEN_CASES_R05 = {
+    # profiles/r05e_fuzz_200_seed8008_per_pixel_rules.log camera 64
+    "ffjet_p55_34ghz_seed8008": dict(fname="FFJET", ename="POLSYNCHPL", iname="formal", spin=0.05213690551730877, mu0=0.0, uout=0.01, nn=(12, 12, 60),
+                                     gridvals=(-9.570136125286059, 10.569561098919507, -4.811191063496265, 15.328506160709301), p1=5.5,
+                                     freqs=[1.035e12, 3.45e11, 3.45e10], i1=26, i2=134, dump=None),
+    # profiles/r05o_fuzz_700_seed424242.log camera 134
+    "ffjet_p55_34ghz_seed424242": dict(fname="FFJET", ename="POLSYNCHPL", iname="formal", spin=0.567049935230656, mu0=-0.42378143169961224, uout=0.02,
+                                       nn=(12, 12, 100), gridvals=(-10.498569236028937, 13.589957295400408, -10.355504459802308, 13.733022071627037),
+                                       p1=5.5, freqs=[1.035e12, 3.45e11, 3.45e10], i1=1, i2=144, dump=None),
+}
+
+
+def open_cases(cases=None, fn="open_cases.npz"):
     import tempfile
     import make_koral3d_dump
+    cases = OPEN_CASES if cases is None else cases
     out = {}
     with tempfile.TemporaryDirectory() as td:
-        make_koral3d_dump.write(td, n1=32, n2=32, n3=16)          # the sweep's dump (tools/fuzz_cameras.py)
-        for name, case in OPEN_CASES.items():
+        if any(c["dump"] for c in cases.values()):
+            make_koral3d_dump.write(td, n1=32, n2=32, n3=16)          # the sweep's dump (tools/fuzz_cameras.py)
+        for name, case in cases.items():
             kw = {k: v for k, v in case.items() if k not in ("freqs", "i1", "i2", "dump")}
             if case["dump"]:
                 kw["datadir"] = td
@@ -918,7 +934,7 @@ def open_cases():
             out[name + "_ivals"] = ref.astype(np.float32); out[name + "_npts"] = npts
             out[name + "_peak"] = pk; out[name + "_cond"] = cond; out[name + "_amp"] = amp
             print(name, "cond", cond.max(axis=1), "amp", amp.max(axis=1))
-    np.savez_compressed(os.path.join(G, "open_cases.npz"), **out)
+    np.savez_compressed(os.path.join(G, fn), **out)
 
 
 def delo_vacuum_pocket_ray():
@@ -978,6 +994,7 @@ if __name__ == "__main__":
     standard2()
     polar_camera()
     open_cases()
+    open_cases(OPEN_CASES_R05, "open_cases_r05.npz")
     delo_vacuum_pocket_ray()
     crosscheck_main()
     print("golden fixtures written to", os.path.abspath(G))

@@ -901,6 +901,41 @@ def test_geokerr_raw_arrays_vs_oracle_on_random_cameras():
     assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], r.stdout[-1500:]
 
 
+OPEN_CASE_SETUP_R05 = {
+    # name: (spin, mu0, uout, nn, gridvals, pixel range, measured error of the third frequency's worst Stokes parameter, pinned bar)
+    "ffjet_p55_34ghz_seed8008": (0.05213690551730877, 0.0, 0.01, (12, 12, 60),
+                                 (-9.570136125286059, 10.569561098919507, -4.811191063496265, 15.328506160709301), 26, 134, 2.64e-6, 6e-6),
+    "ffjet_p55_34ghz_seed424242": (0.567049935230656, -0.42378143169961224, 0.02, (12, 12, 100),
+                                   (-10.498569236028937, 13.589957295400408, -10.355504459802308, 13.733022071627037), 1, 144, 2.2e-5, 5e-5),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPEN_CASE_SETUP_R05))
+def test_open_cases_of_the_r05_sweeps_vs_compiled_reference(fdev, name):
+    # The two FFJET cameras the per-pixel rules of tools/fuzz_cameras.py leave above the 2e-6 line, frozen against the COMPILED
+    # reference's image (tests/golden/open_cases_r05.npz <- tests/make_golden.py:OPEN_CASES_R05): POLSYNCHPL with p = 5.5, formal, at
+    # 1035 / 345 / 34.5 GHz.  At the two upper frequencies the suite's bar holds.  At 34.5 GHz -- a tenth of the nominal frequency, Faraday-thick
+    # rays whose Q, U, V turn by radians per step -- the reference's own image moves by 7e-8 / 1.4e-7 of a peak under one-ulp perturbations of its
+    # inputs (cond) and by 1,360x / 2,350x any relative change of the frequency (amp): the device's 2.6e-6 / 2.2e-5 are what a relative
+    # frequency error of 2e-9 / 9e-9 does there.  They stay ON RECORD as open (not waived: the per-pixel rule does not explain them by the
+    # pixel's own response); the bar pinned here is twice the measured value, so that the cases cannot get worse unnoticed.
+    from grtrans_amd import capi
+    g = np.load(os.path.join(G, "open_cases_r05.npz"))
+    spin, mu0, uout, nn, gv, i1, i2, measured, pinned = OPEN_CASE_SETUP_R05[name]
+    cam = capi.make_camera(1, gv, nn, spin, mu0, uout, -0.5)
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 5.5)
+    freqs = [1.035e12, 3.45e11, 3.45e10]
+    ref, pk, cond, amp = g[name + "_ivals"].astype(np.float64), g[name + "_peak"], g[name + "_cond"], g[name + "_amp"]
+    assert amp[2].max() > 1000.0 and cond[2].max() > 5e-8          # (the regime, as the compiled reference itself shows it)
+    pix, _, status, _ = capi.trace_tile(cam, i1, i2, "FFJET", em, freqs, "formal")
+    assert np.array_equal(status, g[name + "_npts"])
+    for k in range(3):
+        assert np.array_equal(np.isfinite(pix[k]), np.isfinite(ref[k])), (name, k)
+        okm = np.isfinite(ref[k]).all(axis=1)
+        err = np.abs(pix[k][okm].astype(np.float64) - ref[k][okm]).max(axis=0) / pk[k]
+        assert np.all(err <= (2e-6 if k < 2 else pinned)), (name, k, err)
+
+
 def test_differential_compilation_same_inputs_through_two_code_objects(tmp_path):
     # VERDICT r04 weak #3 / next #3a: correctness of the shipped object has twice depended on what the register allocator did with a live
     # value (DESIGN 6 defects (3), (5): a copy under a partial exec mask; a live integer overwritten by a register copy) -- a family no
