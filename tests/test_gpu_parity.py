@@ -887,6 +887,14 @@ def test_record_geometry_vs_oracle_on_random_cameras():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_record_vs_oracle.py"), "50", "21"], capture_output=True, text=True, env=env, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], r.stdout[-1500:]
+    # ... and cameras ALMOST on the axis (1 - |mu0| = 1e-6; exactly pole-on: mu0 = 1): the four-real-root class's azimuth was up to 9e-7 off
+    # there until the near-polar rays of such a camera went back to the reference-literal path (grt_launch_setup, r05p)
+    env.pop("GRT_SWEEP_SPIN")
+    for mu0 in ("-0.999999", "1.0"):
+        env["GRT_SWEEP_MU0"] = mu0
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_record_vs_oracle.py"), "30", "61"], capture_output=True, text=True, env=env, timeout=1200)
+        assert r.returncode == 0, (mu0, r.stdout[-3000:] + r.stderr[-2000:])
+        assert "cameras above the bars: 0" in r.stdout.strip().splitlines()[-1], (mu0, r.stdout[-1500:])
 
 
 def test_geokerr_raw_arrays_vs_oracle_on_random_cameras():

@@ -18,6 +18,8 @@ for k in range(N):
     if os.environ.get("GRT_SWEEP_SPIN"):
         a = float(os.environ["GRT_SWEEP_SPIN"])
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
+    if os.environ.get("GRT_SWEEP_MU0"):      # every camera at this inclination
+        mu0 = float(os.environ["GRT_SWEEP_MU0"])
     fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
     nup = int(rng.choice(NUPS)); uout = float(rng.choice([0.01, 0.02, 0.04]))
     nn = (7, 7, nup); gv = (cx - fov / 2, cx + fov / 2, cy - fov / 2, cy + fov / 2)

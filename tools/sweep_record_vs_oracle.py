@@ -23,6 +23,8 @@ for k in range(N):
     if os.environ.get("GRT_SWEEP_SPIN"):      # every camera at this spin (the draws above are still made: same stream)
         a = float(os.environ["GRT_SWEEP_SPIN"])
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
+    if os.environ.get("GRT_SWEEP_MU0"):      # every camera at this inclination
+        mu0 = float(os.environ["GRT_SWEEP_MU0"])
     fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
     nup = int(rng.choice(NUPS))
     uout = float(rng.choice([0.01, 0.02, 0.04]))
@@ -33,6 +35,7 @@ for k in range(N):
     pix, _, status, st = capi.trace_tile(cam, 1, npx, "FFJET", em, [3.45e11], "formal")
     rec = capi.download_steps(0, npx, cam.nup + cam.next)
     o = O.Oracle(nn=nn, spin=a, mu0=mu0, gridvals=gv, uout=uout)
+    ocam = o.camera() if abs(mu0) == 1.0 else None      # pole-on: phi is measured from the pixel's own position angle (geodesics.f90:339-341)
     e = dict(r=0.0, th=0.0, phi=0.0, lam=0.0); where = {}
     ok_counts = True
     for i in range(1, npx + 1):
@@ -46,10 +49,11 @@ for k in range(N):
         r, th, ph, lam = (rec[f][i - 1][:n] for f in range(4))
         er = np.max(np.abs(r * g["u"] - 1.0))
         et = np.max(np.abs(th - np.arccos(np.clip(g["mu"], -1, 1))))
-        ep = np.max(np.abs((cam.phi0 - ph) - g["dphi"])) / max(1.0, np.max(np.abs(g["dphi"])))
+        phi_ref = cam.phi0 + (np.sign(mu0) * np.arctan2(ocam["beta"][i - 1], ocam["alpha"][i - 1]) if ocam is not None else 0.0)
+        ep = np.max(np.abs((phi_ref - ph) - g["dphi"])) / max(1.0, np.max(np.abs(g["dphi"])))
         el = np.max(np.abs(lam - (g["lam"][n - 1] - g["lam"]))) / (np.max(np.abs(g["lam"][n - 1] - g["lam"])) + 1e-300)
         if os.environ.get("GRT_SWEEP_VERBOSE") and ep > 1e-9:
-            dd = (cam.phi0 - ph) - g["dphi"]
+            dd = (phi_ref - ph) - g["dphi"]
             j = int(np.argmax(np.abs(dd)))
             oc = o.camera()
             print("   ray %d ncase %d n %d: worst point %d diff %.3e; dphi oracle there %.6f; l %.4e q2 %.4e l^2/(q2+a^2) %.2e; diffs at 1, n/2, n: %.1e %.1e %.1e" %
