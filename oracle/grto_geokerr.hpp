@@ -1067,7 +1067,10 @@ inline void geokerr(const Camera &cam, const Pixel &px, GeoRaw &out) {
          q2 = px.q2, su = px.su, sm = px.sm, offset = cam.offset;
   int tpm = px.tpm, tpr = px.tpr, nup = cam.nup, kext = cam.kext, npts = cam.next;
   bool phit = cam.phit != 0, usegeor = cam.usegeor != 0, mufill = cam.mufill != 0;
-  int ntot = nup + npts - 2 * kext;
+  // array length: the driver's nup + next (geodesics.f90 allocates that; class_geokerr.f90:75 takes nup + next - 2 kext, which is SHORTER than
+  // a plunging ray's nup points when next < 2 kext, i.e. nup < 8 with the default fill: r05p, tools/sweep_record_vs_oracle.py at nup = 3 showed
+  // the third point of such rays missing here while the compiled reference has it)
+  int ntot = nup + npts;
   out.u.assign(ntot, 0.0); out.mu.assign(ntot, 0.0); out.dt.assign(ntot, 0.0);
   out.dphi.assign(ntot, 0.0); out.lam.assign(ntot, 0.0);
   out.tpm.assign(ntot, 0); out.tpr.assign(ntot, 0);
