@@ -9,6 +9,8 @@ from grtrans_amd import capi
 from oracle import orabind as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 NUPS = [int(v) for v in os.environ.get("GRT_SWEEP_NUPS", "40,100,200,400,427,512,900").split(",")]
+UOUTS = [float(v) for v in os.environ.get("GRT_SWEEP_UOUTS", "0.01,0.02,0.04").split(",")]
+FOVMAX = float(os.environ.get("GRT_SWEEP_FOV_MAX", "40"))
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = capi.Device(0)
 BARS = dict(u=1e-10, mu=1e-9, dt=1e-9, dphi=1e-8, lam=1e-9)
@@ -20,8 +22,8 @@ for k in range(N):
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
     if os.environ.get("GRT_SWEEP_MU0"):      # every camera at this inclination
         mu0 = float(os.environ["GRT_SWEEP_MU0"])
-    fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
-    nup = int(rng.choice(NUPS)); uout = float(rng.choice([0.01, 0.02, 0.04]))
+    fov = float(rng.uniform(4.0, FOVMAX)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
+    nup = int(rng.choice(NUPS)); uout = float(rng.choice(UOUTS))
     nn = (7, 7, nup); gv = (cx - fov / 2, cx + fov / 2, cy - fov / 2, cy + fov / 2)
     cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
     o = O.Oracle(nn=nn, spin=a, mu0=mu0, gridvals=gv, uout=uout)

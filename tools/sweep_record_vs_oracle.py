@@ -13,6 +13,8 @@ from grtrans_amd import capi
 from oracle import orabind as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 NUPS = [int(v) for v in os.environ.get("GRT_SWEEP_NUPS", "40,100,200,400,427,512,900").split(",")]      # (odd values: KMAX sits on an integer)
+UOUTS = [float(v) for v in os.environ.get("GRT_SWEEP_UOUTS", "0.01,0.02,0.04").split(",")]
+FOVMAX = float(os.environ.get("GRT_SWEEP_FOV_MAX", "40"))
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = capi.Device(0); dev.load_tables(); dev.load_ffjet()
 em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
@@ -25,9 +27,9 @@ for k in range(N):
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
     if os.environ.get("GRT_SWEEP_MU0"):      # every camera at this inclination
         mu0 = float(os.environ["GRT_SWEEP_MU0"])
-    fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
+    fov = float(rng.uniform(4.0, FOVMAX)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
     nup = int(rng.choice(NUPS))
-    uout = float(rng.choice([0.01, 0.02, 0.04]))
+    uout = float(rng.choice(UOUTS))
     nn = (7, 7, nup)
     gv = (cx - fov / 2, cx + fov / 2, cy - fov / 2, cy + fov / 2)
     cam = capi.make_camera(1, gv, nn, a, mu0, uout, -0.5)
@@ -51,7 +53,9 @@ for k in range(N):
         et = np.max(np.abs(th - np.arccos(np.clip(g["mu"], -1, 1))))
         phi_ref = cam.phi0 + (np.sign(mu0) * np.arctan2(ocam["beta"][i - 1], ocam["alpha"][i - 1]) if ocam is not None else 0.0)
         ep = np.max(np.abs((phi_ref - ph) - g["dphi"])) / max(1.0, np.max(np.abs(g["dphi"])))
-        el = np.max(np.abs(lam - (g["lam"][n - 1] - g["lam"]))) / (np.max(np.abs(g["lam"][n - 1] - g["lam"])) + 1e-300)
+        # lambda = LAMBDAI(n) - LAMBDAI is a difference of numbers of size 1/u0 ~ 5e8 in the reference itself: never finer than a few units
+        # of THEIR last place (large uout: the stored points' own lambda is of order 1)
+        el = np.max(np.abs(lam - (g["lam"][n - 1] - g["lam"]))) / max(np.max(np.abs(g["lam"][n - 1] - g["lam"])), 1e8 * np.spacing(np.max(np.abs(g["lam"]))))
         if os.environ.get("GRT_SWEEP_VERBOSE") and ep > 1e-9:
             dd = (phi_ref - ph) - g["dphi"]
             j = int(np.argmax(np.abs(dd)))

@@ -7,6 +7,8 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from grtrans_amd import capi
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+UOUTS = [float(v) for v in os.environ.get("GRT_SWEEP_UOUTS", "0.01,0.02,0.04").split(",")]
+FOVMAX = float(os.environ.get("GRT_SWEEP_FOV_MAX", "40"))
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = capi.Device(0); dev.load_tables(); dev.load_ffjet()
 em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
@@ -16,9 +18,9 @@ q = []
 for k in range(N):
     a = float(rng.uniform(-0.998, 0.998)) if rng.random() > 0.1 else float(rng.choice([0.998, -0.998, 0.5, 0.9375]))
     mu0 = float(rng.uniform(0.0, 0.999)) * (1 if rng.random() > 0.2 else -1)
-    fov = float(rng.uniform(4.0, 40.0)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
+    fov = float(rng.uniform(4.0, FOVMAX)); cx, cy = float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))
     nup = int(rng.choice([40, 60, 100, 200, 400, 427, 450, 512, 640, 900, 1100]))
-    uout = float(rng.choice([0.01, 0.02, 0.04]))
+    uout = float(rng.choice(UOUTS))
     nn = (14, 14, nup)
     cam = capi.make_camera(1, (cx - fov / 2, cx + fov / 2, cy - fov / 2, cy + fov / 2), nn, a, mu0, uout, -0.5)
     npx = nn[0] * nn[1]
