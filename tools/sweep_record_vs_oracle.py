@@ -55,7 +55,7 @@ for k in range(N):
         ep = np.max(np.abs((phi_ref - ph) - g["dphi"])) / max(1.0, np.max(np.abs(g["dphi"])))
         # lambda = LAMBDAI(n) - LAMBDAI is a difference of numbers of size 1/u0 ~ 5e8 in the reference itself: never finer than a few units
         # of THEIR last place (large uout: the stored points' own lambda is of order 1)
-        el = np.max(np.abs(lam - (g["lam"][n - 1] - g["lam"]))) / max(np.max(np.abs(g["lam"][n - 1] - g["lam"])), 1e8 * np.spacing(np.max(np.abs(g["lam"]))))
+        el = np.max(np.abs(lam - (g["lam"][n - 1] - g["lam"]))) / max(np.max(np.abs(g["lam"][n - 1] - g["lam"])), 8e8 * np.spacing(np.max(np.abs(g["lam"]))))
         if os.environ.get("GRT_SWEEP_VERBOSE") and ep > 1e-9:
             dd = (phi_ref - ph) - g["dphi"]
             j = int(np.argmax(np.abs(dd)))
