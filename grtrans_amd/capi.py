@@ -236,6 +236,12 @@ def geo_split(enable):
     check(lib().grt_set_geo_split(C.c_int(1 if enable else 0)), "grt_set_geo_split")
 
 
+def class_merge(mode):
+    """-1 (default): by pass size; 0: one transfer launch per ray class (two streams); 1: one launch over both classes (a rank's share
+    of a multi-GPU image).  Bit-identical results either way."""
+    check(lib().grt_set_class_merge(C.c_int(int(mode))), "grt_set_class_merge")
+
+
 def download_steps(ray0, nrays, maxpts):
     out = np.zeros((8, nrays, maxpts))
     check(lib().grt_download_steps(C.c_int64(ray0), C.c_int64(nrays), C.c_int(maxpts),

@@ -20,8 +20,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" size_t grt_sizeof_realray(void);
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
-                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split, int *todo, int *todo_count,
-                                     hipStream_t phi_stream, hipEvent_t ev_geo, hipEvent_t ev_phi);
+                                     long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split, int *todo, int *todo_count);
 extern "C" hipError_t grt_launch_trim(hipStream_t s, GrtRay *rays, const int *live, const int *nlive_dev, int nrays, int *ray_npts,
                                       double *steps, long long ray_stride, long long field_stride, int nfields,
                                       int tfield);
@@ -51,8 +50,6 @@ struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // the generic-class launches run beside the fast-class ones
-  hipStream_t stream3 = nullptr;      // r05: grt_phi_kernel + its left-overs beside the transfer kernel, when that kernel does not read phi
-  hipEvent_t evp[2] = {nullptr, nullptr};
   hipEvent_t evj[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   // fluid + tables
@@ -116,8 +113,11 @@ struct Ctx {
   long long t0_version = 0;
   int force_time = 0;                   // grt_debug_ray: every point carries its coordinate time whatever the fluid model
   int geo_reuse = 1;                    // grt_set_geo_reuse
+  bool geo_split_forced = false;        // GRT_GEO_SPLIT was set: grt_set_geo_split leaves the mode alone
   int geo_split = 1;                    // grt_set_geo_split: record-mode trace of the four-real-root class by the image-only kernel with the azimuth in line (r05m); 0: the fused kernel
   int class_order = 3;
+  int class_merge = -1;                // grt_set_class_merge: -1 by pass size, 0 two transfer launches (one per ray class), 1 one merged launch
+  bool class_merge_forced = false;     // GRT_CLASS_MERGE given: the call leaves it alone
   bool class_order_forced = false;     // GRT_CLASS_ORDER given: its wait bit holds for every pass size
   long long geo_passes = 0;             // passes that launched the set-up + geodesic kernels (grt_geo_passes)
   int n_class[2] = {0, 0};              // class sizes of the resident record
@@ -150,7 +150,6 @@ int grow(T *&p, size_t &cap, size_t need) {
 void drain() {
   if (C.stream) (void)hipStreamSynchronize(C.stream);
   if (C.stream2) (void)hipStreamSynchronize(C.stream2);
-  if (C.stream3) (void)hipStreamSynchronize(C.stream3);
 }
 
 struct EventPair {       // destroyed on every exit path
@@ -185,15 +184,10 @@ int grt_init(int device) {
     const char *po = std::getenv("GRT_CLASS_ORDER");
     C.class_order = po ? std::atoi(po) : 7;
     C.class_order_forced = po != nullptr;
-    if (const char *gs = std::getenv("GRT_GEO_SPLIT")) C.geo_split = std::atoi(gs) ? 1 : 0;      // (A/B runs of the fused record-mode kernel)      // (A/B runs of the fused record-mode kernel)
+    if (const char *cm = std::getenv("GRT_CLASS_MERGE")) { C.class_merge = std::atoi(cm) ? 1 : 0; C.class_merge_forced = true; }
+    if (const char *gs = std::getenv("GRT_GEO_SPLIT")) { C.geo_split = std::atoi(gs) ? 1 : 0; C.geo_split_forced = true; }      // (A/B runs of the fused record-mode kernel)
     HIPCHK(hipStreamCreateWithPriority(&C.stream2, hipStreamNonBlocking, (C.class_order & 2) ? greatest : least));
   }
-  {      // lowest priority: the azimuth kernel's 6-waves-per-SIMD blocks must not take the CUs ahead of the transfer kernel's blocks
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    HIPCHK(hipStreamCreateWithPriority(&C.stream3, hipStreamNonBlocking, least));
-  }
-  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&C.evp[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&C.evj[i], hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreate(&C.ev[i]));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&C.evk[i]));
@@ -219,9 +213,6 @@ int grt_free(void) {
   if (C.stream2) (void)hipStreamDestroy(C.stream2);
   for (int i = 0; i < 3; ++i)
     if (C.evj[i]) (void)hipEventDestroy(C.evj[i]);
-  for (int i = 0; i < 2; ++i)
-    if (C.evp[i]) (void)hipEventDestroy(C.evp[i]);
-  if (C.stream3) (void)hipStreamDestroy(C.stream3);
   C = Ctx();
   return 0;
 }
@@ -589,8 +580,17 @@ int grt_set_record_steps(int enable) {
 }
 
 int grt_set_geo_split(int enable) {
+  if (!C.init) return GRT_E_NOTINIT;      // (grt_init sets the default; a switch thrown before it would be lost)
+  if (C.geo_split_forced) return 0;       // GRT_GEO_SPLIT in the environment decides for the whole process (A/B runs)
   C.geo_split = enable ? 1 : 0;
   C.geo.valid = false;                  // a resident record made the other way is not re-used across the switch
+  return 0;
+}
+
+int grt_set_class_merge(int mode) {
+  if (!C.init) return GRT_E_NOTINIT;
+  if (mode < -1 || mode > 1) return GRT_E_BADARG;
+  if (!C.class_merge_forced) C.class_merge = mode;
   return 0;
 }
 
@@ -806,13 +806,18 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
     // launched FIRST on the high-priority stream: launched second it trailed the fast-class kernels by up to 40 ms.
     LAUNCHCHK(hipEventRecord(C.evj[0], C.stream));
     LAUNCHCHK(hipStreamWaitEvent(C.stream2, C.evj[0], 0));
-    bool phi_joined = true;
+    // r06: a SMALL pass (a rank's share of a multi-GPU image: at most a resident round or two of the lane-per-ray transfer kernel) traces
+    // both classes with ONE transfer launch behind both geodesic kernels (grt_transfer_kernel, from_back < 0).  The second launch's few waves
+    // became third waves on their SIMDs and set the pace of the whole round: rank 3 of 8 of the headline camera 9.5 -> 7.9 ms, predicted
+    // N = 8 efficiency 0.69 -> 0.86 (profiles/r06b_*).  A whole image keeps the two chains: its generic transfer hides under the fast geodesics.
+    // grt_set_class_merge / GRT_CLASS_MERGE=0|1 decide for every size (A/B runs, tests of both forms).
+    const bool merged = C.class_merge >= 0 ? C.class_merge != 0 : (nch <= 400000 && !C.class_order_forced);
     for (int turn = 0; turn < 2; ++turn) {
       const bool generic = ((C.class_order & 1) != 0) == (turn == 0);
       if (generic) {
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream2, 0, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, nch, C.d_steps,
-                                   rstride, fstride, nfields, tfield, t0c, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr));
+                                   rstride, fstride, nfields, tfield, t0c, 0, 0, nullptr, nullptr));
         if (!reuse && cam->usegeor)
           LAUNCHCHK(grt_launch_trim(C.stream2, C.d_rays, C.d_live, C.d_counters + 1, nch, C.d_npts + off, C.d_steps, rstride, fstride,
                                     nfields, tfield));
@@ -828,32 +833,30 @@ static int trace_common(const grt_camera *cam, int nranges, const int64_t *los, 
           LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evj[2], 0));
         }
         // (pixvals, npix_tile and i1 are the whole tile's: a ray's slot is its pixel index minus the tile's i1)
+        if (!merged)
         LAUNCHCHK(grt_launch_transfer(C.stream2, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc,
                                       nfreq, C.d_freqs, C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps,
                                       rstride, fstride, nfields, tfield, C.d_stepcount, C.d_counters + 1, nch));
         LAUNCHCHK(hipEventRecord(C.evj[1], C.stream2));
       } else {
-        // r05: when the transfer kernel does not read the azimuth (2-D fluid model, no extra=1: phi is only an output of the record) the
-        // azimuth kernels of the split trace run on a third, lowest-priority stream BESIDE the transfer kernel instead of in front of
-        // it.  Measured (profiles/r05e_phi_beside.log, r05i_kernel_stats_phi_inline.csv): a whole 1024^2 image 56.0 ms either way within the
-        // boxes' spread (57.1 -> 56.6 ... 56.9 at first); a rank's share of an 8-GPU run 9.7 -> 10.0 ms (its one resident round of transfer
-        // waves is latency-bound and loses more to the neighbour than the chain saves).  The step is work-conserving: the chain stays IN
-        // FRONT of the transfer kernel (kernel durations then add up to the step); GRT_PHI_INLINE=0 puts it beside for experiments.
-        static const char *pin = std::getenv("GRT_PHI_INLINE");
-        const bool phi_beside = !reuse && C.geo_split && !(nextra || fluid_model == GRT_FLUID_HARM3D || fluid_model == GRT_FLUID_IHARM || is_koral) &&
-                                (pin && std::atoi(pin) == 0);
+        // (r05e: the azimuth kernels of the split trace on a third, lowest-priority stream BESIDE the transfer kernel when that kernel does not
+        //  read phi -- a whole 1024^2 image 56.0 ms either way, a rank's share of an 8-GPU run 9.7 -> 10.0 ms: profiles/r05e_phi_beside.log.  The
+        //  chain stays IN FRONT of the transfer kernel; the experiment is tools/experiments/r05_phi_beside.patch)
         if (!reuse)
           LAUNCHCHK(grt_launch_geo(C.stream, 1, cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, nch, C.d_steps, rstride, fstride,
-                                   nfields, tfield, t0c, 0, C.geo_split, C.d_phitodo, C.d_counters + 2, phi_beside ? C.stream3 : nullptr, C.evp[0], C.evp[1]));
-        phi_joined = phi_joined && !phi_beside;
+                                   nfields, tfield, t0c, 0, C.geo_split, C.d_phitodo, C.d_counters + 2));
         LAUNCHCHK(hipEventRecord(C.evk[0], C.stream));
+        if (!merged)
         LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
                                       C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
                                       fstride, nfields, tfield, C.d_stepcount, C.d_counters, 0));
       }
     }
     LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evj[1], 0));
-    if (!phi_joined) LAUNCHCHK(hipStreamWaitEvent(C.stream, C.evp[1], 0));      // (the azimuth chain on the third stream, if it was used)
+    if (merged)      // both classes' geodesics are done (evj[1]: the generic chain's end): one launch over front and back of live[]
+      LAUNCHCHK(grt_launch_transfer(C.stream, kflag, kfluid, em->type, nextra != 0, cam, C.d_rays, C.d_live, nch, &fd, &C.tables, em, &plc, nfreq, C.d_freqs,
+                                    C.d_pixvals, nrays, nvals + nextra, C.d_npts + off, (long long)off, C.d_steps, rstride,
+                                    fstride, nfields, tfield, C.d_stepcount, C.d_counters, -nch));
     LAUNCHCHK(hipEventRecord(C.ev[2], C.stream));
     int ncls[2] = {0, 0};
     LAUNCHCHK(hipMemcpyAsync(ncls, C.d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
@@ -1031,8 +1034,8 @@ int grt_geokerr_rays(int64_t nrays, double u0, double uout, double mu0, double a
   HIPCHK(hipMemsetAsync(C.d_counters, 0, 4 * sizeof(int), C.stream));
   HIPCHK(hipMemsetAsync(C.d_steps, 0, (size_t)nf * n * rstride * sizeof(double), C.stream));
   hipError_t e = grt_launch_setup(C.stream, &cam, 1, n, C.d_rays, C.d_npts, C.d_live, C.d_counters, C.d_rrays, 3, &rin, nullptr, 0);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
-  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 0, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters + 1, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr);
+  if (e == hipSuccess) e = grt_launch_geo(C.stream, 1, &cam, C.d_rays, C.d_rrays, C.d_live, C.d_counters, n, C.d_steps, rstride, fstride, nf, 4, nullptr, 1, 0, nullptr, nullptr);
   if (e != hipSuccess) { drain(); return (int)e; }
   HIPCHK(hipStreamSynchronize(C.stream));
   // outputs: [nrays][nup+next-2kext], a ray's points first, zeros behind them

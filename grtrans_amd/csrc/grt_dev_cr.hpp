@@ -12,25 +12,31 @@
 #pragma once
 #include "grt_types.h"
 #include <math.h>
-#pragma clang fp contract(off)
+// The mode is set INSIDE each function body: a file-scope pragma here, and the `contract(fast)` that used to close the header,
+// silently changed the mode of whatever the includer compiled next (tests/hostsim and the oracle include this from contract(off) code).
+#if defined(__clang__)
+#define GRT_CR_NC _Pragma("clang fp contract(off)")
+#else
+#define GRT_CR_NC
+#endif
 namespace grtd {
 struct DD { double hi, lo; };
-GRT_HD DD dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; DD r; r.hi = s; r.lo = (a - (s - bb)) + (b - bb); return r; }
-GRT_HD DD dd_quick(double a, double b) { const double s = a + b; DD r; r.hi = s; r.lo = b - (s - a); return r; }      // |a| >= |b|
-GRT_HD DD dd_two_prod(double a, double b) { const double p = a * b; DD r; r.hi = p; r.lo = fma(a, b, -p); return r; }
-GRT_HD DD dd_add(DD x, DD y) {
+GRT_HD DD dd_two_sum(double a, double b) { GRT_CR_NC const double s = a + b, bb = s - a; DD r; r.hi = s; r.lo = (a - (s - bb)) + (b - bb); return r; }
+GRT_HD DD dd_quick(double a, double b) { GRT_CR_NC const double s = a + b; DD r; r.hi = s; r.lo = b - (s - a); return r; }      // |a| >= |b|
+GRT_HD DD dd_two_prod(double a, double b) { GRT_CR_NC const double p = a * b; DD r; r.hi = p; r.lo = fma(a, b, -p); return r; }
+GRT_HD DD dd_add(DD x, DD y) { GRT_CR_NC
   DD s = dd_two_sum(x.hi, y.hi), t = dd_two_sum(x.lo, y.lo);
   s.lo += t.hi; s = dd_quick(s.hi, s.lo); s.lo += t.lo;
   return dd_quick(s.hi, s.lo);
 }
-GRT_HD DD dd_add_d(DD x, double y) { DD s = dd_two_sum(x.hi, y); s.lo += x.lo; return dd_quick(s.hi, s.lo); }
-GRT_HD DD dd_mul(DD x, DD y) { DD p = dd_two_prod(x.hi, y.hi); p.lo += x.hi * y.lo + x.lo * y.hi; return dd_quick(p.hi, p.lo); }
-GRT_HD DD dd_mul_d(DD x, double y) { DD p = dd_two_prod(x.hi, y); p.lo += x.lo * y; return dd_quick(p.hi, p.lo); }
-GRT_HD DD dd_neg(DD x) { DD r; r.hi = -x.hi; r.lo = -x.lo; return r; }
+GRT_HD DD dd_add_d(DD x, double y) { GRT_CR_NC DD s = dd_two_sum(x.hi, y); s.lo += x.lo; return dd_quick(s.hi, s.lo); }
+GRT_HD DD dd_mul(DD x, DD y) { GRT_CR_NC DD p = dd_two_prod(x.hi, y.hi); p.lo += x.hi * y.lo + x.lo * y.hi; return dd_quick(p.hi, p.lo); }
+GRT_HD DD dd_mul_d(DD x, double y) { GRT_CR_NC DD p = dd_two_prod(x.hi, y); p.lo += x.lo * y; return dd_quick(p.hi, p.lo); }
+GRT_HD DD dd_neg(DD x) { GRT_CR_NC DD r; r.hi = -x.hi; r.lo = -x.lo; return r; }
 
 // sin and cos of a double, as double-doubles (relative error ~1e-31): reduction by multiples of pi/2 held in three parts (the first two
 // with 33-bit mantissas: k * part is exact for |k| < 2^20), Taylor series on |r| <= pi/4.
-GRT_HD void dd_sincos(double x, DD &s, DD &c) {
+GRT_HD void dd_sincos(double x, DD &s, DD &c) { GRT_CR_NC
   const double P1 = 0x1.921fb544p+0, P2 = 0x1.0b4611a6p-34, P3 = 0x1.3198a2e037073p-69, P4 = 0x1.129024e088a68p-123;      // pi/2 = P1 + P2 + P3 + P4
   const double k = rint(x * 0.63661977236758138);
   DD r = dd_two_sum(x, -k * P1);
@@ -56,9 +62,9 @@ GRT_HD void dd_sincos(double x, DD &s, DD &c) {
   else if (q == 2) { s = dd_neg(sr); c = dd_neg(cr); }
   else { s = dd_neg(cr); c = sr; }
 }
-GRT_HD double cr_cos(double x) { DD s, c; dd_sincos(x, s, c); return c.hi + c.lo; }
+GRT_HD double cr_cos(double x) { GRT_CR_NC DD s, c; dd_sincos(x, s, c); return c.hi + c.lo; }
 // acos: the library's value (within an ulp or two), one Newton step on cos y = x in double-double
-GRT_HD double cr_acos(double x) {
+GRT_HD double cr_acos(double x) { GRT_CR_NC
   if (!(fabs(x) < 1.0)) return acos(x);
   const double y0 = acos(x);
   DD s, c;
@@ -69,7 +75,7 @@ GRT_HD double cr_acos(double x) {
   return y.hi;                                  // (two_sum's hi IS the correctly rounded sum of y0 and corr)
 }
 // x^(3/2), x > 0: sqrt in double-double (one Newton step from the correctly rounded double), times x
-GRT_HD double cr_pow15(double x) {
+GRT_HD double cr_pow15(double x) { GRT_CR_NC
   if (!(x > 0.0) || !(x < 1e300)) return pow(x, 1.5);
   const double s0 = sqrt(x);
   const DD s2 = dd_two_prod(s0, s0);
@@ -79,4 +85,3 @@ GRT_HD double cr_pow15(double x) {
   return p.hi + p.lo;
 }
 }  // namespace grtd
-#pragma clang fp contract(fast)

@@ -1082,6 +1082,9 @@ GRT_HD double phi_mu_theta(const RealRay &K, double iu) { return phi_mu_theta_c(
 // without a short theta series, l = 0 (GEOPHITIME adds pi per polar turning point there), su != 1.
 // r05e: the plunging rays are served too -- the Hermite rule holds along most of such a ray, and grt_phi_kernel takes the segments where
 // its indicator fails (the last few before the horizon) from Carlson's forms (cplx_upair), lane by lane.
-GRT_HD bool phi_hermite_ray(const RealRay &K) { return K.zok && K.pok && K.l != 0.0 && K.su == 1.0; }
+// (hA, hB are finite only for r+ != r-; |a| = 1 sends the ray to the fused kernel)
+GRT_HD bool phi_hermite_ray(const RealRay &K) {
+  return K.zok && K.pok && K.l != 0.0 && K.su == 1.0 && fabs(K.hA) <= 1.7e308 && fabs(K.hB) <= 1.7e308;
+}
 
 }  // namespace grtd

@@ -266,6 +266,11 @@ __device__ __forceinline__ double wave_up1c(double x, double carry) {
 #ifndef GRT_PHI_TOL
 #define GRT_PHI_TOL 2.0e-10
 #endif
+// The Hermite rule's error indicator is kept NaN-sticky: `a > b ? a : b` drops a NaN and `errmax > tol` is false for one, so a
+// non-finite term (hA / hB with r+ = r- at |a| = 1, u exactly on 1/r+, a NaN I_u) would have passed through the suffix sum into the azimuth of
+// every lower point instead of sending the ray to the fused kernel.  A ray is kept only when its indicator is KNOWN to be small.
+__device__ __forceinline__ double ind_max(double acc, double v) { return (v > acc || v != v) ? v : acc; }
+__device__ __forceinline__ bool ind_fails(double acc, double tol) { return !(acc <= tol); }
 #ifndef GRT_PHI_TOL_SEG      // plunging rays: a segment whose indicator passes this is recomputed with Carlson's forms (cheap: be strict)
 #define GRT_PHI_TOL_SEG 1.0e-11
 #endif
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(AZI ? GRT_WPE_GEO
       if (seg) {
         double T3;
         T = hermite_seg(g, gu, Iu - iu, T3);
-        errmax = dmax(errmax, fabs(T - T3));
+        errmax = ind_max(errmax, fabs(T - T3));
       }
       const double Ssum = wave_suffix_sum(T, cS, lane);
       cS = first_lane(Ssum); cI = first_lane(iu);
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(AZI ? GRT_WPE_GEO
     const HermG gB = hermite_gu(K, fabs(usB), usB < 0.0 ? -1.0 : 1.0);
     double T3;
     const double Tb = hermite_seg(gB, cG, cI - iuB, T3);
-    errmax = dmax(errmax, fabs(Tb - T3));
+    errmax = ind_max(errmax, fabs(Tb - T3));
     const double dS = (cS + Tb) - SA;
     // (this wave's own stores of the first phase are read back, lane by lane the address it wrote: program order of one lane's accesses to
     //  one address holds without a cache write-back -- an agent-scope fence here cost 24 ms at 1024^2)
@@ -578,8 +583,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(AZI ? GRT_WPE_GEO
   }
   }
   if (AZI && inl) {      // the error indicator over the wave: a ray that fails is traced again by the fused phi-only kernel (which overwrites phi)
-    for (int d = 32; d >= 1; d >>= 1) errmax = dmax(errmax, __shfl_xor(errmax, d));
-    if (lane == 0 && errmax > GRT_PHI_TOL) todo[atomicAdd(todo_count, 1)] = rayidx;
+    for (int d = 32; d >= 1; d >>= 1) errmax = ind_max(errmax, __shfl_xor(errmax, d));
+    if (lane == 0 && ind_fails(errmax, GRT_PHI_TOL)) todo[atomicAdd(todo_count, 1)] = rayidx;
   }
   slot0 += gridDim.x * GRT_WAVES_PER_BLOCK;
   } while ((FAST == 0 || PHIONLY) && slot0 < *nlive_dev * nchg);     // only the generic class (and the phi-only left-overs) stride on a capped grid; a fast-class wave serves one ray
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
         // A plunging ray (two real roots and a complex pair: it ends on the horizon, where G_u has its pole): the segments whose
         // indicator fails -- the last few -- take Carlson's forms between the two recorded points (cplx_upair; wave-uniform test, the lanes
         // that pass sit idle meanwhile: one chunk of a ray's seven as a rule).  T = phiu(upper) - phiu(lower) = kphi (S(u) - S(u_upper)).
-        const bool redo = ind > GRT_PHI_TOL_SEG;
+        const bool redo = ind_fails(ind, GRT_PHI_TOL_SEG);
         if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
           if (redo) {
             UPart D;
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
           }
         }
       }
-      errmax = dmax(errmax, ind);
+      errmax = ind_max(errmax, ind);
     }
     // suffix sum down the wave, S_k = T_k + ... + T_62 + (the chunk above): inside each row of 16 lanes by DPP row shifts (a lane
     // past the row's end reads 0), then the totals of the rows above -- lane 0 of each row holds its row's -- added in
@@ -719,8 +724,8 @@ __global__ __launch_bounds__(64 * GRT_WAVES_PER_BLOCK, GRT_OCC(4)) void grt_phi_
     }
   }
   // the error indicator, over the wave: a ray that fails is traced again by the fused kernel (which overwrites phi)
-  for (int d = 32; d >= 1; d >>= 1) errmax = dmax(errmax, __shfl_xor(errmax, d));
-  if (lane == 0 && errmax > GRT_PHI_TOL) todo[atomicAdd(todo_count, 1)] = rayidx;
+  for (int d = 32; d >= 1; d >>= 1) errmax = ind_max(errmax, __shfl_xor(errmax, d));
+  if (lane == 0 && ind_fails(errmax, GRT_PHI_TOL)) todo[atomicAdd(todo_count, 1)] = rayidx;
   asm volatile("" ::"v"(touched));      // (the prefetch's destination register lives until here)
   }
 }
@@ -857,7 +862,13 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
 #endif
   // class size from the set-up kernel's device counter (no host round trip between the launches); the grid covers the
   // worst case nlive_arg and surplus blocks leave before they stage anything
-  const int nlive = nlive_dev ? *nlive_dev : nlive_arg;
+  // from_back < 0 (r06): BOTH ray classes in this one launch -- slots 0 .. n_fast - 1 read live[] from the front, the rest the generic
+  // class from the back of its -from_back entries (nlive_dev[0], nlive_dev[1]: the set-up kernel's two counters).  A rank's share of a
+  // multi-GPU image is ONE resident round of this lane-per-ray kernel (131,072 rays = two waves on every SIMD): the handful of waves a
+  // second launch for the generic class put on top of it ran as THIRD waves of their SIMDs -- those SIMDs' waves at 2/3 speed, 4.4 -> 6.0 ms
+  // for the round and as much for the generic launch itself (profiles/r06_timelines_before.txt).  Merged, the class fills up the last waves.
+  const int nfirst = nlive_dev ? *nlive_dev : nlive_arg;
+  const int nlive = (from_back < 0) ? nfirst + nlive_dev[1] : nfirst;
   if ((int)(blockIdx.x * GRT_XFER_THREADS) >= nlive) return;
   const double *lfreqs = freqs + nfreq;      // log(freqs), appended by the host
   __shared__ double s_tile[NW][4][64 * TS];
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
   const int nf = (nfreq - f0 < FB) ? (nfreq - f0) : FB;
   const bool first_batch = (blockIdx.y == 0);
   const bool record = (nfields > GRT_F_I) && first_batch;
-  const int rayidx = has_ray ? (from_back ? live[from_back - 1 - slot] : live[slot]) : 0;   // generic class: filled from the back of live[]
+  const int rayidx = has_ray ? (from_back > 0 ? live[from_back - 1 - slot] : ((from_back < 0 && slot >= nfirst) ? live[-from_back - 1 - (slot - nfirst)] : live[slot])) : 0;   // generic class: filled from the back of live[]
   const int n = has_ray ? rays[rayidx].npts : 0;
   int nmax = n;
   for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
@@ -1617,7 +1628,7 @@ extern "C" hipError_t grt_launch_setup(hipStream_t s, const GrtCam *cam, long lo
 extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam, const GrtRay *rays, const void *rrays,
                                      const int *live, const int *nlive_dev, int nrays, double *steps,
                                      long long ray_stride, long long field_stride, int nfields, int tfield, const double *t0, int raw, int split,
-                                     int *todo, int *todo_count, hipStream_t phi_stream, hipEvent_t ev_geo, hipEvent_t ev_phi) {
+                                     int *todo, int *todo_count) {
   if (nrays <= 0) return hipSuccess;
   unsigned nblk = (unsigned)((nrays + GRT_WAVES_PER_BLOCK - 1) / GRT_WAVES_PER_BLOCK);
   // the generic class is small as a rule: a capped grid that strides over its (ray, chunk) items
@@ -1642,21 +1653,13 @@ extern "C" hipError_t grt_launch_geo(hipStream_t s, int fast, const GrtCam *cam,
     hipLaunchKernelGGL((grt_geo_kernel<1, 0, true, false, true>), g, b, 0, s, *cam, rays, rr, live, nlive_dev, nrays, steps, ray_stride, field_stride, nfields, tfield, t0, raw, todo, todo_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // phi_stream: the azimuth kernels run there, after this stream's image-only kernel (ev_geo), and record ev_phi when done -- the
-    // caller's transfer kernel does not read phi and starts beside them
-    hipStream_t ps = phi_stream ? phi_stream : s;
-    if (phi_stream) {
-      if ((e = hipEventRecord(ev_geo, s)) != hipSuccess) return e;
-      if ((e = hipStreamWaitEvent(phi_stream, ev_geo, 0)) != hipSuccess) return e;
-    }
-    e = grt_launch_phi(ps, cam, rays, rrays, nrays, todo, todo_count, steps, ray_stride, field_stride);
+    // (r05e ran the azimuth kernels on a third stream beside the transfer kernel: no gain, tools/experiments/r05_phi_beside.patch)
+    e = grt_launch_phi(s, cam, rays, rrays, nrays, todo, todo_count, steps, ray_stride, field_stride);
     if (e != hipSuccess) return e;
     note_launch("grt_geo_kernelILi1ELi2ELb0ELb1ELb0EE");
-    hipLaunchKernelGGL((grt_geo_kernel<1, 2, false, true>), dim3(nblk > 2048u ? 2048u : nblk), b, 0, ps, *cam, rays, rr, (const int *)todo, (const int *)todo_count, nrays, steps,
+    hipLaunchKernelGGL((grt_geo_kernel<1, 2, false, true>), dim3(nblk > 2048u ? 2048u : nblk), b, 0, s, *cam, rays, rr, (const int *)todo, (const int *)todo_count, nrays, steps,
                        ray_stride, field_stride, nfields, tfield, t0, raw, (int *)nullptr, (int *)nullptr);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (phi_stream) return hipEventRecord(ev_phi, phi_stream);
-    return hipSuccess;
+    return hipGetLastError();
   }
   bool launched = false;
 #define GRT_GEO_CASE(F, P)                                                                                              \

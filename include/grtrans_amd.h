@@ -255,8 +255,17 @@ int grt_set_record_steps(int enable);
  * image-only geodesic kernel with GEOPHITIME's phi (geokerr_wrapper.f:1648-2357) taken in line -- a Hermite sum over Mino time for the
  * u side, the theta series for the mu side (r05m; r05a-l: a second kernel, grt_phi_kernel, which still serves the plunging rays);
  * 0: the fused record-mode kernel with Carlson's forms (kept as the A/B reference: the two must agree to rounding).
- * Slow-light traces (coordinate time wanted) and the other ray classes are fused either way. */
+ * Slow-light traces (coordinate time wanted) and the other ray classes are fused either way.
+ * GRT_E_NOTINIT before grt_init; GRT_GEO_SPLIT=0|1 in the environment (A/B runs) fixes the mode for the process and the call is a no-op. */
 int grt_set_geo_split(int enable);
+/* How the two ray classes of a pass (fast: closed forms; generic: the reference-literal GEOKERR path -- a fraction of a per cent of the rays)
+ * reach the transfer kernel.  0: one transfer launch per class on two streams (the generic class's walk hides under the fast class's
+ * geodesics: right for a whole image); 1: ONE launch over both classes behind both geodesic kernels (right for a rank's share of a
+ * multi-GPU image, where a second launch's few waves slow the single resident round of the first: DESIGN 7); -1 (default): by pass
+ * size (merged up to 400,000 rays).  Results are bit-identical either way (tests/test_gpu_parity.py).  No reference counterpart: the
+ * reference's pixel loop is one OpenMP loop over all rays (pgrtrans.f90:196-212).
+ * GRT_E_NOTINIT before grt_init, GRT_E_BADARG outside -1..1; GRT_CLASS_MERGE=0|1 in the environment fixes the mode for the process. */
+int grt_set_class_merge(int mode);
 int grt_download_steps(int64_t ray0, int64_t nrays, int maxpts, double *out);
 
 /* replaces the debug=1 dump of grtrans_driver (grtrans_driver.f90:94-110, 341-421; parser read_geodebug_file.py): the arrays of

@@ -221,6 +221,38 @@ def test_trace_ranges_one_launch_equals_per_range_calls(dev, monkeypatch):
     assert not np.array_equal(a1, a2) and np.array_equal(a3, a2[:, :a3.shape[1]])
 
 
+def test_merged_and_per_class_transfer_launches_are_bit_identical(dev):
+    # r06 (grt_set_class_merge): a pass of at most 400,000 rays -- a rank's share of a multi-GPU image, and every camera of this
+    # suite -- walks both ray classes in ONE transfer launch (fast class from the front of live[], generic class from its back); a whole
+    # image keeps one launch per class on two streams.  Same kernel, same per-lane arithmetic: image, status, ray-steps and the per-step
+    # record must be the same bits either way.  (The differential-compilation sweep also runs its second object with GRT_CLASS_MERGE=0.)
+    from grtrans_amd import capi, tiling
+    em = capi.make_emis("POLSYNCHPL", 3.4e9, 2.0, 70.0, 100., 1e5, 3.5)
+    cases = []
+    cam = capi.make_camera(1, (-40., 20., -20., 40.), (48, 40, 120), 0.998, 0.906, 0.01, -0.5)      # the headline camera: generic rays around alpha = 0
+    cases.append((cam, [(1, 48 * 40)], "FFJET", em, [FREQ], "formal", True))
+    cases.append((cam, tiling.ranges(1, 3, 7, 48 * 40 - 5, 40, 3), "FFJET", em, [2.3e11, FREQ, 9e11], "delo", False))
+    cam0 = capi.make_camera(1, (-12., 12., -12., 12.), (40, 40, 100), 0.0, 0.5, 0.02, -0.5)          # Schwarzschild: cubic class + generic class
+    cases.append((cam0, [(1, 1600)], "FFJET", em, [FREQ], "formal", True))
+    camp = capi.make_camera(1, (-6., 6., -6., 6.), (40, 40, 100), 0.9, 0.999, 0.02, -0.5)            # nearly pole-on: many near-polar (generic) rays
+    cases.append((camp, [(1, 1600)], "FFJET", em, [FREQ], "delo", True))
+    try:
+        for cam_, rng, fname, em_, freqs, iname, rec in cases:
+            got = []
+            for mode in (0, 1, -1):
+                capi.class_merge(mode)
+                capi.record_steps(rec)
+                pix, _, status, st = capi.trace_ranges(cam_, rng, fname, em_, freqs, iname)
+                r = capi.download_steps(0, min(len(status), 512), cam_.nup + cam_.next) if rec else None
+                got.append((pix, status, st.ray_steps, r))
+            for g in got[1:]:
+                assert np.array_equal(g[0], got[0][0], equal_nan=True) and np.array_equal(g[1], got[0][1]) and g[2] == got[0][2]
+                if rec:
+                    assert np.array_equal(g[3], got[0][3], equal_nan=True)
+    finally:
+        capi.class_merge(-1); capi.record_steps(False)
+
+
 def test_multi_frequency_matches_single(dev):
     nn = (24, 24, 100)
     freqs = [2.3e11, 3.45e11, 6.9e11]
@@ -962,9 +994,11 @@ def test_differential_compilation_same_inputs_through_two_code_objects(tmp_path)
     for tag, lib in (("product", None), ("diff", diff)):
         env = dict(os.environ)
         env.pop("GRTRANS_AMD_LIB", None)
+        env.pop("GRT_CLASS_MERGE", None)
         if lib:
             env["GRTRANS_AMD_LIB"] = lib
             env.pop("GRT_LOG_LAUNCHES", None)      # (the other object's instantiations are not the product's: not for the coverage log)
+            env["GRT_CLASS_MERGE"] = "0"           # r06: ... and the other launch form -- one transfer launch per ray class where the product merges them for cameras this small
         o = str(tmp_path / (tag + ".npz"))
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diff_sweep.py"), o, "600", "20261003"], check=True, env=env, timeout=1500)
         outs.append(np.load(o, allow_pickle=False))
