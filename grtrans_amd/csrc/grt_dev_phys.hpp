@@ -103,6 +103,30 @@ GRT_HD Metric blmetric_cov_sc(double r, double sth, double cth, double a) {
 }
 GRT_HD Metric blmetric_cov(double r, double th, double a) { return blmetric_cov_sc(r, sin(th), cos(th), a); }
 
+// r06: REAL(4) quotients through a SHARED fp64 reciprocal.  hipcc's IEEE fp32 division is div_scale x2, v_rcp_f32, five fma, div_fmas, div_fixup
+// (~52 SIMD cycles) and the REAL(4) metric + LNRF transform of a step take eleven of them over six different denominators.  The REAL(4) quotient
+// of two REAL(4) numbers is the fp32 rounding of ANY fp64 approximation good to 2^-50: a / b cannot lie closer than 2^-49 (relative) to a midpoint
+// of two fp32 numbers (|A 2^24 - N B| >= 1 for 24-bit integers A, B and an odd N), and (double)a * frcp((double)b) is good to 2^-51.4.  One
+// reciprocal per denominator (~28 cycles), three instructions per quotient.  Bit-equal to the division on 3.6e6 random ordinary operand pairs and
+// on 0 / x, x / 0, x / inf (tools/experiments/seed_accuracy.hip: `_s` keeps the hardware's 1/0 = inf, 1/inf = 0); the islands stay bit-identical
+// to the host's (tests/fp32_island_check.hip, which now also holds f32_div itself to '/').  The host build divides.
+struct F32Rcp {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_F32_DIV_VIA_F64)
+  double r;
+#else
+  float b;
+#endif
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_NO_F32_DIV_VIA_F64)
+GRT_HD F32Rcp f32_rcp(float b) { F32Rcp R; R.r = frcp_s((double)b); return R; }            // any denominator (0 and inf as the division has them)
+GRT_HD F32Rcp f32_rcp_pos(float b) { F32Rcp R; R.r = frcp((double)b); return R; }          // a denominator that is an ordinary positive number
+GRT_HD float f32_div(float a, const F32Rcp &R) { return (float)((double)a * R.r); }
+#else
+GRT_HD F32Rcp f32_rcp(float b) { F32Rcp R; R.b = b; return R; }
+GRT_HD F32Rcp f32_rcp_pos(float b) { F32Rcp R; R.b = b; return R; }
+GRT_HD float f32_div(float a, const F32Rcp &R) { return a / R.b; }
+#endif
+
 // single-precision metric, promoted to double slots (blmetric_cov_real + assign_metric_real)
 GRT_HD Metric blmetric_cov_real(float r, float th, float a, const F32Trig *ft = nullptr) {
   GRT_NO_CONTRACT
@@ -113,11 +137,12 @@ GRT_HD Metric blmetric_cov_real(float r, float th, float a, const F32Trig *ft = 
   float rho2 = r * r + a * a * cth * cth;
   float t = r * r + a * a;
   float sigma = t * t - a * a * delta * sth * sth;
-  m.g[0] = (double)(-(delta - a * a * sth * sth) / rho2);
-  m.g[3] = (double)(-2.f * a * r * sth * sth / rho2);
-  m.g[4] = (double)(rho2 / delta);
+  const F32Rcp irho2 = f32_rcp(rho2), idelta = f32_rcp(delta);      // (rho2 = 0 on the ring singularity only; delta = 0 on the horizon)
+  m.g[0] = (double)f32_div(-(delta - a * a * sth * sth), irho2);
+  m.g[3] = (double)f32_div(-2.f * a * r * sth * sth, irho2);
+  m.g[4] = (double)f32_div(rho2, idelta);
   m.g[7] = (double)rho2;
-  m.g[9] = (double)(sigma / rho2 * sth * sth);
+  m.g[9] = (double)(f32_div(sigma, irho2) * sth * sth);
   return m;
 }
 
@@ -160,14 +185,15 @@ GRT_HD void lnrf_frame_inv_real(float vr, float vt, float omega, float r, float 
   float t = r * r + a * a;
   float AR = t * t - a * a * D * (1.f - mu * mu);
   float RHO = r * r + a * a * mu * mu;
-  float ENU = sqrt(D * RHO / AR);
-  float EMU1 = sqrt(RHO / D);
+  const F32Rcp iAR = f32_rcp(AR), iD = f32_rcp(D), iRHO = f32_rcp(RHO);      // (D and RHO: the metric's delta and rho2, same bits)
+  float ENU = sqrt(f32_div(D * RHO, iAR));
+  float EMU1 = sqrt(f32_div(RHO, iD));
   float EMU2 = sqrt(RHO);
-  float EPSI = sqrt(1.f - mu * mu) * sqrt(AR / RHO);
-  float OM = 2.f * a * r / AR;
-  vrl = ENU / EMU1 * vr;
-  vtl = ENU / EMU2 * vt;
-  vpl = ENU / EPSI * omega + OM;
+  float EPSI = sqrt(1.f - mu * mu) * sqrt(f32_div(AR, iRHO));
+  float OM = f32_div(2.f * a * r, iAR);
+  vrl = f32_div(ENU, f32_rcp(EMU1)) * vr;
+  vtl = f32_div(ENU, f32_rcp(EMU2)) * vt;
+  vpl = f32_div(ENU, f32_rcp(EPSI)) * omega + OM;
   if (!(D > 0.f)) { vrl = 0.f; vtl = 0.f; vpl = 0.f; }
 }
 
@@ -196,7 +222,8 @@ GRT_HD void transport_perpk(const double *k, double r, double sth, double cth, d
 template <bool WANT_ANG = true>
 GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double alpha, double beta, double mus, const double *u,
                            const double *b, const double *k, double &s2xi, double &c2xi, double &ang, double &g, double *cang = nullptr,
-                           double *dbg15 = nullptr /* debug=1: aahat(3), aa(4), khat(4), bhat(4) of comoving_ortho_debug, kerr.f90:564-584 */) {
+                           double *dbg15 = nullptr /* debug=1: aahat(3), aa(4), khat(4), bhat(4) of comoving_ortho_debug, kerr.f90:564-584 */,
+                           double *ginv = nullptr /* r06: 1/g = the tetrad's k^t itself -- g is formed as its reciprocal, and the step used to invert it back */) {
   Metric m = blmetric_cov_sc(r, sth, cth, a);
   double gtt = m.g[0], gtp = m.g[3], grr = m.g[4], gmm = m.g[7], gpp = m.g[9];
   double ut = u[0], ur = u[1], um = u[2], up = u[3];
@@ -251,6 +278,7 @@ GRT_NI void comoving_ortho(double r, double sth, double cth, double a, double al
   ang = WANT_ANG ? acos(t) : 0.0;
   if (cang) *cang = t;
   g = ikt;
+  if (ginv) *ginv = khatt;
   if (dbg15) {
     dbg15[0] = aahat1; dbg15[1] = aahat2; dbg15[2] = aahat3;
     dbg15[3] = aa[0]; dbg15[4] = aa[1]; dbg15[5] = aa[2]; dbg15[6] = aa[3];
@@ -405,30 +433,33 @@ struct PLPoint { double itanth, nubperp, lnub, A, kperp, omega0; };
 
 // plain: SYNCHPL (synchpl, polsynchemis.f90:657) forms nu_B,perp with sin(th) itself, POLSYNCHPL with sin(th) + 1e-10
 // (s0, c0) = sin, cos of the angle between field and wave vector
-GRT_HD void polsynchpl_point_sc(const GrtPLConst &C, double nnth, double B, double s0, double c0, PLPoint &P, bool plain = false) {
+// gmul (r06): the redshift factor g of the point.  The frequency loop needs log x = log(nu_B,perp / nu) with nu = nu_obs / g: lnub carries
+// log(nu_B,perp g) -- ONE logarithm a point where log nu_B,perp and log g were two -- and polsynchpl_freq is handed log nu_obs.
+GRT_HD void polsynchpl_point_sc(const GrtPLConst &C, double nnth, double B, double s0, double c0, PLPoint &P, bool plain = false, double gmul = 1.0) {
   const double nufloor = 1e-10, thsafe = 1e-10;
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
   double tanth = fdiv(s0, c0) + fsign(1.0, c0) * thsafe;
   P.itanth = frcp(tanth);
   double sinth = s0 + (plain ? 0.0 : thsafe);
   P.nubperp = B * (ec / m / c / 2.0 / pi) * sinth + nufloor;      // (the constant is folded: no IEEE division per step)
-  P.lnub = log(P.nubperp);
+  P.lnub = flog(P.nubperp * gmul);
   P.A = C.A0 * nnth;
   P.kperp = P.A * (ec * ec / m / c) * frcp(P.nubperp);
   P.omega0 = P.nubperp * 2.0 * pi;
 }
 
-GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P, bool plain = false) {
+GRT_HD void polsynchpl_point(const GrtPLConst &C, double nnth, double B, double th, PLPoint &P, bool plain = false, double gmul = 1.0) {
   double s0, c0;
 #if defined(__HIP_DEVICE_COMPILE__)
   sincos(th, &s0, &c0);
 #else
   s0 = sin(th); c0 = cos(th);
 #endif
-  polsynchpl_point_sc(C, nnth, B, s0, c0, P, plain);
+  polsynchpl_point_sc(C, nnth, B, s0, c0, P, plain, gmul);
 }
 
-// lnu = log(nu): log x = log(nub/nu) = lnub - lnu, so a frequency costs exponentials only
+// lnu = log(nu) -- or log(nu_obs) when P.lnub carries the redshift factor (polsynchpl_point_sc: gmul): log x = log(nub/nu) = lnub - lnu, so a
+// frequency costs exponentials only
 GRT_HD void polsynchpl_freq(const GrtTables &T, const GrtPLConst &C, const PLPoint &P, double nu, double lnu, double *e) {
   const double ec = PH_e, m = PH_m, c = PH_c, pi = PH_pi;
   const double l15 = 0.4054651081081644;                   // log(1.5)

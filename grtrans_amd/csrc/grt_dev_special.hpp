@@ -18,22 +18,23 @@ GRT_HD double sq(double x) { return x * x; }
 // Per-point division / square root.  hipcc expands an fp64 '/' or sqrt() into the IEEE-exact sequence
 // (div_scale, rcp, 5 fma, div_fmas, div_fixup: ~12 instructions; sqrt ~17 with its denormal scaling);
 // the per-point code needs neither denormal nor overflow handling (all operands are O(1e-30..1e30)),
-// so it uses the seed instruction plus Newton/Goldschmidt refinement: <= 1 ulp, 6-9 instructions.
+// so it uses the seed instruction plus one refinement step: <= 1 ulp (1.24 for the reciprocal root), 4-8 instructions.
 // Once-per-ray code keeps the exact forms.  The host build (tests/hostsim) maps them to '/' and sqrt.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GRT_IEEE_DIVSQRT)
+// r06: the seeds are good to 2^-24.4 (v_rcp_f64) / 2^-24.2 (v_rsq_f64) -- measured, tools/experiments/seed_accuracy.hip -- so ONE third-order
+// step (r (1 + e + e^2), y (1 + e/2 + 3 e^2/8): error e^3 = 2^-73) reaches what two Newton steps did (1.00 / 1.24 ulp at worst over 4e6
+// arguments, the same as before) with 3 instead of 4 and 5 instead of 8 fp64 instructions; the square root's second Goldschmidt
+// correction changed nothing in 4e6 trials (correctly rounded with one) and is gone.  fp64 instructions are what the kernels' time is
+// made of (4 SIMD cycles each, the seed 16: tools/experiments/dp_rate_bench.hip).
 GRT_HD double frcp(double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  return r;
+  const double r = __builtin_amdgcn_rcp(b), e = fma(-b, r, 1.0);
+  return fma(r, fma(e, e, e), r);
 }
-// frcp for arguments that may be 0 or infinite: the Newton steps turn the hardware's correct 1/0 = inf, 1/inf = 0 into NaN
+// frcp for arguments that may be 0 or infinite: the refinement turns the hardware's correct 1/0 = inf, 1/inf = 0 into NaN
 // (0 x inf inside the residual), so the seed is kept when the residual is not a number
 GRT_HD double frcp_s(double b) {
-  const double r = __builtin_amdgcn_rcp(b);
-  const double r1 = fma(fma(-b, r, 1.0), r, r);
-  const double e = fma(-b, r1, 1.0);
-  return (fabs(e) <= 1.0) ? fma(e, r1, r1) : r;
+  const double r = __builtin_amdgcn_rcp(b), e = fma(-b, r, 1.0);
+  return (fabs(e) <= 1.0) ? fma(r, fma(e, e, e), r) : r;
 }
 GRT_HD double fdiv(double a, double b) {
   double r = frcp(b), q = a * r;
@@ -45,7 +46,6 @@ GRT_HD double fsqrt(double x) {
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);
-  g = fma(fma(-g, g, x), h, g);
   return (x == 0.0) ? 0.0 : g;
 }
 // fsqrt for arguments that are never zero (sums of squares plus one, reciprocals of positive means, the radicands of a segment
@@ -56,18 +56,13 @@ GRT_HD double fsqrt_nz(double x) {
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);
-  g = fma(fma(-g, g, x), h, g);
   return g;
 }
-// 1 / sqrt(x) from the hardware's reciprocal square root and two Newton steps (<= 1 ulp): 9 instructions where frcp(fsqrt(x)) is 18 --
+// 1 / sqrt(x) from the hardware's reciprocal square root and one third-order step (<= 1.24 ulp): 6 instructions where frcp(fsqrt(x)) is 12 --
 // the comoving tetrad normalises five vectors per step (r05)
 GRT_HD double frsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = fma(-(x * y), y, 1.0);
-  y = fma(0.5 * y, e, y);
-  e = fma(-(x * y), y, 1.0);
-  y = fma(0.5 * y, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x), e = fma(-(x * y), y, 1.0);
+  return fma(y, e * fma(e, 0.375, 0.5), y);
 }
 #else
 GRT_HD double frsqrt(double x) { return 1.0 / sqrt(x); }
@@ -95,6 +90,34 @@ GRT_HD double fexp(double x) {
   p = fma(t, p, 1.0);
   p = fma(t, p, 1.0);
   return ldexp(p, (int)dn);
+}
+// log for arguments that are ordinary positive numbers (normal, finite; anything else is NOT handled: no NaN / zero / subnormal paths).
+// r06: the library's log is a double-double evaluation -- 74 fp64 instructions and a reciprocal, ~370 SIMD cycles -- and the power-law
+// step took two of them (log nu_B,perp and log g: 8.6 % of grt_transfer_kernel<2,13,4,1,false,2>).  x = 2^e m with m in [sqrt(1/2), sqrt 2),
+// s = (m - 1)/(m + 1), log m = 2 s + 2 s z (1/3 + z/5 + ... + z^9/21), z = s^2 <= 0.0295 (truncation 6e-19 of log m); e ln2 in two parts.
+// 20 fp64 instructions and frcp (~140 cycles).  Against an 80-bit log over 1e-300 ... 1e300 and around 1: <= 2.4 ulp, i.e. 4e-16 relative
+// (where e ln2 and log m cancel by a factor of two; correcting the quotient s brings 2.0) -- log x feeds exponentials and table positions
+// (tests/test_hostsim_fast.py::test_flog...).
+GRT_HD double flog(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double m = __builtin_amdgcn_frexp_mant(x);
+  int e = __builtin_amdgcn_frexp_exp(x);
+#else
+  int e;
+  double m = frexp(x, &e);
+#endif
+  const bool lo = m < 0.70710678118654752;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0, r = frcp(m + 1.0);
+  const double s = f * r, z = s * s;
+  double p = 2.0 / 21.0;
+  p = fma(z, p, 2.0 / 19.0); p = fma(z, p, 2.0 / 17.0); p = fma(z, p, 2.0 / 15.0); p = fma(z, p, 2.0 / 13.0); p = fma(z, p, 2.0 / 11.0);
+  p = fma(z, p, 2.0 / 9.0); p = fma(z, p, 2.0 / 7.0); p = fma(z, p, 2.0 / 5.0); p = fma(z, p, 2.0 / 3.0);
+  const double lm = fma(s * z, p, s + s);
+  const double de = (double)e;
+  // ln2 = hi + lo, hi with 32 trailing zero bits: e hi is exact for |e| < 2^11
+  return fma(de, 0x1.62e42fee00000p-1, fma(de, 0x1.a39ef35793c76p-33, lm));
 }
 GRT_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
 GRT_HD double powm1(int n) { return (n & 1) ? -1.0 : 1.0; }

@@ -1031,13 +1031,13 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
         FluidPoint fl;
         const F32Trig ftv = f32_trig(th, sth, cth);
         ffjet_sample(fd.fj, r, th, (float)cam_a, fl, &ftv);
-        double s2xi, c2xi, ang, g, cang;
-        comoving_ortho<false>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
+        double s2xi, c2xi, ang, g, cang, ginv;
+        comoving_ortho<false>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang, nullptr, &ginv);
         const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
         const double ncgsnth = (double)fl.rho * emk.nfac, bcgs = (double)fl.bmag * emk.bfac;
         PLPoint plp;
-        polsynchpl_point_sc(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, fsqrt((1.0 - cang) * (1.0 + cang)), cang, plp, false);
-        const double cur[10] = {plp.itanth, plp.nubperp, plp.lnub, plp.A, g, log(g), s2xi, c2xi, lam_i - lam_prev, valid ? (lam_1 - lam_i) : 0.0};
+        polsynchpl_point_sc(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, fsqrt((1.0 - cang) * (1.0 + cang)), cang, plp, false, g);
+        const double cur[10] = {plp.itanth, plp.nubperp, plp.lnub, plp.A, g, ginv /* (r06: 1/g = k^t of the tetrad; log g rides in lnub) */, s2xi, c2xi, lam_i - lam_prev, valid ? (lam_1 - lam_i) : 0.0};
         const int curf = (valid ? 1 : 0) | ((valid && (ip + 1 < n)) ? 2 : 0);
 #pragma unroll
         for (int k2 = 0; k2 < TS; ++k2)
@@ -1078,12 +1078,12 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
             plp.itanth = cur[0]; plp.nubperp = cur[1]; plp.lnub = cur[2]; plp.A = cur[3];
             plp.kperp = plp.A * (PH_e * PH_e / PH_m / PH_c) * frcp(plp.nubperp);      // (as polsynchpl_point_sc forms them)
             plp.omega0 = plp.nubperp * 2.0 * PH_pi;
-            const double g = cur[4], lg = cur[5], s2xi = cur[6], c2xi = cur[7], dx = cur[8];
-            const double igs = frcp(g);
+            const double g = cur[4], s2xi = cur[6], c2xi = cur[7], dx = cur[8];
+            const double igs = cur[5];
             GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
             plck.iy = 0;
             double e11[11];
-            polsynchpl_freq(tbl, plck, plp, fr * igs, lfr - lg, e11);
+            polsynchpl_freq(tbl, plck, plp, fr * igs, lfr, e11);
             facl += valid ? e11[0] * cur[9] : 0.0;
 #pragma unroll
             for (int c = 0; c < 7; ++c)
@@ -1180,10 +1180,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
       if (FLUID == GRT_FLUID_KORAL3D)
         koral3d_sample(fd.h3, s_harm, r, th, valid ? phi_i : 0.0, (float)cam_a, fl, kela,                                  // kela carries Be
                        slowlight ? slice_time_index(fd.h3.nt, fd.h3.tstep, r, t_i, r_1, (float)cam_a) : 0, ft);
-      double s2xi, c2xi, ang, g, cang;
+      double s2xi, c2xi, ang, g, cang, igs;      // (igs = 1/g: the tetrad's k^t, r06)
       // the power-law emissivity takes sin and cos of the field / wave-vector angle, not the angle: no acos + sincos pair per step
       constexpr bool WANT_ANG = EXTRA || !((EMIS == GRT_EMIS_POLSYNCHPL && FLUID == GRT_FLUID_FFJET) || EMIS == GRT_EMIS_POLSYNCHTH || EMIS == GRT_EMIS_POLSYNCHSYMTH);
-      comoving_ortho<WANT_ANG>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang);
+      comoving_ortho<WANT_ANG>(r, sth, cth, cam_a, alpha, beta, karg_load<double>(karg_fresh(), offsetof(XferKargHead, cam) + offsetof(GrtCam, mu0)), fl.u, fl.b, kv, s2xi, c2xi, ang, g, &cang, nullptr, &igs);
       // convert_fluidvars_* (fluid.f90:1164-1172 FFJET, :1249-1259 SPHACC, :957-973 HARM)
       double ncgs = 0.0, ncgsnth = 0.0, bcgs = 0.0, tcgs = 0.0;
       const GrtEmis emk = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em));
@@ -1196,11 +1196,10 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
       PLPoint plp;
       if (!WANT_ANG && EMIS == GRT_EMIS_POLSYNCHPL)
         polsynchpl_point_sc(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, fsqrt((1.0 - cang) * (1.0 + cang)), cang, plp,
-                            IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
+                            IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL, g);
       else if (EMIS == GRT_EMIS_POLSYNCHPL || EMIS == GRT_EMIS_HYBRIDTHPL)
         polsynchpl_point(karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), ncgsnth, bcgs, ang, plp,
-                         IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL);
-      const double lg = log(g), igs = frcp(g);      // (1/g once per step: the frequency loop divides by g twice per frequency)
+                         IFLAG == GRT_INT_QUAD && EMIS == GRT_EMIS_POLSYNCHPL && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL, g);
       const double dx = lam_i - lam_prev;                  // x(k) - x(k+1) > 0: the previous trip was point k+1
       const bool step = valid && (k < n);
       double xJK[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // EXTRA: j_I and K(1:7) of the first frequency after rotate/invariant/cgs
@@ -1216,7 +1215,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
           if (EMIS == GRT_EMIS_POLSYNCHPL) {
             GrtPLConst plck = karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc));
             if (PL_LDS) plck.iy = 0;                       // the LDS copy holds the p-bin's row only
-            polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f] - lg, e11);
+            polsynchpl_freq(tbl, plck, plp, nu, lfreqs[f0 + f], e11);
             // SYNCHPL (nvals = 1; same instantiation): j_I with the REAL(4) sqrt(3.) of polsynchemis.f90:665
             if (IFLAG == GRT_INT_QUAD && karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type == GRT_EMIS_SYNCHPL)
               e11[0] *= (double)1.7320508075688772f / 1.7320508075688772;
@@ -1241,7 +1240,7 @@ __global__ __launch_bounds__(GRT_XFER_THREADS, GRT_XFER_OCC(TSH, FB, EMIS, FLUID
             // the table rows at two blocks per CU, so the power-law tables are read through the scalar/L1 path here.
             double epl[11];
             polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
-            polsynchpl_freq(tb, karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), plp, nu, lfreqs[f0 + f] - lg, epl);
+            polsynchpl_freq(tb, karg_load<GrtPLConst>(karg_fresh(), offsetof(XferKargHead, plc)), plp, nu, lfreqs[f0 + f], epl);
             const int etype = karg_load<GrtEmis>(karg_fresh(), offsetof(XferKargHead, em)).type;
 #pragma unroll
             for (int c = 0; c < 4; ++c) e11[c] = (etype == GRT_EMIS_HYBRIDTHPL) ? e11[c] + epl[c] : (etype == GRT_EMIS_HYBRIDTH ? e11[c] : epl[c]);
@@ -1466,8 +1465,8 @@ __global__ __launch_bounds__(64, GRT_OCC(2)) void grt_debug_kernel(GrtCam cam, c
     double e11[11];
     if (EMIS == GRT_EMIS_POLSYNCHPL) {
       PLPoint plp;
-      polsynchpl_point(plc, ncgsnth, bcgs, ang, plp);
-      polsynchpl_freq(tb, plc, plp, nu, log(freq) - log(g), e11);
+      polsynchpl_point(plc, ncgsnth, bcgs, ang, plp, false, g);      // (as the transfer kernel forms it: log g inside lnub)
+      polsynchpl_freq(tb, plc, plp, nu, log(freq), e11);
     } else {
       polsynchth_fast(nu, ncgs, bcgs, tcgs, ang, e11);
     }

@@ -587,6 +587,7 @@ void hs_delo_step_via_map(const double *j0, const double *K0, const double *j1, 
   for (int i = 0; i < 4; ++i) Iout[i] = M.A[i][0] * Iin[0] + M.A[i][1] * Iin[1] + M.A[i][2] * Iin[2] + M.A[i][3] * Iin[3] + M.b[i];
 }
 void hs_polsynchpl(double nu, double nnth, double B, double th, double *e11) { polsynchpl_fast(g_T, g_plc, nu, nnth, B, th, e11); }
+double hs_flog(double x) { return flog(x); }      // the lean log of the power-law step (grt_dev_special.hpp, r06)
 double hs_fexp(double x) { return fexp(x); }      // the lean exp of the power-law coefficients and the transfer steps (grt_dev_special.hpp)
 void hs_formal_step(const double *j4, const double *K7, double dx, const double *Iin, double *Iout) {
   // the form the transfer kernel runs: O applied to j dx + I without forming O (grt_dev_phys.hpp:formal_apply)

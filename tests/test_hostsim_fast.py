@@ -459,6 +459,24 @@ def test_fexp_is_exp_to_one_ulp_and_saturates_like_it(L):
     assert np.isnan(L.hs_fexp(float("nan")))
 
 
+def test_flog_is_log_to_two_and_a_half_ulp(L):
+    # grt_dev_special.hpp:flog (r06) -- the library log is a double-double evaluation (~370 SIMD cycles) and the power-law step took two of
+    # them; flog = frexp + atanh series + one reciprocal, for ordinary positive numbers only.  Against an 80-bit log over the whole
+    # exponent range, around 1 (where log loses its leading digits) and on the octave boundaries the reduction switches at.
+    L.hs_flog.restype = C.c_double
+    L.hs_flog.argtypes = [C.c_double]
+    rng = np.random.default_rng(12)
+    xs = np.concatenate([10.0 ** rng.uniform(-300.0, 300.0, 40000), 10.0 ** rng.uniform(-3.0, 14.0, 40000), 1.0 + rng.uniform(-0.3, 0.45, 20000),
+                         1.0 + rng.uniform(-1e-6, 1e-6, 5000), np.sqrt(0.5) * (1.0 + rng.uniform(-1e-12, 1e-12, 2000)), [1.0, 2.0, 0.5, 1.5, 1e-300, 1e300]])
+    got = np.array([L.hs_flog(float(x)) for x in xs])
+    want = np.log(xs.astype(np.longdouble))
+    ulp = np.spacing(np.abs(want.astype(np.float64)))
+    ulp[want == 0] = 5e-324
+    err = np.abs(got.astype(np.longdouble) - want) / ulp
+    assert float(err.max()) <= 2.5, float(err.max())
+    assert L.hs_flog(1.0) == 0.0
+
+
 def test_power_law_emissivity_follows_the_reference_across_its_own_discontinuity(L):
     # r04, fuzz seed 2718 camera 620 (FFJET POLSYNCHPL, p = 5.5, 345 GHz): the reference's j_I jumps by 1.8 % across one node of its G(x) table
     # lookup while alpha_I is continuous (polsynchemis.f90:62-92, 608-629 as the oracle restates them), and one point of a ray sat 3e-8 (relative, in
