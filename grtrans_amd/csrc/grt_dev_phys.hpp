@@ -519,7 +519,7 @@ GRT_HD double besseli0(double x) {
   double ax = fabs(x);
   if (ax < 3.75) return poly(sq(x * (1.0 / 3.750)), p, 7);
   const double iax = frcp(ax), y = 3.750 * iax;
-  return (exp(ax) * fsqrt(iax)) * poly(y, q, 9);
+  return (fexp(ax) * fsqrt(iax)) * poly(y, q, 9);
 }
 GRT_HD double besseli1(double x) {
   const double p[7] = {0.50, 0.878905940, 0.514988690, 0.150849340, 0.2658733e-10, 0.301532e-20, 0.32411e-30};
@@ -527,23 +527,24 @@ GRT_HD double besseli1(double x) {
                               0.2282967e-10, -0.2895312e-10, 0.1787654e-10, -0.420059e-20};
   double ax = fabs(x), r;
   if (ax < 3.75) r = ax * poly(sq(x * (1.0 / 3.750)), p, 7);
-  else { const double iax = frcp(ax), y = 3.750 * iax; r = (exp(ax) * fsqrt(iax)) * poly(y, q, 9); }
+  else { const double iax = frcp(ax), y = 3.750 * iax; r = (fexp(ax) * fsqrt(iax)) * poly(y, q, 9); }
   if (x < 0.0) r = -r;
   return r;
 }
 GRT_HD double besselk0(double x) {
   const double p[7] = {-0.57721566, 0.42278420, 0.23069756, 0.3488590e-1, 0.262698e-2, 0.10750e-3, 0.74e-5};
   const double q[7] = {1.25331414, -0.7832358e-1, 0.2189568e-1, -0.1062446e-1, 0.587872e-2, -0.251540e-2, 0.53208e-3};
-  if (x <= 2.0) { double y = x * x / 4.0; return (-log(x / 2.0) * besseli0(x)) + poly(y, p, 7); }
+  // (r06: flog / fexp -- the argument is 1/theta_e of a warm plasma, an ordinary positive number; NaN propagates through both)
+  if (x <= 2.0) { double y = x * x / 4.0; return (-flog(x / 2.0) * besseli0(x)) + poly(y, p, 7); }
   const double ix = frcp(x), y = 2.0 * ix;
-  return (exp(-x) * fsqrt(ix)) * poly(y, q, 7);
+  return (fexp(-x) * fsqrt(ix)) * poly(y, q, 7);
 }
 GRT_HD double besselk1(double x) {
   const double p[7] = {1.0, 0.15443144, -0.67278579, -0.18156897, -0.1919402e-1, -0.110404e-2, -0.4686e-4};
   const double q[7] = {1.25331414, 0.23498619, -0.3655620e-1, 0.1504268e-1, -0.780353e-2, 0.325614e-2, -0.68245e-3};
-  if (x <= 2.0) { double y = x * x / 4.0; return (log(x / 2.0) * besseli1(x)) + frcp(x) * poly(y, p, 7); }
+  if (x <= 2.0) { double y = x * x / 4.0; return (flog(x / 2.0) * besseli1(x)) + frcp(x) * poly(y, p, 7); }
   const double ix = frcp(x), y = 2.0 * ix;
-  return (exp(-x) * fsqrt(ix)) * poly(y, q, 7);
+  return (fexp(-x) * fsqrt(ix)) * poly(y, q, 7);
 }
 GRT_HD double besselk(int n, double x) {
   double tox = 2.0 / x, bkm = besselk0(x), bk = besselk1(x);
@@ -555,7 +556,8 @@ GRT_HD double bnu(double T, double nu) {   // polsynchemis.f90:1014
   double b;
   const double xh = nu * (PH_h / PH_k) * frcp_s(T);      // h nu / k T (constants folded: reciprocals, no IEEE division; T = 0 -> inf as before)
   if (xh < 1e-6) b = nu * nu * (2.0 * PH_k / PH_c2) * T;
-  else b = nu * nu * nu * (2.0 * PH_h / PH_c2) * frcp_s(exp(xh) - 1.0);
+  // (r06: fexp; xh = inf at T = 0 -- the one argument fexp does not take -- gives the same exp = inf capped at 800; NaN stays NaN)
+  else b = nu * nu * nu * (2.0 * PH_h / PH_c2) * frcp_s(fexp((xh > 800.0) ? 800.0 : xh) - 1.0);
   if (b == 0) b = 2.220446049250313e-16;   // epsilon(T)
   return b;
 }
@@ -689,7 +691,7 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   const double xm = fdiv(nu, nuc);
   const double x13 = cbrt(xm), x23 = x13 * x13;
   const double i13 = frcp(x13), i23 = i13 * i13, ixm = i23 * i13;
-  const double ex = exp(-1.8899 * x13);
+  const double ex = fexp(-1.8899 * x13);      // (r06: the lean exp / log below -- their arguments are finite; the one that can be zero is guarded)
   const double iix = 2.5651 * (1.0 + 1.92 * i13 + .9977 * i23) * ex;
   const double iqx = 2.5651 * (1.0 + .93193 * i13 + .499873 * i23) * ex;
   const double ivx = (1.81384 * ixm + 3.42319 * i23 + 0.0292545 * frcp(fsqrt(xm)) + 2.03773 * i13) * ex;
@@ -718,8 +720,10 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   const double omega0 = B * (ec / m / c);
   const double x = thetae * fsqrt(1.4142135623730951 * sth * (omega0 * (1e3 / 2.0 / pi)) * frcp(nu));
   // jffunc, shgmfunc (polsynchemis.f90:799-822)
-  const double lx = log(x);
-  const double e472 = exp(x * (-1.0 / 47.2));
+  // (x = 0 -- no field, or a wave vector along it: log x = -inf, and every use below is exp(c log x) with c > 0 = 0 -- takes log(1e-300):
+  //  the same zeros to the last bit, without an infinity for the lean functions; NaN stays NaN)
+  const double lx = flog((x < 1e-300) ? 1e-300 : x);
+  const double e472 = fexp(x * (-1.0 / 47.2));
   // extraterm = (...) (1/2 + 1/2 tanh(10 (ln x - ln 120))) is EXACTLY zero below x = 13: tanh of an argument under -22 is -1.0 in both
   // the device's and glibc's libm, and the bracket is finite (the 1e-16 under the logarithm keeps exp(-8/3 ln x) below 4e42).  At the
   // observing frequencies of the BASELINE configurations x = theta_e sqrt(sqrt2 sin(th) 1e3 nu_B / nu) is of order 1-10, so a wave
@@ -732,10 +736,12 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
 #else
   if (!TSKIP || !(targ < -22.0)) {
 #endif
-    const double lxe = log(x + 1e-16);
-    extraterm = (.011 * e472 - 369.69342869090826 * exp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh(targ));
+    const double lxe = flog(x + 1e-16);
+    extraterm = (.011 * e472 - 369.69342869090826 * fexp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh(targ));
   }
-  const double jff = 2.011 * exp(exp(1.035 * lx) * (-1.0 / 4.7)) - cos(x / 2.0) * exp(exp(1.2 * lx) * (-1.0 / 2.73)) - .011 * e472 + extraterm;
+  double shx, chx;
+  fast_sincos(0.5 * x, &shx, &chx);      // (x is of order 1 ... 1e4: no large-argument path needed)
+  const double jff = 2.011 * fexp(fexp(1.035 * lx) * (-1.0 / 4.7)) - chx * fexp(fexp(1.2 * lx) * (-1.0 / 2.73)) - .011 * e472 + extraterm;
   const double w = 2.0 * pi * nu, iw = frcp(w), iw3 = iw * iw * iw;
   // No DIVERGENT branch on thetae (r03).  The if-else that stood here was where hipcc's register allocator saved two loop-carried
   // accumulators of a transfer kernel under the `then` side's exec mask (tools/check_flow_copies.py).  The branch is now
@@ -751,7 +757,7 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
 #endif
     const double it = frcp(warm ? thetae : 1.0);
     const double k0 = besselk0(it), k1 = besselk1(it), k2 = k0 + 2.0 * thetae * k1, ik2 = frcp(k2);     // besselk(2, 1/thetae)
-    const double shgm = (double)0.43793091f * log(1.0 + (double)0.00185777f * exp((double)1.50316886f * lx));
+    const double shgm = (double)0.43793091f * flog(1.0 + (double)0.00185777f * fexp((double)1.50316886f * lx));
     // (the step function is exactly 1 above theta_e = 2.1 -- tanh(22) = 1.0 in double --: hot zones skip the tanh, wave-uniformly)
     const double sarg = (thetae - 1.0) * 20.0;
     double step = 1.0;

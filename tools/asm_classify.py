@@ -90,8 +90,14 @@ tot = sum(cls.values())
 valu = sum(v for k, v in cls.items() if k not in ("LDS", "VMEM", "SMEM", "wait/nop", "SALU", "other"))
 print("static instructions %d, VALU %d" % (tot, valu))
 for k, v in cls.most_common(): print("  %-16s %6d  %5.1f %%" % (k, v, 100.0 * v / tot))
+# r06: estimated SIMD cycles by the measured cost model (tools/experiments/dp_rate_bench.hip, sgpr_const_bench.hip): an fp64 / fp32 /
+# integer vector instruction 4 cycles, a transcendental seed (v_rcp / v_rsq / v_sqrt / v_exp / v_log, fp64 or fp32) 16, a register move ~2;
+# scalar, memory and wait instructions issue beside the vector pipe
+W = collections.defaultdict(lambda: 4, {"f64 seed": 16, "f32 seed": 16, "mov/select": 3, "LDS": 0, "VMEM": 0, "SMEM": 0, "wait/nop": 0, "SALU": 0, "other": 0})
+cyc = {key: sum(W[k] * n for k, n in wherecls[key].items()) for key in where}
+print("estimated vector-pipe cycles (static): %d" % sum(cyc.values()))
 print("by source %s (top %d):" % (by, top))
 order = ["f64 fma", "f64 mul", "f64 add", "f64 seed", "f64 other", "f32 arith", "f32 packed", "f32 seed", "f32 other", "cvt", "mov/select", "int cmp", "int/addr/logic", "lane ops", "LDS", "VMEM", "SMEM", "SALU", "wait/nop"]
-print("  %-44s %6s | %s" % ("", "all", " ".join("%5s" % o.replace("f64 ", "d.").replace("f32 ", "s.").replace("mov/select", "mov").replace("int/addr/logic", "int").replace("wait/nop", "wait")[:5] for o in order)))
-for key, v in where.most_common(top):
-    print("  %-44s %6d | %s" % (key[:44], v, " ".join("%5d" % wherecls[key][o] for o in order)))
+print("  %-44s %6s %6s | %s" % ("", "cycles", "all", " ".join("%5s" % o.replace("f64 ", "d.").replace("f32 ", "s.").replace("mov/select", "mov").replace("int/addr/logic", "int").replace("wait/nop", "wait")[:5] for o in order)))
+for key, c in sorted(cyc.items(), key=lambda kv: -kv[1])[:top]:
+    print("  %-44s %6d %6d | %s" % (key[:44], c, where[key], " ".join("%5d" % wherecls[key][o] for o in order)))
