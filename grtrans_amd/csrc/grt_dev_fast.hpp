@@ -41,11 +41,13 @@ GRT_HD double rc7(double x, double y) {
     ave = (1.0 / 3.0) * (xt + yt + yt);
     s = yt - ave;
   }
-  const double ia = frcp(ave);
+  // (r06: 1/sqrt(ave) from ONE reciprocal-root seed, 1/ave as its square -- it only scales the small s -- where a reciprocal and a square root
+  //  were two seeds: a seed is 16 SIMD cycles and its refinement 12-28 more)
+  const double ra = frsqrt(ave), ia = ra * ra;
   s = s * ia;
   const double poly = 0.3 + s * (1.0 / 7.0 + s * (0.375 + s * (9.0 / 22.0 + s * (159.0 / 208.0 + s * (9.0 / 8.0 + s * (4275.0 / 2176.0 +
                       s * (985.0 / 304.0 + s * (1449.0 / 256.0 + s * (28875.0 / 2944.0 + s * (445039.0 / 25600.0))))))))));
-  return w * (1.0 + s * s * poly) * fsqrt_nz(ia);
+  return w * (1.0 + s * s * poly) * ra;
 }
 
 
@@ -120,31 +122,34 @@ GRT_HD void carlson_bundle(double x, double y, double z, const double *p, double
     zt = .25 * (zt + alamb);
   }
   {  // R_F (DLMF 19.36.1)
-    double inv = frcp(avef), X = (avef - xt) * inv, Y = (avef - yt) * inv, Z = -X - Y;
+    const double rinv = frsqrt(avef);      // (r06: as in rc7 -- X, Y are corrections of order TOL, the reciprocal root carries the value)
+    double inv = rinv * rinv, X = (avef - xt) * inv, Y = (avef - yt) * inv, Z = -X - Y;
     double E2 = X * Y - Z * Z, E3 = X * Y * Z;
     orf = (1.0 - E2 * (1.0 / 10.0) + E3 * (1.0 / 14.0) + E2 * E2 * (1.0 / 24.0) - (3.0 / 44.0) * E2 * E3 - 5.0 / 208.0 * E2 * E2 * E2 +
-           3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 * (1.0 / 16.0)) * fsqrt_nz(inv);
+           3.0 / 104.0 * E3 * E3 + E2 * E2 * E3 * (1.0 / 16.0)) * rinv;
   }
   ord = 0.0;
   if (WD) {  // R_D (DLMF 19.36.2 with the elementary symmetric functions of X,Y,Z,Z,Z)
-    double inv = frcp(aved), X = (aved - xt) * inv, Y = (aved - yt) * inv, Z = -(X + Y) * (1.0 / 3.0);
+    const double rinv = frsqrt(aved);
+    double inv = rinv * rinv, X = (aved - xt) * inv, Y = (aved - yt) * inv, Z = -(X + Y) * (1.0 / 3.0);
     double E2 = X * Y - 6.0 * Z * Z, E3 = (3.0 * X * Y - 8.0 * Z * Z) * Z, E4 = 3.0 * (X * Y - Z * Z) * Z * Z, E5 = X * Y * Z * Z * Z;
     double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
                  E2 * E2 * E2 * (1.0 / 16.0) + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
                  9.0 / 68.0 * (E3 * E4 + E2 * E5);
-    ord = 3.0 * sumd + fac * ser * inv * fsqrt_nz(inv);
+    ord = 3.0 * sumd + fac * ser * inv * rinv;
   }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
   for (int k = 0; k < NJ; ++k) {  // R_J (DLMF 19.36.2 with X,Y,Z,P,P)
-    double inv = frcp(avej[k]), X = (avej[k] - xt) * inv, Y = (avej[k] - yt) * inv, Z = (avej[k] - zt) * inv, P = -(X + Y + Z) / 2.0;
+    const double rinv = frsqrt(avej[k]);
+    double inv = rinv * rinv, X = (avej[k] - xt) * inv, Y = (avej[k] - yt) * inv, Z = (avej[k] - zt) * inv, P = -(X + Y + Z) / 2.0;
     double E2 = X * Y + X * Z + Y * Z - 3.0 * P * P, E3 = X * Y * Z + 2.0 * E2 * P + 4.0 * P * P * P,
            E4 = (2.0 * X * Y * Z + E2 * P + 3.0 * P * P * P) * P, E5 = X * Y * Z * P * P;
     double ser = 1.0 - 3.0 / 14.0 * E2 + E3 * (1.0 / 6.0) + 9.0 / 88.0 * E2 * E2 - 3.0 / 22.0 * E4 - 9.0 / 52.0 * E2 * E3 + 3.0 / 26.0 * E5 -
                  E2 * E2 * E2 * (1.0 / 16.0) + 3.0 / 40.0 * E3 * E3 + 3.0 / 20.0 * E2 * E4 + 45.0 / 272.0 * E2 * E2 * E3 -
                  9.0 / 68.0 * (E3 * E4 + E2 * E5);
-    double r = 6.0 * sumj[k] + fac * ser * inv * fsqrt_nz(inv);
+    double r = 6.0 * sumj[k] + fac * ser * inv * rinv;
     if (neg[k]) r = aa[k] * (bb[k] * r + 3.0 * (rcx[k] - orf));
     orj[k] = r;
   }

@@ -445,10 +445,10 @@ GRT_HD void sncndn_ladder(const AgmLadder &L, double uu, double emmc, double &sn
       b = L.em[ii - 1];
       a = c * a;
       c = dn * c;
-      dn = fdiv(L.en[ii - 1] + a, b + a);
-      a = fdiv(c, b);
+      dn = (L.en[ii - 1] + a) * frcp(b + a);      // (r06: as sncndn_ladder_z below -- one reciprocal a level, b's own comes with the ladder)
+      a = c * L.iem[ii - 1];
     }
-    a = frcp(fsqrt(c * c + 1.0));
+    a = frsqrt(c * c + 1.0);                      // (r06: one reciprocal-root seed where a square root and a reciprocal were two)
     sn = (sn < 0.0) ? -a : a;
     cn = c * sn;
   }
@@ -490,7 +490,7 @@ GRT_HD void sncndn_ladder_z(const AgmLadder &L, double uu, double emmc, double &
       z = L.opk[ii - 1] * z + (b - L.en[ii - 1]) * r * a;
     }
     zeta = z;
-    a = frcp(fsqrt_nz(c * c + 1.0));
+    a = frsqrt(c * c + 1.0);
     sn = (sn < 0.0) ? -a : a;
     cn = c * sn;
   }
