@@ -689,8 +689,9 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   const double thetae = T * (k / m / c / c) + thetaemin, th2 = thetae * thetae;
   const double nuc = B * sth * (3.0 * ec / 4.0 / pi / m / c) * th2 + nucminval;
   const double xm = fdiv(nu, nuc);
-  const double x13 = cbrt(xm), x23 = x13 * x13;
-  const double i13 = frcp(x13), i23 = i13 * i13, ixm = i23 * i13;
+  double x13, i13;
+  fcbrt_pair(xm, x13, i13);      // (r06: x^(1/3) and its reciprocal from one REAL(4) seed and one third-order step)
+  const double x23 = x13 * x13, i23 = i13 * i13, ixm = i23 * i13;
   const double ex = fexp(-1.8899 * x13);      // (r06: the lean exp / log below -- their arguments are finite; the one that can be zero is guarded)
   const double iix = 2.5651 * (1.0 + 1.92 * i13 + .9977 * i23) * ex;
   const double iqx = 2.5651 * (1.0 + .93193 * i13 + .499873 * i23) * ex;
@@ -737,7 +738,7 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   if (!TSKIP || !(targ < -22.0)) {
 #endif
     const double lxe = flog(x + 1e-16);
-    extraterm = (.011 * e472 - 369.69342869090826 * fexp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * tanh(targ));
+    extraterm = (.011 * e472 - 369.69342869090826 * fexp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * ftanh(targ));
   }
   double shx, chx;
   fast_sincos(0.5 * x, &shx, &chx);      // (x is of order 1 ... 1e4: no large-argument path needed)
@@ -762,9 +763,9 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
     const double sarg = (thetae - 1.0) * 20.0;
     double step = 1.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (!TSKIP || __builtin_amdgcn_ballot_w64(warm && !(sarg > 22.0)) != 0ull) step = 0.5 + 0.5 * tanh(sarg);
+    if (!TSKIP || __builtin_amdgcn_ballot_w64(warm && !(sarg > 22.0)) != 0ull) step = 0.5 + 0.5 * ftanh(sarg);
 #else
-    if (!TSKIP || !(sarg > 22.0)) step = 0.5 + 0.5 * tanh(sarg);
+    if (!TSKIP || !(sarg > 22.0)) step = 0.5 + 0.5 * ftanh(sarg);
 #endif
     const double w11 = e11c * (k1 * ik2 + 6.0 * thetae) * (sth * sth), w12 = e12c * (k0 - step * shgm) * ik2 * cth;
     eps11m22 = warm ? w11 : eps11m22;

@@ -119,6 +119,31 @@ GRT_HD double flog(double x) {
   // ln2 = hi + lo, hi with 32 trailing zero bits: e hi is exact for |e| < 2^11
   return fma(de, 0x1.62e42fee00000p-1, fma(de, 0x1.a39ef35793c76p-33, lm));
 }
+// tanh for the two smooth switches of the thermal Faraday coefficients, (1/2)(1 + tanh x): (1 - t)/(1 + t) with t = e^(-2|x|), |x| capped at 22
+// (t = 8e-20: the quotient is exactly 1, as the library's tanh is beyond 19.1).  Absolute error <= 2e-16 -- the granularity of a double next to
+// +-1, which is all the switch can resolve; NOT relatively accurate near 0.  NaN propagates.  ~115 cycles where the library's is ~3x that (r06).
+GRT_HD double ftanh(double x) {
+  const double ax = fabs(x), xa = (ax > 22.0) ? 22.0 : ax;
+  const double t = fexp(-2.0 * xa);
+  return copysign((1.0 - t) * frcp(1.0 + t), x);
+}
+// x^(-1/3) and x^(1/3) for the thermal coefficients' x = nu/nu_c (an ordinary positive number; anything outside 1e-30 ... 1e30 or NaN takes the
+// library): the REAL(4) seed 2^(-log2(x)/3) from the hardware's log2 / exp2 (good to ~2e-6), ONE third-order step of z <- z (1 + e/3 + 2 e^2/9),
+// e = 1 - x z^3 (remainder 14/81 e^3 ~ 1e-17), then x^(1/3) = x z^2.  ~3 ulp; ~80 cycles for BOTH values where the library's cbrt and a reciprocal
+// were a few hundred (r06).
+GRT_HD void fcbrt_pair(double x, double &c, double &ic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (x > 1e-30 && x < 1e30) {
+    const double z = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 3.0f));
+    const double z2 = z * z, e = fma(-x, z2 * z, 1.0);
+    ic = fma(z, e * fma(e, 2.0 / 9.0, 1.0 / 3.0), z);
+    c = x * (ic * ic);
+    return;
+  }
+#endif
+  c = cbrt(x);
+  ic = 1.0 / c;
+}
 GRT_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
 GRT_HD double powm1(int n) { return (n & 1) ? -1.0 : 1.0; }
 GRT_HD int fint(double x) { return (int)x; }

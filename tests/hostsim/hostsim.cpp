@@ -613,3 +613,4 @@ int hs_disk_pixel_pol(const GrtCam *cam, float mbh, float mdot, float rin, float
   return disk_pixel(*cam, d, ii, nfreq, freqs, pix, 4 + nextra, 4, nextra, 1);
 }
 }
+extern "C" double hs_ftanh(double x) { return grtd::ftanh(x); }      // the switch function of the thermal Faraday coefficients (r06)

@@ -477,6 +477,21 @@ def test_flog_is_log_to_two_and_a_half_ulp(L):
     assert L.hs_flog(1.0) == 0.0
 
 
+def test_ftanh_is_tanh_to_the_granularity_of_a_double_next_to_one(L):
+    # grt_dev_special.hpp:ftanh (r06) -- the two smooth switches (1/2)(1 + tanh x) of the thermal Faraday coefficients: absolute error <= 3e-16 everywhere
+    # (a double next to +-1 resolves 1.1e-16), exactly +-1 from |x| = 20 on (polsynchth_fast's wave-uniform short cuts rest on tanh(x <= -22) = -1.0), odd, NaN in NaN out
+    L.hs_ftanh.restype = C.c_double
+    L.hs_ftanh.argtypes = [C.c_double]
+    rng = np.random.default_rng(13)
+    xs = np.concatenate([rng.uniform(-30.0, 30.0, 60000), rng.uniform(-1.0, 1.0, 20000), rng.uniform(-1e-6, 1e-6, 5000), [0.0, 19.0, -19.0, 21.9, -21.9]])
+    got = np.array([L.hs_ftanh(float(x)) for x in xs])
+    want = np.tanh(xs.astype(np.longdouble))
+    assert float(np.abs(got.astype(np.longdouble) - want).max()) <= 3e-16
+    for x in (20.0, 22.0, 23.0, 700.0, 1e300):
+        assert L.hs_ftanh(x) == 1.0 and L.hs_ftanh(-x) == -1.0
+    assert L.hs_ftanh(0.0) == 0.0 and np.isnan(L.hs_ftanh(float("nan")))
+
+
 def test_power_law_emissivity_follows_the_reference_across_its_own_discontinuity(L):
     # r04, fuzz seed 2718 camera 620 (FFJET POLSYNCHPL, p = 5.5, 345 GHz): the reference's j_I jumps by 1.8 % across one node of its G(x) table
     # lookup while alpha_I is continuous (polsynchemis.f90:62-92, 608-629 as the oracle restates them), and one point of a ray sat 3e-8 (relative, in

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the library built with tools/experiments/r06_pipelined_pass.patch: GRT_CLASS_MERGE=2 is that patch's mode)
 # tools/r06_pipe.sh LIB: on the GPU box -- a rank's share of the headline camera with the merged transfer launch (GRT_CLASS_MERGE=1) against the
 # pipelined small pass (2) at 2 / 4 / 8 parts: rank 3 of 8 (1-column tiles), rank 1 of 8 and rank 5 of 8 (strips), rank 1 of 4, rank 0 of 2
 export GRTRANS_AMD_LIB=${1:-}
