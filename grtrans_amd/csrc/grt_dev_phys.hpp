@@ -535,14 +535,14 @@ GRT_HD double besselk0(double x) {
   const double p[7] = {-0.57721566, 0.42278420, 0.23069756, 0.3488590e-1, 0.262698e-2, 0.10750e-3, 0.74e-5};
   const double q[7] = {1.25331414, -0.7832358e-1, 0.2189568e-1, -0.1062446e-1, 0.587872e-2, -0.251540e-2, 0.53208e-3};
   // (r06: flog / fexp -- the argument is 1/theta_e of a warm plasma, an ordinary positive number; NaN propagates through both)
-  if (x <= 2.0) { double y = x * x / 4.0; return (-flog(x / 2.0) * besseli0(x)) + poly(y, p, 7); }
+  if (x <= 2.0) { double y = x * x / 4.0; return (-flog_pos(x / 2.0) * besseli0(x)) + poly(y, p, 7); }
   const double ix = frcp(x), y = 2.0 * ix;
   return (fexp(-x) * fsqrt(ix)) * poly(y, q, 7);
 }
 GRT_HD double besselk1(double x) {
   const double p[7] = {1.0, 0.15443144, -0.67278579, -0.18156897, -0.1919402e-1, -0.110404e-2, -0.4686e-4};
   const double q[7] = {1.25331414, 0.23498619, -0.3655620e-1, 0.1504268e-1, -0.780353e-2, 0.325614e-2, -0.68245e-3};
-  if (x <= 2.0) { double y = x * x / 4.0; return (flog(x / 2.0) * besseli1(x)) + frcp(x) * poly(y, p, 7); }
+  if (x <= 2.0) { double y = x * x / 4.0; return (flog_pos(x / 2.0) * besseli1(x)) + frcp(x) * poly(y, p, 7); }
   const double ix = frcp(x), y = 2.0 * ix;
   return (fexp(-x) * fsqrt(ix)) * poly(y, q, 7);
 }
@@ -723,7 +723,7 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
   // jffunc, shgmfunc (polsynchemis.f90:799-822)
   // (x = 0 -- no field, or a wave vector along it: log x = -inf, and every use below is exp(c log x) with c > 0 = 0 -- takes log(1e-300):
   //  the same zeros to the last bit, without an infinity for the lean functions; NaN stays NaN)
-  const double lx = flog((x < 1e-300) ? 1e-300 : x);
+  const double lx = flog_pos((x < 1e-300) ? 1e-300 : x);
   const double e472 = fexp(x * (-1.0 / 47.2));
   // extraterm = (...) (1/2 + 1/2 tanh(10 (ln x - ln 120))) is EXACTLY zero below x = 13: tanh of an argument under -22 is -1.0 in both
   // the device's and glibc's libm, and the bracket is finite (the 1e-16 under the logarithm keeps exp(-8/3 ln x) below 4e42).  At the
@@ -737,7 +737,7 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
 #else
   if (!TSKIP || !(targ < -22.0)) {
 #endif
-    const double lxe = flog(x + 1e-16);
+    const double lxe = flog_pos(x + 1e-16);
     extraterm = (.011 * e472 - 369.69342869090826 * fexp((-8.0 / 3.0) * lxe)) * (0.5 + 0.5 * ftanh(targ));
   }
   double shx, chx;
@@ -758,7 +758,7 @@ GRT_HD void polsynchth_fast(double nu, double n, double B, double T, double thet
 #endif
     const double it = frcp(warm ? thetae : 1.0);
     const double k0 = besselk0(it), k1 = besselk1(it), k2 = k0 + 2.0 * thetae * k1, ik2 = frcp(k2);     // besselk(2, 1/thetae)
-    const double shgm = (double)0.43793091f * flog(1.0 + (double)0.00185777f * fexp((double)1.50316886f * lx));
+    const double shgm = (double)0.43793091f * flog_pos(1.0 + (double)0.00185777f * fexp((double)1.50316886f * lx));
     // (the step function is exactly 1 above theta_e = 2.1 -- tanh(22) = 1.0 in double --: hot zones skip the tanh, wave-uniformly)
     const double sarg = (thetae - 1.0) * 20.0;
     double step = 1.0;

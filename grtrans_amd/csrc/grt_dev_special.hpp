@@ -91,14 +91,18 @@ GRT_HD double fexp(double x) {
   p = fma(t, p, 1.0);
   return ldexp(p, (int)dn);
 }
-// log for arguments that are ordinary positive numbers (normal, finite; anything else is NOT handled: no NaN / zero / subnormal paths).
+// log for arguments that are ordinary positive numbers (the lean path; subnormals are NOT handled by it, everything else falls back to the library).
 // r06: the library's log is a double-double evaluation -- 74 fp64 instructions and a reciprocal, ~370 SIMD cycles -- and the power-law
 // step took two of them (log nu_B,perp and log g: 8.6 % of grt_transfer_kernel<2,13,4,1,false,2>).  x = 2^e m with m in [sqrt(1/2), sqrt 2),
 // s = (m - 1)/(m + 1), log m = 2 s + 2 s z (1/3 + z/5 + ... + z^9/21), z = s^2 <= 0.0295 (truncation 6e-19 of log m); e ln2 in two parts.
 // 20 fp64 instructions and frcp (~140 cycles).  Against an 80-bit log over 1e-300 ... 1e300 and around 1: <= 2.4 ulp, i.e. 4e-16 relative
 // (where e ln2 and log m cancel by a factor of two; correcting the quotient s brings 2.0) -- log x feeds exponentials and table positions
 // (tests/test_hostsim_fast.py::test_flog...).
-GRT_HD double flog(double x) {
+// flog_pos: the lean path alone, for arguments that are positive by construction (NaN propagates through it).
+// flog: the same value for ordinary arguments, and the library's answers -- log 0 = -inf, log(negative) = NaN, log(inf) = inf -- patched in by
+// selects (no branch: a divergent fall-back to the library's log cost the thermal kernels, which call this three times a step, 5 % --
+// profiles/r06q_* against r06p_*; four compares and selects cost 1 %).
+GRT_HD double flog_pos(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double m = __builtin_amdgcn_frexp_mant(x);
   int e = __builtin_amdgcn_frexp_exp(x);
@@ -118,6 +122,11 @@ GRT_HD double flog(double x) {
   const double de = (double)e;
   // ln2 = hi + lo, hi with 32 trailing zero bits: e hi is exact for |e| < 2^11
   return fma(de, 0x1.62e42fee00000p-1, fma(de, 0x1.a39ef35793c76p-33, lm));
+}
+GRT_HD double flog(double x) {
+  const double v = flog_pos(x);
+  const double special = (x == 0.0) ? -__builtin_huge_val() : ((x > 0.0) ? x /* +inf */ : __builtin_nan(""));      // (x NaN: NaN)
+  return (x > 0.0 && x < 1.7976931348623157e308) ? v : special;
 }
 // tanh for the two smooth switches of the thermal Faraday coefficients, (1/2)(1 + tanh x): (1 - t)/(1 + t) with t = e^(-2|x|), |x| capped at 22
 // (t = 8e-20: the quotient is exactly 1, as the library's tanh is beyond 19.1).  Absolute error <= 2e-16 -- the granularity of a double next to

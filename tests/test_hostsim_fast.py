@@ -475,6 +475,7 @@ def test_flog_is_log_to_two_and_a_half_ulp(L):
     err = np.abs(got.astype(np.longdouble) - want) / ulp
     assert float(err.max()) <= 2.5, float(err.max())
     assert L.hs_flog(1.0) == 0.0
+    assert L.hs_flog(0.0) == -np.inf and L.hs_flog(float("inf")) == np.inf and np.isnan(L.hs_flog(-1.0)) and np.isnan(L.hs_flog(float("nan")))      # (the library's answers)
 
 
 def test_ftanh_is_tanh_to_the_granularity_of_a_double_next_to_one(L):
