@@ -1964,6 +1964,20 @@ def test_fp32_islands_bit_identical_on_device_and_host():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_device_square_root_is_the_correctly_rounded_one_and_never_below_the_side_of_a_square():
+    # r06: formal_apply forms rt = fsqrt(h^2 + ap^2) and lam2 = fsqrt(rt - h); with ap = 0 -- most cells of a GRMHD dump at some frequency -- a root
+    # one ulp below |h| makes lam2 NaN.  A cheaper root (one third-order step, 0.75 ulp) did exactly that for one build (tools/experiments/r06_sqrt3.patch:
+    # 147 of 700 sweep cameras).  tests/sqrt_square_check.hip runs the product's fsqrt over 2.7e8 (h, ap) pairs on the device: never below |h|, always
+    # the correctly rounded root.
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "sqrt_square_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas", "-mllvm", "-disable-machine-licm",
+                               "-I", os.path.join(ROOT, "grtrans_amd", "csrc"), os.path.join(ROOT, "tests", "sqrt_square_check.hip"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "below |h|: 0; different from the correctly rounded root: 0" in r.stdout, r.stdout + r.stderr
+
+
 # cameras a random sweep (tools/fuzz_cameras.py 300 31) found: one ray each crosses a bin edge of the power-law G(x)
 # tables within 1e-7, where the reference's emissivity is discontinuous (0.5% in j_I); with the REAL(4) fluid variables
 # one ulp off, that pixel moved by 4e-5 .. 2e-4 of the Stokes peak
