@@ -1,6 +1,6 @@
 // tests/sqrt_square_check.hip (test infrastructure; built by __graft_entry__.build(), run by tests/test_gpu_parity.py) -- r06: the property the formal step leans on (grt_dev_phys.hpp:formal_apply: rt = fsqrt(h h + ap ap), lam2 = fsqrt(rt - h)):
 // fsqrt(fl(h^2)) >= |h|, and fsqrt correctly rounded, for the product's fsqrt (rsq seed, one coupled Goldschmidt step, ONE correction since r06) on the device.
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast-honor-pragmas -mllvm -disable-machine-licm -I grtrans_amd/csrc tests/sqrt_square_check.hip -o tests/sqrt_square_check
+// make -C grtrans_amd/csrc -f Makefile -f ../../tests/checks.mk ../../tests/sqrt_square_check   (the product Makefile's compiler and flags)
 // (r06 tried a cheaper root -- one third-order step, 0.75 ulp -- as the general fsqrt: sqrt(h^2) came out one ulp below |h| and the formal step returned NaN: DESIGN 4)
 #include <hip/hip_runtime.h>
 #include <cstdio>

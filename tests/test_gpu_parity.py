@@ -1972,8 +1972,7 @@ def test_device_square_root_is_the_correctly_rounded_one_and_never_below_the_sid
     import subprocess
     exe = os.path.join(ROOT, "tests", "sqrt_square_check")
     if not os.path.exists(exe):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas", "-mllvm", "-disable-machine-licm",
-                               "-I", os.path.join(ROOT, "grtrans_amd", "csrc"), os.path.join(ROOT, "tests", "sqrt_square_check.hip"), "-o", exe])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grtrans_amd", "csrc"), "-f", "Makefile", "-f", "../../tests/checks.mk", "../../tests/sqrt_square_check"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "below |h|: 0; different from the correctly rounded root: 0" in r.stdout, r.stdout + r.stderr
 
